@@ -1,0 +1,79 @@
+"""ctypes binding of libia_hip.so (declared in include/ia_hip.h).
+
+The library is the product: if it cannot be loaded, every GPU op raises -- there is no
+silent PyTorch fallback for device tensors.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+from . import build as _build
+
+_lock = threading.Lock()
+_lib = None
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+DTYPE_ID = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
+
+# name -> argtypes, mirroring include/ia_hip.h
+_SIGNATURES = {
+    'ia_version': [],
+    'ia_last_error': [ctypes.c_char_p, ctypes.c_size_t],
+    'ia_device_count': [],
+    'ia_bias_act': [c_void_p] * 6 + [c_int, c_int64, c_int, c_int64, c_int, c_int, c_float, c_float, c_float, c_void_p],
+    'ia_upfirdn2d': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _i64p, c_int, c_int, _i64p,
+                     c_int, c_int, _i64p] + [c_int] * 7 + [c_float, c_void_p],
+}
+
+
+def declared_symbols():
+    """Entry points parsed from include/ia_hip.h (used by the CPU-side export test)."""
+    import re
+    hdr = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'include', 'ia_hip.h')
+    with open(hdr) as fh:
+        text = fh.read()
+    return sorted(set(re.findall(r'^\s*(?:int|size_t)\s+(ia_[a-z0-9_]+)\s*\(', text, flags=re.M)))
+
+
+def load():
+    """Load (building it first if the .so is absent) and type the C-ABI library."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            path = _build.build()
+        lib = ctypes.CDLL(path)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_size_t if name == 'ia_last_error' else c_int
+        if lib.ia_version() != 1:
+            raise RuntimeError(f'libia_hip.so ABI version {lib.ia_version()} != 1; rebuild with python -m invertavatar_amd.build')
+        _lib = lib
+        return lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    load().ia_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f'{what}: {last_error()} (ia_status {status})')
+
+
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream, as an integer for ctypes."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def strides64(t):
+    return (ctypes.c_int64 * t.ndim)(*t.stride())

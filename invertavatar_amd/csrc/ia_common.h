@@ -1,0 +1,60 @@
+// Shared host-side helpers for libia_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/ia_hip.h"
+
+namespace ia {
+
+// Thread-local last-error text; the only mutable state in the library.
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(IA_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return IA_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kNumCU = 256;      // MI355X
+constexpr int kNumXCD = 8;
+
+// Streaming kernels: enough blocks to fill 256 CUs x 8 blocks, grid-stride beyond that.
+inline int streaming_grid(int64_t work_items, int block) {
+    int64_t g = ceil_div(work_items, block);
+    int64_t cap = (int64_t)kNumCU * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// fp32 <-> storage conversions used by every kernel template.
+template <class T> struct Num;
+template <> struct Num<float> {
+    using compute_t = float;
+    __device__ static float load(const float* p) { return *p; }
+    __device__ static void store(float* p, float v) { *p = v; }
+};
+template <> struct Num<__half> {
+    using compute_t = float;
+    __device__ static float load(const __half* p) { return __half2float(*p); }
+    __device__ static void store(__half* p, float v) { *p = __float2half(v); }
+};
+template <> struct Num<double> {
+    using compute_t = double;
+    __device__ static double load(const double* p) { return *p; }
+    __device__ static void store(double* p, double v) { *p = v; }
+};
+
+}  // namespace ia
+
+#define IA_REQUIRE(cond, ...) \
+    do { if (!(cond)) return ia::fail(IA_ERR_INVALID_ARG, __VA_ARGS__); } while (0)

@@ -1,0 +1,184 @@
+// ia_upfirdn2d: zero-insert up-sampling -> pad/crop -> 2-D FIR -> decimation, per channel.
+//
+//   out[oy,ox] = gain * sum_{ky,kx} K[ky,kx] * U[oy*down + ky, ox*down + kx]
+//   U[Y,X]     = x[(Y - pad0y)/upy, (X - pad0x)/upx]  when both divisions are exact and in range, else 0
+//   K          = f flipped in both axes unless `flip` (true convolution by default)
+//
+// (reference op definition torch_utils/ops/upfirdn2d.py:169-213, size rule
+// upfirdn2d.cpp:39-40.)  Two kernels:
+//   * tiled:   contiguous NCHW, down 1, square up in {1,2}, filter <= 8x8 -- the two shapes the generator hits
+//              (4x4 blur after the stride-2 transposed conv; 2x up-sampling of the skip image).  A 64x16 output
+//              tile per 256-thread workgroup; the input halo tile and the pre-flipped, pre-gained filter are
+//              staged in LDS; rows are read/written as full 256-byte wave accesses.  Only the non-zero
+//              polyphase taps are visited.
+//   * generic: any strides (channels_last), any up/down, filter <= 32x32.
+// HBM-bound: algorithmic traffic = (in_h*in_w + out_h*out_w) * sizeof(T) bytes per channel.
+#include "ia_common.h"
+
+namespace {
+
+struct Geo {
+    int n, c, in_h, in_w, out_h, out_w;
+    int64_t xs[4], ys[4];
+    int f_h, f_w;
+    int upx, upy, downx, downy, padx0, pady0;
+    float gain;
+};
+
+constexpr int kMaxTaps = 32 * 32;
+
+__device__ __forceinline__ int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// Stage K[ky][kx] = gain * f[flip ? ky : fh-1-ky][flip ? kx : fw-1-kx] into LDS.
+__device__ __forceinline__ void stage_filter(float* k_lds, const float* f, int f_h, int f_w, int64_t fs0, int64_t fs1,
+                                             int flip, float gain) {
+    for (int i = threadIdx.x; i < f_h * f_w; i += blockDim.x) {
+        int ky = i / f_w, kx = i - ky * f_w;
+        int sy = flip ? ky : f_h - 1 - ky, sx = flip ? kx : f_w - 1 - kx;
+        k_lds[i] = f[sy * fs0 + sx * fs1] * gain;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void upfirdn2d_generic(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ y,
+                                                        Geo g, int64_t fs0, int64_t fs1, int flip) {
+    using S = typename ia::Num<T>::compute_t;
+    __shared__ float k_lds[kMaxTaps];
+    stage_filter(k_lds, f, g.f_h, g.f_w, fs0, fs1, flip, g.gain);
+    __syncthreads();
+    const int64_t total = (int64_t)g.n * g.c * g.out_h * g.out_w;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool chan_minor = g.ys[1] == 1;  // channels_last: walk channels fastest so stores stay coalesced
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int ox, oy, ch, nb;
+        int64_t r = i;
+        if (chan_minor) { ch = r % g.c; r /= g.c; ox = r % g.out_w; r /= g.out_w; oy = r % g.out_h; nb = r / g.out_h; }
+        else { ox = r % g.out_w; r /= g.out_w; oy = r % g.out_h; r /= g.out_h; ch = r % g.c; nb = r / g.c; }
+        const int by = oy * g.downy - g.pady0, bx = ox * g.downx - g.padx0;
+        // first tap whose up-sampled coordinate lands on a real sample
+        int ky0 = ((-by) % g.upy + g.upy) % g.upy, kx0 = ((-bx) % g.upx + g.upx) % g.upx;
+        const T* xp = x + nb * g.xs[0] + ch * g.xs[1];
+        S acc = 0;
+        for (int ky = ky0; ky < g.f_h; ky += g.upy) {
+            int iy = (by + ky) / g.upy;
+            if (by + ky < 0 || iy >= g.in_h) continue;
+            for (int kx = kx0; kx < g.f_w; kx += g.upx) {
+                int ix = (bx + kx) / g.upx;
+                if (bx + kx < 0 || ix >= g.in_w) continue;
+                acc += ia::Num<T>::load(xp + iy * g.xs[2] + ix * g.xs[3]) * (S)k_lds[ky * g.f_w + kx];
+            }
+        }
+        ia::Num<T>::store(y + nb * g.ys[0] + ch * g.ys[1] + oy * g.ys[2] + ox * g.ys[3], acc);
+    }
+}
+
+// Tiled kernel.  TW x TH outputs per workgroup; thread t -> column t % TW, rows (t / TW) * RPT .. +RPT-1.
+constexpr int TW = 64, TH = 16, RPT = 4;
+static_assert(TW * (TH / RPT) == 256, "tile must map onto 256 threads");
+
+template <class T, int UP, int FS>
+__global__ __launch_bounds__(256) void upfirdn2d_tiled(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ y,
+                                                      Geo g, int64_t fs0, int64_t fs1, int flip) {
+    constexpr int NT = (FS + UP - 1) / UP;               // non-zero taps per axis for one output phase
+    constexpr int IH = (TH + FS - 2) / UP + 2;           // input rows a tile can touch
+    constexpr int IW = (TW + FS - 2) / UP + 2;
+    constexpr int IWP = IW + 1;                           // +1 column: rows start on different banks
+    __shared__ float k_lds[FS * FS];
+    __shared__ float in_lds[IH * IWP];
+
+    const int tiles_x = (g.out_w + TW - 1) / TW;
+    const int tile = blockIdx.x;
+    const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+    const int64_t plane = blockIdx.y;                     // n * c planes, contiguous NCHW
+    const T* xp = x + plane * (int64_t)g.in_h * g.in_w;
+    T* yp = y + plane * (int64_t)g.out_h * g.out_w;
+
+    const int iy0 = floor_div(oy0 - g.pady0, UP), ix0 = floor_div(ox0 - g.padx0, UP);
+    stage_filter(k_lds, f, FS, FS, fs0, fs1, flip, g.gain);
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        int r = i / IW, cidx = i - r * IW;
+        int iy = iy0 + r, ix = ix0 + cidx;
+        float v = 0.f;
+        if (iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w) v = (float)ia::Num<T>::load(xp + (int64_t)iy * g.in_w + ix);
+        in_lds[r * IWP + cidx] = v;
+    }
+    __syncthreads();
+
+    const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * RPT;
+    const int ox = ox0 + tx;
+    if (ox >= g.out_w) return;
+    const int bx = ox - g.padx0;
+    const int kx0 = ((-bx) % UP + UP) % UP;
+    const int lx = floor_div(bx + kx0, UP) - ix0;         // LDS column of the first tap
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int oy = oy0 + ty + r;
+        if (oy >= g.out_h) break;
+        const int by = oy - g.pady0;
+        const int ky0 = ((-by) % UP + UP) % UP;
+        const int ly = floor_div(by + ky0, UP) - iy0;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int ky = ky0 + a * UP;
+            if (ky >= FS) break;
+#pragma unroll
+            for (int bb = 0; bb < NT; ++bb) {
+                const int kx = kx0 + bb * UP;
+                if (kx >= FS) break;
+                acc = fmaf(in_lds[(ly + a) * IWP + lx + bb], k_lds[ky * FS + kx], acc);
+            }
+        }
+        ia::Num<T>::store(yp + (int64_t)oy * g.out_w + ox, acc);
+    }
+}
+
+template <class T>
+int launch(const void* x, const float* f, void* y, const Geo& g, int64_t fs0, int64_t fs1, int flip, hipStream_t s) {
+    const bool nchw = g.xs[3] == 1 && g.xs[2] == g.in_w && g.xs[1] == (int64_t)g.in_h * g.in_w &&
+                      g.xs[0] == (int64_t)g.c * g.in_h * g.in_w && g.ys[3] == 1 && g.ys[2] == g.out_w &&
+                      g.ys[1] == (int64_t)g.out_h * g.out_w && g.ys[0] == (int64_t)g.c * g.out_h * g.out_w;
+    const bool tiled_ok = nchw && g.downx == 1 && g.downy == 1 && g.upx == g.upy && g.f_h == g.f_w &&
+                          (int64_t)g.n * g.c <= 65535 && sizeof(T) <= 4;
+    if (tiled_ok && (g.upx == 1 || g.upx == 2) && (g.f_w == 4)) {
+        dim3 grid(((g.out_w + TW - 1) / TW) * ((g.out_h + TH - 1) / TH), g.n * g.c);
+        if (g.upx == 1) hipLaunchKernelGGL((upfirdn2d_tiled<T, 1, 4>), grid, dim3(256), 0, s, (const T*)x, f, (T*)y, g, fs0, fs1, flip);
+        else hipLaunchKernelGGL((upfirdn2d_tiled<T, 2, 4>), grid, dim3(256), 0, s, (const T*)x, f, (T*)y, g, fs0, fs1, flip);
+        return ia::check_launch("ia_upfirdn2d(tiled)");
+    }
+    const int64_t total = (int64_t)g.n * g.c * g.out_h * g.out_w;
+    hipLaunchKernelGGL((upfirdn2d_generic<T>), dim3(ia::streaming_grid(total, 256)), dim3(256), 0, s,
+                       (const T*)x, f, (T*)y, g, fs0, fs1, flip);
+    return ia::check_launch("ia_upfirdn2d(generic)");
+}
+
+}  // namespace
+
+extern "C" int ia_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                            int n, int c, int in_h, int in_w, const int64_t* h_x_stride,
+                            int f_h, int f_w, const int64_t* h_f_stride,
+                            int out_h, int out_w, const int64_t* h_y_stride,
+                            int upx, int upy, int downx, int downy, int padx0, int pady0,
+                            int flip, float gain, void* stream) {
+    IA_REQUIRE(x && f && y && h_x_stride && h_f_stride && h_y_stride, "null pointer argument");
+    IA_REQUIRE(n > 0 && c > 0 && in_h > 0 && in_w > 0, "x has zero size");
+    IA_REQUIRE(f_h >= 1 && f_w >= 1, "f must be at least 1x1");
+    IA_REQUIRE(upx >= 1 && upy >= 1, "upsampling factor must be at least 1");
+    IA_REQUIRE(downx >= 1 && downy >= 1, "downsampling factor must be at least 1");
+    IA_REQUIRE(out_h >= 1 && out_w >= 1, "output must be at least 1x1");
+    IA_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX, "x is too large");
+    IA_REQUIRE((int64_t)n * c * out_h * out_w <= INT32_MAX, "output is too large");
+    if (f_h * f_w > kMaxTaps) return ia::fail(IA_ERR_UNSUPPORTED, "filter %dx%d exceeds the 32x32 tap limit", f_h, f_w);
+    Geo g;
+    g.n = n; g.c = c; g.in_h = in_h; g.in_w = in_w; g.out_h = out_h; g.out_w = out_w;
+    for (int i = 0; i < 4; ++i) { g.xs[i] = h_x_stride[i]; g.ys[i] = h_y_stride[i]; }
+    g.f_h = f_h; g.f_w = f_w; g.upx = upx; g.upy = upy; g.downx = downx; g.downy = downy;
+    g.padx0 = padx0; g.pady0 = pady0; g.gain = gain;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case IA_F32: return launch<float>(x, f, y, g, h_f_stride[0], h_f_stride[1], flip, s);
+        case IA_F16: return launch<__half>(x, f, y, g, h_f_stride[0], h_f_stride[1], flip, s);
+        case IA_F64: return launch<double>(x, f, y, g, h_f_stride[0], h_f_stride[1], flip, s);
+        default: return ia::fail(IA_ERR_INVALID_ARG, "unsupported dtype %d", dtype);
+    }
+}

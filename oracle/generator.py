@@ -1,0 +1,194 @@
+"""Oracle restatement of the Next3D++ generator forward pass (SURVEY.md 8a rows
+N2-N8, G1-G3, S1).  Works on a flat ``{reference parameter name: tensor}`` dict
+(names per SURVEY.md C14) so it shares no code with the product's nn.Modules.
+Test infrastructure only.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops, renderer
+
+BBOX_256 = (57, 185, 64, 192)  # triplane_v20.py:114
+
+
+def sub(sd, prefix):
+    """View of the entries below `prefix.` with the prefix stripped."""
+    n = len(prefix) + 1
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix + '.')}
+
+
+def mapping(sd, z, c, num_ws, truncation_psi=1.0, truncation_cutoff=None, lr_mul=0.01, num_layers=2):
+    """MappingNetwork.forward.  Reference: networks_stylegan2_new.py:233-268."""
+    def norm2(v):
+        return v * (v.square().mean(dim=1, keepdim=True) + 1e-8).rsqrt()
+    x = norm2(z.float())
+    y = norm2(ops.fully_connected(c.float(), sd['embed.weight'], sd['embed.bias']))
+    x = torch.cat([x, y], 1)
+    for i in range(num_layers):
+        x = ops.fully_connected(x, sd[f'fc{i}.weight'], sd[f'fc{i}.bias'], lr_mul, 'lrelu')
+    x = x.unsqueeze(1).repeat(1, num_ws, 1)
+    if truncation_psi != 1:
+        cut = num_ws if truncation_cutoff is None else truncation_cutoff
+        x[:, :cut] = sd['w_avg'].lerp(x[:, :cut], truncation_psi)
+    return x
+
+
+def synthesis_layer(sd, x, w, up, noise_mode, fused=True, gain=1.0, conv_clamp=None):
+    """SynthesisLayer.forward.  Reference: training/networks_stylegan2.py:311-330."""
+    styles = ops.fully_connected(w, sd['affine.weight'], sd['affine.bias'])
+    noise = None
+    if noise_mode == 'const':
+        noise = sd['noise_const'] * sd['noise_strength']
+    y = ops.modulated_conv2d(x, sd['weight'], styles, noise=noise, up=up, padding=1,
+                             resample_filter=sd['resample_filter'], fused=fused)
+    clamp = conv_clamp * gain if conv_clamp is not None else None
+    return ops.bias_act(y, sd['bias'], act='lrelu', gain=ops.SQRT2 * gain, clamp=clamp)
+
+
+def to_rgb(sd, x, w, fused=True, conv_clamp=None):
+    """ToRGBLayer.forward.  Reference: training/networks_stylegan2.py:351-357."""
+    in_ch = sd['weight'].shape[1]
+    styles = ops.fully_connected(w, sd['affine.weight'], sd['affine.bias']) * (1 / math.sqrt(in_ch))
+    y = ops.modulated_conv2d(x, sd['weight'], styles, demodulate=False, fused=fused)
+    return ops.bias_act(y, sd['bias'], clamp=conv_clamp)
+
+
+def synthesis_block(sd, x, img, ws, condition=None, noise_mode='const', fused=True, conv_clamp=None):
+    """SynthesisBlock.forward, architecture 'skip', fp32.
+    Reference: networks_stylegan2_new.py:417-467 (SR: training/networks_stylegan2.py:417-460)."""
+    wi = 0
+    if 'const' in sd:
+        x = sd['const'].unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
+        x = synthesis_layer(sub(sd, 'conv1'), x, ws[:, wi], 1, noise_mode, fused, conv_clamp=conv_clamp); wi += 1
+    else:
+        x = synthesis_layer(sub(sd, 'conv0'), x, ws[:, wi], 2, noise_mode, fused, conv_clamp=conv_clamp); wi += 1
+        if condition is not None:  # CS-SFT, :448-452
+            half = x.shape[1] // 2
+            x = torch.cat([x[:, :half], x[:, half:] * condition[0] + condition[1]], 1)
+        x = synthesis_layer(sub(sd, 'conv1'), x, ws[:, wi], 1, noise_mode, fused, conv_clamp=conv_clamp); wi += 1
+    if img is not None:
+        img = ops.upsample2d(img, sd['resample_filter'])
+    y = to_rgb(sub(sd, 'torgb'), x, ws[:, wi], fused, conv_clamp)
+    img = img + y if img is not None else y
+    return x, img
+
+
+def synthesis_network(sd, ws, cond_list=None, return_list=False, feat_conditions=None, img_resolution=256,
+                      out_res=(32, 256), noise_mode='const', fused=True):
+    """SynthesisNetwork.forward.  Reference: networks_stylegan2_new.py:509-548."""
+    res_list = [2 ** i for i in range(2, int(math.log2(img_resolution)) + 1)]
+    x = img = None
+    feats = []
+    start = int(math.log2(out_res[0])) - 2
+    end = int(math.log2(out_res[1])) - 2
+    w_idx = 0
+    for idx, res in enumerate(res_list):
+        bsd = sub(sd, f'b{res}')
+        n_conv = 1 if res == 4 else 2
+        cur = ws[:, w_idx:w_idx + n_conv + 1]
+        w_idx += n_conv
+        cond = feat_conditions.get(res) if feat_conditions is not None else None
+        x, img = synthesis_block(bsd, x, img, cur, cond, noise_mode, fused)
+        if idx >= start:
+            if return_list:
+                if idx == start:
+                    feats.append(img.clone())
+                feats.append(x.clone())
+            if cond_list is not None:
+                if idx == start:
+                    a = cond_list[0][:, -1:]
+                    img = cond_list[0][:, :-1] * a + img * (1 - a)
+                if idx < end:
+                    cimg = cond_list[1 + idx - start]
+                    a = cimg[:, -1:]
+                    x = cimg[:, :-1] * a + x * (1 - a)
+    if return_list:
+        feats.append(img)
+        return feats
+    return img
+
+
+def rasterize(texture_feats, uvcoords_image, static_feats, bbox_256=BBOX_256):
+    """TriPlaneGenerator.rasterize.  Reference: triplane_v20.py:317-339."""
+    uv = uvcoords_image.float()
+    grid, alpha = uv[..., :2], uv[..., 2:].permute(0, 3, 1, 2)
+    full_alpha, mouth = renderer.fill_mouth(alpha.clone())
+    upper = mouth.clone()
+    upper[:, :, :87] = 0
+    upper_alpha = torch.clamp(alpha + upper, 0, 1)
+    outs = []
+    for tex, sta in zip(texture_feats, static_feats):
+        res = tex.shape[2]
+        bb = [round(i * res / 256) for i in bbox_256]
+        rend = ops.resize_bilinear_aa(ops.grid_sample_bilinear(tex, grid), (res, res))
+        a = ops.resize_bilinear_aa(alpha, (res, res))
+        s = ops.resize_bilinear_aa(sta[:, :, bb[0]:bb[1], bb[2]:bb[3]], (res, res))
+        outs.append(torch.cat([rend * a + s * (1 - a), ops.resize_bilinear_aa(upper_alpha, (res, res))], 1))
+    return outs, full_alpha, mouth
+
+
+def blend_planes(stitch, full_alpha, static_plane, bbox_256=BBOX_256):
+    """Paste the 128^2-resized stitch into plane 0 and alpha-blend.
+    Reference: triplane_v20.py:119-128."""
+    y0, y1, x0, x1 = bbox_256
+    s_canvas = torch.zeros_like(stitch)
+    a_canvas = torch.zeros_like(full_alpha)
+    s_canvas[:, :, y0:y1, x0:x1] = ops.resize_bilinear_aa(stitch, (128, 128))
+    a_canvas[:, :, y0:y1, x0:x1] = ops.resize_bilinear_aa(full_alpha, (128, 128))
+    planes = static_plane.clone()
+    planes[:, 0] = s_canvas * a_canvas + static_plane[:, 0] * (1 - a_canvas)
+    return planes
+
+
+def superresolution_8xdc(sd, rgb, x, ws, noise_mode='none', fused=True, conv_clamp=None):
+    """SuperresolutionHybrid8XDC.forward, fp32.  Reference: superresolution.py:278-289."""
+    ws3 = ws[:, -1:, :].repeat(1, 3, 1)
+    if x.shape[-1] != 128:
+        x = ops.resize_bilinear_aa(x, (128, 128))
+        rgb = ops.resize_bilinear_aa(rgb, (128, 128))
+    x, rgb = synthesis_block(sub(sd, 'block0'), x, rgb, ws3, None, noise_mode, fused, conv_clamp)
+    x, rgb = synthesis_block(sub(sd, 'block1'), x, rgb, ws3, None, noise_mode, fused, conv_clamp)
+    return rgb
+
+
+def split_static(static_feats):
+    """triplane_v20.py:109-112: keep plane 0 of the two 96-channel entries."""
+    b = static_feats[0].shape[0]
+    plane = static_feats[-1].view(b, 3, 32, *static_feats[-1].shape[-2:])
+    out = list(static_feats)
+    out[0] = static_feats[0].view(b, 3, 32, *static_feats[0].shape[-2:])[:, 0]
+    out[-1] = plane[:, 0]
+    return out, plane
+
+
+def synthesis(sd, ws, c, uvcoords_image, jitter, nrr=128, texture_feats=None, static_feats=None, fused=True,
+              return_all=False):
+    """TriPlaneGenerator.synthesis / synthesis_withTexture, evaluation=True, noise_mode='const'.
+    Reference: triplane_v20.py:89-150 and :152-244."""
+    cam = c[:, -25:]
+    c2w = cam[:, :16].reshape(-1, 4, 4)
+    k = cam[:, 16:25].reshape(-1, 3, 3)
+    rays_o, rays_d = renderer.ray_sampler_zxc(c2w, k, nrr)
+    if texture_feats is None:
+        texture_feats = synthesis_network(sub(sd, 'texture_backbone.synthesis'), ws, return_list=True, fused=fused)
+    if static_feats is None:
+        static_feats = synthesis_network(sub(sd, 'backbone.synthesis'), ws, return_list=True, fused=fused)
+    static_for_raster, static_plane = split_static(static_feats)
+    cond, full_alpha, mouth = rasterize(texture_feats, uvcoords_image, static_for_raster)
+    stitch = synthesis_network(sub(sd, 'face_backbone.synthesis'), ws, cond_list=cond, fused=fused)
+    planes = blend_planes(stitch, full_alpha, static_plane)
+    dec = sub(sd, 'decoder')
+    feat, depth, wsum = renderer.render(planes, dec, rays_o, rays_d, jitter)
+    b = ws.shape[0]
+    feature_image = feat.permute(0, 2, 1).reshape(b, feat.shape[-1], nrr, nrr).contiguous()
+    depth_image = depth.permute(0, 2, 1).reshape(b, 1, nrr, nrr)
+    rgb = feature_image[:, :3]
+    image = superresolution_8xdc(sub(sd, 'superresolution'), rgb, feature_image, ws)
+    out = dict(image=image, image_raw=rgb, image_depth=depth_image)
+    if return_all:
+        out.update(feature_image=feature_image, triplane=planes, texture=texture_feats, static=static_feats,
+                   cond=cond, full_alpha=full_alpha, stitch=stitch)
+    return out

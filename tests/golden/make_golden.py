@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference).  The reference's files never travel:
+this script imports them, feeds them the seed-determined inputs of
+``invertavatar_amd.synthetic`` and stores input/output vectors as .npz.  Three modules the
+reference imports but the container lacks are stubbed: ``turtle``,
+``torchvision`` (unused on the path) and ``cv2`` (only ``floodFill`` is reached; stubbed with
+scipy.ndimage connected-component labelling, 4-connectivity).
+
+Usage:  python tests/golden/make_golden.py [--only ops,camera,renderer,small,full,names]
+"""
+import argparse
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, '..', '..'))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+
+from invertavatar_amd import synthetic  # noqa: E402
+
+
+def install_stubs():
+    import scipy.ndimage as ndi
+    t = types.ModuleType('turtle')
+    t.update = lambda *a, **k: None
+    sys.modules['turtle'] = t
+    tv = types.ModuleType('torchvision')
+    tv.transforms = types.ModuleType('torchvision.transforms')
+    sys.modules['torchvision'] = tv
+    sys.modules['torchvision.transforms'] = tv.transforms
+    cv2 = types.ModuleType('cv2')
+    cv2.FLOODFILL_FIXED_RANGE = 1 << 16
+
+    def flood_fill(img, mask, seed, new_val, lo, up, flags):
+        x, y = seed
+        sv = img[y, x]
+        lab, _ = ndi.label((img >= sv - lo[0]) & (img <= sv + up[0]))
+        img[lab == lab[y, x]] = new_val[0]
+        return 0
+    cv2.floodFill = flood_fill
+    sys.modules['cv2'] = cv2
+
+
+@contextlib.contextmanager
+def injected_jitter(jit):
+    """Replace torch.rand_like for the duration of one reference call (renderer.py:406)."""
+    orig = torch.rand_like
+
+    def fake(t, *a, **k):
+        assert tuple(t.shape) == tuple(jit.shape), (t.shape, jit.shape)
+        return jit.to(t.dtype)
+    torch.rand_like = fake
+    try:
+        yield
+    finally:
+        torch.rand_like = orig
+
+
+def npz(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f'{name}: {os.path.getsize(path) / 1e6:.2f} MB, {len(arrays)} arrays')
+
+
+def rnd(seed, *shape):
+    return torch.from_numpy(np.random.RandomState(seed).randn(*shape).astype(np.float32))
+
+
+# --------------------------------------------------------------------------------------------
+def gen_ops():
+    from torch_utils.ops import bias_act, upfirdn2d, conv2d_resample
+    from training.networks_stylegan2 import modulated_conv2d
+    import torch.nn.functional as F
+    out = {}
+    x = rnd(1, 2, 6, 9, 7) * 2
+    b = rnd(2, 6)
+    for act in bias_act.activation_funcs:
+        out[f'bias_act/{act}'] = bias_act.bias_act(x, b, act=act)
+    out['bias_act/lrelu_clamp'] = bias_act.bias_act(x, b, act='lrelu', gain=0.7, clamp=0.9)
+    out['bias_act/linear_dim3'] = bias_act.bias_act(x, rnd(3, 7), dim=3, act='linear', gain=2.0)
+    out['bias_act/nobias'] = bias_act.bias_act(x, None, act='lrelu', alpha=0.1)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    out['filter/1331'] = f
+    out['filter/sep8'] = upfirdn2d.setup_filter([1, 2, 3, 4, 4, 3, 2, 1], gain=2.0, flip_filter=True)
+    xi = rnd(4, 2, 5, 13, 11)
+    out['upfirdn2d/blur_pad1'] = upfirdn2d.upfirdn2d(xi, f, padding=[1, 1, 1, 1], gain=4)
+    out['upfirdn2d/up2'] = upfirdn2d.upsample2d(xi, f)
+    out['upfirdn2d/down2'] = upfirdn2d.downsample2d(xi, f)
+    out['upfirdn2d/mixed'] = upfirdn2d.upfirdn2d(xi, rnd(5, 3, 5).abs(), up=[2, 3], down=[3, 2], padding=[2, -1, 0, 3],
+                                                 flip_filter=True, gain=1.5)
+    out['upfirdn2d/sep'] = upfirdn2d.upfirdn2d(xi, torch.tensor([1., 3., 3., 1.]) / 8, up=2, padding=[2, 1, 2, 1], gain=4)
+    w = rnd(6, 8, 5, 3, 3)
+    out['conv2d_resample/up2'] = conv2d_resample.conv2d_resample(xi, w, f, up=2, padding=1, flip_weight=False)
+    out['conv2d_resample/plain'] = conv2d_resample.conv2d_resample(xi, w, f, up=1, padding=1, flip_weight=True)
+    out['conv2d_resample/down2'] = conv2d_resample.conv2d_resample(xi, w, f, down=2, padding=1)
+    styles = rnd(7, 2, 5) * 0.5 + 1
+    noise = rnd(8, 26, 22) * 0.1
+    out['modconv/up2_fused'] = modulated_conv2d(xi, w, styles, noise=noise, up=2, padding=1, resample_filter=f,
+                                                flip_weight=False, fused_modconv=True)
+    out['modconv/up2_unfused'] = modulated_conv2d(xi, w, styles, noise=noise, up=2, padding=1, resample_filter=f,
+                                                  flip_weight=False, fused_modconv=False)
+    out['modconv/plain_fused'] = modulated_conv2d(xi, w, styles, padding=1, fused_modconv=True)
+    out['modconv/torgb'] = modulated_conv2d(xi, rnd(9, 3, 5, 1, 1), styles, demodulate=False, fused_modconv=True)
+    img = rnd(10, 1, 4, 37, 41)
+    out['resize_aa/down'] = F.interpolate(img, size=(16, 16), mode='bilinear', antialias=True)
+    out['resize_aa/up'] = F.interpolate(img, size=(64, 50), mode='bilinear', antialias=True)
+    grid = torch.from_numpy(np.random.RandomState(11).uniform(-1.2, 1.2, (1, 9, 10, 2)).astype(np.float32))
+    out['grid_sample'] = F.grid_sample(img, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+    npz('ops.npz', **out)
+
+
+def gen_camera():
+    import math
+    from camera_utils import LookAtPoseSampler, FOV_to_intrinsics
+    poses = [(math.pi / 2, math.pi / 2), (math.pi / 2 + 0.35, math.pi / 2 - 0.3), (1.1, 1.9)]
+    mats = [LookAtPoseSampler.sample(y, p, torch.tensor([0, 0, 0.2]), radius=2.7)[0] for y, p in poses]
+    npz('camera.npz', yaw_pitch=np.array(poses), cam2world=torch.stack(mats), intrinsics=FOV_to_intrinsics(18.837))
+
+
+def gen_renderer():
+    """Stage-level fixture: the reference's ImportanceRenderer_bsMotion + OSGDecoder + ray sampler on random planes."""
+    from training_avatar_texture.triplane_v20 import OSGDecoder
+    from training_avatar_texture.volumetric_rendering.renderer import ImportanceRenderer_bsMotion, fill_mouth
+    from training_avatar_texture.volumetric_rendering.ray_sampler import RaySampler_zxc
+    frames, nrr = [3, 77], 16
+    planes = rnd(20, 2, 3, 32, 64, 64)
+    dec = OSGDecoder(32, {'decoder_lr_mul': 1, 'decoder_output_dim': 32})
+    synthetic.fill_parameters(dec, salt=5)
+    cams = synthetic.camera_labels(frames)
+    ro, rd = RaySampler_zxc()(cams[:, :16].view(-1, 4, 4), cams[:, 16:25].view(-1, 3, 3), nrr)
+    jit = synthetic.jitter(frames, nrr * nrr)
+    ren = ImportanceRenderer_bsMotion()
+    rec = {'march': [], 'search': [], 'sort': [], 'fine': []}
+    ren.ray_marcher.register_forward_hook(lambda m, i, o: rec['march'].append((i[0], i[1], i[2], o)))
+    orig_search, orig_sort, orig_imp = torch.searchsorted, torch.sort, ren.sample_importance
+
+    def search(cdf, u, **k):
+        r = orig_search(cdf, u, **k)
+        rec['search'].append((cdf, u, r))
+        return r
+
+    def sort(t, **k):
+        r = orig_sort(t, **k)
+        rec['sort'].append(r[1])
+        return r
+
+    def imp(*a, **k):
+        r = orig_imp(*a, **k)
+        rec['fine'].append(r)
+        return r
+    torch.searchsorted, torch.sort, ren.sample_importance = search, sort, imp
+    try:
+        with injected_jitter(jit):
+            rgb, depth, wsum = ren(planes, dec, ro, rd, synthetic.rendering_kwargs(), evaluation=True)
+    finally:
+        torch.searchsorted, torch.sort = orig_search, orig_sort
+    (cc, dc, zc, (_, _, wc)), (ca, da, za, _) = rec['march']
+    cdf, u, inds = rec['search'][0]
+    # known-answer set for fill_mouth: empty, full, ring with hole, hole touching the border, two holes
+    masks = np.zeros((5, 1, 32, 32), np.float32)
+    masks[1] = 1
+    masks[2, 0, 6:26, 6:26] = 1; masks[2, 0, 12:18, 10:22] = 0
+    masks[3, 0, 4:28, 4:28] = 1; masks[3, 0, 10:16, 0:14] = 0
+    masks[4, 0, 3:29, 3:29] = 1; masks[4, 0, 8:12, 8:14] = 0; masks[4, 0, 18:24, 15:25] = 0
+    full, mouth = fill_mouth(torch.from_numpy(masks).clone(), blur_mouth_edge=False)
+    npz('renderer.npz', frames=np.array(frames), nrr=nrr, rays_o=ro, rays_d=rd, rgb=rgb, depth=depth, wsum=wsum,
+        z_coarse=zc, den_coarse=dc, col_coarse=cc, w_coarse=wc, z_fine=rec['fine'][0], cdf=cdf, u=u, inds=inds,
+        order=rec['sort'][0], z_all=za, den_all=da,
+        fill_masks=masks, fill_full=full, fill_mouth=mouth)
+
+
+def build_reference_generator(width):
+    from training_avatar_texture.triplane_v20 import TriPlaneGenerator
+    g = TriPlaneGenerator(**synthetic.generator_kwargs(width)).eval().requires_grad_(False)
+    synthetic.fill_parameters(g)
+    return g
+
+
+def sub4(t):
+    return t[..., ::4, ::4]
+
+
+def gen_generator(width):
+    g = build_reference_generator(width)
+    frames = [5, 60] if width == 'small' else [5]
+    nrr = 32 if width == 'small' else 64
+    z = synthetic.latent(0, 1)
+    ws = g.mapping(z, synthetic.conditioning_camera(), truncation_psi=0.7, truncation_cutoff=14).repeat(len(frames), 1, 1)
+    c = synthetic.camera_labels(frames)
+    uv = synthetic.uv_conditions(frames)
+    jit = synthetic.jitter(frames, nrr * nrr)
+    with injected_jitter(jit):
+        out = g.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=nrr, noise_mode='const',
+                          evaluation=True, return_featmap=True)
+    arrays = dict(frames=np.array(frames), nrr=nrr, ws=ws, image_raw=out['image_raw'], image_depth=out['image_depth'],
+                  feature_image=out['feature_image'], triplane_sub4=sub4(out['triplane']))
+    if width == 'small':
+        arrays['image'] = out['image'][:1]
+        arrays['image_sub4'] = sub4(out['image'])
+        for i, t in enumerate(out['texture']):
+            arrays[f'texture{i}'] = t if t.numel() < 300000 else sub4(t)
+        # generator left in train() mode -> non-fused modulated conv (eval_seq.py:92)
+        g.train()
+        with injected_jitter(jit):
+            out_t = g.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=nrr, noise_mode='const', evaluation=True)
+        g.eval()
+        arrays['image_trainmode_sub4'] = sub4(out_t['image'])
+        # drive-loop entry point with cached backbones (eval_seq.py:169-170,212)
+        tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        with injected_jitter(jit):
+            out_w = g.synthesis_withTexture(ws, tex, c, {'uvcoords_image': uv}, static_feats=sta,
+                                            neural_rendering_resolution=nrr, noise_mode='const', evaluation=True)
+        arrays['image_withtexture_sub4'] = sub4(out_w['image'])
+    else:
+        arrays['image_sub4'] = sub4(out['image'])
+        arrays['image_mean_abs'] = out['image'].abs().mean()
+    npz(f'generator_{width}.npz', **arrays)
+
+
+def gen_names():
+    """(name, shape, dtype) of every parameter/buffer: the checkpoint-compatibility contract."""
+    for width, fname in (('full', 'generator_state_names.txt'), ('small', 'generator_state_names_small.txt')):
+        g = build_reference_generator(width)
+        lines = [f'{n}\t{tuple(t.shape)}\t{str(t.dtype).replace("torch.", "")}' for n, t in sorted(g.state_dict().items())]
+        with open(os.path.join(HERE, fname), 'w') as fh:
+            fh.write('\n'.join(lines) + '\n')
+        print(f'{fname}: {len(lines)} tensors, {sum(p.numel() for p in g.parameters())} parameters')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='ops,camera,renderer,small,full,names')
+    args = ap.parse_args()
+    install_stubs()
+    sys.path.insert(0, REF)
+    torch.manual_seed(0)
+    todo = args.only.split(',')
+    with torch.no_grad():
+        if 'ops' in todo: gen_ops()
+        if 'camera' in todo: gen_camera()
+        if 'renderer' in todo: gen_renderer()
+        if 'small' in todo: gen_generator('small')
+        if 'full' in todo: gen_generator('full')
+        if 'names' in todo: gen_names()
+
+
+if __name__ == '__main__':
+    main()

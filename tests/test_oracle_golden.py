@@ -1,0 +1,190 @@
+"""Pins the CPU oracle against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import generator as OG
+from oracle import ops as O
+from oracle import renderer as OR
+from invertavatar_amd import synthetic
+from conftest import rnd, max_abs
+
+ACTS = ['linear', 'relu', 'lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish']
+
+
+@pytest.mark.parametrize('act', ACTS)
+def test_bias_act(golden, act):
+    g = golden('ops.npz')
+    x, b = rnd(1, 2, 6, 9, 7) * 2, rnd(2, 6)
+    assert max_abs(O.bias_act(x, b, act=act), g[f'bias_act/{act}']) <= 1e-6
+
+
+def test_bias_act_variants(golden):
+    g = golden('ops.npz')
+    x, b = rnd(1, 2, 6, 9, 7) * 2, rnd(2, 6)
+    assert max_abs(O.bias_act(x, b, act='lrelu', gain=0.7, clamp=0.9), g['bias_act/lrelu_clamp']) <= 1e-6
+    assert max_abs(O.bias_act(x, rnd(3, 7), dim=3, act='linear', gain=2.0), g['bias_act/linear_dim3']) <= 1e-6
+    assert max_abs(O.bias_act(x, None, act='lrelu', alpha=0.1), g['bias_act/nobias']) <= 1e-6
+
+
+def test_filters(golden):
+    g = golden('ops.npz')
+    assert torch.equal(O.setup_filter([1, 3, 3, 1]), g['filter/1331'])
+    assert max_abs(O.setup_filter([1, 2, 3, 4, 4, 3, 2, 1], gain=2.0, flip_filter=True), g['filter/sep8']) <= 1e-7
+
+
+def test_upfirdn2d(golden):
+    g = golden('ops.npz')
+    f = O.setup_filter([1, 3, 3, 1])
+    x = rnd(4, 2, 5, 13, 11)
+    assert max_abs(O.upfirdn2d(x, f, padding=(1, 1, 1, 1), gain=4), g['upfirdn2d/blur_pad1']) <= 2e-6
+    assert max_abs(O.upsample2d(x, f), g['upfirdn2d/up2']) <= 2e-6
+    assert max_abs(O.upfirdn2d(x, f, down=2, padding=(1, 1, 1, 1)), g['upfirdn2d/down2']) <= 2e-6
+    assert max_abs(O.upfirdn2d(x, rnd(5, 3, 5).abs(), up=(2, 3), down=(3, 2), padding=(2, -1, 0, 3), flip_filter=True,
+                               gain=1.5), g['upfirdn2d/mixed']) <= 5e-6
+    assert max_abs(O.upfirdn2d(x, torch.tensor([1., 3., 3., 1.]) / 8, up=2, padding=(2, 1, 2, 1), gain=4),
+                   g['upfirdn2d/sep']) <= 2e-6
+
+
+def test_conv_and_modconv(golden):
+    g = golden('ops.npz')
+    f = O.setup_filter([1, 3, 3, 1])
+    x, w = rnd(4, 2, 5, 13, 11), rnd(6, 8, 5, 3, 3)
+    up = torch.cat([O.conv2d_up2(x[i:i + 1], w, f) for i in range(2)])
+    assert max_abs(up, g['conv2d_resample/up2']) <= 2e-5
+    styles, noise = rnd(7, 2, 5) * 0.5 + 1, rnd(8, 26, 22) * 0.1
+    for fused, key in ((True, 'modconv/up2_fused'), (False, 'modconv/up2_unfused')):
+        y = O.modulated_conv2d(x, w, styles, noise=noise, up=2, padding=1, resample_filter=f, fused=fused)
+        assert max_abs(y, g[key]) <= 2e-5
+    assert max_abs(O.modulated_conv2d(x, w, styles, padding=1), g['modconv/plain_fused']) <= 2e-5
+    assert max_abs(O.modulated_conv2d(x, rnd(9, 3, 5, 1, 1), styles, demodulate=False), g['modconv/torgb']) <= 2e-5
+
+
+def test_resize_and_grid_sample(golden):
+    g = golden('ops.npz')
+    img = rnd(10, 1, 4, 37, 41)
+    assert max_abs(O.resize_bilinear_aa(img, (16, 16)), g['resize_aa/down']) <= 2e-6
+    # up-sampling is not on the generator path; aten computes its tap weights in fp32 (oracle: fp64)
+    assert max_abs(O.resize_bilinear_aa(img, (64, 50)), g['resize_aa/up']) <= 2e-5
+    grid = torch.from_numpy(np.random.RandomState(11).uniform(-1.2, 1.2, (1, 9, 10, 2)).astype(np.float32))
+    assert max_abs(O.grid_sample_bilinear(img, grid), g['grid_sample']) <= 5e-6  # fp32 tap-sum order
+
+
+def test_camera(golden):
+    g = golden('camera.npz')
+    for (yaw, pitch), ref in zip(g['yaw_pitch'].tolist(), g['cam2world']):
+        assert max_abs(torch.from_numpy(synthetic.look_at_pose(yaw, pitch)).float(), ref) <= 2e-6
+    assert max_abs(torch.from_numpy(synthetic.intrinsics()).float(), g['intrinsics']) <= 1e-6
+
+
+def _decoder():
+    sd = {k: torch.empty(s) for k, s in (('net.0.weight', (64, 32)), ('net.0.bias', (64,)),
+                                         ('net.2.weight', (33, 64)), ('net.2.bias', (33,)))}
+    return synthetic.fill_parameters(sd, salt=5)
+
+
+def test_ray_sampler_and_linspace(golden):
+    g = golden('renderer.npz')
+    cams = synthetic.camera_labels(g['frames'].tolist())
+    ro, rd = OR.ray_sampler_zxc(cams[:, :16].view(-1, 4, 4), cams[:, 16:25].view(-1, 3, 3), g['nrr'])
+    assert max_abs(ro, g['rays_o']) <= 1e-6 and max_abs(rd, g['rays_d']) <= 1e-6
+    for a, b, n in ((2.25, 3.3, 48), (0.0, 1.0, 48), (2.2563, 3.3063, 48), (-1.5, 7.25, 17)):
+        assert torch.equal(OR.linspace_f32(a, b, n), torch.linspace(a, b, n))
+
+
+def test_renderer_stages(golden):
+    g = golden('renderer.npz')
+    frames, nrr = g['frames'].tolist(), g['nrr']
+    planes = rnd(20, 2, 3, 32, 64, 64)
+    jit = synthetic.jitter(frames, nrr * nrr)
+    rgb, depth, wsum, aux = OR.render(planes, _decoder(), g['rays_o'], g['rays_d'], jit, return_aux=True)
+    assert torch.equal(aux['z_coarse'], g['z_coarse'])
+    assert max_abs(aux['den_coarse'], g['den_coarse']) <= 2e-5
+    assert max_abs(aux['w_coarse'], g['w_coarse']) <= 1e-5
+    assert max_abs(aux['z_fine'], g['z_fine']) <= 1e-5
+    assert max_abs(rgb, g['rgb']) <= 1e-5
+    assert max_abs(depth, g['depth']) <= 1e-5
+    assert max_abs(wsum, g['wsum']) <= 1e-5
+
+
+def test_importance_index_buffers_bit_exact(golden):
+    """Given the reference's own coarse weights and depths, the integer buffers are identical."""
+    g = golden('renderer.npz')
+    z_f, ibuf = OR.sample_importance(g['z_coarse'], g['w_coarse'], 48)
+    assert torch.equal(ibuf['cdf'], g['cdf'])
+    assert torch.equal(ibuf['inds'], g['inds'])
+    assert torch.equal(z_f, g['z_fine'])
+    # all three u == 1 cases of SURVEY.md C10 must be present in the fixture
+    last = g['cdf'][:, -1]
+    assert (last > 1).any() and (last == 1).any() and (last < 1).any()
+    z_all = torch.cat([g['z_coarse'], g['z_fine']], -2)
+    _, order = torch.sort(z_all, dim=-2)
+    assert torch.equal(order, g['order'])
+    srt = torch.gather(z_all, -2, order)
+    assert (srt[:, :, 1:] > srt[:, :, :-1]).all(), 'fixture has depth ties: sort order would be ill-defined'
+
+
+def test_fill_mouth_known_answers(golden):
+    g = golden('renderer.npz')
+    full, mouth = OR.fill_mouth(g['fill_masks'].clone())
+    assert torch.equal(full, g['fill_full']) and torch.equal(mouth, g['fill_mouth'])
+    assert mouth[0].sum() == 0 and mouth[1].sum() == 0      # empty / full masks have no hole
+    assert mouth[2].sum() == 6 * 12                          # enclosed hole is filled
+    assert mouth[3].sum() == 0                               # hole open to the border is outside
+    assert mouth[4].sum() == 4 * 6 + 6 * 10                  # two holes
+
+
+def blank_state(width):
+    """Flat {name: tensor} dict with the reference's names/shapes (fixture text file), filled by name."""
+    import ast, os
+    from conftest import GOLDEN
+    fname = 'generator_state_names.txt' if width == 'full' else 'generator_state_names_small.txt'
+    sd = {}
+    for line in open(os.path.join(GOLDEN, fname)):
+        name, shape, _ = line.rstrip('\n').split('\t')
+        sd[name] = O.setup_filter([1, 3, 3, 1]) if name.endswith('resample_filter') else torch.empty(ast.literal_eval(shape))
+    return synthetic.fill_parameters(sd)
+
+
+@pytest.fixture(scope='module')
+def small_state():
+    return blank_state('small')
+
+
+def _inputs(g):
+    frames, nrr = g['frames'].tolist(), g['nrr']
+    return (g['ws'], synthetic.camera_labels(frames), synthetic.uv_conditions(frames),
+            synthetic.jitter(frames, nrr * nrr), nrr)
+
+
+def test_mapping(golden, small_state):
+    g = golden('generator_small.npz')
+    ws = OG.mapping(OG.sub(small_state, 'backbone.mapping'), synthetic.latent(0, 1), synthetic.conditioning_camera(),
+                    num_ws=14, truncation_psi=0.7, truncation_cutoff=14)
+    assert max_abs(ws, g['ws'][:1]) <= 1e-5
+
+
+def test_generator_small(golden, small_state):
+    g = golden('generator_small.npz')
+    ws, c, uv, jit, nrr = _inputs(g)
+    out = OG.synthesis(small_state, ws, c, uv, jit, nrr=nrr, return_all=True)
+    for i, t in enumerate(out['texture']):
+        ref = g[f'texture{i}']
+        assert max_abs(t if t.shape == ref.shape else t[..., ::4, ::4], ref) <= 5e-5, i
+    assert max_abs(out['triplane'][..., ::4, ::4], g['triplane_sub4']) <= 5e-5
+    assert max_abs(out['feature_image'], g['feature_image']) <= 5e-5
+    assert max_abs(out['image_depth'], g['image_depth']) <= 5e-5
+    assert max_abs(out['image'][:1], g['image']) <= 1e-4
+    assert max_abs(out['image'][..., ::4, ::4], g['image_sub4']) <= 1e-4
+
+
+def test_generator_small_trainmode_and_withtexture(golden, small_state):
+    g = golden('generator_small.npz')
+    ws, c, uv, jit, nrr = _inputs(g)
+    out = OG.synthesis(small_state, ws, c, uv, jit, nrr=nrr, fused=False)
+    assert max_abs(out['image'][..., ::4, ::4], g['image_trainmode_sub4']) <= 1e-4
+    tex = OG.synthesis_network(OG.sub(small_state, 'texture_backbone.synthesis'), ws, return_list=True)
+    sta = OG.synthesis_network(OG.sub(small_state, 'backbone.synthesis'), ws, return_list=True)
+    out = OG.synthesis(small_state, ws, c, uv, jit, nrr=nrr, texture_feats=tex, static_feats=sta)
+    assert max_abs(out['image'][..., ::4, ::4], g['image_withtexture_sub4']) <= 1e-4
