@@ -10,6 +10,16 @@ def _ptr(t):
     return t.data_ptr() if (t is not None and t.numel() > 0) else None
 
 
+def _is_dense(t):
+    """Non-overlapping and dense: some permutation of the dims is contiguous."""
+    expect = 1
+    for size, stride in sorted(((sz, st) for sz, st in zip(t.shape, t.stride()) if sz > 1), key=lambda p: p[1]):
+        if stride != expect:
+            return False
+        expect *= size
+    return True
+
+
 def _check_device(t, what):
     if not t.is_cuda:
         raise RuntimeError(f'{what} must reside on the GPU (got {t.device})')
@@ -20,7 +30,7 @@ def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
     _check_device(x, 'x')
     if x.dtype not in _lib.DTYPE_ID:
         raise RuntimeError(f'bias_act: unsupported dtype {x.dtype}')
-    if not x.is_non_overlapping_and_dense():
+    if not _is_dense(x):
         raise RuntimeError('x must be non-overlapping and dense')
     has_b = b is not None and b.numel() > 0
     if has_b:
@@ -39,6 +49,8 @@ def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
     y = torch.empty_like(x)  # preserves strides for dense tensors
     if y.stride() != x.stride():
         raise RuntimeError('y must have the same layout as x')
+    if x.numel() == 0:
+        return y
     lib = _lib.load()
     with torch.cuda.device(x.device):
         st = lib.ia_bias_act(_ptr(x), _ptr(b) if has_b else None, _ptr(xref), _ptr(yref), _ptr(dy), _ptr(y),
