@@ -88,6 +88,53 @@ int ia_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                  int upx, int upy, int downx, int downy, int padx0, int pady0,
                  int flip, float gain, void* stream);
 
+/*
+ * ia_upfirdn2d with the tail of a StyleGAN2 SynthesisLayer fused in:
+ *     y = clamp(act(FIR(x) + noise * noise_strength + bias[c]) * act_gain)
+ * Replaces the upfirdn2d call of conv2d_resample (torch_utils/ops/conv2d_resample.py:128) plus the noise add
+ * and bias_act of SynthesisLayer.forward (training/networks_stylegan2.py:318-329) for up-sampling layers.
+ *   x  : [n, c, in_h, in_w] contiguous NCHW of `dtype` (f32/f16);  f : [f_h, f_w] contiguous float32
+ *   noise : [out_h*out_w] float32 or NULL;  noise_strength : device scalar float32 or NULL (= 1)
+ *   bias  : [c] of `dtype` or NULL;  act : IA_ACT_LINEAR | IA_ACT_LRELU;  clamp < 0 disables
+ *   up in {1, 2}, 4x4 filter; other shapes return IA_ERR_UNSUPPORTED (use ia_upfirdn2d + ia_bias_act).
+ */
+int ia_upfirdn2d_bias_act(const void* x, const float* f, const float* noise, const float* noise_strength,
+                          const void* bias, void* y, int dtype, int n, int c, int in_h, int in_w,
+                          int f_h, int f_w, int out_h, int out_w, int up, int padx0, int pady0,
+                          int flip, float fir_gain, int act, float alpha, float act_gain, float clamp, void* stream);
+
+/*
+ * Dense fp32 convolution of one StyleGAN2 layer on MFMA (v_mfma_f32_32x32x2_f32), with the modulation,
+ * demodulation and the layer tail fused:
+ *     y[b,o] = clamp(act(demod[b,o] * conv(x[b] * styles[b,:], w)[o] + noise * noise_strength + bias[o]) * gain) + residual
+ * Replaces modulated_conv2d (training/networks_stylegan2.py:34-91) -> conv2d_resample
+ * (torch_utils/ops/conv2d_resample.py:114-136) -> cuDNN conv2d / conv_transpose2d
+ * (torch_utils/ops/conv2d_gradfix.py:37-45), and for the stride-1 form the bias_act after it (:327-329).
+ *   x        : [B, I, H, W] float32 contiguous
+ *   wk       : weights repacked as [ksize*ksize][I][O] float32 (tap-major, O contiguous) from the reference's
+ *              [O, I, kh, kw]; tap = ky*ksize + kx, no spatial flip
+ *   styles   : [B, I] or NULL;  demod : [B, O] or NULL (see ia_modconv_demod)
+ *   transposed = 0 : stride 1, zero padding ksize/2 (correlation, as F.conv2d);  y : [B, O, H, W]
+ *   transposed = 1 : 3x3, stride 2, no padding = F.conv_transpose2d(x, w^T, stride=2);  y : [B, O, 2H+1, 2W+1];
+ *                    only `demod` is applied (noise/bias/residual must be NULL, act linear) -- the FIR and the
+ *                    tail follow in ia_upfirdn2d_bias_act
+ *   ksplit   : number of in-channel splits (from ia_conv2d_plan); > 1 needs `scratch` of the planned size
+ */
+int ia_conv2d_mfma(const float* x, const float* wk, const float* styles, const float* demod,
+                   const float* noise, const float* noise_strength, const float* bias, const float* residual,
+                   float* y, float* scratch, size_t scratch_bytes,
+                   int B, int I, int O, int H, int W, int ksize, int transposed,
+                   int act, float alpha, float gain, float clamp, int ksplit, void* stream);
+
+/* Host-only planner for ia_conv2d_mfma: split-K factor that fills 256 CUs and the scratch it needs. */
+int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int* h_ksplit, size_t* h_scratch_bytes);
+
+/*
+ * Demodulation coefficients demod[b,o] = rsqrt(sum_i styles[b,i]^2 * wsq[o,i] + 1e-8) with
+ * wsq[o,i] = sum_{ky,kx} w[o,i,ky,kx]^2 (training/networks_stylegan2.py:60-64).
+ */
+int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B, int I, int O, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,10 @@ _SIGNATURES = {
     'ia_bias_act': [c_void_p] * 6 + [c_int, c_int64, c_int, c_int64, c_int, c_int, c_float, c_float, c_float, c_void_p],
     'ia_upfirdn2d': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, _i64p, c_int, c_int, _i64p,
                      c_int, c_int, _i64p] + [c_int] * 7 + [c_float, c_void_p],
+    'ia_upfirdn2d_bias_act': [c_void_p] * 6 + [c_int] * 13 + [c_float, c_int, c_float, c_float, c_float, c_void_p],
+    'ia_conv2d_mfma': [c_void_p] * 10 + [ctypes.c_size_t] + [c_int] * 8 + [c_float, c_float, c_float, c_int, c_void_p],
+    'ia_conv2d_plan': [c_int] * 7 + [ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_size_t)],
+    'ia_modconv_demod': [c_void_p] * 3 + [c_int] * 3 + [c_void_p],
 }
 
 

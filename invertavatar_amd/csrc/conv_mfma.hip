@@ -1,0 +1,347 @@
+// ia_conv2d_mfma: the dense convolutions of the StyleGAN2 stack as fp32 implicit GEMMs on
+// v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak on gfx950).
+//
+// Replaces, for one layer, the reference's modulated_conv2d -> conv2d_resample -> cuDNN
+// conv2d / conv_transpose2d chain (training/networks_stylegan2.py:34-91,
+// torch_utils/ops/conv2d_resample.py:114-136, torch_utils/ops/conv2d_gradfix.py:37-45) and, for the
+// stride-1 form, the bias_act that follows it (networks_stylegan2.py:327-329).
+//
+// Formulation (mathematically the reference's non-fused modconv branch, networks_stylegan2.py:70-79):
+//     y[b,o] = act( d[b,o] * conv(x[b] * s[b,:], w)[o] + noise + bias[o] ) * gain   (+ residual)
+// so ONE weight tensor serves the whole batch: the style s scales the input patch while it is staged
+// into LDS, the demodulation d scales the accumulator in the epilogue.
+//
+// GEMM mapping: D[o, p] = sum_k A[o, k] * B[k, p];  A = weights (rows = out channels), B = input patch
+// (cols = output points), k = (tap, in-channel).  With A = weights the MFMA result registers hold, per
+// lane, one POINT and 16 channels, so stores along the flattened point index are 128-byte coalesced in
+// NCHW.  Points are a contiguous range of the row-major output grid, so one kernel serves every
+// resolution from 4x4 to 512x512.  Both operands are read from LDS as conflict-free ds_read_b32
+// (32 consecutive channels / 32 consecutive points per half-wave).
+//
+//   stride-1 "conv":       out[y,x]          = sum w[o,i,ky,kx] * x[i, y+ky-pad, x+kx-pad]       (correlation)
+//   stride-2 "transposed": out[2m+py,2n+px] += sum w[o,i,ky,kx] * x[i, m-ky/2, n-kx/2], ky%2==py, kx%2==px
+//                          (= F.conv_transpose2d(x, w^T, stride 2)); the four output
+//                          phases of a point (m,n) share one input patch and live in four accumulators.
+//
+// Low-resolution layers have too few output tiles to fill 256 CUs, so the in-channel range can be
+// split over blockIdx.z (split-K); partial sums go to caller scratch and a second kernel reduces them in
+// a fixed order (deterministic) and applies the epilogue.
+#include "ia_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CC = 8;               // in-channels staged per K chunk
+constexpr int kPatchFloats = 800;   // per-channel LDS patch capacity (floats)
+
+struct Geo {
+    int B, I, O, H, W;     // input
+    int GH, GW;            // point grid: conv H x W, transposed (H+1) x (W+1)
+    int OH, OW;            // output image
+    int S, ci_per_split;   // split-K
+};
+
+struct Epi {
+    const float* demod;           // [B,O] or null
+    const float* noise;           // [OH*OW] or null
+    const float* noise_strength;  // device scalar (may be null => 1)
+    const float* bias;            // [O] or null
+    const float* residual;        // [B,O,OH,OW] or null, added after the clamp
+    int act;                      // IA_ACT_LINEAR or IA_ACT_LRELU
+    float alpha, gain, clamp;
+};
+
+__device__ __forceinline__ float epilogue(float v, int b, int o, int64_t pix, int64_t ohw, const Geo& g, const Epi& e, float ns) {
+    if (e.demod) v *= e.demod[b * g.O + o];
+    if (e.noise) v = fmaf(e.noise[pix], ns, v);
+    if (e.bias) v += e.bias[o];
+    if (e.act == IA_ACT_LRELU) v = v > 0.f ? v : v * e.alpha;
+    v *= e.gain;
+    if (e.clamp >= 0.f) v = fminf(fmaxf(v, -e.clamp), e.clamp);
+    if (e.residual) v += e.residual[((int64_t)b * g.O + o) * ohw + pix];
+    return v;
+}
+
+// FO x FP fragments (32 channels x 32 points each) per wave, WO x WP waves per workgroup.
+template <int KS, bool TR, int FO, int FP, int WO, int WP, bool PARTIAL>
+__global__ __launch_bounds__(WO * WP * 64) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wk,
+                                                                 const float* __restrict__ styles, float* __restrict__ y,
+                                                                 Geo g, Epi e) {
+    constexpr int NT = KS * KS;
+    constexpr int NPH = TR ? 4 : 1;
+    constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
+    constexpr int PAD = TR ? 0 : KS / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w_lds = lds;                       // [NT*CC][BO]
+    float* p_lds = lds + NT * CC * BO;        // [CC][PSZ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wo = wave / WP, wp = wave % WP;
+    const int o0 = blockIdx.y * BO;
+    const int b = blockIdx.z / g.S, split = blockIdx.z % g.S;
+    const int npts = g.GH * g.GW;
+    const int p0 = blockIdx.x * BP;
+    const int p_last = min(p0 + BP, npts) - 1;
+    const int r_first = p0 / g.GW, r_last = p_last / g.GW;
+    const bool multi = r_last > r_first;
+    // input window this tile reads
+    int row_lo, row_hi, col_lo, col_hi;
+    if (TR) {
+        row_lo = r_first - 1; row_hi = r_last;
+        col_lo = multi ? -1 : (p0 - r_first * g.GW) - 1;
+        col_hi = multi ? g.W : (p_last - r_first * g.GW);
+    } else {
+        row_lo = r_first - PAD; row_hi = r_last + PAD;
+        col_lo = multi ? -PAD : (p0 - r_first * g.GW) - PAD;
+        col_hi = multi ? g.W - 1 + PAD : (p_last - r_first * g.GW) + PAD;
+    }
+    const int PH = row_hi - row_lo + 1, PW = col_hi - col_lo + 1, PSZ = PH * PW;
+    const float inv_psz = 1.0f / (float)PSZ, inv_pw = 1.0f / (float)PW;
+
+    // per-lane patch offset of each point fragment (points past the grid alias the last valid one)
+    int base[FP];
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp) {
+        int p = min(p0 + (wp * FP + fp) * 32 + l31, p_last);
+        int r = p / g.GW, c = p - r * g.GW;
+        base[fp] = (TR ? (r - row_lo) * PW + (c - col_lo) : (r - PAD - row_lo) * PW + (c - PAD - col_lo)) + half * PSZ;
+    }
+    int toff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int ky = t / KS, kx = t % KS;
+        toff[t] = TR ? -((ky >> 1) * PW + (kx >> 1)) : ky * PW + kx;
+    }
+
+    f32x16 acc[NPH][FO][FP];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+            for (int fp = 0; fp < FP; ++fp)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] = 0.f;
+
+    const int ci_begin = split * g.ci_per_split, ci_end = min(ci_begin + g.ci_per_split, g.I);
+    const float* xb = x + (int64_t)b * g.I * g.H * g.W;
+    const float* sb = styles ? styles + (int64_t)b * g.I : nullptr;
+    const bool o_vec = (g.O % 4) == 0;
+
+    for (int ci0 = ci_begin; ci0 < ci_end; ci0 += CC) {
+        __syncthreads();
+        // ---- stage the style-scaled input patch: p_lds[cc][pr][pc]
+        for (int e_ = tid; e_ < CC * PSZ; e_ += NTHREADS) {
+            const int cc = (int)(((float)e_ + 0.5f) * inv_psz);
+            const int rem = e_ - cc * PSZ;
+            const int pr = (int)(((float)rem + 0.5f) * inv_pw);
+            const int pc = rem - pr * PW;
+            const int ci = ci0 + cc, iy = row_lo + pr, ix = col_lo + pc;
+            float v = 0.f;
+            if (ci < ci_end && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+                v = xb[((int64_t)ci * g.H + iy) * g.W + ix];
+                if (sb) v *= sb[ci];
+            }
+            p_lds[e_] = v;
+        }
+        // ---- stage the weight slab: w_lds[tap*CC + cc][o]   (global layout [tap][I][O], o contiguous)
+        for (int e_ = tid; e_ < NT * CC * (BO / 4); e_ += NTHREADS) {
+            const int row = e_ / (BO / 4), o4 = (e_ - row * (BO / 4)) * 4;
+            const int tap = row / CC, cc = row - tap * CC;
+            const int ci = ci0 + cc, o = o0 + o4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < ci_end) {
+                const float* src = wk + ((int64_t)tap * g.I + ci) * g.O + o;
+                if (o_vec && o + 3 < g.O) v = *(const float4*)src;
+                else {
+                    if (o < g.O) v.x = src[0];
+                    if (o + 1 < g.O) v.y = src[1];
+                    if (o + 2 < g.O) v.z = src[2];
+                    if (o + 3 < g.O) v.w = src[3];
+                }
+            }
+            *(float4*)(w_lds + row * BO + o4) = v;
+        }
+        __syncthreads();
+        // ---- MFMA over the chunk: k-pair = channels (2cp, 2cp+1) of one tap; lane half picks the channel
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int ph = TR ? (((t / KS) & 1) * 2 + ((t % KS) & 1)) : 0;
+#pragma unroll
+            for (int cp = 0; cp < CC / 2; ++cp) {
+                float a[FO], bv[FP];
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo) a[fo] = w_lds[(t * CC + 2 * cp + half) * BO + (wo * FO + fo) * 32 + l31];
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp) bv[fp] = p_lds[2 * cp * PSZ + base[fp] + toff[t]];
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp)
+                        acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fo], bv[fp], acc[ph][fo][fp], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue / partial store.  C/D map: row(channel) = (r&3) + 8*(r>>2) + 4*half, col(point) = l31
+    const int64_t ohw = (int64_t)g.OH * g.OW;
+    const float ns = (!PARTIAL && e.noise) ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
+    float* yb = PARTIAL ? y + ((int64_t)(split * g.B + b) * g.O) * ohw : y + ((int64_t)b * g.O) * ohw;
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp) {
+        const int p = p0 + (wp * FP + fp) * 32 + l31;
+        if (p >= npts) continue;
+        const int pr = p / g.GW, pc = p - pr * g.GW;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            int64_t pix;
+            if (TR) {
+                const int oy = 2 * pr + (ph >> 1), ox = 2 * pc + (ph & 1);
+                if (oy >= g.OH || ox >= g.OW) continue;
+                pix = (int64_t)oy * g.OW + ox;
+            } else pix = p;
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (o >= g.O) continue;
+                    float v = acc[ph][fo][fp][r];
+                    if (!PARTIAL) v = epilogue(v, b, o, pix, ohw, g, e, ns);
+                    yb[(int64_t)o * ohw + pix] = v;
+                }
+        }
+    }
+}
+
+// Split-K second pass: y = epilogue(sum_s part[s]) in fixed order.
+__global__ __launch_bounds__(256) void conv_reduce_kernel(const float* __restrict__ part, float* __restrict__ y, Geo g, Epi e) {
+    const int64_t ohw = (int64_t)g.OH * g.OW, per_split = (int64_t)g.B * g.O * ohw;
+    const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_split; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < g.S; ++s) v += part[s * per_split + i];
+        const int64_t pix = i % ohw;
+        const int bo = (int)(i / ohw);
+        y[i] = epilogue(v, bo / g.O, bo % g.O, pix, ohw, g, e, ns);
+    }
+}
+
+template <int KS, bool TR, int FO, int FP, int WO, int WP>
+int launch(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g, const Epi& e, hipStream_t s) {
+    constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NT = KS * KS;
+    const int npts = g.GH * g.GW;
+    dim3 grid((npts + BP - 1) / BP, (g.O + BO - 1) / BO, g.B * g.S), block(WO * WP * 64);
+    // largest per-channel patch any tile of this launch stages (mirrors the window logic of the kernel)
+    int worst = 0;
+    for (int t = 0; t < (int)grid.x; ++t) {
+        const int q0 = t * BP, q1 = (q0 + BP < npts ? q0 + BP : npts) - 1;
+        const int r0 = q0 / g.GW, r1 = q1 / g.GW, halo = TR ? 1 : 2 * (KS / 2);
+        const int ph = r1 - r0 + 1 + halo;
+        const int pw = (r1 > r0) ? g.W + (TR ? 2 : 2 * (KS / 2)) : (q1 - q0 + 1) + halo;
+        if (ph * pw > worst) worst = ph * pw;
+    }
+    if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d floats exceeds the LDS budget", worst);
+    const size_t lds = (size_t)(NT * CC * BO + CC * kPatchFloats) * sizeof(float);
+    if (g.S > 1) {
+        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, true>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, block, lds, s, x, wk, styles, scratch, g, e);
+        const int64_t n = (int64_t)g.B * g.O * g.OH * g.OW;
+        hipLaunchKernelGGL(conv_reduce_kernel, dim3(ia::streaming_grid(n, 256)), dim3(256), 0, s, scratch, y, g, e);
+    } else {
+        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, false>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, block, lds, s, x, wk, styles, y, g, e);
+    }
+    return ia::check_launch("ia_conv2d_mfma");
+}
+
+// Tile family per layer shape: (32ch x 256pt) for narrow outputs, (128ch x 128pt) otherwise; transposed
+// always (64ch x 64pt x 4 phases).
+void tile_dims(int O, int transposed, int* bo, int* bp) {
+    if (transposed) { *bo = 64; *bp = 64; }
+    else if (O <= 32) { *bo = 32; *bp = 256; }
+    else { *bo = 128; *bp = 128; }
+}
+
+}  // namespace
+
+extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int* h_ksplit,
+                              size_t* h_scratch_bytes) {
+    IA_REQUIRE(h_ksplit && h_scratch_bytes, "null output pointer");
+    IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
+    int bo, bp;
+    tile_dims(O, transposed, &bo, &bp);
+    const int npts = transposed ? (H + 1) * (W + 1) : H * W;
+    const int64_t blocks = (int64_t)((npts + bp - 1) / bp) * ((O + bo - 1) / bo) * B;
+    const int chunks = (I + CC - 1) / CC;
+    int s = 1;
+    // aim for >= 2 workgroups per CU, keep >= 2 chunks (16 channels x taps) of work per split
+    while (blocks * s < 2 * ia::kNumCU && s * 2 <= chunks / 2 && s < 64) s *= 2;
+    *h_ksplit = s;
+    const int64_t oh = transposed ? 2 * H + 1 : H, ow = transposed ? 2 * W + 1 : W;
+    *h_scratch_bytes = s > 1 ? (size_t)s * B * O * oh * ow * sizeof(float) : 0;
+    return IA_OK;
+}
+
+extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styles, const float* demod,
+                              const float* noise, const float* noise_strength, const float* bias, const float* residual,
+                              float* y, float* scratch, size_t scratch_bytes,
+                              int B, int I, int O, int H, int W, int ksize, int transposed,
+                              int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
+    IA_REQUIRE(x && wk && y, "x, wk and y must be device pointers");
+    IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
+    IA_REQUIRE(ksize == 1 || ksize == 3, "kernel size must be 1 or 3");
+    IA_REQUIRE(!transposed || ksize == 3, "the transposed form is 3x3 stride 2 only");
+    IA_REQUIRE(act == IA_ACT_LINEAR || act == IA_ACT_LRELU, "conv epilogue supports linear and lrelu");
+    IA_REQUIRE(ksplit >= 1, "ksplit must be >= 1");
+    IA_REQUIRE(!transposed || (noise == nullptr && bias == nullptr && residual == nullptr && act == IA_ACT_LINEAR),
+               "the transposed form only applies the demodulation; FIR + bias_act follow in ia_fir_bias_act");
+    Geo g;
+    g.B = B; g.I = I; g.O = O; g.H = H; g.W = W;
+    g.GH = transposed ? H + 1 : H; g.GW = transposed ? W + 1 : W;
+    g.OH = transposed ? 2 * H + 1 : H; g.OW = transposed ? 2 * W + 1 : W;
+    IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
+    const int chunks = (I + CC - 1) / CC;
+    if (ksplit > chunks) ksplit = chunks;
+    g.S = ksplit;
+    g.ci_per_split = ((chunks + ksplit - 1) / ksplit) * CC;
+    if (ksplit > 1) {
+        const size_t need = (size_t)ksplit * B * O * g.OH * g.OW * sizeof(float);
+        IA_REQUIRE(scratch && scratch_bytes >= need, "split-K needs %zu bytes of scratch, got %zu", need, scratch_bytes);
+    }
+    Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp};
+    hipStream_t s = (hipStream_t)stream;
+    if (transposed) return launch<3, true, 1, 1, 2, 2>(x, wk, styles, y, scratch, g, e, s);
+    if (O <= 32) {
+        return ksize == 3 ? launch<3, false, 1, 2, 1, 4>(x, wk, styles, y, scratch, g, e, s)
+                          : launch<1, false, 1, 2, 1, 4>(x, wk, styles, y, scratch, g, e, s);
+    }
+    return ksize == 3 ? launch<3, false, 2, 2, 2, 2>(x, wk, styles, y, scratch, g, e, s)
+                      : launch<1, false, 2, 2, 2, 2>(x, wk, styles, y, scratch, g, e, s);
+}
+
+// d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + 1e-8): demodulation coefficients of the modulated conv
+// (training/networks_stylegan2.py:63-64), with wsq[o,i] = sum_taps w[o,i,ky,kx]^2 precomputed per layer.
+__global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq,
+                                                    float* __restrict__ d, int B, int I, int O) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * O) return;
+    const int b = wave / O, o = wave - b * O;
+    float acc = 0.f;
+    for (int i = lane; i < I; i += 64) { const float s = styles[b * I + i]; acc = fmaf(s * s, wsq[(int64_t)o * I + i], acc); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) d[wave] = 1.0f / sqrtf(acc + 1e-8f);
+}
+
+extern "C" int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B, int I, int O, void* stream) {
+    IA_REQUIRE(styles && wsq && demod, "null pointer argument");
+    IA_REQUIRE(B > 0 && I > 0 && O > 0, "empty tensor");
+    const int waves = B * O;
+    hipLaunchKernelGGL(demod_kernel, dim3((waves * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, styles, wsq, demod, B, I, O);
+    return ia::check_launch("ia_modconv_demod");
+}

@@ -27,6 +27,17 @@ struct Geo {
 
 constexpr int kMaxTaps = 32 * 32;
 
+// Optional fused tail of a SynthesisLayer (noise + bias + lrelu * gain + clamp), applied to the FIR result
+// while it is still in registers: saves the separate bias_act pass over the activation tensor
+// (training/networks_stylegan2.py:318-329).
+struct Tail {
+    const float* noise;           // [out_h*out_w] or null
+    const float* noise_strength;  // device scalar or null (=1)
+    const void* bias;             // [c] of T or null
+    int act;                      // IA_ACT_LINEAR / IA_ACT_LRELU
+    float alpha, gain, clamp;
+};
+
 __device__ __forceinline__ int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 // Stage K[ky][kx] = gain * f[flip ? ky : fh-1-ky][flip ? kx : fw-1-kx] into LDS.
@@ -76,9 +87,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(const T* __restrict__ x
 constexpr int TW = 64, TH = 16, RPT = 4;
 static_assert(TW * (TH / RPT) == 256, "tile must map onto 256 threads");
 
-template <class T, int UP, int FS>
+template <class T, int UP, int FS, bool TAIL>
 __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ y,
-                                                      Geo g, int64_t fs0, int64_t fs1, int flip) {
+                                                      Geo g, int64_t fs0, int64_t fs1, int flip, Tail tail) {
     constexpr int NT = (FS + UP - 1) / UP;               // non-zero taps per axis for one output phase
     constexpr int IH = (TH + FS - 2) / UP + 2;           // input rows a tile can touch
     constexpr int IW = (TW + FS - 2) / UP + 2;
@@ -107,6 +118,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T* __restrict__ x, 
     const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * RPT;
     const int ox = ox0 + tx;
     if (ox >= g.out_w) return;
+    float t_bias = 0.f, t_ns = 0.f;
+    if (TAIL) {
+        if (tail.bias) t_bias = (float)ia::Num<T>::load((const T*)tail.bias + (plane % g.c));
+        if (tail.noise) t_ns = tail.noise_strength ? *tail.noise_strength : 1.f;
+    }
     const int bx = ox - g.padx0;
     const int kx0 = ((-bx) % UP + UP) % UP;
     const int lx = floor_div(bx + kx0, UP) - ix0;         // LDS column of the first tap
@@ -129,23 +145,38 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T* __restrict__ x, 
                 acc = fmaf(in_lds[(ly + a) * IWP + lx + bb], k_lds[ky * FS + kx], acc);
             }
         }
+        if (TAIL) {
+            if (tail.noise) acc = fmaf(tail.noise[(int64_t)oy * g.out_w + ox], t_ns, acc);
+            acc += t_bias;
+            if (tail.act == IA_ACT_LRELU) acc = acc > 0.f ? acc : acc * tail.alpha;
+            acc *= tail.gain;
+            if (tail.clamp >= 0.f) acc = fminf(fmaxf(acc, -tail.clamp), tail.clamp);
+        }
         ia::Num<T>::store(yp + (int64_t)oy * g.out_w + ox, acc);
     }
 }
 
 template <class T>
-int launch(const void* x, const float* f, void* y, const Geo& g, int64_t fs0, int64_t fs1, int flip, hipStream_t s) {
+bool tiled_eligible(const Geo& g) {
     const bool nchw = g.xs[3] == 1 && g.xs[2] == g.in_w && g.xs[1] == (int64_t)g.in_h * g.in_w &&
                       g.xs[0] == (int64_t)g.c * g.in_h * g.in_w && g.ys[3] == 1 && g.ys[2] == g.out_w &&
                       g.ys[1] == (int64_t)g.out_h * g.out_w && g.ys[0] == (int64_t)g.c * g.out_h * g.out_w;
-    const bool tiled_ok = nchw && g.downx == 1 && g.downy == 1 && g.upx == g.upy && g.f_h == g.f_w &&
-                          (int64_t)g.n * g.c <= 65535 && sizeof(T) <= 4;
-    if (tiled_ok && (g.upx == 1 || g.upx == 2) && (g.f_w == 4)) {
-        dim3 grid(((g.out_w + TW - 1) / TW) * ((g.out_h + TH - 1) / TH), g.n * g.c);
-        if (g.upx == 1) hipLaunchKernelGGL((upfirdn2d_tiled<T, 1, 4>), grid, dim3(256), 0, s, (const T*)x, f, (T*)y, g, fs0, fs1, flip);
-        else hipLaunchKernelGGL((upfirdn2d_tiled<T, 2, 4>), grid, dim3(256), 0, s, (const T*)x, f, (T*)y, g, fs0, fs1, flip);
-        return ia::check_launch("ia_upfirdn2d(tiled)");
-    }
+    return nchw && g.downx == 1 && g.downy == 1 && g.upx == g.upy && g.f_h == g.f_w && (int64_t)g.n * g.c <= 65535 &&
+           sizeof(T) <= 4 && (g.upx == 1 || g.upx == 2) && g.f_w == 4;
+}
+
+template <class T, bool TAIL>
+int launch_tiled(const void* x, const float* f, void* y, const Geo& g, int64_t fs0, int64_t fs1, int flip, const Tail& tail,
+                 hipStream_t s) {
+    dim3 grid(((g.out_w + TW - 1) / TW) * ((g.out_h + TH - 1) / TH), g.n * g.c);
+    if (g.upx == 1) hipLaunchKernelGGL((upfirdn2d_tiled<T, 1, 4, TAIL>), grid, dim3(256), 0, s, (const T*)x, f, (T*)y, g, fs0, fs1, flip, tail);
+    else hipLaunchKernelGGL((upfirdn2d_tiled<T, 2, 4, TAIL>), grid, dim3(256), 0, s, (const T*)x, f, (T*)y, g, fs0, fs1, flip, tail);
+    return ia::check_launch(TAIL ? "ia_upfirdn2d_bias_act" : "ia_upfirdn2d(tiled)");
+}
+
+template <class T>
+int launch(const void* x, const float* f, void* y, const Geo& g, int64_t fs0, int64_t fs1, int flip, hipStream_t s) {
+    if (tiled_eligible<T>(g)) return launch_tiled<T, false>(x, f, y, g, fs0, fs1, flip, Tail{}, s);
     const int64_t total = (int64_t)g.n * g.c * g.out_h * g.out_w;
     hipLaunchKernelGGL((upfirdn2d_generic<T>), dim3(ia::streaming_grid(total, 256)), dim3(256), 0, s,
                        (const T*)x, f, (T*)y, g, fs0, fs1, flip);
@@ -181,4 +212,24 @@ extern "C" int ia_upfirdn2d(const void* x, const float* f, void* y, int dtype,
         case IA_F64: return launch<double>(x, f, y, g, h_f_stride[0], h_f_stride[1], flip, s);
         default: return ia::fail(IA_ERR_INVALID_ARG, "unsupported dtype %d", dtype);
     }
+}
+
+extern "C" int ia_upfirdn2d_bias_act(const void* x, const float* f, const float* noise, const float* noise_strength,
+                                     const void* bias, void* y, int dtype, int n, int c, int in_h, int in_w,
+                                     int f_h, int f_w, int out_h, int out_w, int up, int padx0, int pady0,
+                                     int flip, float fir_gain, int act, float alpha, float act_gain, float clamp, void* stream) {
+    IA_REQUIRE(x && f && y, "null pointer argument");
+    IA_REQUIRE(n > 0 && c > 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, "empty tensor");
+    IA_REQUIRE(act == IA_ACT_LINEAR || act == IA_ACT_LRELU, "fused tail supports linear and lrelu");
+    IA_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, "tensor is too large");
+    Geo g;
+    g.n = n; g.c = c; g.in_h = in_h; g.in_w = in_w; g.out_h = out_h; g.out_w = out_w;
+    g.xs[3] = 1; g.xs[2] = in_w; g.xs[1] = (int64_t)in_h * in_w; g.xs[0] = (int64_t)c * in_h * in_w;
+    g.ys[3] = 1; g.ys[2] = out_w; g.ys[1] = (int64_t)out_h * out_w; g.ys[0] = (int64_t)c * out_h * out_w;
+    g.f_h = f_h; g.f_w = f_w; g.upx = g.upy = up; g.downx = g.downy = 1; g.padx0 = padx0; g.pady0 = pady0; g.gain = fir_gain;
+    Tail tail{noise, noise_strength, bias, act, alpha, act_gain, clamp};
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == IA_F32 && tiled_eligible<float>(g)) return launch_tiled<float, true>(x, f, y, g, f_w, 1, flip, tail, s);
+    if (dtype == IA_F16 && tiled_eligible<__half>(g)) return launch_tiled<__half, true>(x, f, y, g, f_w, 1, flip, tail, s);
+    return ia::fail(IA_ERR_UNSUPPORTED, "ia_upfirdn2d_bias_act: needs contiguous NCHW f32/f16, up in {1,2}, 4x4 filter");
 }

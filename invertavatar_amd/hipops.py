@@ -1,0 +1,102 @@
+"""Tensor-level wrappers over the C ABI for the generator's fused HIP stages.
+
+Each function allocates its output with torch (device memory is plumbing), passes raw
+pointers to libia_hip.so on torch's current stream and raises on any non-zero status.
+None of them has a CPU path: they are only ever called with device tensors."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_ID = {'linear': 1, 'lrelu': 3}
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t, what):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f'{what} must be a contiguous float32 device tensor')
+    return t
+
+
+def pack_conv_weight(w):
+    """[O, I, kh, kw] -> [kh*kw, I, O] (tap-major, out-channel contiguous): the layout ia_conv2d_mfma reads."""
+    o, i, kh, kw = w.shape
+    return w.detach().permute(2, 3, 1, 0).reshape(kh * kw, i, o).contiguous()
+
+
+def weight_sq_sum(w):
+    """wsq[o, i] = sum over taps of w^2: the static half of the demodulation reduction."""
+    return w.detach().float().square().sum(dim=[2, 3]).contiguous()
+
+
+def modconv_demod(styles, wsq):
+    b, i = styles.shape
+    o = wsq.shape[0]
+    d = torch.empty(b, o, device=styles.device, dtype=torch.float32)
+    st = _lib.load().ia_modconv_demod(_p(_f32c(styles, 'styles')), _p(_f32c(wsq, 'wsq')), _p(d), b, i, o, _lib.stream_ptr(styles.device))
+    _lib.check(st, 'ia_modconv_demod')
+    return d
+
+
+_scratch = {}
+
+
+def _scratch_buffer(device, nbytes):
+    """Grow-only per-device scratch for split-K partial sums (caller-owned memory, as the ABI requires)."""
+    buf = _scratch.get(device)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _scratch[device] = buf
+    return buf
+
+
+def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None, bias=None, residual=None,
+                ksize=3, transposed=False, act='linear', alpha=0.2, gain=1.0, clamp=None, ksplit=None):
+    """One fused StyleGAN2 convolution (see ia_conv2d_mfma in include/ia_hip.h)."""
+    _f32c(x, 'x'); _f32c(wk, 'wk')
+    b, i, h, w = x.shape
+    taps, wi, o = wk.shape
+    if taps != ksize * ksize or wi != i:
+        raise RuntimeError(f'packed weight {tuple(wk.shape)} does not match ksize {ksize}, in-channels {i}')
+    for name, t in (('styles', styles), ('demod', demod), ('noise', noise), ('bias', bias), ('residual', residual)):
+        if t is not None:
+            _f32c(t, name)
+    lib = _lib.load()
+    plan_s, plan_bytes = ctypes.c_int(0), ctypes.c_size_t(0)
+    _lib.check(lib.ia_conv2d_plan(b, i, o, h, w, ksize, int(transposed), ctypes.byref(plan_s), ctypes.byref(plan_bytes)), 'ia_conv2d_plan')
+    if ksplit is None:
+        ksplit = plan_s.value
+    oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (h, w)
+    y = torch.empty(b, o, oh, ow, device=x.device, dtype=torch.float32)
+    scratch, nbytes = None, 0
+    if ksplit > 1:
+        nbytes = ksplit * b * o * oh * ow * 4
+        scratch = _scratch_buffer(x.device, nbytes)
+    with torch.cuda.device(x.device):
+        st = lib.ia_conv2d_mfma(_p(x), _p(wk), _p(styles), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(residual),
+                                _p(y), _p(scratch), nbytes, b, i, o, h, w, ksize, int(transposed), ACT_ID[act], float(alpha),
+                                float(gain), float(-1 if clamp is None else clamp), int(ksplit), _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_conv2d_mfma')
+    return y
+
+
+def upfirdn2d_bias_act(x, f, noise=None, noise_strength=None, bias=None, up=1, pad0=(1, 1), out_hw=None, fir_gain=1.0,
+                       act='linear', alpha=0.2, act_gain=1.0, clamp=None, flip=False):
+    """FIR + noise + bias + activation in one pass (see ia_upfirdn2d_bias_act)."""
+    if not (x.is_cuda and x.is_contiguous() and x.dtype in (torch.float32, torch.float16)):
+        raise RuntimeError('x must be a contiguous f32/f16 device tensor')
+    n, c, ih, iw = x.shape
+    fh, fw = f.shape
+    y = torch.empty(n, c, out_hw[0], out_hw[1], device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        st = _lib.load().ia_upfirdn2d_bias_act(_p(x), _p(_f32c(f, 'f')), _p(noise), _p(noise_strength), _p(bias), _p(y),
+                                               _lib.DTYPE_ID[x.dtype], n, c, ih, iw, fh, fw, out_hw[0], out_hw[1], int(up),
+                                               int(pad0[0]), int(pad0[1]), 1 if flip else 0, float(fir_gain), ACT_ID[act],
+                                               float(alpha), float(act_gain), float(-1 if clamp is None else clamp),
+                                               _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_upfirdn2d_bias_act')
+    return y
