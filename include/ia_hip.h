@@ -135,6 +135,45 @@ int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed,
  */
 int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B, int I, int O, void* stream);
 
+/*
+ * The fused importance renderer: one launch replaces ImportanceRenderer_bsMotion.forward(evaluation=True)
+ * (training_avatar_texture/volumetric_rendering/renderer.py:309-351) together with sample_from_planes (:85-97),
+ * OSGDecoder.forward (training_avatar_texture/triplane_v20.py:426-438) and MipRayMarcher2.run_forward
+ * (volumetric_rendering/ray_marcher.py:25-57).
+ *   planes_cl : [B, 3, plane_h, plane_w, 32] float32 -- the tri-planes in CHANNELS-LAST order (the reference's
+ *               [B, 3, 32, H, W] permuted so that a texel's 32 channels are one 128-byte line)
+ *   rays_o/d  : [B, R, 3];  jitter : [B, R, 48] in [0,1), the stratified-sampling noise of renderer.py:406
+ *   dist      : device scalar = mean |ray origin| over the WHOLE batch (renderer.py:311); ray_start/end are
+ *               derived from it in-kernel exactly as :313 does in Python doubles
+ *   w0,b0,w1,b1 : OSGDecoder parameters net.0.weight [64,32], net.0.bias [64], net.2.weight [33,64], net.2.bias [33]
+ *               (un-scaled; lr_multiplier = decoder_lr_mul is applied as FullyConnectedLayer does)
+ *   n_coarse / n_importance : must both be 48 (train_avatar_texture.py:341-342); others -> IA_ERR_UNSUPPORTED
+ *   rgb  : [B, R, 32] composited features scaled to (-1, 1);  depth : [B, R] clamped to the batch-global sample
+ *          range;  wsum : [B, R] sum of compositing weights
+ *   minmax_scratch : 2 * ia_render_rays_grid(B, R) floats of caller scratch
+ *   dbg_* : optional stage outputs for parity tests (NULL in production): fine depths [B,R,48], searchsorted
+ *          indices [B,R,48] (int32), merge order [B,R,96] (int32, < 48 = coarse sample, >= 48 = fine sample),
+ *          coarse weights [B,R,47], coarse densities [B,R,48]
+ */
+int ia_render_rays(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
+                   const float* dist, const float* w0, const float* b0, const float* w1, const float* b1,
+                   float lr_multiplier, float box_warp, int white_back,
+                   int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
+                   float* rgb, float* depth, float* wsum, float* minmax_scratch,
+                   float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
+                   void* stream);
+
+/* Number of persistent workgroups ia_render_rays launches for (B, R); sizes minmax_scratch. Host-only. */
+int ia_render_rays_grid(int B, int R);
+
+/*
+ * Stage entry for parity tests: smoothed inverse-CDF importance resampling (renderer.py:410-469, det=True) and the
+ * stable merge order (unify_samples :372-382) from GIVEN coarse depths [nrays,48] and coarse weights [nrays,47].
+ * Runs the same device code as ia_render_rays.  z_fine [nrays,48], inds [nrays,48] int32, order [nrays,96] int32.
+ */
+int ia_importance_stage(const float* z_coarse, const float* w_coarse, float* z_fine, int* inds, int* order,
+                        int nrays, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

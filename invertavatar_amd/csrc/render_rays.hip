@@ -1,0 +1,499 @@
+// ia_render_rays: the whole importance renderer for one ray per wavefront, fused.
+//
+//   coarse depths (stratified + injected jitter) -> tri-plane gather -> OSG decoder (density only)
+//   -> ray march weights -> smoothed inverse-CDF importance resampling -> merge (stable, coarse first)
+//   -> tri-plane gather + full decoder on the 96 merged samples -> composite -> rgb[32], depth, weight sum
+//
+// Replaces ImportanceRenderer_bsMotion.forward (training_avatar_texture/volumetric_rendering/renderer.py:
+// 309-351 with sample_stratified :384-408, run_model :353-363, sample_from_planes :85-97,
+// sample_importance/sample_pdf :410-469, unify_samples :372-382), OSGDecoder.forward
+// (training_avatar_texture/triplane_v20.py:426-438) and MipRayMarcher2.run_forward
+// (volumetric_rendering/ray_marcher.py:25-57).  No [B, R*S, 32] intermediate ever reaches HBM: the only
+// traffic is the planes (read through L2), rays/jitter in and 34 floats per ray out.
+//
+// Work decomposition (wave64, one ray per wave, 16 samples x 4 lane-quarters per step):
+//   lane = s + 16*q : s = sample within the group of 16, q = quarter.  The decoder runs on
+//   v_mfma_f32_16x16x4_f32 as D[unit, sample] = W[unit, k] * X[k, sample]; with that orientation
+//     - the tri-plane gather feeds the B operand directly: quarter q fetches channels 8q..8q+7 (32 bytes) of
+//       each of the 12 texels of its sample from channels-last planes,
+//     - layer-1 results land as 16 hidden units per lane which ARE the B operand of layer 2 (k permuted
+//       identically on the weight side), so no cross-lane shuffle sits between gather, layer 1 and layer 2,
+//     - the density row (1 of 33 outputs) is a 16-term VALU dot product + 2 butterfly adds instead of a
+//       second, 94%-empty MFMA tile.
+//   fp32 MFMA == fmaf chain bitwise (exact fp32); weights (pre-scaled by the FullyConnectedLayer gains) live in
+//   LDS in fragment order, staged once per persistent workgroup.
+//   The coarse pass evaluates the density only; coarse colours are recomputed in merged order in the final
+//   pass, which costs +25% decoder FLOPs and removes 12.7 KB/ray of colour storage.
+//
+// Numerical contract: linspace bit rule of CPU torch; cumulative products / sums accumulate
+// in fp64 and round each prefix to fp32 like CPU torch.cumprod / cumsum; searchsorted(right=True) semantics and
+// the 47-bin / 45-weight quirk of sample_importance are preserved.
+#include "ia_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NS = 48;            // coarse samples == importance samples (depth_resolution[_importance])
+constexpr int NM = 2 * NS;        // merged
+constexpr int WAVES = 4;          // rays per workgroup pass
+
+struct Params {
+    const float* planes;          // [B][3][PH][PW][32] channels-last fp32
+    const float* rays_o;          // [B][R][3]
+    const float* rays_d;          // [B][R][3]
+    const float* jitter;          // [B][R][48]
+    const float* dist;            // device scalar: batch mean of |ray origin| (renderer.py:311)
+    const float* w0; const float* b0; const float* w1; const float* b1;   // decoder parameters, reference layout
+    float w0_gain, w1_gain, b_gain;
+    float box_scale;              // 2 / box_warp
+    int B, R, PH, PW;
+    int white_back;
+    float* rgb;                   // [B][R][32]
+    float* depth;                 // [B][R]   un-clamped (may be +inf), see ia_render_finalize
+    float* wsum;                  // [B][R]
+    float* minmax;                // [gridDim.x][2] per-workgroup min / max of all sample depths
+    // optional stage outputs for parity tests (null in production)
+    float* dbg_z_fine;            // [B][R][48]
+    int* dbg_inds;                // [B][R][48]
+    int* dbg_order;               // [B][R][96]
+    float* dbg_w_coarse;          // [B][R][47]
+    float* dbg_sigma_coarse;      // [B][R][48]
+};
+
+// LDS image (floats)
+constexpr int A1_OFF = 0;                       // [4 tiles][8 ksteps][64 lanes]
+constexpr int A2_OFF = A1_OFF + 4 * 8 * 64;     // [2 tiles][16 ksteps][64 lanes]
+constexpr int WS_OFF = A2_OFF + 2 * 16 * 64;    // [16 ksteps][4 quarters]   density row of layer 2
+constexpr int B0_OFF = WS_OFF + 64;             // [64]
+constexpr int B1_OFF = B0_OFF + 64;             // [33] (+pad)
+constexpr int SCR_OFF = B1_OFF + 40;            // per-wave scratch
+constexpr int SCR = 10 * NS;                    // tc, sc, wc, av, pdf, cdf, bins, tf (8 x 48) + tm (96)
+constexpr int LDS_FLOATS = SCR_OFF + WAVES * SCR;
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float softplus_fast(float x) { return x > 20.f ? x : __logf(1.f + __expf(x)); }
+
+// CPU torch.linspace bit rule.
+__device__ __forceinline__ float linspace_at(float s, float e, float step, int k, int n) {
+    return (k < n / 2) ? __fmaf_rn(step, (float)k, s) : __fmaf_rn(-step, (float)(n - 1 - k), e);
+}
+
+// Bilinear, zero-padded, align_corners=False gather of channels [8q, 8q+8) of the three planes at one point,
+// averaged over the planes (sample_from_planes + the mean of OSGDecoder.forward).
+__device__ __forceinline__ void gather_features(const float* __restrict__ planes_b, int PH, int PW, int q,
+                                                float x, float y, float z, float (&f)[8]) {
+    float acc[3][8];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const float gx = (p == 2) ? z : x;
+        const float gy = (p == 0) ? y : (p == 1 ? z : x);
+        const float ix = (gx + 1.f) * (0.5f * (float)PW) - 0.5f;
+        const float iy = (gy + 1.f) * (0.5f * (float)PH) - 0.5f;
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float fx = ix - x0f, fy = iy - y0f;
+        // clamp before the int conversion so far-away points cannot overflow; they are masked below anyway
+        const int x0 = (int)fminf(fmaxf(x0f, -2.f), (float)PW + 1.f), y0 = (int)fminf(fmaxf(y0f, -2.f), (float)PH + 1.f);
+        const float* pl = planes_b + (int64_t)p * PH * PW * 32 + 8 * q;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[p][c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+            const float wgt = ((t & 1) ? fx : 1.f - fx) * ((t >> 1) ? fy : 1.f - fy);
+            if (xi >= 0 && xi < PW && yi >= 0 && yi < PH) {
+                const float4* src = (const float4*)(pl + ((int64_t)yi * PW + xi) * 32);
+                const float4 a = src[0], b = src[1];
+                acc[p][0] = fmaf(a.x, wgt, acc[p][0]); acc[p][1] = fmaf(a.y, wgt, acc[p][1]);
+                acc[p][2] = fmaf(a.z, wgt, acc[p][2]); acc[p][3] = fmaf(a.w, wgt, acc[p][3]);
+                acc[p][4] = fmaf(b.x, wgt, acc[p][4]); acc[p][5] = fmaf(b.y, wgt, acc[p][5]);
+                acc[p][6] = fmaf(b.z, wgt, acc[p][6]); acc[p][7] = fmaf(b.w, wgt, acc[p][7]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] = (acc[0][c] + acc[1][c] + acc[2][c]) / 3.f;
+}
+
+// Layer 1 (32 -> 64, softplus) on MFMA.  In: f[8] = channels 8q..8q+7 of this lane's sample.
+// Out: h[T][r] = hidden unit 16T + 4q + r of this lane's sample.
+__device__ __forceinline__ void decoder_hidden(const float* __restrict__ lds, int lane, int q, const float (&f)[8], f32x4 (&h)[4]) {
+#pragma unroll
+    for (int T = 0; T < 4; ++T) h[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+            h[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[A1_OFF + (T * 8 + t) * 64 + lane], f[t], h[T], 0, 0, 0);
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[T][r] = softplus_fast(h[T][r] + lds[B0_OFF + 16 * T + 4 * q + r]);
+}
+
+// Density: output row 0 of layer 2.  Each lane owns 16 of the 64 hidden units; butterfly over the 4 quarters.
+__device__ __forceinline__ float decoder_sigma(const float* __restrict__ lds, int q, const f32x4 (&h)[4]) {
+    float part = 0.f;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(h[T][r], lds[WS_OFF + (T * 4 + r) * 4 + q], part);
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    return part + lds[B1_OFF];
+}
+
+// Colours: output rows 1..32 of layer 2 on MFMA.  c[U][r] = channel 16U + 4q + r of this lane's sample.
+__device__ __forceinline__ void decoder_rgb(const float* __restrict__ lds, int lane, int q, const f32x4 (&h)[4], f32x4 (&c)[2]) {
+    c[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    c[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int U = 0; U < 2; ++U)
+                c[U] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[A2_OFF + (U * 16 + T * 4 + r) * 64 + lane], h[T][r], c[U], 0, 0, 0);
+#pragma unroll
+    for (int U = 0; U < 2; ++U)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = c[U][r] + lds[B1_OFF + 1 + 16 * U + 4 * q + r];
+            c[U][r] = (1.f / (1.f + __expf(-v))) * 1.002f - 0.001f;   // sigmoid * (1 + 2e-3) - 1e-3
+        }
+}
+
+// Smoothed inverse-CDF importance resampling of one ray, all in per-wave LDS scratch.
+//   in : tc[48] coarse depths, wc[47] coarse weights        out: tf[48] fine depths, returns ind for lane < 48
+__device__ __forceinline__ int importance_resample(float* scr, int lane) {
+    float* tc = scr; float* wc = scr + 2 * NS; float* av = scr + 3 * NS; float* pdf = scr + 4 * NS;
+    float* cdf = scr + 5 * NS; float* bins = scr + 6 * NS; float* tf = scr + 7 * NS;
+    // max_pool1d(2,1,pad 1) then avg_pool1d(2,1), + 0.01 (renderer.py:421-423); bins = depth midpoints (:425)
+    if (lane < NS - 1) {
+        const float wl = lane > 0 ? wc[lane - 1] : -INFINITY, wm = wc[lane], wr = lane + 1 < NS - 1 ? wc[lane + 1] : -INFINITY;
+        av[lane] = (fmaxf(wl, wm) + fmaxf(wm, wr)) * 0.5f + 0.01f;
+        bins[lane] = 0.5f * (tc[lane] + tc[lane + 1]);
+    }
+    wave_sync();
+    // pdf over the 45 interior weights (renderer.py:426,443-444).  The normaliser reproduces the summation ORDER of
+    // CPU torch.sum over a contiguous row (ATen SumKernel vectorized_inner_sum: 8-lane vectors, 4-way ILP cascade,
+    // scalar tail first, then the 8 lane partials) because the last importance sample (u == 1) compares against
+    // cdf[45] ~= 1 and flips with a 1-ulp change of the total.
+    if (lane < 8) {
+        float part = (av[1 + lane] + 1e-5f) + (av[33 + lane] + 1e-5f);
+        part += av[9 + lane] + 1e-5f;
+        part += av[17 + lane] + 1e-5f;
+        part += av[25 + lane] + 1e-5f;
+        pdf[lane] = part;                                   // scratch use of pdf[0..7]
+    }
+    wave_sync();
+    float total = 0.f;
+    for (int j = 41; j <= NS - 3; ++j) total += av[j] + 1e-5f;
+    for (int j = 0; j < 8; ++j) total += pdf[j];
+    wave_sync();
+    if (lane < NS - 3) pdf[lane] = (av[lane + 1] + 1e-5f) / total;
+    wave_sync();
+    // cdf[0] = 0, cdf[j] = fl32(sum_{i<j} pdf[i]) accumulated sequentially in fp64 (CPU torch.cumsum, C10)
+    if (lane < NS - 2) {
+        double run = 0.0;
+        for (int i = 0; i < lane; ++i) run += (double)pdf[i];
+        cdf[lane] = (float)run;
+    }
+    wave_sync();
+    int ind = 0;
+    if (lane < NS) {
+        const float ustep = 1.0f / (float)(NS - 1);
+        const float u = linspace_at(0.f, 1.f, ustep, lane, NS);
+        for (int j = 0; j < NS - 2; ++j) ind += (cdf[j] <= u) ? 1 : 0;          // searchsorted(right=True)
+        const int below = max(ind - 1, 0), above = min(ind, NS - 3);
+        const float c0 = cdf[below], c1 = cdf[above], b0 = bins[below], b1 = bins[above];
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.f;
+        tf[lane] = b0 + (u - c0) / denom * (b1 - b0);
+    }
+    wave_sync();
+    return ind;
+}
+
+// Stable merge of two ascending 48-lists into tm[96]; returns this lane's (coarse, fine) destination slots.
+__device__ __forceinline__ void merge_sorted(float* scr, int lane, int& pos_c, int& pos_f) {
+    float* tc = scr; float* tf = scr + 7 * NS; float* tm = scr + 8 * NS;
+    pos_c = pos_f = 0;
+    if (lane < NS) {
+        const float a = tc[lane], b = tf[lane];
+        int nc = 0, nf = 0;
+        for (int j = 0; j < NS; ++j) { nc += (tf[j] < a) ? 1 : 0; nf += (tc[j] <= b) ? 1 : 0; }
+        pos_c = lane + nc; pos_f = lane + nf;
+        tm[pos_c] = a; tm[pos_f] = b;
+    }
+    wave_sync();
+}
+
+__global__ __launch_bounds__(WAVES * 64) void render_rays_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane & 15, q = lane >> 4;
+
+    // ---- stage decoder weights in MFMA-fragment order
+    for (int e = tid; e < 4 * 8 * 64; e += WAVES * 64) {
+        const int l = e & 63, t = (e >> 6) & 7, T = e >> 9;
+        lds[A1_OFF + e] = p.w0[(16 * T + (l & 15)) * 32 + 8 * (l >> 4) + t] * p.w0_gain;
+    }
+    for (int e = tid; e < 2 * 16 * 64; e += WAVES * 64) {
+        const int l = e & 63, k = (e >> 6) & 15, U = e >> 10;     // k = T*4 + r
+        lds[A2_OFF + e] = p.w1[(1 + 16 * U + (l & 15)) * 64 + 16 * (k >> 2) + 4 * (l >> 4) + (k & 3)] * p.w1_gain;
+    }
+    if (tid < 64) {
+        const int k = tid >> 2, qq = tid & 3;
+        lds[WS_OFF + tid] = p.w1[16 * (k >> 2) + 4 * qq + (k & 3)] * p.w1_gain;
+        lds[B0_OFF + tid] = p.b0[tid] * p.b_gain;
+    }
+    if (tid < 33) lds[B1_OFF + tid] = p.b1[tid] * p.b_gain;
+    __syncthreads();
+
+    float* scr = lds + SCR_OFF + wave * SCR;
+    float* tc = scr; float* sc = scr + NS; float* wc = scr + 2 * NS; float* tm = scr + 8 * NS;
+
+    // depth range: renderer.py:311-313,404-406 (python doubles, fp32 tensors)
+    const double dist = (double)(*p.dist);
+    const float t_start = (float)(dist - 0.45), t_end = (float)(dist + 0.6);
+    const float t_step = (t_end - t_start) / (float)(NS - 1);
+    const float t_delta = (float)(((dist + 0.6) - (dist - 0.45)) / (double)(NS - 1));
+    float blk_min = INFINITY, blk_max = 0.f;
+
+    const int nrays = p.B * p.R;
+    for (int ray0 = blockIdx.x * WAVES; ray0 < nrays; ray0 += gridDim.x * WAVES) {
+        const int ray = ray0 + wave;
+        if (ray >= nrays) continue;                      // wave-uniform
+        const int b = ray / p.R;
+        const float* planes_b = p.planes + (int64_t)b * 3 * p.PH * p.PW * 32;
+        const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
+        const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
+
+        // ---- coarse pass: density only
+        if (lane < NS) tc[lane] = linspace_at(t_start, t_end, t_step, lane, NS) + p.jitter[(int64_t)ray * NS + lane] * t_delta;
+        wave_sync();
+#pragma unroll 1
+        for (int g = 0; g < NS / 16; ++g) {
+            const float t = tc[16 * g + s];
+            float f[8]; f32x4 h[4];
+            gather_features(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale,
+                            (oz + t * dz) * p.box_scale, f);
+            decoder_hidden(lds, lane, q, f, h);
+            const float sg = decoder_sigma(lds, q, h);
+            if (q == 0) sc[16 * g + s] = sg;
+        }
+        wave_sync();
+        // ---- coarse ray march: weights only (ray_marcher.py:26-42)
+        {
+            float alpha = 0.f;
+            double fac = 1.0;
+            if (lane < NS - 1) {
+                const float delta = tc[lane + 1] - tc[lane];
+                const float dm = softplus_fast((sc[lane] + sc[lane + 1]) * 0.5f - 1.f);
+                alpha = 1.f - __expf(-(dm * delta));
+                fac = (double)(1.f - alpha + 1e-10f);
+            }
+            double incl = fac;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const double u = __shfl_up(incl, off); if (lane >= off) incl *= u; }
+            const double excl_up = __shfl_up(incl, 1);
+            const float trans = lane == 0 ? 1.f : (float)excl_up;
+            if (lane < NS - 1) {
+                wc[lane] = alpha * trans;
+                if (p.dbg_w_coarse) p.dbg_w_coarse[(int64_t)ray * (NS - 1) + lane] = alpha * trans;
+            }
+            if (p.dbg_sigma_coarse && lane < NS) p.dbg_sigma_coarse[(int64_t)ray * NS + lane] = sc[lane];
+        }
+        wave_sync();
+        // ---- importance resampling + merge
+        const int ind = importance_resample(scr, lane);
+        int pos_c, pos_f;
+        merge_sorted(scr, lane, pos_c, pos_f);
+        if (lane < NS) {
+            if (p.dbg_z_fine) p.dbg_z_fine[(int64_t)ray * NS + lane] = scr[7 * NS + lane];
+            if (p.dbg_inds) p.dbg_inds[(int64_t)ray * NS + lane] = ind;
+            if (p.dbg_order) { p.dbg_order[(int64_t)ray * NM + pos_c] = lane; p.dbg_order[(int64_t)ray * NM + pos_f] = NS + lane; }
+        }
+        blk_min = fminf(blk_min, tm[0]);
+        blk_max = fmaxf(blk_max, tm[NM - 1]);
+
+        // ---- final pass over the 96 merged samples, 16 at a time; lane s composites the interval that ENDS at its sample
+        float acc_c[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc_c[c] = 0.f;
+        float acc_w = 0.f, acc_z = 0.f;
+        double carry_T = 1.0;
+        float prev_t = 0.f, prev_sg = 0.f, prev_c[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) prev_c[c] = 0.f;
+#pragma unroll 1
+        for (int g = 0; g < NM / 16; ++g) {
+            const float t = tm[16 * g + s];
+            float f[8]; f32x4 h[4], col[2];
+            gather_features(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale,
+                            (oz + t * dz) * p.box_scale, f);
+            decoder_hidden(lds, lane, q, f, h);
+            const float sg = decoder_sigma(lds, q, h);
+            decoder_rgb(lds, lane, q, h, col);
+            float cur_c[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) cur_c[c] = col[c >> 2][c & 3];
+            // neighbour (previous sample) values: lane s-1 of the same quarter, or the carry from the previous group
+            float nb_t = __shfl_up(t, 1, 16), nb_sg = __shfl_up(sg, 1, 16), nb_c[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) nb_c[c] = __shfl_up(cur_c[c], 1, 16);
+            if (s == 0) {
+                nb_t = prev_t; nb_sg = prev_sg;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) nb_c[c] = prev_c[c];
+            }
+            const bool has_interval = (g > 0) || (s > 0);
+            float alpha = 0.f;
+            double fac = 1.0;
+            if (has_interval) {
+                const float dm = softplus_fast((nb_sg + sg) * 0.5f - 1.f);
+                alpha = 1.f - __expf(-(dm * (t - nb_t)));
+                fac = (double)(1.f - alpha + 1e-10f);
+            }
+            double incl = fac;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) { const double u = __shfl_up(incl, off, 16); if (s >= off) incl *= u; }
+            const double up1 = __shfl_up(incl, 1, 16);
+            const double excl = (s == 0) ? 1.0 : up1;
+            const float trans = (float)(carry_T * excl);
+            carry_T *= __shfl(incl, 15, 16);
+            const float wgt = alpha * trans;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc_c[c] = fmaf(wgt, (nb_c[c] + cur_c[c]) * 0.5f, acc_c[c]);
+            acc_w += wgt;
+            acc_z = fmaf(wgt, (nb_t + t) * 0.5f, acc_z);
+            prev_t = __shfl(t, 15, 16); prev_sg = __shfl(sg, 15, 16);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) prev_c[c] = __shfl(cur_c[c], 15, 16);
+        }
+        // reduce the 16 lanes of each quarter
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc_c[c] += __shfl_xor(acc_c[c], off, 16);
+            acc_w += __shfl_xor(acc_w, off, 16);
+            acc_z += __shfl_xor(acc_z, off, 16);
+        }
+        if (s == 0) {
+            float* out = p.rgb + (int64_t)ray * 32;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float v = acc_c[c];
+                if (p.white_back) v = v + 1.f - acc_w;
+                out[16 * (c >> 2) + 4 * q + (c & 3)] = v * 2.f - 1.f;
+            }
+            if (q == 0) {
+                float dpt = acc_z / acc_w;
+                if (dpt != dpt) dpt = INFINITY;             // nan_to_num(nan -> +inf), ray_marcher.py:49
+                p.depth[ray] = dpt;
+                p.wsum[ray] = acc_w;
+            }
+        }
+        wave_sync();
+    }
+    // per-workgroup depth range for the batch-global clamp (ray_marcher.py:50)
+    __syncthreads();
+    float* red = lds + SCR_OFF;
+    if (lane == 0) { red[2 * wave] = blk_min; red[2 * wave + 1] = blk_max; }
+    __syncthreads();
+    if (tid == 0) {
+        float mn = red[0], mx = red[1];
+        for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, red[2 * w]); mx = fmaxf(mx, red[2 * w + 1]); }
+        p.minmax[2 * blockIdx.x] = mn; p.minmax[2 * blockIdx.x + 1] = mx;
+    }
+}
+
+// depth = clamp(depth, min over all sample depths, max over all sample depths)
+__global__ __launch_bounds__(256) void render_finalize_kernel(float* depth, const float* minmax, int nblocks, int n) {
+    __shared__ float s_mn[256], s_mx[256];
+    float mn = INFINITY, mx = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { mn = fminf(mn, minmax[2 * i]); mx = fmaxf(mx, minmax[2 * i + 1]); }
+    s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { s_mn[threadIdx.x] = fminf(s_mn[threadIdx.x], s_mn[threadIdx.x + off]); s_mx[threadIdx.x] = fmaxf(s_mx[threadIdx.x], s_mx[threadIdx.x + off]); }
+        __syncthreads();
+    }
+    mn = s_mn[0]; mx = s_mx[0];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) depth[i] = fminf(fmaxf(depth[i], mn), mx);
+}
+
+// Stage kernel for parity tests: importance resampling + merge order from GIVEN coarse depths/weights.
+__global__ __launch_bounds__(64) void importance_stage_kernel(const float* z_coarse, const float* w_coarse, float* z_fine, int* inds,
+                                                              int* order, int nrays) {
+    __shared__ float scr[SCR];
+    const int lane = threadIdx.x;
+    for (int ray = blockIdx.x; ray < nrays; ray += gridDim.x) {
+        if (lane < NS) scr[lane] = z_coarse[(int64_t)ray * NS + lane];
+        if (lane < NS - 1) scr[2 * NS + lane] = w_coarse[(int64_t)ray * (NS - 1) + lane];
+        wave_sync();
+        const int ind = importance_resample(scr, lane);
+        int pos_c, pos_f;
+        merge_sorted(scr, lane, pos_c, pos_f);
+        if (lane < NS) {
+            z_fine[(int64_t)ray * NS + lane] = scr[7 * NS + lane];
+            inds[(int64_t)ray * NS + lane] = ind;
+            order[(int64_t)ray * NM + pos_c] = lane;
+            order[(int64_t)ray * NM + pos_f] = NS + lane;
+        }
+        wave_sync();
+    }
+}
+
+}  // namespace
+
+extern "C" int ia_render_rays_grid(int B, int R) {
+    const int64_t quads = ((int64_t)B * R + WAVES - 1) / WAVES;
+    const int64_t cap = (int64_t)ia::kNumCU * 4;
+    return (int)(quads < cap ? quads : cap);
+}
+
+extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
+                              const float* dist, const float* w0, const float* b0, const float* w1, const float* b1,
+                              float lr_multiplier, float box_warp, int white_back,
+                              int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
+                              float* rgb, float* depth, float* wsum, float* minmax_scratch,
+                              float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
+                              void* stream) {
+    IA_REQUIRE(planes_cl && rays_o && rays_d && jitter && dist && w0 && b0 && w1 && b1, "null input pointer");
+    IA_REQUIRE(rgb && depth && wsum && minmax_scratch, "null output pointer");
+    IA_REQUIRE(B > 0 && R > 0 && plane_h > 0 && plane_w > 0, "empty tensor");
+    if (n_coarse != NS || n_importance != NS)
+        return ia::fail(IA_ERR_UNSUPPORTED, "depth_resolution=%d / depth_resolution_importance=%d: this build is specialised for 48/48",
+                        n_coarse, n_importance);
+    IA_REQUIRE(box_warp > 0.f, "box_warp must be positive");
+    Params p;
+    p.planes = planes_cl; p.rays_o = rays_o; p.rays_d = rays_d; p.jitter = jitter; p.dist = dist;
+    p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
+    p.w0_gain = lr_multiplier / sqrtf(32.f); p.w1_gain = lr_multiplier / sqrtf(64.f); p.b_gain = lr_multiplier;
+    p.box_scale = 2.f / box_warp;
+    p.B = B; p.R = R; p.PH = plane_h; p.PW = plane_w; p.white_back = white_back;
+    p.rgb = rgb; p.depth = depth; p.wsum = wsum; p.minmax = minmax_scratch;
+    p.dbg_z_fine = dbg_z_fine; p.dbg_inds = dbg_inds; p.dbg_order = dbg_order; p.dbg_w_coarse = dbg_w_coarse;
+    p.dbg_sigma_coarse = dbg_sigma_coarse;
+    const int grid = ia_render_rays_grid(B, R);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(render_rays_kernel, dim3(grid), dim3(WAVES * 64), LDS_FLOATS * sizeof(float), s, p);
+    int st = ia::check_launch("ia_render_rays");
+    if (st != IA_OK) return st;
+    hipLaunchKernelGGL(render_finalize_kernel, dim3(ia::streaming_grid((int64_t)B * R, 256)), dim3(256), 0, s, depth, minmax_scratch, grid, B * R);
+    return ia::check_launch("ia_render_rays(finalize)");
+}
+
+extern "C" int ia_importance_stage(const float* z_coarse, const float* w_coarse, float* z_fine, int* inds, int* order,
+                                   int nrays, void* stream) {
+    IA_REQUIRE(z_coarse && w_coarse && z_fine && inds && order && nrays > 0, "bad argument");
+    const int grid = nrays < 4096 ? nrays : 4096;
+    hipLaunchKernelGGL(importance_stage_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, z_coarse, w_coarse, z_fine, inds, order, nrays);
+    return ia::check_launch("ia_importance_stage");
+}

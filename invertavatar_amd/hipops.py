@@ -100,3 +100,54 @@ def upfirdn2d_bias_act(x, f, noise=None, noise_strength=None, bias=None, up=1, p
                                                _lib.stream_ptr(x.device))
     _lib.check(st, 'ia_upfirdn2d_bias_act')
     return y
+
+
+def planes_channels_last(planes):
+    """[B, 3, C, H, W] -> [B, 3, H, W, C] contiguous: the layout ia_render_rays gathers from."""
+    return planes.permute(0, 1, 3, 4, 2).contiguous()
+
+
+def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_multiplier=1.0, box_warp=1.0, white_back=False,
+                n_coarse=48, n_importance=48, debug=False):
+    """Fused importance renderer (see ia_render_rays).  Returns (rgb [B,R,32], depth [B,R,1], wsum [B,R,1][, aux])."""
+    for name, t in (('planes', planes_cl), ('rays_o', rays_o), ('rays_d', rays_d), ('jitter', jitter), ('dist', dist),
+                    ('w0', w0), ('b0', b0), ('w1', w1), ('b1', b1)):
+        _f32c(t, name)
+    b, three, ph, pw, c = planes_cl.shape
+    if three != 3 or c != 32:
+        raise RuntimeError(f'planes must be [B,3,H,W,32] channels-last, got {tuple(planes_cl.shape)}')
+    r = rays_o.shape[1]
+    if tuple(jitter.shape[:3]) != (b, r, n_coarse):
+        raise RuntimeError(f'jitter must be [B,R,{n_coarse}(,1)], got {tuple(jitter.shape)}')
+    dev = planes_cl.device
+    lib = _lib.load()
+    rgb = torch.empty(b, r, 32, device=dev)
+    depth = torch.empty(b, r, 1, device=dev)
+    wsum = torch.empty(b, r, 1, device=dev)
+    scratch = torch.empty(2 * lib.ia_render_rays_grid(b, r), device=dev)
+    aux = {}
+    if debug:
+        aux = dict(z_fine=torch.empty(b, r, 48, device=dev), inds=torch.empty(b, r, 48, device=dev, dtype=torch.int32),
+                   order=torch.empty(b, r, 96, device=dev, dtype=torch.int32), w_coarse=torch.empty(b, r, 47, device=dev),
+                   sigma_coarse=torch.empty(b, r, 48, device=dev))
+    with torch.cuda.device(dev):
+        st = lib.ia_render_rays(_p(planes_cl), _p(rays_o), _p(rays_d), _p(jitter), _p(dist), _p(w0), _p(b0), _p(w1), _p(b1),
+                                float(lr_multiplier), float(box_warp), int(bool(white_back)), b, r, ph, pw, int(n_coarse),
+                                int(n_importance), _p(rgb), _p(depth), _p(wsum), _p(scratch), _p(aux.get('z_fine')),
+                                _p(aux.get('inds')), _p(aux.get('order')), _p(aux.get('w_coarse')), _p(aux.get('sigma_coarse')),
+                                _lib.stream_ptr(dev))
+    _lib.check(st, 'ia_render_rays')
+    return (rgb, depth, wsum, aux) if debug else (rgb, depth, wsum)
+
+
+def importance_stage(z_coarse, w_coarse):
+    """Importance resampling + merge order from given coarse depths/weights (parity-test entry)."""
+    n = z_coarse.shape[0]
+    dev = z_coarse.device
+    z_fine = torch.empty(n, 48, device=dev)
+    inds = torch.empty(n, 48, device=dev, dtype=torch.int32)
+    order = torch.empty(n, 96, device=dev, dtype=torch.int32)
+    st = _lib.load().ia_importance_stage(_p(_f32c(z_coarse, 'z_coarse')), _p(_f32c(w_coarse, 'w_coarse')), _p(z_fine), _p(inds),
+                                         _p(order), n, _lib.stream_ptr(dev))
+    _lib.check(st, 'ia_importance_stage')
+    return z_fine, inds, order

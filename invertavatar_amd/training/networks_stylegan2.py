@@ -1,0 +1,524 @@
+"""StyleGAN2 generator layers on the MI355X backend.
+
+Public names, constructor arguments, parameter/buffer names and forward signatures follow the
+reference (training/networks_stylegan2.py: modulated_conv2d :34, FullyConnectedLayer :96,
+Conv2dLayer :132, MappingNetwork :190, SynthesisLayer :276, ToRGBLayer :340, SynthesisBlock :365,
+SynthesisNetwork :470, Generator :517) so that reference checkpoints load by name
+(SURVEY.md C14).  What differs is the execution on device tensors:
+
+  * a SynthesisLayer is ONE fused MFMA convolution (``ia_conv2d_mfma``: style-scaled input patch,
+    demodulation, noise, bias, lrelu, gain and clamp in the epilogue); up-sampling layers are the
+    stride-2 transposed MFMA convolution followed by ``ia_upfirdn2d_bias_act`` (FIR + the same tail);
+  * a ToRGBLayer is the 1x1 MFMA convolution with the bias and the up-sampled skip image added in
+    its epilogue;
+  * weights are repacked once per layer into the tap-major layout the kernel reads.
+
+CPU tensors take the plain-torch route through ``conv2d_resample``/``bias_act`` exactly as the
+reference does.  The discriminator classes of the reference file are training-only and out of scope.
+"""
+import math
+
+import numpy as np
+import torch
+
+from ..torch_utils import misc, persistence
+from ..torch_utils.ops import bias_act, conv2d_resample, fma, upfirdn2d
+from .. import hipops
+
+# Blocks built with use_fp16 run their convolutions in fp32 on this backend (a superset of the
+# reference's fp16 precision); an fp16-MFMA convolution is a later-round item.
+FP16_BLOCKS_COMPUTE_FP32 = True
+
+
+@misc.profiled_function
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+class _PackedWeights:
+    """Per-layer cache of the kernel-side weight layouts, rebuilt when the parameter changes."""
+
+    def __init__(self):
+        self.key = None
+        self.wk = None
+        self.wsq = None
+
+    def get(self, weight):
+        key = (weight.data_ptr(), weight._version, weight.device, weight.dtype)
+        if key != self.key:
+            w32 = weight.detach().float()
+            self.wk = hipops.pack_conv_weight(w32)
+            self.wsq = hipops.weight_sq_sum(w32)
+            self.key = key
+        return self.wk, self.wsq
+
+
+def _on_device(x):
+    return x.device.type == 'cuda'
+
+
+def _needs_autograd(*tensors):
+    """The fused HIP stages are forward-only; anything that must be differentiated takes the torch route."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _hip_conv_ok(x, weight, up, down):
+    kh, kw = weight.shape[2:]
+    return (_on_device(x) and x.dtype == torch.float32 and down == 1 and kh == kw and
+            ((up == 1 and kh in (1, 3)) or (up == 2 and kh == 3)))
+
+
+@misc.profiled_function
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
+                     flip_weight=True, fused_modconv=True):
+    """Modulated convolution, reference signature (training/networks_stylegan2.py:34-48).
+
+    Device fp32 tensors with the generator's layer shapes run on the MFMA kernel; everything else
+    (CPU, exotic shapes) follows the reference's two torch formulations."""
+    batch = x.shape[0]
+    out_ch, in_ch, kh, kw = weight.shape
+    misc.assert_shape(weight, [out_ch, in_ch, kh, kw])
+    misc.assert_shape(x, [batch, in_ch, None, None])
+    misc.assert_shape(styles, [batch, in_ch])
+
+    if (_hip_conv_ok(x, weight, up, down) and padding == kh // 2 and flip_weight == (up == 1)
+            and (noise is None or noise.ndim <= 2 or noise.shape[0] == 1) and not _needs_autograd(x, weight, styles, noise)):
+        w32 = weight.float()
+        wk = hipops.pack_conv_weight(w32)
+        styles = styles.float().contiguous()
+        demod = hipops.modconv_demod(styles, hipops.weight_sq_sum(w32)) if demodulate else None
+        x = x.contiguous()
+        if up == 1:
+            nz = None if noise is None else noise.reshape(-1).float().contiguous()
+            return hipops.conv2d_mfma(x, wk, styles, demod, noise=nz, ksize=kh)
+        t = hipops.conv2d_mfma(x, wk, styles, demod, ksize=3, transposed=True)
+        nz = None if noise is None else noise.reshape(-1).float().contiguous()
+        return hipops.upfirdn2d_bias_act(t, resample_filter, noise=nz, up=1, pad0=(1, 1),
+                                         out_hw=(x.shape[2] * 2, x.shape[3] * 2), fir_gain=4.0)
+
+    # torch formulations (CPU tensors and shapes without a kernel)
+    if x.dtype == torch.float16 and demodulate:
+        weight = weight * (1 / np.sqrt(in_ch * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+    w = dcoefs = None
+    if demodulate or fused_modconv:
+        w = weight.unsqueeze(0) * styles.reshape(batch, 1, -1, 1, 1)
+    if demodulate:
+        dcoefs = (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+    if not fused_modconv:
+        x = x * styles.to(x.dtype).reshape(batch, -1, 1, 1)
+        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
+                                            flip_weight=flip_weight)
+        if demodulate and noise is not None:
+            x = fma.fma(x, dcoefs.to(x.dtype).reshape(batch, -1, 1, 1), noise.to(x.dtype))
+        elif demodulate:
+            x = x * dcoefs.to(x.dtype).reshape(batch, -1, 1, 1)
+        elif noise is not None:
+            x = x.add_(noise.to(x.dtype))
+        return x
+    if demodulate:
+        w = w * dcoefs.reshape(batch, -1, 1, 1, 1)
+    x = x.reshape(1, -1, *x.shape[2:])
+    w = w.reshape(-1, in_ch, kh, kw)
+    x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
+                                        groups=batch, flip_weight=flip_weight)
+    x = x.reshape(batch, -1, *x.shape[2:])
+    if noise is not None:
+        x = x.add_(noise)
+    return x
+
+
+@persistence.persistent_class
+class FullyConnectedLayer(torch.nn.Module):
+    def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.activation = activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+    def extra_repr(self):
+        return f'in_features={self.in_features:d}, out_features={self.out_features:d}, activation={self.activation:s}'
+
+
+@persistence.persistent_class
+class Conv2dLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, trainable=True):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.activation = activation
+        self.up = up
+        self.down = down
+        self.conv_clamp = conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt)
+        bias = torch.zeros([out_channels]) if bias else None
+        if trainable:
+            self.weight = torch.nn.Parameter(weight)
+            self.bias = torch.nn.Parameter(bias) if bias is not None else None
+        else:
+            self.register_buffer('weight', weight)
+            if bias is not None:
+                self.register_buffer('bias', bias)
+            else:
+                self.bias = None
+
+    def forward(self, x, gain=1):
+        w = self.weight * self.weight_gain
+        b = self.bias.to(x.dtype) if self.bias is not None else None
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+
+    def extra_repr(self):
+        return (f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, '
+                f'activation={self.activation:s}, up={self.up}, down={self.down}')
+
+
+@persistence.persistent_class
+class MappingNetwork(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.998):
+        super().__init__()
+        self.z_dim = z_dim
+        self.c_dim = c_dim
+        self.w_dim = w_dim
+        self.num_ws = num_ws
+        self.num_layers = num_layers
+        self.w_avg_beta = w_avg_beta
+        if embed_features is None:
+            embed_features = w_dim
+        if c_dim == 0:
+            embed_features = 0
+        if layer_features is None:
+            layer_features = w_dim
+        widths = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(widths[idx], widths[idx + 1], activation=activation,
+                                                          lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        x = None
+        with torch.autograd.profiler.record_function('input'):
+            if self.z_dim > 0:
+                misc.assert_shape(z, [None, self.z_dim])
+                x = normalize_2nd_moment(z.to(torch.float32))
+            if self.c_dim > 0:
+                misc.assert_shape(c, [None, self.c_dim])
+                y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+                x = torch.cat([x, y], dim=1) if x is not None else y
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if update_emas and self.w_avg_beta is not None:
+            with torch.autograd.profiler.record_function('update_w_avg'):
+                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            with torch.autograd.profiler.record_function('broadcast'):
+                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            with torch.autograd.profiler.record_function('truncate'):
+                assert self.w_avg_beta is not None
+                if self.num_ws is None or truncation_cutoff is None:
+                    x = self.w_avg.lerp(x, truncation_psi)
+                else:
+                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+    def extra_repr(self):
+        return f'z_dim={self.z_dim:d}, c_dim={self.c_dim:d}, w_dim={self.w_dim:d}, num_ws={self.num_ws:d}'
+
+
+@persistence.persistent_class
+class SynthesisLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True, activation='lrelu',
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.w_dim = w_dim
+        self.resolution = resolution
+        self.up = up
+        self.use_noise = use_noise
+        self.activation = activation
+        self.conv_clamp = conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt))
+        if use_noise:
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self._packed = _PackedWeights()
+
+    def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp):
+        """conv + demod + noise + bias + lrelu + clamp on the MFMA path (one or two launches)."""
+        wk, wsq = self._packed.get(self.weight)
+        styles = styles.float().contiguous()
+        demod = hipops.modconv_demod(styles, wsq)
+        x = x.float().contiguous()
+        const_noise = self.use_noise and noise_mode == 'const'
+        nz = self.noise_const.reshape(-1) if const_noise else None
+        ns = self.noise_strength.detach().float().reshape(1) if const_noise else None
+        bias = self.bias.detach().float()
+        res = self.resolution
+        if self.use_noise and noise_mode == 'random':  # per-sample noise: keep it outside the fused tail
+            rnd_noise = torch.randn([x.shape[0], 1, res, res], device=x.device) * self.noise_strength
+            if self.up == 1:
+                y = hipops.conv2d_mfma(x, wk, styles, demod, ksize=3)
+            else:
+                t = hipops.conv2d_mfma(x, wk, styles, demod, ksize=3, transposed=True)
+                y = hipops.upfirdn2d_bias_act(t, self.resample_filter, up=1, pad0=(1, 1), out_hw=(res, res), fir_gain=4.0)
+            return bias_act.bias_act(y + rnd_noise, bias, act=self.activation, gain=act_gain, clamp=act_clamp)
+        if self.up == 1:
+            return hipops.conv2d_mfma(x, wk, styles, demod, nz, ns, bias, ksize=3, act=self.activation, gain=act_gain,
+                                      clamp=act_clamp)
+        t = hipops.conv2d_mfma(x, wk, styles, demod, ksize=3, transposed=True)
+        return hipops.upfirdn2d_bias_act(t, self.resample_filter, nz, ns, bias, up=1, pad0=(1, 1), out_hw=(res, res),
+                                         fir_gain=4.0, act=self.activation, act_gain=act_gain, clamp=act_clamp)
+
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+        assert noise_mode in ['random', 'const', 'none']
+        in_res = self.resolution // self.up
+        misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
+        styles = self.affine(w)
+        act_gain = self.act_gain * gain
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if (_on_device(x) and self.activation in hipops.ACT_ID and self.weight.shape[2] == 3 and self.up in (1, 2)
+                and not _needs_autograd(x, w, self.weight, self.bias)):
+            return self._fused_device_forward(x, styles, noise_mode, act_gain, act_clamp).to(x.dtype)
+        noise = None
+        if self.use_noise and noise_mode == 'random':
+            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
+        if self.use_noise and noise_mode == 'const':
+            noise = self.noise_const * self.noise_strength
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
+                             resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
+        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)
+
+    def extra_repr(self):
+        return (f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}, '
+                f'resolution={self.resolution:d}, up={self.up}, activation={self.activation:s}')
+
+
+@persistence.persistent_class
+class ToRGBLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.w_dim = w_dim
+        self.conv_clamp = conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self._packed = _PackedWeights()
+
+    def forward(self, x, w, fused_modconv=True, residual=None):
+        """`residual` (fp32, output-shaped) is added after the clamp: the skip-image add of
+        SynthesisBlock folded into this layer's epilogue on the device path."""
+        styles = self.affine(w) * self.weight_gain
+        if _on_device(x) and self.weight.shape[2] == 1 and not _needs_autograd(x, w, self.weight, self.bias, residual):
+            wk, _ = self._packed.get(self.weight)
+            res = None if residual is None else residual.float().contiguous()
+            return hipops.conv2d_mfma(x.float().contiguous(), wk, styles.float().contiguous(), None, bias=self.bias.detach().float(),
+                                      residual=res, ksize=1, act='linear', clamp=self.conv_clamp)
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+        x = bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+        if residual is not None:
+            x = residual + x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+        return x
+
+    def extra_repr(self):
+        return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}'
+
+
+@persistence.persistent_class
+class SynthesisBlock(torch.nn.Module):
+    """One resolution of the synthesis network ('skip' architecture on the generator path).
+
+    `condition` = (scale, shift) applies the CS-SFT modulation of the inversion encoder to the upper
+    half of the channels between the two convolutions
+    (training_avatar_texture/networks_stylegan2_new.py:448-452); the stock block never passes it."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture='skip',
+                 resample_filter=[1, 3, 3, 1], conv_clamp=256, use_fp16=False, fp16_channels_last=False,
+                 fused_modconv_default=True, **layer_kwargs):
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels = in_channels
+        self.w_dim = w_dim
+        self.resolution = resolution
+        self.img_channels = img_channels
+        self.is_last = is_last
+        self.architecture = architecture
+        self.use_fp16 = use_fp16
+        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.fused_modconv_default = fused_modconv_default
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_conv = 0
+        self.num_torgb = 0
+        if in_channels == 0:
+            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
+        if in_channels != 0:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
+                                        resample_filter=resample_filter, conv_clamp=conv_clamp,
+                                        channels_last=self.channels_last, **layer_kwargs)
+            self.num_conv += 1
+        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp,
+                                    channels_last=self.channels_last, **layer_kwargs)
+        self.num_conv += 1
+        if is_last or architecture == 'skip':
+            self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp,
+                                    channels_last=self.channels_last)
+            self.num_torgb += 1
+        if in_channels != 0 and architecture == 'resnet':
+            self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2,
+                                    resample_filter=resample_filter, channels_last=self.channels_last)
+
+    def forward(self, x, img, ws, condition=None, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
+        _ = update_emas
+        misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
+        w_iter = iter(ws.unbind(dim=1))
+        if ws.device.type != 'cuda' or FP16_BLOCKS_COMPUTE_FP32:
+            force_fp32 = True
+        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
+        fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        if fused_modconv is None:
+            fused_modconv = self.fused_modconv_default
+        if fused_modconv == 'inference_only':
+            fused_modconv = (not self.training)
+
+        if self.in_channels == 0:
+            x = self.const.to(dtype=dtype, memory_format=fmt).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        else:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
+            x = x.to(dtype=dtype, memory_format=fmt)
+
+        if self.in_channels == 0:
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+        elif self.architecture == 'resnet':
+            y = self.skip(x, gain=np.sqrt(0.5))
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=np.sqrt(0.5), **layer_kwargs)
+            x = y.add_(x)
+        else:
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            if condition is not None:
+                half = int(x.size(1) // 2)
+                x = torch.cat([x[:, :half], x[:, half:] * condition[0] + condition[1]], dim=1)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+
+        if img is not None:
+            misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        if self.is_last or self.architecture == 'skip':
+            img = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, residual=img)
+            img = img.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+
+        assert x.dtype == dtype
+        assert img is None or img.dtype == torch.float32
+        return x, img
+
+    def extra_repr(self):
+        return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
+
+
+def _block_plan(img_resolution, channel_base, channel_max, num_fp16_res):
+    log2 = int(np.log2(img_resolution))
+    resolutions = [2 ** i for i in range(2, log2 + 1)]
+    channels = {res: min(channel_base // res, channel_max) for res in resolutions}
+    fp16_from = max(2 ** (log2 + 1 - num_fp16_res), 8)
+    return log2, resolutions, channels, fp16_from
+
+
+@persistence.persistent_class
+class SynthesisNetwork(torch.nn.Module):
+    """Stock StyleGAN2 synthesis network (training/networks_stylegan2.py:470-515)."""
+
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=4, **block_kwargs):
+        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
+        super().__init__()
+        self.w_dim = w_dim
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.num_fp16_res = num_fp16_res
+        self.img_resolution_log2, self.block_resolutions, channels, fp16_from = _block_plan(img_resolution, channel_base,
+                                                                                          channel_max, num_fp16_res)
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            block = SynthesisBlock(channels[res // 2] if res > 4 else 0, channels[res], w_dim=w_dim, resolution=res,
+                                   img_channels=img_channels, is_last=(res == img_resolution), use_fp16=(res >= fp16_from),
+                                   **block_kwargs)
+            self.num_ws += block.num_conv
+            if res == img_resolution:
+                self.num_ws += block.num_torgb
+            setattr(self, f'b{res}', block)
+
+    def _split_ws(self, ws):
+        out, idx = [], 0
+        with torch.autograd.profiler.record_function('split_ws'):
+            misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+            ws = ws.to(torch.float32)
+            for res in self.block_resolutions:
+                block = getattr(self, f'b{res}')
+                out.append(ws.narrow(1, idx, block.num_conv + block.num_torgb))
+                idx += block.num_conv
+        return out
+
+    def forward(self, ws, **block_kwargs):
+        x = img = None
+        for res, cur_ws in zip(self.block_resolutions, self._split_ws(ws)):
+            x, img = getattr(self, f'b{res}')(x, img, cur_ws, **block_kwargs)
+        return img
+
+    def extra_repr(self):
+        return (f'w_dim={self.w_dim:d}, num_ws={self.num_ws:d}, img_resolution={self.img_resolution:d}, '
+                f'img_channels={self.img_channels:d}, num_fp16_res={self.num_fp16_res:d}')
+
+
+@persistence.persistent_class
+class Generator(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim = z_dim
+        self.c_dim = c_dim
+        self.w_dim = w_dim
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)

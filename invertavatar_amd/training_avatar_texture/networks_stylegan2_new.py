@@ -1,0 +1,71 @@
+"""Conditioned StyleGAN2 backbone of Next3D++ (reference: training_avatar_texture/networks_stylegan2_new.py).
+
+Relative to the stock network the reference adds exactly three things, all in the forward pass
+(SURVEY.md 2.1 row 12), and this module adds exactly those on top of
+``training.networks_stylegan2``:
+
+  * ``cond_list``  -- rasterised neural-texture images pasted over the skip image at 32^2 and over
+    the feature maps at 32/64/128^2 through their alpha channel (:523-540);
+  * ``return_list`` -- the multi-resolution feature list [img@32, x@32, x@64, x@128, x@256, img@256];
+  * ``feat_conditions`` -- per-resolution CS-SFT (scale, shift) pairs from the inversion encoder;
+and ``mapping_ws`` on the Generator so that the three backbones can share one mapping width.
+"""
+import numpy as np
+import torch
+
+from ..torch_utils import misc, persistence
+from ..training import networks_stylegan2 as _base
+from ..training.networks_stylegan2 import (normalize_2nd_moment, modulated_conv2d, FullyConnectedLayer, Conv2dLayer,  # noqa: F401
+                                           MappingNetwork, SynthesisLayer, ToRGBLayer, SynthesisBlock)
+
+
+@persistence.persistent_class
+class SynthesisNetwork(_base.SynthesisNetwork):
+    def forward(self, ws, cond_list, return_list, feat_conditions=None, return_imgs=False, out_res=(32, 256), **block_kwargs):
+        assert not (return_list and return_imgs)
+        first = int(np.log2(out_res[0])) - 2                       # index of the first tapped block (32^2)
+        last = (self.img_resolution_log2 - 2) if len(out_res) == 1 else (int(np.log2(out_res[1])) - 2)
+        x = img = None
+        feats, imgs = [], []
+        for idx, (res, cur_ws) in enumerate(zip(self.block_resolutions, self._split_ws(ws))):
+            cond = feat_conditions[res] if (feat_conditions is not None and res in feat_conditions.keys()) else None
+            x, img = getattr(self, f'b{res}')(x, img, cur_ws, cond, **block_kwargs)
+            if idx < first:
+                continue
+            if return_list:
+                if idx == first:
+                    feats.append(img.clone())
+                feats.append(x.clone())
+            if cond_list is not None:
+                if idx == first:   # face region copied straight into the skip image
+                    alpha = cond_list[0][:, -1:]
+                    img = cond_list[0][:, :-1] * alpha + img * (1 - alpha)
+                if idx < last:     # ... and into the features of the next block's input
+                    c = cond_list[1 + idx - first]
+                    x = c[:, :-1] * c[:, -1:] + x * (1 - c[:, -1:])
+        if return_list:
+            feats.append(img)
+            return feats
+        if return_imgs:
+            return imgs
+        return img
+
+
+@persistence.persistent_class
+class Generator(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_ws=-1, mapping_kwargs={}, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim = z_dim
+        self.c_dim = c_dim
+        self.w_dim = w_dim
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        if mapping_ws == -1:
+            mapping_ws = self.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=mapping_ws, **mapping_kwargs)
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
