@@ -174,6 +174,15 @@ int ia_render_rays_grid(int B, int R);
 int ia_importance_stage(const float* z_coarse, const float* w_coarse, float* z_fine, int* inds, int* order,
                         int nrays, void* stream);
 
+/*
+ * Mouth-hole mask of the rasterised face alpha, entirely on the device.
+ * Replaces the cv2.floodFill round trip of fill_mouth(images, blur_mouth_edge=False)
+ * (training_avatar_texture/volumetric_rendering/renderer.py:716-741): v = alpha*255; pixels with
+ * v(0,0) <= v <= v(0,0)+254 that are 4-connected to pixel (0,0) are "outside";  mouth = outside ? 0 : (255 - v)/255.
+ *   alpha, mouth : [B, H, W] float32 contiguous.  H*(W+4) bytes must fit in LDS (<= 150 KiB; 256x256 is 65 KiB).
+ */
+int ia_fill_mouth(const float* alpha, float* mouth, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,7 @@ _SIGNATURES = {
     'ia_render_rays': [c_void_p] * 9 + [c_float, c_float, c_int] + [c_int] * 6 + [c_void_p] * 9 + [c_void_p],
     'ia_render_rays_grid': [c_int, c_int],
     'ia_importance_stage': [c_void_p] * 5 + [c_int, c_void_p],
+    'ia_fill_mouth': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
 }
 
 

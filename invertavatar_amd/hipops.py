@@ -151,3 +151,14 @@ def importance_stage(z_coarse, w_coarse):
                                          _p(order), n, _lib.stream_ptr(dev))
     _lib.check(st, 'ia_importance_stage')
     return z_fine, inds, order
+
+
+def fill_mouth(alpha):
+    """alpha [B,1,H,W] -> mouth mask [B,1,H,W] (see ia_fill_mouth)."""
+    _f32c(alpha, 'alpha')
+    b, one, h, w = alpha.shape
+    mouth = torch.empty_like(alpha)
+    with torch.cuda.device(alpha.device):
+        st = _lib.load().ia_fill_mouth(_p(alpha), _p(mouth), b * one, h, w, _lib.stream_ptr(alpha.device))
+    _lib.check(st, 'ia_fill_mouth')
+    return mouth

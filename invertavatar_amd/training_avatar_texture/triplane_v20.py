@@ -1,0 +1,240 @@
+"""Next3D++ (v20) animatable tri-plane generator on the MI355X backend.
+
+API mirror of the reference's training_avatar_texture/triplane_v20.py: ``TriPlaneGenerator`` with
+``mapping`` (:64), ``synthesis`` (:89), ``synthesis_withTexture`` (:152), ``synthesis_withCondition`` (:246),
+``rasterize`` (:317), ``sample`` / ``sample_mixed`` (:341,:373), ``forward`` (:404) and ``OSGDecoder`` (:415),
+with the reference's parameter names, argument meaning and return-dict keys.
+
+Pipeline of one frame:
+  texture backbone + static backbone (StyleGAN2, fused MFMA convolutions)
+  -> rasterize: UV lookup of the neural texture, AA resize, alpha blend over the static features, mouth fill
+     on the GPU (``ia_fill_mouth``; the reference round-trips through cv2 on the host)
+  -> face backbone conditioned on those maps -> 128^2 stitch pasted into plane 0 -> blended tri-planes
+  -> fused importance renderer (``ia_render_rays``: one launch) -> 32-channel 128^2 feature image
+  -> super-resolution head -> 512^2 RGB.
+
+Differences from the reference that do not change results: the three copies of the "rasterize / face
+backbone / blend / render / SR" tail (:116-150, :179-244, :277-315) are one method here; ``rasterize`` can
+skip the two levels the face backbone never reads (networks_stylegan2_new.py:536-540 with end_layer 6);
+the stratified-sampling noise can be injected (``jitter=``) for reproducible evaluation.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import dnnlib
+from ..torch_utils import persistence
+from ..training.networks_stylegan2 import FullyConnectedLayer
+from .networks_stylegan2_new import Generator as StyleGAN2Backbone_cond
+from .volumetric_rendering.renderer import ImportanceRenderer, ImportanceRenderer_bsMotion, fill_mouth  # noqa: F401
+from .volumetric_rendering.ray_sampler import RaySampler, RaySampler_zxc  # noqa: F401
+
+BBOX_256 = [57, 185, 64, 192]   # face region of the frontal plane, in 256^2 pixels (triplane_v20.py:114)
+N_COND_LEVELS_USED = 4          # cond_list entries the face backbone consumes
+
+
+def _aa_resize(x, size):
+    return F.interpolate(x, size=(size, size), mode='bilinear', antialias=True)
+
+
+@persistence.persistent_class
+class TriPlaneGenerator(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, topology_path=None, sr_num_fp16_res=0,
+                 mapping_kwargs={}, rendering_kwargs={}, sr_kwargs={}, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim = z_dim
+        self.c_dim = c_dim
+        self.w_dim = w_dim
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.renderer = ImportanceRenderer_bsMotion()
+        self.ray_sampler = RaySampler_zxc()
+        common = dict(img_resolution=256, mapping_kwargs=mapping_kwargs, **synthesis_kwargs)
+        self.texture_backbone = StyleGAN2Backbone_cond(z_dim, c_dim, w_dim, img_channels=32, **common)
+        self.face_backbone = StyleGAN2Backbone_cond(z_dim, c_dim, w_dim, img_channels=32, **common)
+        self.backbone = StyleGAN2Backbone_cond(z_dim, c_dim, w_dim, img_channels=32 * 3, mapping_ws=self.texture_backbone.num_ws,
+                                               **common)
+        self.superresolution = dnnlib.util.construct_class_by_name(
+            class_name=rendering_kwargs['superresolution_module'], channels=32, img_resolution=img_resolution,
+            sr_num_fp16_res=sr_num_fp16_res, sr_antialias=rendering_kwargs['sr_antialias'], **sr_kwargs)
+        self.decoder = OSGDecoder(32, {'decoder_lr_mul': rendering_kwargs.get('decoder_lr_mul', 1), 'decoder_output_dim': 32})
+        self.neural_rendering_resolution = 128
+        self.rendering_kwargs = rendering_kwargs
+        self.fill_mouth = True
+
+    # ------------------------------------------------------------------ latent mapping
+    def mapping(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        if self.rendering_kwargs['c_gen_conditioning_zero']:
+            c = torch.zeros_like(c)
+        c = c[:, :self.c_dim]   # drop expression labels
+        return self.backbone.mapping(z, c * self.rendering_kwargs.get('c_scale', 0), truncation_psi=truncation_psi,
+                                     truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+
+    # ------------------------------------------------------------------ helpers
+    def _rays(self, c, neural_rendering_resolution):
+        cam = c[:, -25:]
+        if neural_rendering_resolution is None:
+            neural_rendering_resolution = self.neural_rendering_resolution
+        else:
+            self.neural_rendering_resolution = neural_rendering_resolution
+        origins, dirs = self.ray_sampler(cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3), neural_rendering_resolution)
+        return origins, dirs, neural_rendering_resolution
+
+    @staticmethod
+    def _split_static(static_feats):
+        """The static backbone emits 96 = 3 x 32 channels; levels 0 and 5 carry all three planes and the
+        rasteriser only blends over plane 0 of them (:109-112, :180-181)."""
+        b = static_feats[0].shape[0]
+        plane = static_feats[-1].view(b, 3, 32, *static_feats[-1].shape[-2:])
+        first = static_feats[0].view(b, 3, 32, *static_feats[0].shape[-2:])[:, 0]
+        return [first] + list(static_feats[1:-1]) + [plane[:, 0]], plane
+
+    def _blend_planes(self, stitch, full_alpha, static_plane):
+        """Paste the 128^2-resized face stitch + alpha into the bbox of plane 0; planes 1-2 stay static (:119-128)."""
+        y0, y1, x0, x1 = BBOX_256
+        canvas = torch.zeros_like(stitch)
+        alpha = torch.zeros_like(full_alpha)
+        canvas[:, :, y0:y1, x0:x1] = _aa_resize(stitch, 128)
+        alpha[:, :, y0:y1, x0:x1] = _aa_resize(full_alpha, 128)
+        planes = static_plane.clone()
+        planes[:, 0] = canvas * alpha + static_plane[:, 0] * (1 - alpha)
+        return planes
+
+    def _planes(self, ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, all_levels=False):
+        static_for_raster, static_plane = self._split_static(static_feats)
+        assert len(static_for_raster) == len(texture_feats), (len(static_for_raster), len(texture_feats))
+        cond, full_alpha, _ = self.rasterize(texture_feats, mesh_condition['uvcoords_image'], static_for_raster, BBOX_256,
+                                             levels=None if all_levels else N_COND_LEVELS_USED)
+        stitch = self.face_backbone.synthesis(ws, cond, return_list=False, update_emas=update_emas, **synthesis_kwargs)
+        return self._blend_planes(stitch, full_alpha, static_plane)
+
+    def _render(self, ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs):
+        if evaluation:
+            assert synthesis_kwargs.get('noise_mode') == 'const', ('noise_mode' in synthesis_kwargs, synthesis_kwargs.get('noise_mode'))
+        feats, depth, _ = self.renderer(planes, self.decoder, origins, dirs, self.rendering_kwargs, evaluation=evaluation, jitter=jitter)
+        n = ws.shape[0]
+        feature_image = feats.permute(0, 2, 1).reshape(n, feats.shape[-1], nrr, nrr).contiguous()
+        depth_image = depth.permute(0, 2, 1).reshape(n, 1, nrr, nrr)
+        rgb = feature_image[:, :3]
+        sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'noise_mode'}
+        image = self.superresolution(rgb, feature_image, ws, noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **sr_kwargs)
+        return image, rgb, depth_image, feature_image
+
+    # ------------------------------------------------------------------ public synthesis entry points
+    def synthesis(self, ws, c, mesh_condition, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
+                  use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, **synthesis_kwargs):
+        origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
+        texture_feats = self.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
+        static_feats = self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
+        planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs)
+        image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs)
+        out = {'image': image, 'image_raw': rgb, 'image_depth': depth}
+        if return_featmap:
+            out.update(feature_image=feature_image, triplane=planes, texture=texture_feats)
+        return out
+
+    def synthesis_withTexture(self, ws, texture_feats, c, mesh_condition, static_feats=None, neural_rendering_resolution=None,
+                              update_emas=False, cache_backbone=False, use_cached_backbone=False, evaluation=False, jitter=None,
+                              **synthesis_kwargs):
+        origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
+        if static_feats is None:
+            static_feats = self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
+        planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs)
+        image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs)
+        return {'image': image, 'image_raw': rgb, 'image_depth': depth, 'feature_image': feature_image, 'triplane': planes}
+
+    def synthesis_withCondition(self, ws, c, mesh_condition, gt_texture_feats=None, gt_static_feats=None, texture_feats_conditions=None,
+                                static_feats_conditions=None, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
+                                use_cached_backbone=False, only_image=False, return_feats=False, jitter=None, **synthesis_kwargs):
+        origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
+        texture_feats = gt_texture_feats
+        if texture_feats is None:
+            texture_feats = self.texture_backbone.synthesis(ws, cond_list=None, return_list=True, feat_conditions=texture_feats_conditions,
+                                                            update_emas=update_emas, **synthesis_kwargs)
+        static_feats = gt_static_feats
+        if static_feats is None:
+            static_feats = self.backbone.synthesis(ws, cond_list=None, return_list=True, feat_conditions=static_feats_conditions,
+                                                   update_emas=update_emas, **synthesis_kwargs)
+        planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs)
+        evaluation = synthesis_kwargs.get('noise_mode') == 'const'
+        image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs)
+        if only_image:
+            return {'image': image}
+        out = {'image': image, 'image_raw': rgb, 'image_depth': depth, 'feature_image': feature_image, 'triplane': planes}
+        if return_feats:
+            out['static'] = static_feats
+            out['texture'] = texture_feats
+        return out
+
+    def rasterize(self, texture_feats, uvcoords_image, static_feats, bbox_256, levels=None):
+        """UV-rasterise the neural texture pyramid and blend it over the static features.
+
+        uvcoords_image [B,H,W,3] = (u, v, mask).  Returns (list of [B, C_k+1, res_k, res_k], full_alpha, mouth_masks);
+        the extra channel is the face alpha with the upper part of the mouth hole closed (:324-326).
+        `levels` limits how many pyramid levels are produced (None = all, as the reference)."""
+        uv = uvcoords_image if uvcoords_image.dtype == torch.float32 else uvcoords_image.float()
+        grid, alpha = uv[..., :2], uv[..., 2:].permute(0, 3, 1, 2)
+        full_alpha, mouth = fill_mouth(alpha.clone(), blur_mouth_edge=False)
+        upper = mouth.clone()
+        upper[:, :, :87] = 0
+        upper_alpha = torch.clamp(alpha + upper, min=0, max=1)
+        out = []
+        n = len(texture_feats) if levels is None else min(levels, len(texture_feats))
+        for tex, sta in zip(texture_feats[:n], static_feats[:n]):
+            res = tex.shape[2]
+            y0, y1, x0, x1 = [round(v * res / 256) for v in bbox_256]
+            rend = _aa_resize(F.grid_sample(tex, grid, align_corners=False), res)
+            a = _aa_resize(alpha, res)
+            s = _aa_resize(sta[:, :, y0:y1, x0:x1], res)
+            out.append(torch.cat([rend * a + s * (1 - a), _aa_resize(upper_alpha, res)], dim=1))
+        return out, full_alpha, mouth
+
+    def visualize_mesh_condition(self, mesh_condition, to_imgs=False):
+        uv = mesh_condition['uvcoords_image'].clone().permute(0, 3, 1, 2)
+        full_alpha, _ = fill_mouth(uv[:, 2:].clone(), blur_mouth_edge=False)
+        if not to_imgs:
+            return uv
+        uv[full_alpha.expand(-1, 3, -1, -1) == 0] = -1
+        return [img for img in ((uv + 1) * 127.5).to(dtype=torch.uint8).cpu()]   # uint8 CHW tensors (no torchvision here)
+
+    # ------------------------------------------------------------------ point queries (shape extraction)
+    def _query(self, ws, coordinates, directions, mesh_condition, update_emas, synthesis_kwargs):
+        texture_feats = self.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
+        static_feats = self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
+        planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs)
+        self.renderer.plane_axes = self.renderer.plane_axes.to(planes.device)
+        return self.renderer.run_model(planes, self.decoder, coordinates, directions, self.rendering_kwargs)
+
+    def sample(self, coordinates, directions, z, c, mesh_condition, truncation_psi=1, truncation_cutoff=None, update_emas=False,
+               **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self._query(ws, coordinates, directions, mesh_condition, update_emas, synthesis_kwargs)
+
+    def sample_mixed(self, coordinates, directions, ws, mesh_condition, truncation_psi=1, truncation_cutoff=None, update_emas=False,
+                     **synthesis_kwargs):
+        return self._query(ws, coordinates, directions, mesh_condition, update_emas, synthesis_kwargs)
+
+    def forward(self, z, c, v, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None, update_emas=False,
+                cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, c, v, update_emas=update_emas, neural_rendering_resolution=neural_rendering_resolution,
+                              cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, **synthesis_kwargs)
+
+
+class OSGDecoder(torch.nn.Module):
+    """Tiny MLP that decodes averaged tri-plane features into density + 32 colour channels (:415-438).
+    Inside ``ia_render_rays`` its two layers run on MFMA; this module form serves CPU tensors and point queries."""
+
+    def __init__(self, n_features, options):
+        super().__init__()
+        self.hidden_dim = 64
+        self.net = torch.nn.Sequential(
+            FullyConnectedLayer(n_features, self.hidden_dim, lr_multiplier=options['decoder_lr_mul']),
+            torch.nn.Softplus(),
+            FullyConnectedLayer(self.hidden_dim, 1 + options['decoder_output_dim'], lr_multiplier=options['decoder_lr_mul']))
+
+    def forward(self, sampled_features, ray_directions, sampled_embeddings=None):
+        x = sampled_features.mean(1)
+        n, m, c = x.shape
+        x = self.net(x.view(n * m, c)).view(n, m, -1)
+        rgb = torch.sigmoid(x[..., 1:]) * (1 + 2 * 0.001) - 0.001   # MipNeRF sigmoid clamping
+        return {'rgb': rgb, 'sigma': x[..., 0:1]}

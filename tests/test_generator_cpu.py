@@ -1,0 +1,72 @@
+"""The product's generator modules on CPU tensors (the reference's pure-PyTorch fallback route, BASELINE config 1)
+against the golden fixtures: checks the Python mirror (module wiring, names, shapes) without a GPU."""
+import os
+
+import pytest
+import torch
+
+from invertavatar_amd import synthetic
+from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+from conftest import GOLDEN, max_abs
+
+
+@pytest.fixture(scope='module')
+def small_generator():
+    g = TriPlaneGenerator(**synthetic.generator_kwargs('small')).eval().requires_grad_(False)
+    return synthetic.fill_parameters(g)
+
+
+def test_state_dict_names_match_reference_checkpoint_layout():
+    """Name-for-name, shape-for-shape compatibility with the reference's pickles."""
+    for width, fname in (('small', 'generator_state_names_small.txt'),):
+        g = TriPlaneGenerator(**synthetic.generator_kwargs(width))
+        mine = {n: (tuple(t.shape), str(t.dtype).replace('torch.', '')) for n, t in g.state_dict().items()}
+        ref = {}
+        for line in open(os.path.join(GOLDEN, fname)):
+            n, s, d = line.rstrip('\n').split('\t')
+            ref[n] = (eval(s), d)
+        assert set(mine) == set(ref), (sorted(set(ref) - set(mine))[:5], sorted(set(mine) - set(ref))[:5])
+        assert mine == ref
+
+
+def test_full_width_names_and_parameter_count():
+    ref = [line.split('\t')[0] for line in open(os.path.join(GOLDEN, 'generator_state_names.txt'))]
+    assert len(ref) == 444
+    g = TriPlaneGenerator(**synthetic.generator_kwargs('full'))
+    assert sorted(g.state_dict().keys()) == sorted(ref)
+    assert sum(p.numel() for p in g.parameters()) == 88301010
+
+
+def test_persistence_and_script_attributes(small_generator):
+    g = small_generator
+    assert g.init_kwargs['rendering_kwargs']['depth_resolution'] == 48 and g.init_args == ()
+    assert (g.z_dim, g.c_dim, g.w_dim, g.img_resolution, g.neural_rendering_resolution) == (512, 25, 512, 512, 128)
+    assert g.backbone.mapping.w_avg.shape == (512,)
+    g2 = TriPlaneGenerator(*g.init_args, **g.init_kwargs).eval().requires_grad_(False)
+    from invertavatar_amd.torch_utils import misc
+    misc.copy_params_and_buffers(g, g2, require_all=True)
+    assert all(torch.equal(a, b) for a, b in zip(g.state_dict().values(), g2.state_dict().values()))
+
+
+def test_cpu_synthesis_matches_reference(golden, small_generator):
+    gld = golden('generator_small.npz')
+    frames, nrr = gld['frames'].tolist(), gld['nrr']
+    g = small_generator
+    with torch.no_grad():
+        ws = g.mapping(synthetic.latent(0, 1), synthetic.conditioning_camera(), truncation_psi=0.7, truncation_cutoff=14)
+        assert max_abs(ws, gld['ws'][:1]) <= 1e-5
+        ws = gld['ws']
+        c, uv = synthetic.camera_labels(frames), synthetic.uv_conditions(frames)
+        jit = synthetic.jitter(frames, nrr * nrr)
+        out = g.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=nrr, noise_mode='const', evaluation=True,
+                          return_featmap=True, jitter=jit)
+    assert max_abs(out['feature_image'], gld['feature_image']) <= 5e-5
+    assert max_abs(out['image_depth'], gld['image_depth']) <= 5e-5
+    assert max_abs(out['triplane'][..., ::4, ::4], gld['triplane_sub4']) <= 5e-5
+    assert max_abs(out['image'][:1], gld['image']) <= 1e-4
+    with torch.no_grad():
+        tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        out = g.synthesis_withTexture(ws, tex, c, {'uvcoords_image': uv}, static_feats=sta, neural_rendering_resolution=nrr,
+                                      noise_mode='const', evaluation=True, jitter=jit)
+    assert max_abs(out['image'][..., ::4, ::4], gld['image_withtexture_sub4']) <= 1e-4

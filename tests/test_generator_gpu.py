@@ -1,0 +1,95 @@
+"""End-to-end parity of the HIP generator path against golden outputs of the reference and against the oracle."""
+import pytest
+import torch
+
+from invertavatar_amd import synthetic
+from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+from conftest import max_abs
+
+pytestmark = pytest.mark.gpu
+TOL_RGB = 1e-3   # BASELINE.json: max |dRGB| vs the reference on identical inputs
+
+
+def _build(width):
+    g = TriPlaneGenerator(**synthetic.generator_kwargs(width)).eval().requires_grad_(False)
+    synthetic.fill_parameters(g)
+    return g.cuda()
+
+
+def _inputs(gld):
+    frames, nrr = gld['frames'].tolist(), gld['nrr']
+    return (gld['ws'].cuda(), synthetic.camera_labels(frames).cuda(), synthetic.uv_conditions(frames).cuda(),
+            synthetic.jitter(frames, nrr * nrr).cuda(), nrr)
+
+
+@pytest.fixture(scope='module')
+def small():
+    return _build('small')
+
+
+def test_small_generator_vs_reference(golden, small):
+    gld = golden('generator_small.npz')
+    ws, c, uv, jit, nrr = _inputs(gld)
+    with torch.no_grad():
+        out = small.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=nrr, noise_mode='const',
+                              evaluation=True, return_featmap=True, jitter=jit)
+    for i, t in enumerate(out['texture']):
+        ref = gld[f'texture{i}']
+        t = t.cpu()
+        assert max_abs(t if t.shape == ref.shape else t[..., ::4, ::4], ref) <= 2e-4, i
+    assert max_abs(out['triplane'].cpu()[..., ::4, ::4], gld['triplane_sub4']) <= 2e-4
+    assert max_abs(out['feature_image'].cpu(), gld['feature_image']) <= 5e-4
+    assert max_abs(out['image_depth'].cpu(), gld['image_depth']) <= 5e-4
+    err = max_abs(out['image'].cpu()[:1], gld['image'])
+    print(f'small generator max|dRGB| = {err:.2e}')
+    assert err <= TOL_RGB
+    assert max_abs(out['image'].cpu()[..., ::4, ::4], gld['image_sub4']) <= TOL_RGB
+
+
+def test_small_generator_train_mode_and_with_texture(golden, small):
+    """eval_seq.py leaves the generator in train() mode (non-fused modconv) and caches the two backbones."""
+    gld = golden('generator_small.npz')
+    ws, c, uv, jit, nrr = _inputs(gld)
+    small.train()
+    try:
+        with torch.no_grad():
+            out = small.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=nrr, noise_mode='const', evaluation=True, jitter=jit)
+        assert max_abs(out['image'].cpu()[..., ::4, ::4], gld['image_trainmode_sub4']) <= TOL_RGB
+    finally:
+        small.eval()
+    with torch.no_grad():
+        tex = small.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        sta = small.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        out = small.synthesis_withTexture(ws, tex, c, {'uvcoords_image': uv}, static_feats=sta, neural_rendering_resolution=nrr,
+                                          noise_mode='const', evaluation=True, jitter=jit)
+    assert max_abs(out['image'].cpu()[..., ::4, ::4], gld['image_withtexture_sub4']) <= TOL_RGB
+
+
+def test_full_width_generator_vs_reference(golden):
+    """BASELINE model (88.3 M parameters) at 64^2 neural render against the reference's CPU output."""
+    gld = golden('generator_full.npz')
+    g = _build('full')
+    ws, c, uv, jit, nrr = _inputs(gld)
+    with torch.no_grad():
+        out = g.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=nrr, noise_mode='const', evaluation=True,
+                          return_featmap=True, jitter=jit)
+    assert max_abs(out['feature_image'].cpu(), gld['feature_image']) <= 5e-4
+    assert max_abs(out['triplane'].cpu()[..., ::4, ::4], gld['triplane_sub4']) <= 5e-4
+    err = max_abs(out['image'].cpu()[..., ::4, ::4], gld['image_sub4'])
+    print(f'full generator max|dRGB| = {err:.2e}')
+    assert err <= TOL_RGB
+    assert abs(out['image'].abs().mean().item() - gld['image_mean_abs']) <= 1e-4
+
+
+def test_fill_mouth_known_answers_on_device(golden):
+    from invertavatar_amd.training_avatar_texture.volumetric_rendering.renderer import fill_mouth
+    g = golden('renderer.npz')
+    full, mouth = fill_mouth(g['fill_masks'].cuda(), blur_mouth_edge=False)
+    assert torch.equal(full.cpu(), g['fill_full']) and torch.equal(mouth.cpu(), g['fill_mouth'])
+    # a 256^2 mask with a spiral corridor: many propagation rounds
+    m = torch.ones(1, 1, 256, 256)
+    for k in range(0, 120, 8):
+        m[0, 0, k:256 - k, k] = 0; m[0, 0, k, k:256 - k] = 0; m[0, 0, k:256 - k, 255 - k] = 0; m[0, 0, 255 - k, k + 8:256 - k] = 0
+    cpu_full, cpu_mouth = fill_mouth(m.clone(), blur_mouth_edge=False)
+    dev_full, dev_mouth = fill_mouth(m.cuda(), blur_mouth_edge=False)
+    assert torch.equal(dev_mouth.cpu(), cpu_mouth) and torch.equal(dev_full.cpu(), cpu_full)
