@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of TriPlaneGenerator.synthesis (512^2 output, 128^2 neural render) on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run,
+one rank per GPU, RCCL over xGMI).  A step = one pass of the generator hot path over one batch of synthetic
+frames per rank (BASELINE configs[1]: reenact_avatar_next3d single-seed 512^2 render, nrr=128, 1 frame per call);
+with N ranks the frames of a step are sharded one per rank and collected with a single all-gather
+(configs[3] pattern).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra legs on rank 0 at N == 1 (outside the timed region):
+  roofline     -- per-launch HIP-event timing of the dominant kernel family (the fp32 MFMA convolution) over extra
+                  frames; algorithmic FLOPs per launch / measured duration vs the 157.3 TFLOP/s fp32 MFMA peak
+  cpu_baseline -- the CPU oracle (the reference's pure-PyTorch op path restated) timed on the host cores on a
+                  bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from invertavatar_amd import hipops, synthetic  # noqa: E402
+from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+NRR = 128
+FRAMES_PER_RANK = 1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--width', default='full', choices=['full', 'small'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-frames', type=int, default=3)
+    return ap.parse_args()
+
+
+def setup_distributed(n):
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if n > 1 or world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group('nccl', rank=rank, world_size=world)   # nccl == RCCL on ROCm
+    else:
+        torch.cuda.set_device(0)
+    return rank, world, local
+
+
+def make_step(gen, ws, cams, uvs, jits, world, rank):
+    """Returns step(k): render frame k of this rank and all-gather the uint8-free fp32 images of the step."""
+    gathered = torch.empty(world * FRAMES_PER_RANK, 3, 512, 512, device='cuda') if world > 1 else None
+    n_frames = cams.shape[0]
+
+    def step(k):
+        i = k % n_frames
+        out = gen.synthesis(ws, cams[i:i + 1], {'uvcoords_image': uvs[i:i + 1]}, neural_rendering_resolution=NRR,
+                            noise_mode='const', evaluation=True, jitter=jits[i:i + 1])
+        img = out['image']
+        if world > 1:
+            torch.distributed.all_gather_into_tensor(gathered, img.contiguous())
+            return gathered
+        return img
+    return step
+
+
+def roofline_leg(step, frames=3):
+    """Per-launch timing of every fused stage over `frames` extra frames; dominant family by total time."""
+    hipops.PROFILE = []
+    try:
+        for k in range(frames):
+            step(1000 + k)
+        torch.cuda.synchronize()
+        recs = hipops.PROFILE
+    finally:
+        hipops.PROFILE = None
+    fam = {}
+    for name, flops, nbytes, e0, e1 in recs:
+        key = 'conv2d_mfma' if name.startswith('conv2d_mfma') else name
+        f = fam.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        f['ms'] += e0.elapsed_time(e1); f['flops'] += flops; f['bytes'] += nbytes; f['launches'] += 1
+    dom = max(fam, key=lambda k: fam[k]['ms'])
+    d = fam[dom]
+    achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+    out = dict(bound='mfma', kernel=dom, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+               frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None, launches_per_frame=d['launches'] // frames,
+               avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2), algorithmic_gflop_per_frame=round(d['flops'] / frames / 1e9, 1))
+    others = {}
+    for k, f in fam.items():
+        others[k] = dict(ms_per_frame=round(f['ms'] / frames, 4), tflops=round(f['flops'] / (f['ms'] * 1e-3) / 1e12, 2),
+                         algorithmic_gbs=round(f['bytes'] / (f['ms'] * 1e-3) / 1e9, 1), launches_per_frame=f['launches'] // frames)
+    if 'render_rays' in fam:
+        r = fam['render_rays']
+        others['render_rays']['frac_fp32_peak'] = round(r['flops'] / (r['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        others['render_rays']['frac_hbm_peak'] = round(r['bytes'] / (r['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+    return out, others
+
+
+def cpu_baseline_leg(gen, ws, cams, uvs, jits, frames):
+    """The oracle (test infrastructure, CPU restatement of the reference's torch op path) on the host cores."""
+    from oracle import generator as OG
+    sd = {k: v.detach().cpu() for k, v in gen.state_dict().items()}
+    ws_c, cams_c, uvs_c, jits_c = ws.cpu(), cams.cpu(), uvs.cpu(), jits.cpu()
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        OG.synthesis(sd, ws_c, cams_c[:1], uvs_c[:1], jits_c[:1].unsqueeze(-1), nrr=NRR)   # warm
+        t0 = time.perf_counter()
+        for i in range(frames):
+            j = (i + 1) % cams_c.shape[0]
+            OG.synthesis(sd, ws_c, cams_c[j:j + 1], uvs_c[j:j + 1], jits_c[j:j + 1].unsqueeze(-1), nrr=NRR)
+        dt = time.perf_counter() - t0
+    return dict(value=round(frames / dt, 4), unit='frames/s', cores=cores, kind='port',
+                sample=f'{frames} frames of the same workload (B=1, nrr={NRR}, 512^2 out, fp32) after 1 warm-up frame')
+
+
+def main():
+    args = parse()
+    rank, world, _ = setup_distributed(args.gpus)
+    torch.backends.cudnn.benchmark = False
+    gen = TriPlaneGenerator(**synthetic.generator_kwargs(args.width)).eval().requires_grad_(False)
+    synthetic.fill_parameters(gen)
+    gen = gen.cuda()
+    n_frames = 16
+    # every rank renders its own slice of the orbit: frame index = step * world + rank
+    frames = [(k * world + rank) % 240 for k in range(n_frames)]
+    with torch.no_grad():
+        ws = gen.mapping(synthetic.latent(0, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14)
+        cams = synthetic.camera_labels(frames).cuda()
+        uvs = synthetic.uv_conditions(frames).cuda()
+        jits = synthetic.jitter(frames, NRR * NRR).squeeze(-1).cuda()
+        step = make_step(gen, ws, cams, uvs, jits, world, rank)
+
+        for k in range(args.warmup):
+            step(k)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = t.item()
+
+        result = {
+            'metric': 'frames/sec (512^2 out, 128^2 neural render)', 'value': round(world * FRAMES_PER_RANK * args.steps / dt, 3),
+            'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'TriPlaneGenerator.synthesis, reenact_avatar_next3d single-seed render (BASELINE configs[1]): '
+                                   '512^2 out, neural_rendering_resolution=128, 1 frame per rank per step, all three backbones + '
+                                   'rasterize + fused renderer + SR 8XDC recomputed every frame',
+                       'width': args.width, 'frames_per_rank_per_step': FRAMES_PER_RANK, 'parallelism': f'frame-sharded dp{world}',
+                       'collective': 'one all_gather of the step\'s [N,3,512,512] fp32 frames' if world > 1 else 'none'},
+        }
+        if rank == 0 and world == 1:
+            if not args.no_roofline:
+                result['roofline'], result['kernels'] = roofline_leg(step)
+            if not args.no_cpu_baseline:
+                result['cpu_baseline'] = cpu_baseline_leg(gen, ws, cams, uvs, jits, args.cpu_frames)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -11,6 +11,28 @@ from . import _lib
 
 ACT_ID = {'linear': 1, 'lrelu': 3}
 
+# Optional per-launch timing for bench.py's roofline leg: when PROFILE is a list, every fused stage appends
+# (kernel family, algorithmic FLOPs, algorithmic HBM bytes, start event, end event) recorded on the launch stream.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, family, flops, nbytes):
+        self.args = (family, float(flops), float(nbytes))
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append(self.args + (self.e0, self.e1))
+        return False
+
 
 def _p(t):
     return None if t is None else t.data_ptr()
@@ -76,7 +98,9 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     if ksplit > 1:
         nbytes = ksplit * b * o * oh * ow * 4
         scratch = _scratch_buffer(x.device, nbytes)
-    with torch.cuda.device(x.device):
+    flops = 2.0 * b * h * w * i * o * ksize * ksize
+    traffic = 4.0 * (x.numel() + wk.numel() + y.numel() + (residual.numel() if residual is not None else 0))
+    with torch.cuda.device(x.device), _Timed('conv2d_mfma_t' if transposed else f'conv2d_mfma_k{ksize}', flops, traffic):
         st = lib.ia_conv2d_mfma(_p(x), _p(wk), _p(styles), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(residual),
                                 _p(y), _p(scratch), nbytes, b, i, o, h, w, ksize, int(transposed), ACT_ID[act], float(alpha),
                                 float(gain), float(-1 if clamp is None else clamp), int(ksplit), _lib.stream_ptr(x.device))
@@ -92,7 +116,8 @@ def upfirdn2d_bias_act(x, f, noise=None, noise_strength=None, bias=None, up=1, p
     n, c, ih, iw = x.shape
     fh, fw = f.shape
     y = torch.empty(n, c, out_hw[0], out_hw[1], device=x.device, dtype=x.dtype)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _Timed('upfirdn2d_bias_act', 2.0 * y.numel() * (fh * fw) / (up * up),
+                                             x.element_size() * (x.numel() + y.numel())):
         st = _lib.load().ia_upfirdn2d_bias_act(_p(x), _p(_f32c(f, 'f')), _p(noise), _p(noise_strength), _p(bias), _p(y),
                                                _lib.DTYPE_ID[x.dtype], n, c, ih, iw, fh, fw, out_hw[0], out_hw[1], int(up),
                                                int(pad0[0]), int(pad0[1]), 1 if flip else 0, float(fir_gain), ACT_ID[act],
@@ -130,7 +155,10 @@ def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_mult
         aux = dict(z_fine=torch.empty(b, r, 48, device=dev), inds=torch.empty(b, r, 48, device=dev, dtype=torch.int32),
                    order=torch.empty(b, r, 96, device=dev, dtype=torch.int32), w_coarse=torch.empty(b, r, 47, device=dev),
                    sigma_coarse=torch.empty(b, r, 48, device=dev))
-    with torch.cuda.device(dev):
+    # algorithmic work: 2 passes x 48 samples x (32*64 + 64*33) MACs per ray; planes + rays in, 34 floats out
+    flops = 2.0 * b * r * 96 * 2 * (32 * 64 + 64 * 33)
+    traffic = 4.0 * (planes_cl.numel() + 2 * rays_o.numel() + jitter.numel() + b * r * 34)
+    with torch.cuda.device(dev), _Timed('render_rays', flops, traffic):
         st = lib.ia_render_rays(_p(planes_cl), _p(rays_o), _p(rays_d), _p(jitter), _p(dist), _p(w0), _p(b0), _p(w1), _p(b1),
                                 float(lr_multiplier), float(box_warp), int(bool(white_back)), b, r, ph, pw, int(n_coarse),
                                 int(n_importance), _p(rgb), _p(depth), _p(wsum), _p(scratch), _p(aux.get('z_fine')),
