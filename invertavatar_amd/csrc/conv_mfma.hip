@@ -32,14 +32,14 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CC = 8;               // in-channels staged per K chunk
-constexpr int kPatchFloats = 800;   // per-channel LDS patch capacity (floats)
+constexpr int kPatchFloats = 1024;  // per-channel LDS patch capacity (floats)
 
 struct Geo {
     int B, I, O, H, W;     // input
     int GH, GW;            // point grid: conv H x W, transposed (H+1) x (W+1)
     int OH, OW;            // output image
     int S, ci_per_split;   // split-K
+    int patch_cap;         // floats per channel reserved for the patch in each LDS buffer
 };
 
 struct Epi {
@@ -52,6 +52,42 @@ struct Epi {
     float alpha, gain, clamp;
 };
 
+// Input window of one tile (a contiguous range [p0, p_last] of the row-major point grid), as one or two row
+// segments that share a row stride PW.  Three shapes:
+//   single : the tile lies in one grid row            -> rows x (its columns + halo)
+//   split  : two grid rows of a WIDE image            -> segment 0 = tail of the first row, segment 1 = head of the second
+//   full   : anything else (narrow images, >= 3 rows) -> all needed rows x full width
+// Halo: stride-1 conv reads (r + ky - PAD, c + kx - PAD); the transposed form reads (r - ky/2, c - kx/2).
+struct Window {
+    int r0[2], nr[2], c0[2];   // first input row, row count, first input column of each segment
+    int PW, PSZ;               // shared row stride, floats per channel
+};
+
+__host__ __device__ inline Window tile_window(int p0, int p_last, int GW, int pad, bool tr) {
+    const int up = tr ? 1 : pad, dn = tr ? 0 : pad, lf = tr ? 1 : pad, rt = tr ? 0 : pad;
+    const int r_first = p0 / GW, r_last = p_last / GW;
+    const int c_first = p0 - r_first * GW, c_last = p_last - r_last * GW;
+    const int nrows = up + dn + 1;
+    Window w;
+    w.nr[1] = 0; w.r0[1] = 0; w.c0[1] = 0;
+    if (r_first == r_last) {
+        w.r0[0] = r_first - up; w.nr[0] = nrows; w.c0[0] = c_first - lf; w.PW = (c_last + rt) - w.c0[0] + 1;
+    } else {
+        const int w0 = (GW - 1 + rt) - (c_first - lf) + 1, w1 = (c_last + rt) - (0 - lf) + 1;
+        const int pw_split = w0 > w1 ? w0 : w1, pw_full = GW + lf + rt;
+        const int sz_split = 2 * nrows * pw_split, sz_full = (r_last - r_first + nrows) * pw_full;
+        if (r_last == r_first + 1 && sz_split < sz_full) {
+            w.r0[0] = r_first - up; w.nr[0] = nrows; w.c0[0] = c_first - lf;
+            w.r0[1] = r_last - up;  w.nr[1] = nrows; w.c0[1] = -lf;
+            w.PW = pw_split;
+        } else {
+            w.r0[0] = r_first - up; w.nr[0] = r_last - r_first + nrows; w.c0[0] = -lf; w.PW = pw_full;
+        }
+    }
+    w.PSZ = (w.nr[0] + w.nr[1]) * w.PW;
+    return w;
+}
+
 __device__ __forceinline__ float epilogue(float v, int b, int o, int64_t pix, int64_t ohw, const Geo& g, const Epi& e, float ns) {
     if (e.demod) v *= e.demod[b * g.O + o];
     if (e.noise) v = fmaf(e.noise[pix], ns, v);
@@ -63,8 +99,9 @@ __device__ __forceinline__ float epilogue(float v, int b, int o, int64_t pix, in
     return v;
 }
 
-// FO x FP fragments (32 channels x 32 points each) per wave, WO x WP waves per workgroup.
-template <int KS, bool TR, int FO, int FP, int WO, int WP, bool PARTIAL>
+// FO x FP fragments (32 channels x 32 points each) per wave, WO x WP waves per workgroup, CC in-channels per K chunk,
+// NPOS patch positions staged per thread (>= ceil(worst PSZ / threads), chosen by the host).
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool PARTIAL>
 __global__ __launch_bounds__(WO * WP * 64) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                                  const float* __restrict__ styles, float* __restrict__ y,
                                                                  Geo g, Epi e) {
@@ -73,8 +110,6 @@ __global__ __launch_bounds__(WO * WP * 64) void conv_mfma_kernel(const float* __
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
     constexpr int PAD = TR ? 0 : KS / 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* w_lds = lds;                       // [NT*CC][BO]
-    float* p_lds = lds + NT * CC * BO;        // [CC][PSZ]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -84,29 +119,19 @@ __global__ __launch_bounds__(WO * WP * 64) void conv_mfma_kernel(const float* __
     const int npts = g.GH * g.GW;
     const int p0 = blockIdx.x * BP;
     const int p_last = min(p0 + BP, npts) - 1;
-    const int r_first = p0 / g.GW, r_last = p_last / g.GW;
-    const bool multi = r_last > r_first;
-    // input window this tile reads
-    int row_lo, row_hi, col_lo, col_hi;
-    if (TR) {
-        row_lo = r_first - 1; row_hi = r_last;
-        col_lo = multi ? -1 : (p0 - r_first * g.GW) - 1;
-        col_hi = multi ? g.W : (p_last - r_first * g.GW);
-    } else {
-        row_lo = r_first - PAD; row_hi = r_last + PAD;
-        col_lo = multi ? -PAD : (p0 - r_first * g.GW) - PAD;
-        col_hi = multi ? g.W - 1 + PAD : (p_last - r_first * g.GW) + PAD;
-    }
-    const int PH = row_hi - row_lo + 1, PW = col_hi - col_lo + 1, PSZ = PH * PW;
-    const float inv_psz = 1.0f / (float)PSZ, inv_pw = 1.0f / (float)PW;
+    const Window win = tile_window(p0, p_last, g.GW, PAD, TR);
+    const int PW = win.PW, PSZ = win.PSZ, seg1_off = win.nr[0] * PW;
+    const int r_split = (win.nr[1] > 0) ? p_last / g.GW : (1 << 30);   // points in this grid row use segment 1
+    const float inv_pw = 1.0f / (float)PW;
 
     // per-lane patch offset of each point fragment (points past the grid alias the last valid one)
     int base[FP];
 #pragma unroll
     for (int fp = 0; fp < FP; ++fp) {
-        int p = min(p0 + (wp * FP + fp) * 32 + l31, p_last);
-        int r = p / g.GW, c = p - r * g.GW;
-        base[fp] = (TR ? (r - row_lo) * PW + (c - col_lo) : (r - PAD - row_lo) * PW + (c - PAD - col_lo)) + half * PSZ;
+        const int p = min(p0 + (wp * FP + fp) * 32 + l31, p_last);
+        const int r = p / g.GW, c = p - r * g.GW;
+        const int sg = (r == r_split) ? 1 : 0;
+        base[fp] = sg * seg1_off + (r - PAD - win.r0[sg]) * PW + (c - PAD - win.c0[sg]) + half * PSZ;
     }
     int toff[NT];
 #pragma unroll
@@ -128,60 +153,124 @@ __global__ __launch_bounds__(WO * WP * 64) void conv_mfma_kernel(const float* __
     const int ci_begin = split * g.ci_per_split, ci_end = min(ci_begin + g.ci_per_split, g.I);
     const float* xb = x + (int64_t)b * g.I * g.H * g.W;
     const float* sb = styles ? styles + (int64_t)b * g.I : nullptr;
-    const bool o_vec = (g.O % 4) == 0;
+    const int HW = g.H * g.W;
 
+    // ---- staging plan, fixed for the whole K loop.
+    // Patch: thread owns up to NPOS positions of the window; per position the global offset and a 0/1 mask are
+    // computed once, then every chunk issues CC unconditional loads per position (no branches around loads).
+    int goff[NPOS]; float gmask[NPOS];
+#pragma unroll
+    for (int j = 0; j < NPOS; ++j) {
+        const int pp = tid + j * NTHREADS;
+        const int sg = (pp >= seg1_off && win.nr[1] > 0) ? 1 : 0;
+        const int qq = pp - sg * seg1_off;
+        const int pr = (int)(((float)qq + 0.5f) * inv_pw), pc = qq - pr * PW;
+        const int iy = win.r0[sg] + pr, ix = win.c0[sg] + pc;
+        const bool ok = pp < PSZ && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        goff[j] = ok ? iy * g.W + ix : 0;
+        gmask[j] = ok ? 1.f : 0.f;
+    }
+    // Weights: NWV float4 per thread per chunk from the [tap][I][O] slab; rows = (tap, cc), o contiguous.
+    constexpr int ROWV = BO / 4, NWV = (NT * CC * ROWV + NTHREADS - 1) / NTHREADS;
+    const bool o_full = (g.O % 4) == 0 && (o0 + BO <= g.O);          // block-uniform fast path
+    int w_row[NWV], w_o4[NWV];                                        // this thread's slots of the weight slab
+#pragma unroll
+    for (int k = 0; k < NWV; ++k) {
+        const int e_ = min(tid + k * NTHREADS, NT * CC * ROWV - 1);
+        w_row[k] = e_ / ROWV; w_o4[k] = (e_ - w_row[k] * ROWV) * 4;
+    }
+    float* w_lds = lds;                       // [NT*CC][BO]
+    float* p_lds = lds + NT * CC * BO;        // [CC][PSZ]
+    float pv[NPOS][CC];                       // staged patch values     (global -> registers -> LDS)
+    float sv[CC];                             // style * channel-tail mask of the staged chunk
+    float4 wv[NWV];                           // staged weight vectors
+
+    // All loads of a chunk are unconditional (addresses clamped, masks applied at commit) so that they issue
+    // back-to-back and one wait covers them; the chunk after next is in flight while the current one is multiplied.
+    auto prefetch = [&](int ci0) {
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            const int ci = ci0 + cc;
+            const float sty = sb ? sb[min(ci, g.I - 1)] : 1.f;
+            sv[cc] = ci < ci_end ? sty : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NPOS; ++j)
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) pv[j][cc] = xb[(int64_t)min(ci0 + cc, g.I - 1) * HW + goff[j]];
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) {
+            const int tap = w_row[k] / CC, cc = w_row[k] % CC;
+            const float* src = wk + ((int64_t)tap * g.I + min(ci0 + cc, g.I - 1)) * g.O;
+            const int o = o0 + w_o4[k];
+            if (o_full) wv[k] = *(const float4*)(src + o);
+            else {   // ragged out-channel edge: clamped scalar loads, masked
+                const int last = g.O - 1;
+                wv[k] = make_float4(o < g.O ? src[min(o, last)] : 0.f, o + 1 < g.O ? src[min(o + 1, last)] : 0.f,
+                                    o + 2 < g.O ? src[min(o + 2, last)] : 0.f, o + 3 < g.O ? src[min(o + 3, last)] : 0.f);
+            }
+        }
+    };
+    auto commit = [&]() {   // registers -> LDS: style, zero padding and channel-tail masks folded into one multiply
+#pragma unroll
+        for (int j = 0; j < NPOS; ++j) {
+            const int pp = tid + j * NTHREADS;
+            if (pp < PSZ) {
+#pragma unroll
+                for (int cc = 0; cc < CC; ++cc) p_lds[cc * PSZ + pp] = pv[j][cc] * (sv[cc] * gmask[j]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) {
+            if (tid + k * NTHREADS < NT * CC * ROWV) {
+                // (weights of channels past ci_end need no mask: their patch rows are zeroed through sv[])
+                *(float4*)(w_lds + w_row[k] * BO + w_o4[k]) = wv[k];
+            }
+        }
+    };
+
+    constexpr int NSTEP_K = NT * (CC / 2);                    // k-pairs per chunk
+    constexpr int KP = (FO * FP >= 4) ? 1 : 2;                // k-pairs per pipeline step: >= 4 MFMAs (256 cycles) per step
+    constexpr int NSTEP = NSTEP_K / KP;
+    static_assert(NSTEP_K % KP == 0, "chunk depth must be a multiple of the step depth");
+
+    prefetch(ci_begin);
     for (int ci0 = ci_begin; ci0 < ci_end; ci0 += CC) {
+        __syncthreads();                 // everyone is done reading the previous chunk
+        commit();
         __syncthreads();
-        // ---- stage the style-scaled input patch: p_lds[cc][pr][pc]
-        for (int e_ = tid; e_ < CC * PSZ; e_ += NTHREADS) {
-            const int cc = (int)(((float)e_ + 0.5f) * inv_psz);
-            const int rem = e_ - cc * PSZ;
-            const int pr = (int)(((float)rem + 0.5f) * inv_pw);
-            const int pc = rem - pr * PW;
-            const int ci = ci0 + cc, iy = row_lo + pr, ix = col_lo + pc;
-            float v = 0.f;
-            if (ci < ci_end && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
-                v = xb[((int64_t)ci * g.H + iy) * g.W + ix];
-                if (sb) v *= sb[ci];
+        if (ci0 + CC < ci_end) prefetch(ci0 + CC);   // global loads of the next chunk fly behind the MFMAs below
+        // MFMA over the chunk: k-pair = channels (2cp, 2cp+1) of one tap; lane half picks the channel.  Operand reads
+        // run one step ahead of the MFMAs that consume them (double-buffered registers) so the LDS latency hides
+        // under the >= 256 MFMA cycles of a step.
+        float a_buf[2][KP][FO], b_buf[2][KP][FP];
+        auto load_ops = [&](int st, float (&a)[KP][FO], float (&bv)[KP][FP]) {
+#pragma unroll
+            for (int kk = 0; kk < KP; ++kk) {
+                const int kp = st * KP + kk, t = kp / (CC / 2), cp = kp % (CC / 2);
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo) a[kk][fo] = w_lds[(t * CC + 2 * cp + half) * BO + (wo * FO + fo) * 32 + l31];
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp) bv[kk][fp] = p_lds[2 * cp * PSZ + base[fp] + toff[t]];
             }
-            p_lds[e_] = v;
-        }
-        // ---- stage the weight slab: w_lds[tap*CC + cc][o]   (global layout [tap][I][O], o contiguous)
-        for (int e_ = tid; e_ < NT * CC * (BO / 4); e_ += NTHREADS) {
-            const int row = e_ / (BO / 4), o4 = (e_ - row * (BO / 4)) * 4;
-            const int tap = row / CC, cc = row - tap * CC;
-            const int ci = ci0 + cc, o = o0 + o4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < ci_end) {
-                const float* src = wk + ((int64_t)tap * g.I + ci) * g.O + o;
-                if (o_vec && o + 3 < g.O) v = *(const float4*)src;
-                else {
-                    if (o < g.O) v.x = src[0];
-                    if (o + 1 < g.O) v.y = src[1];
-                    if (o + 2 < g.O) v.z = src[2];
-                    if (o + 3 < g.O) v.w = src[3];
-                }
-            }
-            *(float4*)(w_lds + row * BO + o4) = v;
-        }
-        __syncthreads();
-        // ---- MFMA over the chunk: k-pair = channels (2cp, 2cp+1) of one tap; lane half picks the channel
+        };
+        load_ops(0, a_buf[0], b_buf[0]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int ph = TR ? (((t / KS) & 1) * 2 + ((t % KS) & 1)) : 0;
+        for (int st = 0; st < NSTEP; ++st) {
+            if (st + 1 < NSTEP) load_ops(st + 1, a_buf[(st + 1) & 1], b_buf[(st + 1) & 1]);
 #pragma unroll
-            for (int cp = 0; cp < CC / 2; ++cp) {
-                float a[FO], bv[FP];
-#pragma unroll
-                for (int fo = 0; fo < FO; ++fo) a[fo] = w_lds[(t * CC + 2 * cp + half) * BO + (wo * FO + fo) * 32 + l31];
-#pragma unroll
-                for (int fp = 0; fp < FP; ++fp) bv[fp] = p_lds[2 * cp * PSZ + base[fp] + toff[t]];
+            for (int kk = 0; kk < KP; ++kk) {
+                const int t = (st * KP + kk) / (CC / 2);
+                const int ph = TR ? (((t / KS) & 1) * 2 + ((t % KS) & 1)) : 0;
 #pragma unroll
                 for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
                     for (int fp = 0; fp < FP; ++fp)
-                        acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fo], bv[fp], acc[ph][fo][fp], 0, 0, 0);
+                        acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][fp],
+                                                                               acc[ph][fo][fp], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x100, KP * (FO + FP), 0);   // next step's ds_reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, KP * FO * FP, 0);     // ... then this step's MFMAs
         }
     }
 
@@ -222,49 +311,71 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const float* __restric
     const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_split; i += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.f;
-        for (int s = 0; s < g.S; ++s) v += part[s * per_split + i];
+        int s = 0;
+        for (; s + 8 <= g.S; s += 8) {    // 8 independent loads in flight, summed in split order
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = part[(s + k) * per_split + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += t[k];
+        }
+        for (; s < g.S; ++s) v += part[s * per_split + i];
         const int64_t pix = i % ohw;
         const int bo = (int)(i / ohw);
         y[i] = epilogue(v, bo / g.O, bo % g.O, pix, ohw, g, e, ns);
     }
 }
 
-template <int KS, bool TR, int FO, int FP, int WO, int WP>
-int launch(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g, const Epi& e, hipStream_t s) {
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS>
+int launch_npos(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g_in, const Epi& e,
+                int worst, hipStream_t s) {
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NT = KS * KS;
+    Geo g = g_in;
+    g.patch_cap = (worst + 3) & ~3;                                  // keeps the second buffer 16-byte aligned
     const int npts = g.GH * g.GW;
     dim3 grid((npts + BP - 1) / BP, (g.O + BO - 1) / BO, g.B * g.S), block(WO * WP * 64);
-    // largest per-channel patch any tile of this launch stages (mirrors the window logic of the kernel)
-    int worst = 0;
-    for (int t = 0; t < (int)grid.x; ++t) {
-        const int q0 = t * BP, q1 = (q0 + BP < npts ? q0 + BP : npts) - 1;
-        const int r0 = q0 / g.GW, r1 = q1 / g.GW, halo = TR ? 1 : 2 * (KS / 2);
-        const int ph = r1 - r0 + 1 + halo;
-        const int pw = (r1 > r0) ? g.W + (TR ? 2 : 2 * (KS / 2)) : (q1 - q0 + 1) + halo;
-        if (ph * pw > worst) worst = ph * pw;
-    }
-    if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d floats exceeds the LDS budget", worst);
-    const size_t lds = (size_t)(NT * CC * BO + CC * kPatchFloats) * sizeof(float);
+    const size_t lds = (size_t)(NT * CC * BO + CC * g.patch_cap) * sizeof(float);
+    if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
     if (g.S > 1) {
-        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, true>;
+        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, true>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, grid, block, lds, s, x, wk, styles, scratch, g, e);
         const int64_t n = (int64_t)g.B * g.O * g.OH * g.OW;
         hipLaunchKernelGGL(conv_reduce_kernel, dim3(ia::streaming_grid(n, 256)), dim3(256), 0, s, scratch, y, g, e);
     } else {
-        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, false>;
+        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, false>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, grid, block, lds, s, x, wk, styles, y, g, e);
     }
     return ia::check_launch("ia_conv2d_mfma");
 }
 
-// Tile family per layer shape: (32ch x 256pt) for narrow outputs, (128ch x 128pt) otherwise; transposed
-// always (64ch x 64pt x 4 phases).
-void tile_dims(int O, int transposed, int* bo, int* bp) {
-    if (transposed) { *bo = 64; *bp = 64; }
-    else if (O <= 32) { *bo = 32; *bp = 256; }
-    else { *bo = 128; *bp = 128; }
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC>
+int launch(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g, const Epi& e, hipStream_t s) {
+    constexpr int BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
+    const int npts = g.GH * g.GW, ntiles = (npts + BP - 1) / BP;
+    // largest per-channel patch any tile of this launch stages (same window function as the kernel)
+    int worst = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int q0 = t * BP, q1 = (q0 + BP < npts ? q0 + BP : npts) - 1;
+        const Window w = tile_window(q0, q1, g.GW, TR ? 0 : KS / 2, TR);
+        if (w.PSZ > worst) worst = w.PSZ;
+    }
+    if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d floats exceeds the LDS budget", worst);
+    const int npos = (worst + NTHREADS - 1) / NTHREADS;
+    if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1>(x, wk, styles, y, scratch, g, e, worst, s);
+    if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2>(x, wk, styles, y, scratch, g, e, worst, s);
+    return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4>(x, wk, styles, y, scratch, g, e, worst, s);
+}
+
+constexpr int kChunkConv = 8, kChunkTransposed = 16;
+
+// Tile family per layer shape: (32ch x 256pt) for narrow outputs, (128ch x 128pt) otherwise; the transposed form
+// uses (64ch x 128pt x 4 phases) with 16-channel chunks so that it does as many MFMAs per staged chunk as the conv.
+void tile_dims(int O, int transposed, int* bo, int* bp, int* cc) {
+    if (transposed) { *bo = 64; *bp = 128; *cc = kChunkTransposed; }
+    else if (O <= 32) { *bo = 32; *bp = 256; *cc = kChunkConv; }
+    else { *bo = 128; *bp = 128; *cc = kChunkConv; }
 }
 
 }  // namespace
@@ -273,11 +384,11 @@ extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int 
                               size_t* h_scratch_bytes) {
     IA_REQUIRE(h_ksplit && h_scratch_bytes, "null output pointer");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
-    int bo, bp;
-    tile_dims(O, transposed, &bo, &bp);
+    int bo, bp, cc;
+    tile_dims(O, transposed, &bo, &bp, &cc);
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
     const int64_t blocks = (int64_t)((npts + bp - 1) / bp) * ((O + bo - 1) / bo) * B;
-    const int chunks = (I + CC - 1) / CC;
+    const int chunks = (I + cc - 1) / cc;
     int s = 1;
     // aim for >= 2 workgroups per CU, keep >= 2 chunks (16 channels x taps) of work per split
     while (blocks * s < 2 * ia::kNumCU && s * 2 <= chunks / 2 && s < 64) s *= 2;
@@ -305,23 +416,25 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
     g.GH = transposed ? H + 1 : H; g.GW = transposed ? W + 1 : W;
     g.OH = transposed ? 2 * H + 1 : H; g.OW = transposed ? 2 * W + 1 : W;
     IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
-    const int chunks = (I + CC - 1) / CC;
+    int bo_, bp_, cc;
+    tile_dims(O, transposed, &bo_, &bp_, &cc);
+    const int chunks = (I + cc - 1) / cc;
     if (ksplit > chunks) ksplit = chunks;
     g.S = ksplit;
-    g.ci_per_split = ((chunks + ksplit - 1) / ksplit) * CC;
+    g.ci_per_split = ((chunks + ksplit - 1) / ksplit) * cc;
     if (ksplit > 1) {
         const size_t need = (size_t)ksplit * B * O * g.OH * g.OW * sizeof(float);
         IA_REQUIRE(scratch && scratch_bytes >= need, "split-K needs %zu bytes of scratch, got %zu", need, scratch_bytes);
     }
     Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp};
     hipStream_t s = (hipStream_t)stream;
-    if (transposed) return launch<3, true, 1, 1, 2, 2>(x, wk, styles, y, scratch, g, e, s);
+    if (transposed) return launch<3, true, 1, 2, 2, 2, kChunkTransposed>(x, wk, styles, y, scratch, g, e, s);
     if (O <= 32) {
-        return ksize == 3 ? launch<3, false, 1, 2, 1, 4>(x, wk, styles, y, scratch, g, e, s)
-                          : launch<1, false, 1, 2, 1, 4>(x, wk, styles, y, scratch, g, e, s);
+        return ksize == 3 ? launch<3, false, 1, 2, 1, 4, kChunkConv>(x, wk, styles, y, scratch, g, e, s)
+                          : launch<1, false, 1, 2, 1, 4, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
     }
-    return ksize == 3 ? launch<3, false, 2, 2, 2, 2>(x, wk, styles, y, scratch, g, e, s)
-                      : launch<1, false, 2, 2, 2, 2>(x, wk, styles, y, scratch, g, e, s);
+    return ksize == 3 ? launch<3, false, 2, 2, 2, 2, kChunkConv>(x, wk, styles, y, scratch, g, e, s)
+                      : launch<1, false, 2, 2, 2, 2, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
 }
 
 // d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + 1e-8): demodulation coefficients of the modulated conv
