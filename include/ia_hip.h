@@ -183,6 +183,30 @@ int ia_importance_stage(const float* z_coarse, const float* w_coarse, float* z_f
  */
 int ia_fill_mouth(const float* alpha, float* mouth, int B, int H, int W, void* stream);
 
+/*
+ * One pyramid level of TriPlaneGenerator.rasterize (training_avatar_texture/triplane_v20.py:328-337) in one pass:
+ *     out[:, :C] = AA(grid_sample(texture, uv)) * AA(alpha) + AA(static[:, :, bbox]) * (1 - AA(alpha));  out[:, C] = AA(upper_alpha)
+ * where AA = F.interpolate(bilinear, antialias=True) to res x res and grid_sample = bilinear / zeros / align_corners False.
+ *   tex_cl      : [B, tex_res, tex_res, C] float32 -- the texture level in CHANNELS-LAST order
+ *   uv          : [B, 256, 256, 3] float32 = mesh_condition['uvcoords_image'] (u, v, mask)
+ *   upper_alpha : [B, 256, 256] float32 = clamp(mask + upper-mouth mask, 0, 1) (triplane_v20.py:324-326)
+ *   sta         : static feature level, NCHW with batch stride `sta_batch_stride` elements (lets plane 0 of a 96-channel
+ *                 level be passed without a copy); rows by0:by1, columns bx0:bx1 are resized to res x res
+ *   out         : [B, C+1, res, res] float32;   res in {32, 64, 128}
+ */
+int ia_rasterize_level(const float* tex_cl, const float* uv, const float* upper_alpha, const float* sta, int64_t sta_batch_stride,
+                       float* out, int B, int C, int tex_res, int sta_res, int res, int by0, int by1, int bx0, int bx1, void* stream);
+
+/*
+ * Tri-plane blend of triplane_v20.py:119-128, written straight in the renderer's layout: the 256^2 face stitch and the
+ * mouth-filled alpha are AA-resized to (y1-y0)^2 = 128^2, pasted at rows y0:y1 / columns x0:x1 of plane 0 and blended over
+ * the static planes; planes 1-2 are the static planes.
+ *   stitch [B,32,256,256], full_alpha [B,256,256], static_planes [B,3*32,256,256] (batch stride in elements given),
+ *   planes_cl [B,3,256,256,32] float32.
+ */
+int ia_blend_planes(const float* stitch, const float* full_alpha, const float* static_planes, int64_t sta_batch_stride,
+                    float* planes_cl, int B, int y0, int y1, int x0, int x1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

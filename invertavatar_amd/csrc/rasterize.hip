@@ -1,0 +1,248 @@
+// ia_rasterize_level / ia_blend_planes: the glue between the three StyleGAN2 backbones and the renderer.
+//
+// ia_rasterize_level -- one pyramid level of TriPlaneGenerator.rasterize
+// (training_avatar_texture/triplane_v20.py:328-337) in ONE pass:
+//     rend = AA_resize( grid_sample(texture_k, uv) , 256 -> res )          (F.grid_sample + F.interpolate(antialias=True))
+//     a    = AA_resize( alpha, 256 -> res )
+//     s    = AA_resize( static_k[:, :, bbox], bbox -> res )                 (2x up-sampling of the face crop)
+//     out[:, :C] = rend * a + s * (1 - a);   out[:, C] = AA_resize( upper_mouth_alpha, 256 -> res )
+// The reference materialises the 256^2 x C grid_sample result (134 MB at C = 512) and three resized tensors per
+// level.  Here a workgroup owns 4 horizontally adjacent output pixels: it builds, once, the list of source pixels
+// of their anti-aliasing footprint with the four bilinear (texel, weight) pairs of each (LDS), then every thread
+// (= one channel of the CHANNELS-LAST texture, so each gather is a coalesced 256-byte line per wave) walks that
+// list.  Weights follow aten's _upsample_bilinear2d_aa and grid_sampler_2d (C4) in fp32.
+//
+// ia_blend_planes -- the plane blend of triplane_v20.py:119-128 fused with the layout change the renderer wants:
+// AA-resize the face stitch + alpha to 128^2, paste into the bbox of plane 0, blend over the static planes and
+// write the three planes channels-last [B,3,256,256,32].
+#include "ia_common.h"
+
+namespace {
+
+constexpr int kSrc = 256;                  // UV / alpha maps are 256 x 256 (triplane_v20.py:114,322)
+constexpr int PXB = 4;                     // output pixels per workgroup (one float4 store per channel)
+constexpr int kMaxScale = 8;
+constexpr int kMaxRows = 2 * kMaxScale, kMaxCols = (PXB + 1) * kMaxScale;
+
+// aten's anti-aliased triangle filter along one axis: taps [lo, hi) and their normalised weights for output o.
+__device__ __forceinline__ void aa_taps(int o, int n_in, int n_out, int& lo, int& hi, float& center, float& inv, float& total) {
+    const float scale = (float)n_in / (float)n_out;
+    const float support = scale >= 1.f ? scale : 1.f;
+    inv = scale >= 1.f ? 1.f / scale : 1.f;
+    center = scale * ((float)o + 0.5f);
+    lo = max((int)(center - support + 0.5f), 0);
+    hi = min((int)(center + support + 0.5f), n_in);
+    total = 0.f;
+    for (int j = lo; j < hi; ++j) total += fmaxf(0.f, 1.f - fabsf(((float)j - center + 0.5f) * inv));
+}
+__device__ __forceinline__ float aa_weight(int j, float center, float inv, float total) {
+    return fmaxf(0.f, 1.f - fabsf(((float)j - center + 0.5f) * inv)) / total;
+}
+
+struct RastParams {
+    const float* tex_cl;      // [B][Rt][Rt][C]  channels-last texture level
+    const float* uv;          // [B][256][256][3] (u, v, mask)
+    const float* upper;       // [B][256][256]    clamp(mask + upper mouth mask)
+    const float* sta;         // static feature level, NCHW view: element (b,c,y,x) at b*sta_bs + c*Rs*Rs + y*Rs + x
+    float* out;               // [B][C+1][res][res]
+    int64_t sta_bs;
+    int B, C, Rt, Rs, res;
+    int by0, by1, bx0, bx1;   // crop of the static level that is resized to res
+};
+
+__global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
+    __shared__ int4 s_idx[kMaxRows * kMaxCols];     // 4 texel indices (pre-multiplied by C) per source pixel
+    __shared__ float4 s_w[kMaxRows * kMaxCols];     // 4 bilinear weights * row AA weight (0 for padding)
+    __shared__ float4 s_wx[kMaxCols];               // column AA weight of each source column for the 4 output pixels
+    __shared__ float s_alpha[kMaxRows * kMaxCols], s_upper[kMaxRows * kMaxCols];
+    __shared__ float s_a[PXB], s_u[PXB];
+
+    const int tid = threadIdx.x;
+    const int xt = blockIdx.x * PXB, y = blockIdx.y, b = blockIdx.z;
+    const int res = p.res;
+
+    // ---- AA footprint: rows of output row y, columns of output pixels xt .. xt+3
+    int ylo, yhi; float yc, yinv, ytot;
+    aa_taps(y, kSrc, res, ylo, yhi, yc, yinv, ytot);
+    int xlo[PXB], xhi[PXB]; float xc[PXB], xinv[PXB], xtot[PXB];
+#pragma unroll
+    for (int k = 0; k < PXB; ++k) aa_taps(min(xt + k, res - 1), kSrc, res, xlo[k], xhi[k], xc[k], xinv[k], xtot[k]);
+    const int c0 = xlo[0], ncols = xhi[PXB - 1] - c0, nrows = yhi - ylo, nsrc = nrows * ncols;
+
+    for (int i = tid; i < ncols; i += 256) {
+        const int X = c0 + i;
+        float w[PXB];
+#pragma unroll
+        for (int k = 0; k < PXB; ++k) w[k] = (X >= xlo[k] && X < xhi[k] && xt + k < res) ? aa_weight(X, xc[k], xinv[k], xtot[k]) : 0.f;
+        s_wx[i] = make_float4(w[0], w[1], w[2], w[3]);
+    }
+    const float* uvb = p.uv + (int64_t)b * kSrc * kSrc * 3;
+    const float* upb = p.upper + (int64_t)b * kSrc * kSrc;
+    const int Rt = p.Rt;
+    for (int i = tid; i < nsrc; i += 256) {
+        const int r = i / ncols, cidx = i - r * ncols;
+        const int Y = ylo + r, X = c0 + cidx;
+        const float wy = aa_weight(Y, yc, yinv, ytot);
+        const float* px = uvb + ((int64_t)Y * kSrc + X) * 3;
+        const float gx = px[0], gy = px[1];
+        // grid_sampler_2d, bilinear, zeros, align_corners = False
+        const float ix = (gx + 1.f) * (0.5f * (float)Rt) - 0.5f, iy = (gy + 1.f) * (0.5f * (float)Rt) - 0.5f;
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float fx = ix - x0f, fy = iy - y0f;
+        const int x0 = (int)fminf(fmaxf(x0f, -2.f), (float)Rt + 1.f), y0 = (int)fminf(fmaxf(y0f, -2.f), (float)Rt + 1.f);
+        int id[4]; float w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+            const bool ok = xi >= 0 && xi < Rt && yi >= 0 && yi < Rt;
+            id[t] = ok ? (yi * Rt + xi) * p.C : 0;
+            w[t] = ok ? ((t & 1) ? fx : 1.f - fx) * ((t >> 1) ? fy : 1.f - fy) * wy : 0.f;
+        }
+        s_idx[i] = make_int4(id[0], id[1], id[2], id[3]);
+        s_w[i] = make_float4(w[0], w[1], w[2], w[3]);
+        s_alpha[i] = px[2] * wy;
+        s_upper[i] = upb[(int64_t)Y * kSrc + X] * wy;
+    }
+    __syncthreads();
+    // ---- resized alpha / upper-mouth alpha of the 4 output pixels (wave 0)
+    if (tid < 64) {
+        float a[PXB] = {0.f, 0.f, 0.f, 0.f}, u[PXB] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < nsrc; i += 64) {
+            const float4 wx = s_wx[i % ncols];
+            const float av = s_alpha[i], uvv = s_upper[i];
+            a[0] = fmaf(av, wx.x, a[0]); a[1] = fmaf(av, wx.y, a[1]); a[2] = fmaf(av, wx.z, a[2]); a[3] = fmaf(av, wx.w, a[3]);
+            u[0] = fmaf(uvv, wx.x, u[0]); u[1] = fmaf(uvv, wx.y, u[1]); u[2] = fmaf(uvv, wx.z, u[2]); u[3] = fmaf(uvv, wx.w, u[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < PXB; ++k)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { a[k] += __shfl_xor(a[k], off); u[k] += __shfl_xor(u[k], off); }
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < PXB; ++k) { s_a[k] = a[k]; s_u[k] = u[k]; }
+        }
+    }
+    __syncthreads();
+
+    // ---- static crop: 2-tap (per axis) AA up-sampling weights, identical for every channel
+    const int crop_h = p.by1 - p.by0, crop_w = p.bx1 - p.bx0;
+    int sylo, syhi; float syc, syinv, sytot;
+    aa_taps(y, crop_h, res, sylo, syhi, syc, syinv, sytot);
+    int sxlo[PXB], sxhi[PXB]; float sxc[PXB], sxinv[PXB], sxtot[PXB];
+#pragma unroll
+    for (int k = 0; k < PXB; ++k) aa_taps(min(xt + k, res - 1), crop_w, res, sxlo[k], sxhi[k], sxc[k], sxinv[k], sxtot[k]);
+
+    const float* texb = p.tex_cl + (int64_t)b * Rt * Rt * p.C;
+    const int64_t rr = (int64_t)res * res;
+    float* outb = p.out + (int64_t)b * (p.C + 1) * rr + (int64_t)y * res + xt;
+    const bool vec_ok = (xt + PXB <= res) && (res % 4 == 0);
+    for (int c = tid; c < p.C; c += 256) {
+        float acc[PXB] = {0.f, 0.f, 0.f, 0.f};
+        const float* tc = texb + c;
+        for (int i = 0; i < nsrc; ++i) {
+            const int4 id = s_idx[i];
+            const float4 w = s_w[i];
+            const float4 wx = s_wx[i % ncols];
+            float v = tc[id.x] * w.x;
+            v = fmaf(tc[id.y], w.y, v);
+            v = fmaf(tc[id.z], w.z, v);
+            v = fmaf(tc[id.w], w.w, v);
+            acc[0] = fmaf(v, wx.x, acc[0]); acc[1] = fmaf(v, wx.y, acc[1]);
+            acc[2] = fmaf(v, wx.z, acc[2]); acc[3] = fmaf(v, wx.w, acc[3]);
+        }
+        const float* sc = p.sta + (int64_t)b * p.sta_bs + (int64_t)c * p.Rs * p.Rs;
+        float o[PXB];
+#pragma unroll
+        for (int k = 0; k < PXB; ++k) {
+            float sv = 0.f;
+            for (int j = sylo; j < syhi; ++j) {
+                const float wj = aa_weight(j, syc, syinv, sytot);
+                for (int i = sxlo[k]; i < sxhi[k]; ++i)
+                    sv = fmaf(sc[(int64_t)(p.by0 + j) * p.Rs + p.bx0 + i], wj * aa_weight(i, sxc[k], sxinv[k], sxtot[k]), sv);
+            }
+            const float a = s_a[k];
+            o[k] = acc[k] * a + sv * (1.f - a);
+        }
+        float* dst = outb + (int64_t)c * rr;
+        if (vec_ok) *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+        else for (int k = 0; k < PXB && xt + k < res; ++k) dst[k] = o[k];
+    }
+    if (tid < PXB && xt + tid < res) outb[(int64_t)p.C * rr + tid] = s_u[tid];
+}
+
+struct BlendParams {
+    const float* stitch;     // [B][32][256][256]
+    const float* alpha;      // [B][256][256]      full (mouth-filled) alpha
+    const float* sta;        // static planes: element (b, plane, c, y, x) at b*sta_bs + (plane*32 + c)*65536 + y*256 + x
+    float* planes_cl;        // [B][3][256][256][32]
+    int64_t sta_bs;
+    int B, y0, y1, x0, x1;   // bbox of the 128^2 paste (triplane_v20.py:114)
+};
+
+// One thread per (b, plane, y, x): 32 channels.  Plane 0 inside the bbox: AA 256->128 resize of stitch and alpha.
+__global__ __launch_bounds__(256) void blend_planes_kernel(BlendParams p) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int plane = blockIdx.z % 3, b = blockIdx.z / 3;
+    const float* st = p.sta + (int64_t)b * p.sta_bs + (int64_t)plane * 32 * 65536 + (int64_t)y * 256 + x;
+    float v[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = st[(int64_t)c * 65536];
+    if (plane == 0 && y >= p.y0 && y < p.y1 && x >= p.x0 && x < p.x1) {
+        const int oy = y - p.y0, ox = x - p.x0, n_out = p.y1 - p.y0;       // 128
+        int ylo, yhi, xlo, xhi; float yc, yinv, ytot, xc, xinv, xtot;
+        aa_taps(oy, 256, n_out, ylo, yhi, yc, yinv, ytot);
+        aa_taps(ox, 256, n_out, xlo, xhi, xc, xinv, xtot);
+        float a = 0.f, s[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) s[c] = 0.f;
+        const float* sb = p.stitch + (int64_t)b * 32 * 65536;
+        const float* ab = p.alpha + (int64_t)b * 65536;
+        // aten resizes separably (rows of the horizontal pass feed the vertical pass); the two-pass order is kept
+        for (int j = ylo; j < yhi; ++j) {
+            const float wy = aa_weight(j, yc, yinv, ytot);
+            float ra = 0.f, rs[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) rs[c] = 0.f;
+            for (int i = xlo; i < xhi; ++i) {
+                const float wx = aa_weight(i, xc, xinv, xtot);
+                ra = fmaf(ab[j * 256 + i], wx, ra);
+#pragma unroll
+                for (int c = 0; c < 32; ++c) rs[c] = fmaf(sb[(int64_t)c * 65536 + j * 256 + i], wx, rs[c]);
+            }
+            a = fmaf(ra, wy, a);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) s[c] = fmaf(rs[c], wy, s[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v[c] = s[c] * a + v[c] * (1.f - a);
+    }
+    float4* dst = (float4*)(p.planes_cl + ((((int64_t)b * 3 + plane) * 256 + y) * 256 + x) * 32);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dst[c] = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+}
+
+}  // namespace
+
+extern "C" int ia_rasterize_level(const float* tex_cl, const float* uv, const float* upper_alpha, const float* sta, int64_t sta_batch_stride,
+                                  float* out, int B, int C, int tex_res, int sta_res, int res, int by0, int by1, int bx0, int bx1,
+                                  void* stream) {
+    IA_REQUIRE(tex_cl && uv && upper_alpha && sta && out, "null pointer argument");
+    IA_REQUIRE(B > 0 && C > 0 && tex_res > 0 && sta_res > 0 && res > 0, "empty tensor");
+    IA_REQUIRE(by0 >= 0 && by1 > by0 && by1 <= sta_res && bx0 >= 0 && bx1 > bx0 && bx1 <= sta_res, "bbox outside the static level");
+    if (res > kSrc || kSrc % res != 0 || kSrc / res > kMaxScale || kSrc / res < 2)
+        return ia::fail(IA_ERR_UNSUPPORTED, "rasterize level resolution %d: supported are 32, 64, 128 (256 -> res by 8, 4, 2)", res);
+    RastParams p{tex_cl, uv, upper_alpha, sta, out, sta_batch_stride, B, C, tex_res, sta_res, res, by0, by1, bx0, bx1};
+    dim3 grid((res + PXB - 1) / PXB, res, B);
+    hipLaunchKernelGGL(rasterize_level_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return ia::check_launch("ia_rasterize_level");
+}
+
+extern "C" int ia_blend_planes(const float* stitch, const float* full_alpha, const float* static_planes, int64_t sta_batch_stride,
+                               float* planes_cl, int B, int y0, int y1, int x0, int x1, void* stream) {
+    IA_REQUIRE(stitch && full_alpha && static_planes && planes_cl, "null pointer argument");
+    IA_REQUIRE(B > 0, "empty tensor");
+    IA_REQUIRE(y0 >= 0 && y1 <= 256 && x0 >= 0 && x1 <= 256 && y1 - y0 == x1 - x0 && y1 > y0, "bbox must be a square inside 256^2");
+    BlendParams p{stitch, full_alpha, static_planes, planes_cl, sta_batch_stride, B, y0, y1, x0, x1};
+    hipLaunchKernelGGL(blend_planes_kernel, dim3(4, 64, 3 * B), dim3(256), 0, (hipStream_t)stream, p);
+    return ia::check_launch("ia_blend_planes");
+}

@@ -190,3 +190,34 @@ def fill_mouth(alpha):
         st = _lib.load().ia_fill_mouth(_p(alpha), _p(mouth), b * one, h, w, _lib.stream_ptr(alpha.device))
     _lib.check(st, 'ia_fill_mouth')
     return mouth
+
+
+def rasterize_level(tex, uvcoords_image, upper_alpha, sta, bbox, res):
+    """One level of TriPlaneGenerator.rasterize (see ia_rasterize_level).  tex [B,C,Rt,Rt]; sta NCHW (may be a channel
+    slice of a wider tensor as long as channels/rows are dense); returns [B, C+1, res, res]."""
+    b, c, rt, _ = tex.shape
+    tex_cl = tex.permute(0, 2, 3, 1).contiguous()
+    rs = sta.shape[-1]
+    if not (sta.stride(3) == 1 and sta.stride(2) == rs and sta.stride(1) == rs * rs and sta.shape[1] >= c):
+        sta = sta.contiguous()
+    out = torch.empty(b, c + 1, res, res, device=tex.device, dtype=torch.float32)
+    y0, y1, x0, x1 = bbox
+    with torch.cuda.device(tex.device):
+        st = _lib.load().ia_rasterize_level(_p(_f32c(tex_cl, 'tex')), _p(_f32c(uvcoords_image, 'uvcoords_image')),
+                                            _p(_f32c(upper_alpha, 'upper_alpha')), sta.data_ptr(), sta.stride(0), _p(out),
+                                            b, c, rt, rs, res, y0, y1, x0, x1, _lib.stream_ptr(tex.device))
+    _lib.check(st, 'ia_rasterize_level')
+    return out
+
+
+def blend_planes(stitch, full_alpha, static_planes, bbox):
+    """Channels-last blended tri-planes [B,3,256,256,32] (see ia_blend_planes).  static_planes [B,96,256,256]."""
+    b = stitch.shape[0]
+    planes_cl = torch.empty(b, 3, 256, 256, 32, device=stitch.device, dtype=torch.float32)
+    y0, y1, x0, x1 = bbox
+    with torch.cuda.device(stitch.device):
+        st = _lib.load().ia_blend_planes(_p(_f32c(stitch, 'stitch')), _p(_f32c(full_alpha, 'full_alpha')),
+                                         _p(_f32c(static_planes, 'static_planes')), static_planes.stride(0), _p(planes_cl),
+                                         b, y0, y1, x0, x1, _lib.stream_ptr(stitch.device))
+    _lib.check(st, 'ia_blend_planes')
+    return planes_cl

@@ -43,10 +43,10 @@ class _PackedWeights:
         self.wk = None
         self.wsq = None
 
-    def get(self, weight):
-        key = (weight.data_ptr(), weight._version, weight.device, weight.dtype)
+    def get(self, weight, scale=1.0):
+        key = (weight.data_ptr(), weight._version, weight.device, weight.dtype, scale)
         if key != self.key:
-            w32 = weight.detach().float()
+            w32 = weight.detach().float() * scale if scale != 1.0 else weight.detach().float()
             self.wk = hipops.pack_conv_weight(w32)
             self.wsq = hipops.weight_sq_sum(w32)
             self.key = key
@@ -139,8 +139,22 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
         self.weight_gain = lr_multiplier / np.sqrt(in_features)
         self.bias_gain = lr_multiplier
+        self._scaled = None   # (key, weight^T * gain, bias * gain): inference-time cache of the equalised-lr scaling
+
+    def _scaled_params(self, dtype):
+        key = (self.weight.data_ptr(), self.weight._version, None if self.bias is None else self.bias._version, dtype, self.weight.device)
+        if self._scaled is None or self._scaled[0] != key:
+            wt = (self.weight.detach().to(dtype) * self.weight_gain).t().contiguous()
+            b = None if self.bias is None else (self.bias.detach().to(dtype) * self.bias_gain).unsqueeze(0).contiguous()
+            self._scaled = (key, wt, b)
+        return self._scaled[1], self._scaled[2]
 
     def forward(self, x):
+        if not _needs_autograd(x, self.weight, self.bias):
+            wt, b = self._scaled_params(x.dtype)
+            if self.activation == 'linear' and b is not None:
+                return torch.addmm(b, x, wt)
+            return bias_act.bias_act(x.matmul(wt), None if b is None else b.squeeze(0), act=self.activation)
         w = self.weight.to(x.dtype) * self.weight_gain
         b = self.bias
         if b is not None:
@@ -346,12 +360,13 @@ class ToRGBLayer(torch.nn.Module):
     def forward(self, x, w, fused_modconv=True, residual=None):
         """`residual` (fp32, output-shaped) is added after the clamp: the skip-image add of
         SynthesisBlock folded into this layer's epilogue on the device path."""
-        styles = self.affine(w) * self.weight_gain
         if _on_device(x) and self.weight.shape[2] == 1 and not _needs_autograd(x, w, self.weight, self.bias, residual):
-            wk, _ = self._packed.get(self.weight)
+            # weight_gain is folded into the packed weight instead of scaling the styles on every call
+            wk, _ = self._packed.get(self.weight, scale=self.weight_gain)
             res = None if residual is None else residual.float().contiguous()
-            return hipops.conv2d_mfma(x.float().contiguous(), wk, styles.float().contiguous(), None, bias=self.bias.detach().float(),
-                                      residual=res, ksize=1, act='linear', clamp=self.conv_clamp)
+            return hipops.conv2d_mfma(x.float().contiguous(), wk, self.affine(w).float().contiguous(), None,
+                                      bias=self.bias.detach().float(), residual=res, ksize=1, act='linear', clamp=self.conv_clamp)
+        styles = self.affine(w) * self.weight_gain
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         x = bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
         if residual is not None:

@@ -21,7 +21,7 @@ the stratified-sampling noise can be injected (``jitter=``) for reproducible eva
 import torch
 import torch.nn.functional as F
 
-from .. import dnnlib
+from .. import dnnlib, hipops
 from ..torch_utils import persistence
 from ..training.networks_stylegan2 import FullyConnectedLayer
 from .networks_stylegan2_new import Generator as StyleGAN2Backbone_cond
@@ -90,6 +90,14 @@ class TriPlaneGenerator(torch.nn.Module):
 
     def _blend_planes(self, stitch, full_alpha, static_plane):
         """Paste the 128^2-resized face stitch + alpha into the bbox of plane 0; planes 1-2 stay static (:119-128)."""
+        if (stitch.is_cuda and stitch.dtype == torch.float32 and stitch.shape[1:] == (32, 256, 256) and not torch.is_grad_enabled()
+                and static_plane.shape[1:] == (3, 32, 256, 256)):
+            # fused AA-resize + paste + blend, emitted channels-last; returned as the NCHW-shaped view of that buffer
+            b = stitch.shape[0]
+            sta = static_plane.reshape(b, 96, 256, 256)
+            sta = sta if sta.is_contiguous() else sta.contiguous()
+            cl = hipops.blend_planes(stitch.contiguous(), full_alpha.reshape(b, 256, 256).contiguous(), sta, BBOX_256)
+            return cl.permute(0, 1, 4, 2, 3)
         y0, y1, x0, x1 = BBOX_256
         canvas = torch.zeros_like(stitch)
         alpha = torch.zeros_like(full_alpha)
@@ -179,9 +187,15 @@ class TriPlaneGenerator(torch.nn.Module):
         upper_alpha = torch.clamp(alpha + upper, min=0, max=1)
         out = []
         n = len(texture_feats) if levels is None else min(levels, len(texture_feats))
+        fused = uv.is_cuda and uv.shape[1:3] == (256, 256) and not torch.is_grad_enabled()
+        uv_c = uv.contiguous() if fused else None
+        upper_c = upper_alpha.reshape(-1, 256, 256).contiguous() if fused else None
         for tex, sta in zip(texture_feats[:n], static_feats[:n]):
             res = tex.shape[2]
             y0, y1, x0, x1 = [round(v * res / 256) for v in bbox_256]
+            if fused and res in (32, 64, 128) and tex.dtype == torch.float32 and sta.dtype == torch.float32:
+                out.append(hipops.rasterize_level(tex, uv_c, upper_c, sta, (y0, y1, x0, x1), res))
+                continue
             rend = _aa_resize(F.grid_sample(tex, grid, align_corners=False), res)
             a = _aa_resize(alpha, res)
             s = _aa_resize(sta[:, :, y0:y1, x0:x1], res)

@@ -195,7 +195,10 @@ class ImportanceRenderer_bsMotion(_RendererBase):
             jitter = jitter.to(device=planes.device, dtype=torch.float32).reshape(b, r, n_coarse).contiguous()
             dist = torch.norm(ray_origins, dim=-1).mean().reshape(1)      # stays on the device: no host sync
             lr_mul = float(decoder.net[0].bias_gain)
-            return hipops.render_rays(hipops.planes_channels_last(planes), ray_origins.contiguous(), ray_directions.contiguous(),
+            planes_cl = planes.permute(0, 1, 3, 4, 2)          # free when the planes already live channels-last
+            if not planes_cl.is_contiguous():
+                planes_cl = planes_cl.contiguous()
+            return hipops.render_rays(planes_cl, ray_origins.contiguous(), ray_directions.contiguous(),
                                       jitter, dist, decoder.net[0].weight.detach(), decoder.net[0].bias.detach(),
                                       decoder.net[2].weight.detach(), decoder.net[2].bias.detach(), lr_multiplier=lr_mul,
                                       box_warp=rendering_options['box_warp'], white_back=rendering_options.get('white_back', False))

@@ -93,3 +93,33 @@ def test_fill_mouth_known_answers_on_device(golden):
     cpu_full, cpu_mouth = fill_mouth(m.clone(), blur_mouth_edge=False)
     dev_full, dev_mouth = fill_mouth(m.cuda(), blur_mouth_edge=False)
     assert torch.equal(dev_mouth.cpu(), cpu_mouth) and torch.equal(dev_full.cpu(), cpu_full)
+
+
+def test_rasterize_and_blend_kernels_vs_oracle():
+    """ia_rasterize_level / ia_blend_planes against the oracle's rasterize / blend_planes on random feature pyramids."""
+    from oracle import generator as OG
+    from conftest import rnd
+    frames = [17, 100]
+    uv = synthetic.uv_conditions(frames)
+    # make the UV lookup non-trivial: a smooth warp that also leaves the texture on one side (zero padding)
+    uv[..., 0] = uv[..., 0] * 1.05 + 0.04 * torch.sin(3 * uv[..., 1])
+    uv[..., 1] = uv[..., 1] * 0.9 - 0.1
+    chans = [(32, 32), (48, 32), (40, 64), (24, 128)]
+    tex = [rnd(40 + i, 2, c, r, r) for i, (c, r) in enumerate(chans)] + [rnd(50, 2, 8, 256, 256), rnd(51, 2, 32, 256, 256)]
+    sta = [rnd(60, 2, 96, 32, 32)] + [rnd(61 + i, 2, c, r, r) for i, (c, r) in enumerate(chans[1:])] + \
+          [rnd(70, 2, 8, 256, 256), rnd(71, 2, 96, 256, 256)]
+    sta_split, sta_plane = OG.split_static(sta)
+    ref_cond, ref_full, _ = OG.rasterize(tex, uv, sta_split)
+    g = TriPlaneGenerator(**synthetic.generator_kwargs('small')).eval().requires_grad_(False).cuda()
+    with torch.no_grad():
+        split_dev, plane_dev = g._split_static([t.cuda() for t in sta])
+        cond, full, _ = g.rasterize([t.cuda() for t in tex], uv.cuda(), split_dev, [57, 185, 64, 192], levels=4)
+        assert len(cond) == 4
+        for i, (a, b) in enumerate(zip(cond, ref_cond)):
+            assert a.shape == b.shape and max_abs(a.cpu(), b) <= 2e-5, (i, max_abs(a.cpu(), b))
+        assert torch.equal(full.cpu(), ref_full)
+        stitch = rnd(80, 2, 32, 256, 256)
+        ref_planes = OG.blend_planes(stitch, ref_full, sta_plane)
+        planes = g._blend_planes(stitch.cuda(), full, plane_dev)
+        assert planes.shape == ref_planes.shape and max_abs(planes.cpu(), ref_planes) <= 2e-5
+        assert planes.permute(0, 1, 3, 4, 2).is_contiguous()
