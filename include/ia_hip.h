@@ -207,6 +207,23 @@ int ia_rasterize_level(const float* tex_cl, const float* uv, const float* upper_
 int ia_blend_planes(const float* stitch, const float* full_alpha, const float* static_planes, int64_t sta_batch_stride,
                     float* planes_cl, int B, int y0, int y1, int x0, int x1, void* stream);
 
+/*
+ * All affine style vectors and demodulation coefficients of one synthesis network in two launches.
+ * Replaces, per layer, FullyConnectedLayer.forward of `.affine` (training/networks_stylegan2.py:114-127, called at :318
+ * and :353) and the demodulation reduction of modulated_conv2d (:60-64):
+ *     styles[b, soff_l + i] = dot(ws[b, widx_l, :], A_l[i, :]) * wgain_l + bias_l[i] * bgain_l
+ *     demod[b, doff_l + o]  = rsqrt(sum_i styles[b, soff_l + i]^2 * wsq_l[o, i] + 1e-8)
+ *   ws          : [B, num_ws, w_dim] float32
+ *   layer_table : device int64 [L][8] = {A ptr ([I,w_dim] f32), bias ptr ([I] f32), wsq ptr ([O,I] f32 or 0), I, O, widx, soff, doff}
+ *   layer_gains : device float [L][2] = {weight gain, bias gain}
+ *   style_row_layer [style_rows] / demod_row_layer [demod_rows] : device int32 maps from output row to layer
+ *   styles : style_rows * B floats, LAYER-major: layer l occupies [B*soff_l, B*(soff_l+I_l)) as a contiguous [B, I_l] matrix;
+ *   demod  : demod_rows * B floats, same scheme with doff_l / O_l.  All tables are caller-owned and only read during the call.
+ */
+int ia_styles_demod(const float* ws, int B, int num_ws, int w_dim, const int64_t* layer_table, const float* layer_gains,
+                    const int* style_row_layer, int style_rows, const int* demod_row_layer, int demod_rows,
+                    float* styles, float* demod, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

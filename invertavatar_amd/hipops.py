@@ -221,3 +221,72 @@ def blend_planes(stitch, full_alpha, static_planes, bbox):
                                          b, y0, y1, x0, x1, _lib.stream_ptr(stitch.device))
     _lib.check(st, 'ia_blend_planes')
     return planes_cl
+
+
+class StylePlan:
+    """Device tables describing every modulated layer of one synthesis network (see ia_styles_demod).
+
+    `layers` is a list of (module, w_index): module has .affine (FullyConnectedLayer), .weight and `demodulate`
+    semantics given by `hasattr(module, 'noise_strength') or module is a SynthesisLayer` -> passed explicitly."""
+
+    def __init__(self, entries, device):
+        # entries: list of dict(affine=FC module, weight=conv weight param, widx=int, demod=bool)
+        self.entries = entries
+        self.device = device
+        self.key = None
+        self._build()
+
+    def _signature(self):
+        sig = []
+        for e in self.entries:
+            sig += [e['affine'].weight.data_ptr(), e['affine'].weight._version, e['weight'].data_ptr(), e['weight']._version]
+        return tuple(sig)
+
+    def _build(self):
+        rows, soff, doff = [], 0, 0
+        table, gains, srl, drl = [], [], [], []
+        self.keep = []
+        for li, e in enumerate(self.entries):
+            fc = e['affine']
+            a = fc.weight.detach().float().contiguous()
+            bias = fc.bias.detach().float().contiguous() if fc.bias is not None else None
+            i_dim = a.shape[0]
+            wsq = weight_sq_sum(e['weight']) if e['demod'] else None
+            o_dim = e['weight'].shape[0]
+            self.keep += [a, bias, wsq]
+            table.append([a.data_ptr(), bias.data_ptr() if bias is not None else 0, wsq.data_ptr() if wsq is not None else 0,
+                          i_dim, o_dim, e['widx'], soff, doff if e['demod'] else -1])
+            gains.append([float(fc.weight_gain), float(fc.bias_gain)])
+            srl += [li] * i_dim
+            e['soff'], e['I'] = soff, i_dim
+            soff += i_dim
+            if e['demod']:
+                drl += [li] * o_dim
+                e['doff'], e['O'] = doff, o_dim
+                doff += o_dim
+        dev = self.device
+        self.table = torch.tensor(table, dtype=torch.int64, device=dev)
+        self.gains = torch.tensor(gains, dtype=torch.float32, device=dev)
+        self.srl = torch.tensor(srl, dtype=torch.int32, device=dev)
+        self.drl = torch.tensor(drl if drl else [0], dtype=torch.int32, device=dev)
+        self.srows, self.drows = soff, doff
+        self.key = self._signature()
+
+    def run(self, ws):
+        """ws [B, num_ws, w_dim] -> list of (styles [B,I], demod [B,O] or None) per entry (views into two buffers)."""
+        if self._signature() != self.key:
+            self._build()
+        ws = _f32c(ws.float().contiguous(), 'ws')
+        b, num_ws, w_dim = ws.shape
+        styles = torch.empty(b * self.srows, device=ws.device)
+        demod = torch.empty(b * max(self.drows, 1), device=ws.device)
+        with torch.cuda.device(ws.device):
+            st = _lib.load().ia_styles_demod(_p(ws), b, num_ws, w_dim, _p(self.table), _p(self.gains), _p(self.srl), self.srows,
+                                             _p(self.drl), self.drows, _p(styles), _p(demod), _lib.stream_ptr(ws.device))
+        _lib.check(st, 'ia_styles_demod')
+        out = []
+        for e in self.entries:
+            s = styles[b * e['soff']:b * (e['soff'] + e['I'])].view(b, e['I'])
+            d = demod[b * e['doff']:b * (e['doff'] + e['O'])].view(b, e['O']) if e['demod'] else None
+            out.append((s, d))
+        return out

@@ -291,12 +291,14 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self._packed = _PackedWeights()
+        self._pre = None   # (styles, demod) computed for this call by the owning network's StylePlan
 
-    def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp):
+    def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp, demod=None):
         """conv + demod + noise + bias + lrelu + clamp on the MFMA path (one or two launches)."""
         wk, wsq = self._packed.get(self.weight)
         styles = styles.float().contiguous()
-        demod = hipops.modconv_demod(styles, wsq)
+        if demod is None:
+            demod = hipops.modconv_demod(styles, wsq)
         x = x.float().contiguous()
         const_noise = self.use_noise and noise_mode == 'const'
         nz = self.noise_const.reshape(-1) if const_noise else None
@@ -322,12 +324,14 @@ class SynthesisLayer(torch.nn.Module):
         assert noise_mode in ['random', 'const', 'none']
         in_res = self.resolution // self.up
         misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
-        styles = self.affine(w)
+        pre, self._pre = self._pre, None
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         if (_on_device(x) and self.activation in hipops.ACT_ID and self.weight.shape[2] == 3 and self.up in (1, 2)
                 and not _needs_autograd(x, w, self.weight, self.bias)):
-            return self._fused_device_forward(x, styles, noise_mode, act_gain, act_clamp).to(x.dtype)
+            styles, demod = pre if pre is not None else (self.affine(w), None)
+            return self._fused_device_forward(x, styles, noise_mode, act_gain, act_clamp, demod).to(x.dtype)
+        styles = self.affine(w)
         noise = None
         if self.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
@@ -356,6 +360,7 @@ class ToRGBLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
         self._packed = _PackedWeights()
+        self._pre = None
 
     def forward(self, x, w, fused_modconv=True, residual=None):
         """`residual` (fp32, output-shaped) is added after the clamp: the skip-image add of
@@ -364,7 +369,9 @@ class ToRGBLayer(torch.nn.Module):
             # weight_gain is folded into the packed weight instead of scaling the styles on every call
             wk, _ = self._packed.get(self.weight, scale=self.weight_gain)
             res = None if residual is None else residual.float().contiguous()
-            return hipops.conv2d_mfma(x.float().contiguous(), wk, self.affine(w).float().contiguous(), None,
+            pre, self._pre = self._pre, None
+            styles = pre[0] if pre is not None else self.affine(w).float().contiguous()
+            return hipops.conv2d_mfma(x.float().contiguous(), wk, styles, None,
                                       bias=self.bias.detach().float(), residual=res, ksize=1, act='linear', clamp=self.conv_clamp)
         styles = self.affine(w) * self.weight_gain
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
@@ -468,6 +475,41 @@ class SynthesisBlock(torch.nn.Module):
         return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
 
 
+def _modulated_layers(block):
+    """(layer, index into the block's ws, demodulate?) in the order SynthesisBlock.forward consumes ws."""
+    out, k = [], 0
+    if block.in_channels != 0:
+        out.append((block.conv0, k, True)); k += 1
+    out.append((block.conv1, k, True)); k += 1
+    if block.is_last or block.architecture == 'skip':
+        out.append((block.torgb, k, False))
+    return out
+
+
+class _StyleBatcher:
+    """Computes the styles / demodulation coefficients of all layers of a list of blocks in two launches
+    (``ia_styles_demod``) and parks them on the layers for the forward pass that follows."""
+
+    def __init__(self):
+        self.plan = None
+        self.layers = None
+
+    def prepare(self, blocks, ws_offsets, ws, enabled=True):
+        if not (enabled and ws.is_cuda and not _needs_autograd(ws) and not torch.is_grad_enabled()):
+            return
+        if self.plan is None or self.plan.device != ws.device:
+            entries, self.layers = [], []
+            for block, off in zip(blocks, ws_offsets):
+                if block.architecture == 'resnet':
+                    return
+                for layer, k, demod in _modulated_layers(block):
+                    entries.append(dict(affine=layer.affine, weight=layer.weight, widx=off + k, demod=demod))
+                    self.layers.append(layer)
+            self.plan = hipops.StylePlan(entries, ws.device)
+        for layer, pre in zip(self.layers, self.plan.run(ws)):
+            layer._pre = pre
+
+
 def _block_plan(img_resolution, channel_base, channel_max, num_fp16_res):
     log2 = int(np.log2(img_resolution))
     resolutions = [2 ** i for i in range(2, log2 + 1)]
@@ -498,6 +540,16 @@ class SynthesisNetwork(torch.nn.Module):
             if res == img_resolution:
                 self.num_ws += block.num_torgb
             setattr(self, f'b{res}', block)
+        self._style_batcher = _StyleBatcher()
+
+    def _prepare_styles(self, ws):
+        """Batch every affine + demodulation of this network (device inference path only)."""
+        blocks = [getattr(self, f'b{res}') for res in self.block_resolutions]
+        offs, idx = [], 0
+        for blk in blocks:
+            offs.append(idx)
+            idx += blk.num_conv
+        self._style_batcher.prepare(blocks, offs, ws.to(torch.float32))
 
     def _split_ws(self, ws):
         out, idx = [], 0
@@ -512,6 +564,7 @@ class SynthesisNetwork(torch.nn.Module):
 
     def forward(self, ws, **block_kwargs):
         x = img = None
+        self._prepare_styles(ws)
         for res, cur_ws in zip(self.block_resolutions, self._split_ws(ws)):
             x, img = getattr(self, f'b{res}')(x, img, cur_ws, **block_kwargs)
         return img

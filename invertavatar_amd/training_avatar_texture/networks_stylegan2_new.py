@@ -27,6 +27,7 @@ class SynthesisNetwork(_base.SynthesisNetwork):
         last = (self.img_resolution_log2 - 2) if len(out_res) == 1 else (int(np.log2(out_res[1])) - 2)
         x = img = None
         feats, imgs = [], []
+        self._prepare_styles(ws)
         for idx, (res, cur_ws) in enumerate(zip(self.block_resolutions, self._split_ws(ws))):
             cond = feat_conditions[res] if (feat_conditions is not None and res in feat_conditions.keys()) else None
             x, img = getattr(self, f'b{res}')(x, img, cur_ws, cond, **block_kwargs)

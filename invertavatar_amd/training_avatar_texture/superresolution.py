@@ -7,7 +7,7 @@ import torch
 
 from ..torch_utils import misc, persistence
 from ..torch_utils.ops import upfirdn2d
-from ..training.networks_stylegan2 import Conv2dLayer, SynthesisBlock, SynthesisLayer, ToRGBLayer
+from ..training.networks_stylegan2 import Conv2dLayer, SynthesisBlock, SynthesisLayer, ToRGBLayer, _StyleBatcher
 
 
 def _last_w(ws, n=3):
@@ -31,9 +31,16 @@ class _TwoBlockHead(torch.nn.Module):
         self.sr_antialias = sr_antialias
         return sr_num_fp16_res > 0
 
+    def _prepare_styles(self, ws3):
+        if not hasattr(self, '_style_batcher_obj'):
+            object.__setattr__(self, '_style_batcher_obj', _StyleBatcher())
+        if isinstance(self.block0, SynthesisBlock) and isinstance(self.block1, SynthesisBlock):
+            self._style_batcher_obj.prepare([self.block0, self.block1], [0, 0], ws3.to(torch.float32))
+
     def forward(self, rgb, x, ws, **block_kwargs):
         ws = _last_w(ws)
         x, rgb = _fit(x, rgb, self.input_resolution, self.sr_antialias)
+        self._prepare_styles(ws)
         x, rgb = self.block0(x, rgb, ws, **block_kwargs)
         x, rgb = self.block1(x, rgb, ws, **block_kwargs)
         return rgb
