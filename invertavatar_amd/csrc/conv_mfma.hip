@@ -102,7 +102,7 @@ __device__ __forceinline__ float epilogue(float v, int b, int o, int64_t pix, in
 // FO x FP fragments (32 channels x 32 points each) per wave, WO x WP waves per workgroup, CC in-channels per K chunk,
 // NPOS patch positions staged per thread (>= ceil(worst PSZ / threads), chosen by the host).
 template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool PARTIAL>
-__global__ __launch_bounds__(WO * WP * 64) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wk,
+__global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                                  const float* __restrict__ styles, float* __restrict__ y,
                                                                  Geo g, Epi e) {
     constexpr int NT = KS * KS;
@@ -368,7 +368,7 @@ int launch(const float* x, const float* wk, const float* styles, float* y, float
     return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4>(x, wk, styles, y, scratch, g, e, worst, s);
 }
 
-constexpr int kChunkConv = 8, kChunkTransposed = 16;
+constexpr int kChunkConv = 8, kChunkTransposed = 8;
 
 // Tile family per layer shape: (32ch x 256pt) for narrow outputs, (128ch x 128pt) otherwise; the transposed form
 // uses (64ch x 128pt x 4 phases) with 16-channel chunks so that it does as many MFMAs per staged chunk as the conv.

@@ -1,0 +1,50 @@
+"""Frame-sharded data parallelism for batched reenactment.
+
+Frames are independent given (ws, texture/static features), so a batch of frames is split into contiguous
+blocks, one per rank (one process per GPU), and the rendered frames are collected with ONE all-gather over
+RCCL/xGMI.  Two quantities of the reference are batch-global and must not change when the batch is sharded:
+
+  * ``dist`` -- the mean ray-origin norm that sets the depth range (volumetric_rendering/renderer.py:311):
+    computed here from the FULL camera batch on every rank (cameras are 25 floats per frame), no collective;
+  * the depth clamp bounds min/max over all sample depths (ray_marcher.py:50): they only touch ``image_depth`` on
+    rays whose weights vanish; ranks use their local bounds (RGB is unaffected).
+"""
+import torch
+
+
+def shard_range(n_frames, rank, world_size):
+    """Contiguous block [lo, hi) of `n_frames` owned by `rank` (sizes differ by at most one)."""
+    base, extra = divmod(n_frames, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def global_ray_dist(c):
+    """Batch mean of |camera origin| from the labels c [N, >=25]: what torch.norm(ray_origins).mean() evaluates to
+    for the whole batch, since all rays of a frame share one origin."""
+    cam2world = c[:, -25:][:, :16].reshape(-1, 4, 4)
+    return torch.norm(cam2world[:, :3, 3].float(), dim=-1).mean().reshape(1)
+
+
+def render_sharded(generator, ws, c, mesh_condition, rank=0, world_size=1, jitter=None, gather=True, **synthesis_kwargs):
+    """Render frames [lo, hi) of the batch on this rank and all-gather the images.
+
+    ws [N or 1, num_ws, w_dim], c [N, 25+], mesh_condition['uvcoords_image'] [N,256,256,3], jitter [N,R,48] or None.
+    Returns the full [N,3,H,W] batch on every rank (gather=True) or this rank's block."""
+    n = c.shape[0]
+    lo, hi = shard_range(n, rank, world_size)
+    dist = global_ray_dist(c)
+    ws_local = ws[lo:hi] if ws.shape[0] == n else ws.expand(hi - lo, -1, -1)
+    out = generator.synthesis(ws_local, c[lo:hi], {'uvcoords_image': mesh_condition['uvcoords_image'][lo:hi]},
+                              jitter=None if jitter is None else jitter[lo:hi], ray_dist=dist, **synthesis_kwargs)
+    img = out['image'].contiguous()
+    if not gather or world_size == 1:
+        return img
+    sizes = [shard_range(n, r, world_size) for r in range(world_size)]
+    if len({b - a for a, b in sizes}) == 1:      # equal blocks: one all_gather into a preallocated batch
+        full = torch.empty((n,) + tuple(img.shape[1:]), dtype=img.dtype, device=img.device)
+        torch.distributed.all_gather_into_tensor(full, img)
+        return full
+    parts = [torch.empty((b - a,) + tuple(img.shape[1:]), dtype=img.dtype, device=img.device) for a, b in sizes]
+    torch.distributed.all_gather(parts, img)
+    return torch.cat(parts, 0)

@@ -115,10 +115,11 @@ class TriPlaneGenerator(torch.nn.Module):
         stitch = self.face_backbone.synthesis(ws, cond, return_list=False, update_emas=update_emas, **synthesis_kwargs)
         return self._blend_planes(stitch, full_alpha, static_plane)
 
-    def _render(self, ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs):
+    def _render(self, ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist=None):
         if evaluation:
             assert synthesis_kwargs.get('noise_mode') == 'const', ('noise_mode' in synthesis_kwargs, synthesis_kwargs.get('noise_mode'))
-        feats, depth, _ = self.renderer(planes, self.decoder, origins, dirs, self.rendering_kwargs, evaluation=evaluation, jitter=jitter)
+        feats, depth, _ = self.renderer(planes, self.decoder, origins, dirs, self.rendering_kwargs, evaluation=evaluation, jitter=jitter,
+                                        dist=ray_dist)
         n = ws.shape[0]
         feature_image = feats.permute(0, 2, 1).reshape(n, feats.shape[-1], nrr, nrr).contiguous()
         depth_image = depth.permute(0, 2, 1).reshape(n, 1, nrr, nrr)
@@ -129,12 +130,12 @@ class TriPlaneGenerator(torch.nn.Module):
 
     # ------------------------------------------------------------------ public synthesis entry points
     def synthesis(self, ws, c, mesh_condition, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
-                  use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, **synthesis_kwargs):
+                  use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, ray_dist=None, **synthesis_kwargs):
         origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
         texture_feats = self.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
         static_feats = self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
         planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs)
-        image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs)
+        image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist)
         out = {'image': image, 'image_raw': rgb, 'image_depth': depth}
         if return_featmap:
             out.update(feature_image=feature_image, triplane=planes, texture=texture_feats)

@@ -184,7 +184,9 @@ class ImportanceRenderer_bsMotion(_RendererBase):
                 and not options['disparity_space_sampling'] and options.get('clamp_mode') == 'softplus'
                 and options.get('density_noise', 0) == 0 and _is_osg_decoder(decoder) and not torch.is_grad_enabled())
 
-    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, evaluation=False, jitter=None):
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, evaluation=False, jitter=None, dist=None):
+        """`dist` (1-element tensor) overrides the batch mean of |ray origin|: a sharded batch passes the value of the
+        whole batch so that the depth range does not depend on the sharding."""
         if jitter is None:
             jitter, self._jitter = self._jitter, None
         b, r, _ = ray_origins.shape
@@ -193,7 +195,9 @@ class ImportanceRenderer_bsMotion(_RendererBase):
             if jitter is None:
                 jitter = torch.rand(b, r, n_coarse, device=planes.device)
             jitter = jitter.to(device=planes.device, dtype=torch.float32).reshape(b, r, n_coarse).contiguous()
-            dist = torch.norm(ray_origins, dim=-1).mean().reshape(1)      # stays on the device: no host sync
+            if dist is None:
+                dist = torch.norm(ray_origins, dim=-1).mean().reshape(1)  # stays on the device: no host sync
+            dist = dist.to(device=planes.device, dtype=torch.float32).reshape(1)
             lr_mul = float(decoder.net[0].bias_gain)
             planes_cl = planes.permute(0, 1, 3, 4, 2)          # free when the planes already live channels-last
             if not planes_cl.is_contiguous():
@@ -204,7 +208,7 @@ class ImportanceRenderer_bsMotion(_RendererBase):
                                       box_warp=rendering_options['box_warp'], white_back=rendering_options.get('white_back', False))
         # torch definition (CPU tensors, training, non-standard options)
         self.plane_axes = self.plane_axes.to(ray_origins.device)
-        dist = torch.norm(ray_origins, dim=-1).mean().item()
+        dist = torch.norm(ray_origins, dim=-1).mean().item() if dist is None else float(dist.reshape(-1)[0].item())
         depths = self.sample_stratified(ray_origins, dist - 0.45, dist + 0.6, n_coarse, rendering_options['disparity_space_sampling'],
                                         jitter=jitter)
         return self._two_pass(planes, decoder, ray_origins, ray_directions, depths, rendering_options, det=evaluation)

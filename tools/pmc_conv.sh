@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 for sh in "$@"; do
   rm -rf /tmp/pmc
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY \
+  timeout 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES ${PMC_EXTRA:-SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY} \
      --kernel-trace --output-format csv -d /tmp/pmc -o p -- python $GRAFT_REPO_ROOT/tools/bench_conv_one.py $sh > /tmp/pmc.log 2>&1
   python - "$sh" <<'PY'
 import csv, glob, sys
