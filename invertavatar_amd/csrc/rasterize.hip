@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
     for (int k = 0; k < PXB; ++k) aa_taps(min(xt + k, res - 1), kSrc, res, xlo[k], xhi[k], xc[k], xinv[k], xtot[k]);
     const int c0 = xlo[0], ncols = xhi[PXB - 1] - c0, nrows = yhi - ylo, nsrc = nrows * ncols;
 
-    for (int i = tid; i < ncols; i += 256) {
+    for (int i = tid; i < ncols; i += blockDim.x) {
         const int X = c0 + i;
         float w[PXB];
 #pragma unroll
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
     const float* uvb = p.uv + (int64_t)b * kSrc * kSrc * 3;
     const float* upb = p.upper + (int64_t)b * kSrc * kSrc;
     const int Rt = p.Rt;
-    for (int i = tid; i < nsrc; i += 256) {
+    for (int i = tid; i < nsrc; i += blockDim.x) {
         const int r = i / ncols, cidx = i - r * ncols;
         const int Y = ylo + r, X = c0 + cidx;
         const float wy = aa_weight(Y, yc, yinv, ytot);
@@ -136,36 +136,60 @@ __global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
     const int64_t rr = (int64_t)res * res;
     float* outb = p.out + (int64_t)b * (p.C + 1) * rr + (int64_t)y * res + xt;
     const bool vec_ok = (xt + PXB <= res) && (res % 4 == 0);
-    for (int c = tid; c < p.C; c += 256) {
-        float acc[PXB] = {0.f, 0.f, 0.f, 0.f};
-        const float* tc = texb + c;
-        for (int i = 0; i < nsrc; ++i) {
-            const int4 id = s_idx[i];
-            const float4 w = s_w[i];
-            const float4 wx = s_wx[i % ncols];
-            float v = tc[id.x] * w.x;
-            v = fmaf(tc[id.y], w.y, v);
-            v = fmaf(tc[id.z], w.z, v);
-            v = fmaf(tc[id.w], w.w, v);
-            acc[0] = fmaf(v, wx.x, acc[0]); acc[1] = fmaf(v, wx.y, acc[1]);
-            acc[2] = fmaf(v, wx.z, acc[2]); acc[3] = fmaf(v, wx.w, acc[3]);
-        }
-        const float* sc = p.sta + (int64_t)b * p.sta_bs + (int64_t)c * p.Rs * p.Rs;
-        float o[PXB];
+    // each thread owns 4 consecutive channels (one 16-byte gather per texel) when C % 4 == 0, else one channel
+    const int CV = (p.C % 4 == 0) ? 4 : 1;
+    for (int c = tid * CV; c < p.C; c += blockDim.x * CV) {
+        float acc[4][PXB];
 #pragma unroll
-        for (int k = 0; k < PXB; ++k) {
-            float sv = 0.f;
-            for (int j = sylo; j < syhi; ++j) {
-                const float wj = aa_weight(j, syc, syinv, sytot);
-                for (int i = sxlo[k]; i < sxhi[k]; ++i)
-                    sv = fmaf(sc[(int64_t)(p.by0 + j) * p.Rs + p.bx0 + i], wj * aa_weight(i, sxc[k], sxinv[k], sxtot[k]), sv);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < PXB; ++k) acc[j][k] = 0.f;
+        const float* tc = texb + c;
+        if (CV == 4) {
+            for (int i = 0; i < nsrc; ++i) {
+                const int4 id = s_idx[i];
+                const float4 w = s_w[i];
+                const float4 wx = s_wx[i % ncols];
+                const float4 t0 = *(const float4*)(tc + id.x), t1 = *(const float4*)(tc + id.y);
+                const float4 t2 = *(const float4*)(tc + id.z), t3 = *(const float4*)(tc + id.w);
+                const float v[4] = {fmaf(t3.x, w.w, fmaf(t2.x, w.z, fmaf(t1.x, w.y, t0.x * w.x))),
+                                    fmaf(t3.y, w.w, fmaf(t2.y, w.z, fmaf(t1.y, w.y, t0.y * w.x))),
+                                    fmaf(t3.z, w.w, fmaf(t2.z, w.z, fmaf(t1.z, w.y, t0.z * w.x))),
+                                    fmaf(t3.w, w.w, fmaf(t2.w, w.z, fmaf(t1.w, w.y, t0.w * w.x)))};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][0] = fmaf(v[j], wx.x, acc[j][0]); acc[j][1] = fmaf(v[j], wx.y, acc[j][1]);
+                    acc[j][2] = fmaf(v[j], wx.z, acc[j][2]); acc[j][3] = fmaf(v[j], wx.w, acc[j][3]);
+                }
             }
-            const float a = s_a[k];
-            o[k] = acc[k] * a + sv * (1.f - a);
+        } else {
+            for (int i = 0; i < nsrc; ++i) {
+                const int4 id = s_idx[i];
+                const float4 w = s_w[i];
+                const float4 wx = s_wx[i % ncols];
+                const float v = fmaf(tc[id.w], w.w, fmaf(tc[id.z], w.z, fmaf(tc[id.y], w.y, tc[id.x] * w.x)));
+                acc[0][0] = fmaf(v, wx.x, acc[0][0]); acc[0][1] = fmaf(v, wx.y, acc[0][1]);
+                acc[0][2] = fmaf(v, wx.z, acc[0][2]); acc[0][3] = fmaf(v, wx.w, acc[0][3]);
+            }
         }
-        float* dst = outb + (int64_t)c * rr;
-        if (vec_ok) *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-        else for (int k = 0; k < PXB && xt + k < res; ++k) dst[k] = o[k];
+        for (int j = 0; j < CV; ++j) {
+            const float* sc = p.sta + (int64_t)b * p.sta_bs + (int64_t)(c + j) * p.Rs * p.Rs;
+            float o[PXB];
+#pragma unroll
+            for (int k = 0; k < PXB; ++k) {
+                float sv = 0.f;
+                for (int jj = sylo; jj < syhi; ++jj) {
+                    const float wj = aa_weight(jj, syc, syinv, sytot);
+                    for (int i = sxlo[k]; i < sxhi[k]; ++i)
+                        sv = fmaf(sc[(int64_t)(p.by0 + jj) * p.Rs + p.bx0 + i], wj * aa_weight(i, sxc[k], sxinv[k], sxtot[k]), sv);
+                }
+                const float a = s_a[k];
+                o[k] = acc[j][k] * a + sv * (1.f - a);
+            }
+            float* dst = outb + (int64_t)(c + j) * rr;
+            if (vec_ok) *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+            else for (int k = 0; k < PXB && xt + k < res; ++k) dst[k] = o[k];
+        }
     }
     if (tid < PXB && xt + tid < res) outb[(int64_t)p.C * rr + tid] = s_u[tid];
 }
@@ -233,7 +257,9 @@ extern "C" int ia_rasterize_level(const float* tex_cl, const float* uv, const fl
         return ia::fail(IA_ERR_UNSUPPORTED, "rasterize level resolution %d: supported are 32, 64, 128 (256 -> res by 8, 4, 2)", res);
     RastParams p{tex_cl, uv, upper_alpha, sta, out, sta_batch_stride, B, C, tex_res, sta_res, res, by0, by1, bx0, bx1};
     dim3 grid((res + PXB - 1) / PXB, res, B);
-    hipLaunchKernelGGL(rasterize_level_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    // 4 channels per thread: 128 threads cover 512 channels; narrow levels use one wave
+    const int threads = (C % 4 == 0) ? (C >= 512 ? 128 : 64) : 256;
+    hipLaunchKernelGGL(rasterize_level_kernel, grid, dim3(threads), 0, (hipStream_t)stream, p);
     return ia::check_launch("ia_rasterize_level");
 }
 

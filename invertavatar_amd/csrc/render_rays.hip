@@ -116,7 +116,7 @@ __device__ __forceinline__ void gather_features(const float* __restrict__ planes
         }
     }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) f[c] = (acc[0][c] + acc[1][c] + acc[2][c]) / 3.f;
+    for (int c = 0; c < 8; ++c) f[c] = (acc[0][c] + acc[1][c] + acc[2][c]) * (1.f / 3.f);   // mean over planes (<= 1 ulp from x / 3)
 }
 
 // Layer 1 (32 -> 64, softplus) on MFMA.  In: f[8] = channels 8q..8q+7 of this lane's sample.
@@ -163,7 +163,7 @@ __device__ __forceinline__ void decoder_rgb(const float* __restrict__ lds, int l
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v = c[U][r] + lds[B1_OFF + 1 + 16 * U + 4 * q + r];
-            c[U][r] = (1.f / (1.f + __expf(-v))) * 1.002f - 0.001f;   // sigmoid * (1 + 2e-3) - 1e-3
+            c[U][r] = __builtin_amdgcn_rcpf(1.f + __expf(-v)) * 1.002f - 0.001f;   // sigmoid * (1 + 2e-3) - 1e-3 (v_rcp_f32: 1 ulp)
         }
 }
 
@@ -233,7 +233,7 @@ __device__ __forceinline__ void merge_sorted(float* scr, int lane, int& pos_c, i
     wave_sync();
 }
 
-__global__ __launch_bounds__(WAVES * 64) void render_rays_kernel(Params p) {
+__global__ __launch_bounds__(WAVES * 64, 2) void render_rays_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 15, q = lane >> 4;

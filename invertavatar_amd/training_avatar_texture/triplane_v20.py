@@ -79,6 +79,25 @@ class TriPlaneGenerator(torch.nn.Module):
         origins, dirs = self.ray_sampler(cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3), neural_rendering_resolution)
         return origins, dirs, neural_rendering_resolution
 
+    def _start_mouth_fill(self, mesh_condition):
+        """The mouth-hole fill depends only on the UV mask, and its flood is a one-workgroup, latency-bound kernel:
+        start it on a side stream at the top of the frame so that it runs underneath the backbone convolutions."""
+        uv = mesh_condition['uvcoords_image']
+        if not (uv.is_cuda and not torch.is_grad_enabled()):
+            return None
+        if getattr(self, '_side_stream', None) is None or self._side_stream.device != uv.device:
+            object.__setattr__(self, '_side_stream', torch.cuda.Stream(device=uv.device))
+        main = torch.cuda.current_stream(uv.device)
+        self._side_stream.wait_stream(main)
+        with torch.cuda.stream(self._side_stream):
+            alpha = uv.float()[..., 2:].permute(0, 3, 1, 2).contiguous()
+            full_alpha, mouth = fill_mouth(alpha, blur_mouth_edge=False)
+            done = torch.cuda.Event()
+            done.record(self._side_stream)
+        for t in (alpha, full_alpha, mouth):
+            t.record_stream(main)
+        return alpha, full_alpha, mouth, done
+
     @staticmethod
     def _split_static(static_feats):
         """The static backbone emits 96 = 3 x 32 channels; levels 0 and 5 carry all three planes and the
@@ -107,11 +126,11 @@ class TriPlaneGenerator(torch.nn.Module):
         planes[:, 0] = canvas * alpha + static_plane[:, 0] * (1 - alpha)
         return planes
 
-    def _planes(self, ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, all_levels=False):
+    def _planes(self, ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, all_levels=False, mouth=None):
         static_for_raster, static_plane = self._split_static(static_feats)
         assert len(static_for_raster) == len(texture_feats), (len(static_for_raster), len(texture_feats))
         cond, full_alpha, _ = self.rasterize(texture_feats, mesh_condition['uvcoords_image'], static_for_raster, BBOX_256,
-                                             levels=None if all_levels else N_COND_LEVELS_USED)
+                                             levels=None if all_levels else N_COND_LEVELS_USED, _mouth=mouth)
         stitch = self.face_backbone.synthesis(ws, cond, return_list=False, update_emas=update_emas, **synthesis_kwargs)
         return self._blend_planes(stitch, full_alpha, static_plane)
 
@@ -131,10 +150,11 @@ class TriPlaneGenerator(torch.nn.Module):
     # ------------------------------------------------------------------ public synthesis entry points
     def synthesis(self, ws, c, mesh_condition, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
                   use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, ray_dist=None, **synthesis_kwargs):
+        mouth = self._start_mouth_fill(mesh_condition)
         origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
         texture_feats = self.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
         static_feats = self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
-        planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs)
+        planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, mouth=mouth)
         image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist)
         out = {'image': image, 'image_raw': rgb, 'image_depth': depth}
         if return_featmap:
@@ -174,7 +194,7 @@ class TriPlaneGenerator(torch.nn.Module):
             out['texture'] = texture_feats
         return out
 
-    def rasterize(self, texture_feats, uvcoords_image, static_feats, bbox_256, levels=None):
+    def rasterize(self, texture_feats, uvcoords_image, static_feats, bbox_256, levels=None, _mouth=None):
         """UV-rasterise the neural texture pyramid and blend it over the static features.
 
         uvcoords_image [B,H,W,3] = (u, v, mask).  Returns (list of [B, C_k+1, res_k, res_k], full_alpha, mouth_masks);
@@ -182,7 +202,11 @@ class TriPlaneGenerator(torch.nn.Module):
         `levels` limits how many pyramid levels are produced (None = all, as the reference)."""
         uv = uvcoords_image if uvcoords_image.dtype == torch.float32 else uvcoords_image.float()
         grid, alpha = uv[..., :2], uv[..., 2:].permute(0, 3, 1, 2)
-        full_alpha, mouth = fill_mouth(alpha.clone(), blur_mouth_edge=False)
+        if _mouth is not None:   # started on the side stream by synthesis(): join it here
+            alpha, full_alpha, mouth, done = _mouth
+            torch.cuda.current_stream(uv.device).wait_event(done)
+        else:
+            full_alpha, mouth = fill_mouth(alpha.clone(), blur_mouth_edge=False)
         upper = mouth.clone()
         upper[:, :, :87] = 0
         upper_alpha = torch.clamp(alpha + upper, min=0, max=1)
