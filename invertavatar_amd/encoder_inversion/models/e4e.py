@@ -1,0 +1,85 @@
+"""e4e ("encoder for editing") W+ encoder (reference: encoder_inversion/models/e4e.py:22-134).
+
+IR-SE50 trunk with a 3-level feature pyramid; style 0 is predicted from the coarsest map and every other style is a
+delta on top of it (coarse styles from 16^2, middle from 32^2, fine from 64^2)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn import Conv2d, Module
+
+from ...training.networks_stylegan2 import FullyConnectedLayer
+from .helpers import irse50_trunk, run_trunk
+
+
+class GradualStyleBlock(Module):
+    """Stride-2 convs down to 1x1, then an equalised-lr linear layer."""
+
+    def __init__(self, in_c, out_c, spatial):
+        super().__init__()
+        self.out_c = out_c
+        self.spatial = spatial
+        layers = []
+        for k in range(int(np.log2(spatial))):
+            layers += [Conv2d(in_c if k == 0 else out_c, out_c, kernel_size=3, stride=2, padding=1), nn.LeakyReLU()]
+        self.convs = nn.Sequential(*layers)
+        self.linear = FullyConnectedLayer(in_features=out_c, out_features=out_c, bias=True, activation='linear', lr_multiplier=1)
+
+    def forward(self, x):
+        return self.linear(self.convs(x).view(-1, self.out_c))
+
+
+def _upsample_add(x, y):
+    """Bilinear (align_corners=True) resize of x to y's size, plus y (e4e.py:48-65)."""
+    return F.interpolate(x, size=y.shape[-2:], mode='bilinear', align_corners=True) + y
+
+
+class Encoder4Editing(Module):
+    def __init__(self, n_styles=18, inp_ch=3):
+        super().__init__()
+        self.input_layer, self.body = irse50_trunk(inp_ch)
+        self.style_count = n_styles
+        self.coarse_ind = 3
+        self.middle_ind = 7
+        self.styles = nn.ModuleList([GradualStyleBlock(512, 512, 16 if i < self.coarse_ind else 32 if i < self.middle_ind else 64)
+                                     for i in range(n_styles)])
+        self.latlayer1 = nn.Conv2d(256, 512, kernel_size=1, stride=1, padding=0)
+        self.latlayer2 = nn.Conv2d(128, 512, kernel_size=1, stride=1, padding=0)
+
+    def forward(self, x):
+        _, (c1, c2, c3) = run_trunk(self.body, self.input_layer(x), (6, 20, 23))
+        w = self.styles[0](c3).repeat(self.style_count, 1, 1).permute(1, 0, 2)
+        feats = c3
+        for i in range(1, self.style_count):
+            if i == self.coarse_ind:
+                feats = p2 = _upsample_add(c3, self.latlayer1(c2))
+            elif i == self.middle_ind:
+                feats = _upsample_add(p2, self.latlayer2(c1))
+            w[:, i] += self.styles[i](feats)
+        return w
+
+
+class e4e(nn.Module):
+    """Stand-alone wrapper: encoder + face pooling + latent average of a given generator (e4e.py:136-165)."""
+
+    def __init__(self, n_styles=14, if_load_weights=True, generator=None, set_restyle_encoder=False, **unused):
+        super().__init__()
+        self.n_styles = n_styles
+        self.encoder = self.set_encoder(n_styles, inp_ch=3)
+        self.face_pool = torch.nn.AdaptiveAvgPool2d((256, 256))
+        self.generator = generator.train().requires_grad_(False) if generator is not None else None
+        self.register_buffer('latent_avg', self.generator.backbone.mapping.w_avg.reshape(1, 512))
+
+    def set_encoder(self, n_styles, inp_ch):
+        return Encoder4Editing(n_styles, inp_ch)
+
+    def switch_grad(self, nerf_requires_grad=False):
+        for i in range(self.encoder.middle_ind):
+            for p in self.encoder.styles[i].parameters():
+                p.requires_grad = nerf_requires_grad
+
+    def encode(self, x):
+        if x.shape[-1] != 256:
+            x = self.face_pool(x)
+        codes = self.encoder(x)
+        return codes + self.latent_avg.repeat(codes.shape[0], 1, 1)

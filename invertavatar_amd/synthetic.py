@@ -135,3 +135,61 @@ def jitter(frames, n_rays, n_coarse=48):
     volumetric_rendering/renderer.py:406.  One RandomState(1234 + k) stream per frame k."""
     out = [np.random.RandomState(1234 + k).rand(n_rays, n_coarse, 1).astype(np.float32) for k in frames]
     return torch.from_numpy(np.stack(out, 0))
+
+
+def fill_encoder_parameters(net, skip_prefix='generator.', salt=0):
+    """Name-seeded parameters for the plain torch.nn encoders (IR-SE50 trunks, UNets, style heads).
+
+    Unlike the generator's equalised-lr layers these have no built-in weight gain, so weights are drawn with a
+    1/sqrt(fan_in) scale to keep 50 residual units numerically sane; BatchNorm statistics are made non-trivial."""
+    def draw(name, shape, scale=1.0, shift=0.0, absolute=False):
+        rs = np.random.RandomState(_seed(name, salt))
+        v = rs.randn(*shape).astype(np.float32) if len(shape) else np.float32(rs.randn())
+        if absolute:
+            v = np.abs(v)
+        return torch.as_tensor(v * scale + shift, dtype=torch.float32).reshape(shape)
+
+    with torch.no_grad():
+        for mname, mod in net.named_modules():
+            if mname.startswith(skip_prefix) or mname == skip_prefix.rstrip('.'):
+                continue
+            kind = type(mod).__name__
+            own = dict(mod.named_parameters(recurse=False))
+            own.update(dict(mod.named_buffers(recurse=False)))
+            for pname, t in own.items():
+                full = f'{mname}.{pname}' if mname else pname
+                if not t.dtype.is_floating_point or full in ('latent_avg', 'black_uv_bg'):
+                    continue
+                shape = tuple(t.shape)
+                if kind == 'FullyConnectedLayer':
+                    t.copy_(draw(full, shape) if pname == 'weight' else draw(full, shape, 0.1))
+                elif kind == 'BatchNorm2d':
+                    if pname == 'weight': t.copy_(draw(full, shape, 0.1, 1.0))
+                    elif pname == 'running_var': t.copy_(draw(full, shape, 0.1, 1.0, absolute=True))
+                    else: t.copy_(draw(full, shape, 0.1))
+                elif kind == 'PReLU':
+                    t.copy_(draw(full, shape, 0.05, 0.25))
+                elif pname == 'weight' and t.ndim >= 2:
+                    fan_in = int(np.prod(shape[1:]))
+                    t.copy_(draw(full, shape, 1.0 / math.sqrt(fan_in)))
+                else:
+                    t.copy_(draw(full, shape, 0.1))
+        if hasattr(net, 'latent_avg'):
+            net.latent_avg.copy_(net.generator.backbone.mapping.w_avg.reshape(1, 512))
+    return net
+
+
+def source_frames(seed, n, res=512):
+    """n smooth random RGB frames in [-1, 1] (the "real" source frames of the few-shot inversion)."""
+    rs = np.random.RandomState(seed)
+    low = torch.from_numpy(rs.rand(n, 3, res // 16, res // 16).astype(np.float32)) * 2 - 1
+    return torch.nn.functional.interpolate(low, size=(res, res), mode='bilinear', align_corners=False)
+
+
+def source_uv(seed, frames):
+    """x['uv'] [n,6,256,256]: 3 channels of ground-truth texture in UV space + (u, v, mask)."""
+    rs = np.random.RandomState(seed)
+    low = torch.from_numpy(rs.rand(len(frames), 3, 16, 16).astype(np.float32)) * 2 - 1
+    gttex = torch.nn.functional.interpolate(low, size=(256, 256), mode='bilinear', align_corners=False)
+    pverts = uv_conditions(frames).permute(0, 3, 1, 2)
+    return torch.cat([gttex, pverts], 1)

@@ -193,7 +193,8 @@ class ImportanceRenderer_bsMotion(_RendererBase):
         n_coarse = rendering_options['depth_resolution']
         if evaluation and self._fused_ok(planes, decoder, ray_origins, rendering_options):
             if jitter is None:
-                jitter = torch.rand(b, r, n_coarse, device=planes.device)
+                # same call shape as the reference's torch.rand_like(depths_coarse) (renderer.py:406)
+                jitter = torch.rand_like(torch.empty((b, r, n_coarse, 1), device=planes.device))
             jitter = jitter.to(device=planes.device, dtype=torch.float32).reshape(b, r, n_coarse).contiguous()
             if dist is None:
                 dist = torch.norm(ray_origins, dim=-1).mean().reshape(1)  # stays on the device: no host sync

@@ -8,7 +8,7 @@ reference imports but the container lacks are stubbed: ``
 ``torchvision`` (unused on the path) and ``cv2`` (only ``floodFill`` is reached; stubbed with
 scipy.ndimage connected-component labelling, 4-connectivity).
 
-Usage:  python tests/golden/make_golden.py [--only ops,camera,renderer,small,full,names]
+Usage:  python tests/golden/make_golden.py [--only ops,camera,renderer,small,full,names,encoder]
 """
 import argparse
 import contextlib
@@ -227,6 +227,95 @@ def gen_generator(width):
     npz(f'generator_{width}.npz', **arrays)
 
 
+@contextlib.contextmanager
+def fixed_randomness(jit, u_seed=99):
+    """Pin both noise sources of the renderer: the stratified jitter (torch.rand_like, renderer.py:406) and the uniform
+    importance samples drawn when evaluation=False (torch.rand, renderer.py:453)."""
+    orig_like, orig_rand = torch.rand_like, torch.rand
+
+    def fake_like(t, *a, **k):
+        assert tuple(t.shape) == tuple(jit.shape), (t.shape, jit.shape)
+        return jit.to(t.dtype)
+
+    def fake_rand(*size, **k):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        t = torch.from_numpy(np.random.RandomState(u_seed).rand(*shape).astype(np.float32))
+        return t.to(k['device']) if k.get('device') is not None else t
+    torch.rand_like, torch.rand = fake_like, fake_rand
+    try:
+        yield
+    finally:
+        torch.rand_like, torch.rand = orig_like, orig_rand
+
+
+def encoder_inputs(nrr=32):
+    groups = [[0, 8, 16, 24], [4, 12, 20, 28]]
+    data = []
+    for gi, frames in enumerate(groups):
+        data.append(dict(image=synthetic.source_frames(7 + gi, 4), uv=synthetic.source_uv(17 + gi, frames),
+                         c=synthetic.camera_labels(frames), uvcoords=synthetic.uv_conditions(frames),
+                         jitter=synthetic.jitter(frames, nrr * nrr)))
+    drive = [40]
+    return data, dict(c=synthetic.camera_labels(drive), uvcoords=synthetic.uv_conditions(drive), jitter=synthetic.jitter(drive, nrr * nrr))
+
+
+def set_eval_seq_modes(net):
+    """Module modes exactly as eval_seq.py:92-97 leaves them."""
+    net.train()
+    for unet in (net.unet_encoder.triplane_unet, net.unet_encoder.texture_unet):
+        unet.input_layer.eval()
+        unet.body.eval()
+    return net
+
+
+def run_few_shot(net, nrr=32):
+    """encode -> two AR_eval_forward groups with carried GRU state -> one drive frame (eval_seq.py:168-212)."""
+    net.generator.neural_rendering_resolution = nrr
+    groups, drive = encoder_inputs(nrr)
+    g = net.generator
+    ws = net.encode(groups[0]['image'][:1])
+    tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+    sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+    res, r_list = {'w': ws, 'texture': tex, 'static': sta}, [None, None]
+    for grp in groups:
+        with fixed_randomness(grp['jitter']):
+            res, r_list = net.AR_eval_forward({'image': grp['image'], 'uv': grp['uv']}, grp['c'], {'uvcoords_image': grp['uvcoords']},
+                                              ws, r_list, res)
+    with fixed_randomness(drive['jitter']):
+        out = g.synthesis_withTexture(ws, res['texture'], drive['c'], {'uvcoords_image': drive['uvcoords']}, noise_mode='const',
+                                      static_feats=res['static'], evaluation=True)
+    return ws, res, r_list, out['image']
+
+
+def gen_encoder():
+    from encoder_inversion.models.uvnet import inversionNet
+    g = build_reference_generator('full')     # the UNet heads are sized for the full-width feature pyramid
+    net = inversionNet(generator=g, encoding_triplane=True, encoding_texture=True).requires_grad_(False)
+    synthetic.fill_encoder_parameters(net)
+    set_eval_seq_modes(net)
+    ws, res, r_list, image = run_few_shot(net)
+    def thin(name, t):      # spatial sub-sampling with the stride recorded in the key: <name>_s<stride>
+        stride = 1
+        while t[..., ::stride, ::stride].numel() > 50000:
+            stride *= 2
+        arrays[f'{name}_s{stride}'] = t[..., ::stride, ::stride]
+    arrays = dict(ws=ws)
+    thin('drive_image', image)
+    for i, t in enumerate(res['texture']):
+        thin(f'texture{i}', t)
+    for i, t in enumerate(res['static']):
+        thin(f'static{i}', t)
+    for u, states in enumerate(r_list):
+        for k, h in enumerate(states):
+            thin(f'gru{u}_{k}', h)
+    npz('encoder_fewshot.npz', **arrays)
+    lines = [f'{n}\t{tuple(t.shape)}\t{str(t.dtype).replace("torch.", "")}' for n, t in sorted(net.state_dict().items())
+             if not n.startswith('generator.')]
+    with open(os.path.join(HERE, 'encoder_state_names.txt'), 'w') as fh:
+        fh.write('\n'.join(lines) + '\n')
+    print(f'encoder_state_names.txt: {len(lines)} tensors')
+
+
 def gen_names():
     """(name, shape, dtype) of every parameter/buffer: the checkpoint-compatibility contract."""
     for width, fname in (('full', 'generator_state_names.txt'), ('small', 'generator_state_names_small.txt')):
@@ -239,7 +328,7 @@ def gen_names():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='ops,camera,renderer,small,full,names')
+    ap.add_argument('--only', default='ops,camera,renderer,small,full,names,encoder')
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -252,6 +341,7 @@ def main():
         if 'small' in todo: gen_generator('small')
         if 'full' in todo: gen_generator('full')
         if 'names' in todo: gen_names()
+        if 'encoder' in todo: gen_encoder()
 
 
 if __name__ == '__main__':
