@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=3)
+    ap.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
     return ap.parse_args()
 
 
@@ -59,15 +60,18 @@ def setup_distributed(n):
     return rank, world, local
 
 
-def make_step(gen, ws, cams, uvs, jits, world, rank):
-    """Returns step(k): render frame k of this rank and all-gather the uint8-free fp32 images of the step."""
+def make_step(gen, ws, cams, uvs, jits, world, rank, graphed=None):
+    """Returns step(k): render frame k of this rank and all-gather the fp32 images of the step."""
     gathered = torch.empty(world * FRAMES_PER_RANK, 3, 512, 512, device='cuda') if world > 1 else None
     n_frames = cams.shape[0]
 
     def step(k):
         i = k % n_frames
-        out = gen.synthesis(ws, cams[i:i + 1], {'uvcoords_image': uvs[i:i + 1]}, neural_rendering_resolution=NRR,
-                            noise_mode='const', evaluation=True, jitter=jits[i:i + 1])
+        if graphed is not None:
+            out = graphed(ws, cams[i:i + 1], uvs[i:i + 1], jits[i:i + 1])
+        else:
+            out = gen.synthesis(ws, cams[i:i + 1], {'uvcoords_image': uvs[i:i + 1]}, neural_rendering_resolution=NRR,
+                                noise_mode='const', evaluation=True, jitter=jits[i:i + 1])
         img = out['image']
         if world > 1:
             torch.distributed.all_gather_into_tensor(gathered, img.contiguous())
@@ -140,7 +144,21 @@ def main():
         cams = synthetic.camera_labels(frames).cuda()
         uvs = synthetic.uv_conditions(frames).cuda()
         jits = synthetic.jitter(frames, NRR * NRR).squeeze(-1).cuda()
-        step = make_step(gen, ws, cams, uvs, jits, world, rank)
+        eager_step = make_step(gen, ws, cams, uvs, jits, world, rank)
+        graphed, launch_mode = None, 'eager'
+        if not args.eager:
+            from invertavatar_amd.graphed import GraphedSynthesis
+            try:
+                graphed = GraphedSynthesis(gen, batch=FRAMES_PER_RANK, neural_rendering_resolution=NRR)
+                img_g = graphed(ws, cams[:1], uvs[:1], jits[:1])['image'].clone()
+                img_e = eager_step(0)[rank * FRAMES_PER_RANK:(rank + 1) * FRAMES_PER_RANK] if world > 1 else eager_step(0)
+                err = (img_g - img_e).abs().max().item()
+                if not err <= 1e-5:
+                    raise RuntimeError(f'graph replay differs from eager by {err}')
+                launch_mode = 'hipGraph replay (validated against eager: max |d| = %.1e)' % err
+            except Exception as exc:   # fall back to eager launches, and say so in the JSON line
+                graphed, launch_mode = None, f'eager (graph capture unavailable: {exc})'
+        step = make_step(gen, ws, cams, uvs, jits, world, rank, graphed)
 
         for k in range(args.warmup):
             step(k)
@@ -168,11 +186,12 @@ def main():
                                    '512^2 out, neural_rendering_resolution=128, 1 frame per rank per step, all three backbones + '
                                    'rasterize + fused renderer + SR 8XDC recomputed every frame',
                        'width': args.width, 'frames_per_rank_per_step': FRAMES_PER_RANK, 'parallelism': f'frame-sharded dp{world}',
-                       'collective': 'one all_gather of the step\'s [N,3,512,512] fp32 frames' if world > 1 else 'none'},
+                       'collective': 'one all_gather of the step\'s [N,3,512,512] fp32 frames' if world > 1 else 'none',
+                       'launch': launch_mode},
         }
         if rank == 0 and world == 1:
             if not args.no_roofline:
-                result['roofline'], result['kernels'] = roofline_leg(step)
+                result['roofline'], result['kernels'] = roofline_leg(eager_step)
             if not args.no_cpu_baseline:
                 result['cpu_baseline'] = cpu_baseline_leg(gen, ws, cams, uvs, jits, args.cpu_frames)
     if rank == 0:

@@ -224,6 +224,15 @@ int ia_styles_demod(const float* ws, int B, int num_ws, int w_dim, const int64_t
                     const int* style_row_layer, int style_rows, const int* demod_row_layer, int demod_rows,
                     float* styles, float* demod, void* stream);
 
+/*
+ * Camera labels -> ray bundles.  Replaces RaySampler_zxc.forward
+ * (training_avatar_texture/volumetric_rendering/ray_sampler.py:70-107).
+ *   cam : [B, cam_stride] float32, each row = 16 floats cam2world (row-major 4x4) followed by 9 floats intrinsics (row-major 3x3,
+ *         normalised by image size) -- i.e. the last 25 entries of the reference's conditioning label `c`
+ *   rays_o, rays_d : [B, resolution^2, 3] float32, pixel order row-major (y, x), integer pixel centres (no +0.5)
+ */
+int ia_ray_sampler(const float* cam, int cam_stride, float* rays_o, float* rays_d, int B, int resolution, int normalize, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

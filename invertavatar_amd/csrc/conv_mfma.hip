@@ -230,7 +230,7 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
     };
 
     constexpr int NSTEP_K = NT * (CC / 2);                    // k-pairs per chunk
-    constexpr int KP = (FO * FP >= 4) ? 1 : 2;                // k-pairs per pipeline step: >= 4 MFMAs (256 cycles) per step
+    constexpr int KP = (FO * FP >= 4) ? 1 : (FO * FP == 2 ? 2 : 4);   // k-pairs per pipeline step: >= 4 MFMAs (256 cycles) per step
     constexpr int NSTEP = NSTEP_K / KP;
     static_assert(NSTEP_K % KP == 0, "chunk depth must be a multiple of the step depth");
 
@@ -372,8 +372,12 @@ constexpr int kChunkConv = 8, kChunkTransposed = 8;
 
 // Tile family per layer shape: (32ch x 256pt) for narrow outputs, (128ch x 128pt) otherwise; the transposed form
 // uses (64ch x 128pt x 4 phases) with 16-channel chunks so that it does as many MFMAs per staged chunk as the conv.
-void tile_dims(int O, int transposed, int* bo, int* bp, int* cc) {
-    if (transposed) { *bo = 64; *bp = 128; *cc = kChunkTransposed; }
+// Images with <= kSmallPoints output points (4x4 .. 16x16) use a (128ch x 32pt) tile: the MFMA work of a chunk is fixed
+// by the tile, so a 128-point tile would spend 4 us per chunk on padding there.
+constexpr int kSmallPoints = 320;
+void tile_dims(int O, int npts, int transposed, int* bo, int* bp, int* cc) {
+    if (npts <= kSmallPoints && O > 32) { *bo = 128; *bp = 32; *cc = kChunkConv; }
+    else if (transposed) { *bo = 64; *bp = 128; *cc = kChunkTransposed; }
     else if (O <= 32) { *bo = 32; *bp = 256; *cc = kChunkConv; }
     else { *bo = 128; *bp = 128; *cc = kChunkConv; }
 }
@@ -385,13 +389,14 @@ extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int 
     IA_REQUIRE(h_ksplit && h_scratch_bytes, "null output pointer");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
     int bo, bp, cc;
-    tile_dims(O, transposed, &bo, &bp, &cc);
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
+    tile_dims(O, npts, transposed, &bo, &bp, &cc);
     const int64_t blocks = (int64_t)((npts + bp - 1) / bp) * ((O + bo - 1) / bo) * B;
     const int chunks = (I + cc - 1) / cc;
     int s = 1;
     // aim for >= 2 workgroups per CU, keep >= 2 chunks (16 channels x taps) of work per split
-    while (blocks * s < 2 * ia::kNumCU && s * 2 <= chunks / 2 && s < 64) s *= 2;
+    const int min_chunks = (npts <= kSmallPoints) ? 1 : 2;   // chunks of K left per split
+    while (blocks * s < 2 * ia::kNumCU && s * 2 * min_chunks <= chunks && s < 64) s *= 2;
     *h_ksplit = s;
     const int64_t oh = transposed ? 2 * H + 1 : H, ow = transposed ? 2 * W + 1 : W;
     *h_scratch_bytes = s > 1 ? (size_t)s * B * O * oh * ow * sizeof(float) : 0;
@@ -417,7 +422,7 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
     g.OH = transposed ? 2 * H + 1 : H; g.OW = transposed ? 2 * W + 1 : W;
     IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
     int bo_, bp_, cc;
-    tile_dims(O, transposed, &bo_, &bp_, &cc);
+    tile_dims(O, g.GH * g.GW, transposed, &bo_, &bp_, &cc);
     const int chunks = (I + cc - 1) / cc;
     if (ksplit > chunks) ksplit = chunks;
     g.S = ksplit;
@@ -428,6 +433,11 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
     }
     Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp};
     hipStream_t s = (hipStream_t)stream;
+    if (bp_ == 32) {   // small images: 4 waves side by side over 128 out-channels, one 32-point fragment each
+        if (transposed) return launch<3, true, 1, 1, 4, 1, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
+        return ksize == 3 ? launch<3, false, 1, 1, 4, 1, kChunkConv>(x, wk, styles, y, scratch, g, e, s)
+                          : launch<1, false, 1, 1, 4, 1, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
+    }
     if (transposed) return launch<3, true, 1, 2, 2, 2, kChunkTransposed>(x, wk, styles, y, scratch, g, e, s);
     if (O <= 32) {
         return ksize == 3 ? launch<3, false, 1, 2, 1, 4, kChunkConv>(x, wk, styles, y, scratch, g, e, s)

@@ -290,3 +290,16 @@ class StylePlan:
             d = demod[b * e['doff']:b * (e['doff'] + e['O'])].view(b, e['O']) if e['demod'] else None
             out.append((s, d))
         return out
+
+
+def ray_sampler(cam25, resolution, normalize=True):
+    """cam25 [B,25] (cam2world 16 + intrinsics 9) -> rays_o, rays_d [B, res^2, 3] (see ia_ray_sampler)."""
+    cam25 = _f32c(cam25.float().contiguous(), 'cam')
+    b = cam25.shape[0]
+    rays_o = torch.empty(b, resolution * resolution, 3, device=cam25.device)
+    rays_d = torch.empty_like(rays_o)
+    with torch.cuda.device(cam25.device):
+        st = _lib.load().ia_ray_sampler(_p(cam25), cam25.stride(0), _p(rays_o), _p(rays_d), b, int(resolution), int(bool(normalize)),
+                                        _lib.stream_ptr(cam25.device))
+    _lib.check(st, 'ia_ray_sampler')
+    return rays_o, rays_d

@@ -5,6 +5,8 @@ pixel centres at INTEGER coordinates, K scaled to the render resolution, d = nor
 It is written batched (no Python loop over frames, one 3x3 inverse for the whole batch)."""
 import torch
 
+from ... import hipops
+
 
 class RaySampler(torch.nn.Module):
     """EG3D sampler with half-pixel centres (ray_sampler.py:19-63); API surface for the older generators."""
@@ -38,6 +40,9 @@ class RaySampler_zxc(torch.nn.Module):
 
     def forward(self, cam2world_matrix, cam_K, resolution, normalize=True):
         n, dev = cam2world_matrix.shape[0], cam2world_matrix.device
+        if cam2world_matrix.is_cuda and not torch.is_grad_enabled():
+            cam25 = torch.cat([cam2world_matrix.reshape(n, 16), cam_K.reshape(n, 9)], 1)
+            return hipops.ray_sampler(cam25, resolution, normalize)
         k = cam_K.clone()
         k[:, :2] *= resolution
         k_inv = torch.linalg.inv(k)                                           # [N,3,3]

@@ -91,3 +91,11 @@ def test_empty_space_depth_clamp_and_properties():
     assert ref_w.abs().max() == 0 and wsum.abs().max().item() == 0
     assert max_abs(depth.cpu(), ref_depth) <= 1e-5 and torch.isfinite(depth).all()
     assert max_abs(rgb.cpu(), ref_rgb) <= 1e-6      # all -1
+
+
+def test_ray_sampler_kernel():
+    frames = [0, 33, 111]
+    cams = synthetic.camera_labels(frames)
+    ro, rd = OR.ray_sampler_zxc(cams[:, :16].view(-1, 4, 4), cams[:, 16:25].view(-1, 3, 3), 64)
+    o, d = hipops.ray_sampler(cams.cuda(), 64)
+    assert max_abs(o.cpu(), ro) == 0 and max_abs(d.cpu(), rd) <= 2e-6
