@@ -23,9 +23,13 @@
 //                          (= F.conv_transpose2d(x, w^T, stride 2)); the four output
 //                          phases of a point (m,n) share one input patch and live in four accumulators.
 //
-// Low-resolution layers have too few output tiles to fill 256 CUs, so the in-channel range can be
-// split over blockIdx.z (split-K); partial sums go to caller scratch and a second kernel reduces them in
-// a fixed order (deterministic) and applies the epilogue.
+// Scheduling is stream-K: the work of a layer is the list of (tile, K-chunk) units in tile-major order; it is cut into
+// G equal contiguous ranges, one per persistent workgroup ("worker", G = 2 per CU).  A worker that owns a whole tile
+// applies the epilogue and stores it; a worker that owns only part of a tile's K range parks its accumulators in a
+// caller-owned slab, and a fix-up kernel adds the slabs of such tiles in worker order (deterministic) and applies the
+// epilogue.  This balances layers whose tile count is not a multiple of the machine (e.g. the (H+1)x(W+1) point grids of
+// the transposed form: 524 equal workgroups on 512 slots ran as two rounds) and gives low-resolution layers, which have
+// only a handful of tiles, a fine-grained K split for free.
 #include "ia_common.h"
 
 namespace {
@@ -38,9 +42,14 @@ struct Geo {
     int B, I, O, H, W;     // input
     int GH, GW;            // point grid: conv H x W, transposed (H+1) x (W+1)
     int OH, OW;            // output image
-    int S, ci_per_split;   // split-K
-    int patch_cap;         // floats per channel reserved for the patch in each LDS buffer
+    int G;                 // stream-K workers per batch element
+    int C;                 // K chunks per tile
+    int TO, T;             // out-channel tiles, tiles in total (point tiles x out-channel tiles)
+    int patch_cap;         // floats per channel reserved for the patch in LDS
 };
+
+// unit range of worker w: [range_begin(w), range_begin(w+1)) over U = T*C units
+__host__ __device__ inline int64_t range_begin(int w, int64_t U, int G) { return ((int64_t)w * U) / G; }
 
 struct Epi {
     const float* demod;           // [B,O] or null
@@ -101,23 +110,74 @@ __device__ __forceinline__ float epilogue(float v, int b, int o, int64_t pix, in
 
 // FO x FP fragments (32 channels x 32 points each) per wave, WO x WP waves per workgroup, CC in-channels per K chunk,
 // NPOS patch positions staged per thread (>= ceil(worst PSZ / threads), chosen by the host).
-template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool PARTIAL>
+// Accumulator tile -> global memory.  C/D map of the 32x32 MFMA: row(channel) = (r&3) + 8*(r>>2) + 4*half, col(point) = l31.
+template <bool TR, int FO, int FP, int WO, int WP>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][FP], float* __restrict__ y, const Geo& g, const Epi& e,
+                                           int b, int o0, int p0, int tid) {
+    constexpr int NPH = TR ? 4 : 1;
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wo = wave / WP, wp = wave % WP;
+    const int npts = g.GH * g.GW;
+    const int64_t ohw = (int64_t)g.OH * g.OW;
+    const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
+    float* yb = y + ((int64_t)b * g.O) * ohw;
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp) {
+        const int p = p0 + (wp * FP + fp) * 32 + l31;
+        if (p >= npts) continue;
+        const int pr = p / g.GW, pc = p - pr * g.GW;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            int64_t pix;
+            if (TR) {
+                const int oy = 2 * pr + (ph >> 1), ox = 2 * pc + (ph & 1);
+                if (oy >= g.OH || ox >= g.OW) continue;
+                pix = (int64_t)oy * g.OW + ox;
+            } else pix = p;
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (o >= g.O) continue;
+                    yb[(int64_t)o * ohw + pix] = epilogue(acc[ph][fo][fp][r], b, o, pix, ohw, g, e, ns);
+                }
+        }
+    }
+}
+
+// FO x FP fragments (32 channels x 32 points each) per wave, WO x WP waves per workgroup, CC in-channels per K chunk,
+// NPOS patch positions staged per thread (>= ceil(worst PSZ / threads), chosen by the host).
+// SK = false: classic mapping, workgroup = one whole tile (used when the tiles fill whole rounds of the machine);
+// SK = true: stream-K ranges with slab hand-off.
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool SK>
 __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                                  const float* __restrict__ styles, float* __restrict__ y,
-                                                                 Geo g, Epi e) {
+                                                                 float* __restrict__ slabs, Geo g, Epi e) {
     constexpr int NT = KS * KS;
     constexpr int NPH = TR ? 4 : 1;
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
     constexpr int PAD = TR ? 0 : KS / 2;
+    constexpr int NACC = NPH * FO * FP * 16;           // accumulator registers per thread = floats per thread in a slab
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wo = wave / WP, wp = wave % WP;
-    const int o0 = blockIdx.y * BO;
-    const int b = blockIdx.z / g.S, split = blockIdx.z % g.S;
+    const int b = blockIdx.y, worker = blockIdx.x;
     const int npts = g.GH * g.GW;
-    const int p0 = blockIdx.x * BP;
+    const int64_t U = (int64_t)g.T * g.C;
+    const int64_t u_begin = SK ? range_begin(worker, U, g.G) : (int64_t)worker * g.C;
+    const int64_t u_end = SK ? range_begin(worker + 1, U, g.G) : u_begin + g.C;
+    const int first_tile = (int)(u_begin / g.C);
+
+  for (int64_t u = u_begin; u < u_end;) {
+    // ---- one segment: tile `tile`, K chunks [c_lo, c_hi)
+    const int tile = (int)(u / g.C), c_lo = (int)(u - (int64_t)tile * g.C);
+    const int c_hi = (int)min((int64_t)g.C, (int64_t)c_lo + (u_end - u));
+    u += c_hi - c_lo;
+    const int o0 = (tile % g.TO) * BO;
+    const int p0 = (tile / g.TO) * BP;
     const int p_last = min(p0 + BP, npts) - 1;
     const Window win = tile_window(p0, p_last, g.GW, PAD, TR);
     const int PW = win.PW, PSZ = win.PSZ, seg1_off = win.nr[0] * PW;
@@ -150,7 +210,7 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] = 0.f;
 
-    const int ci_begin = split * g.ci_per_split, ci_end = min(ci_begin + g.ci_per_split, g.I);
+    const int ci_begin = c_lo * CC, ci_end = min(c_hi * CC, g.I);
     const float* xb = x + (int64_t)b * g.I * g.H * g.W;
     const float* sb = styles ? styles + (int64_t)b * g.I : nullptr;
     const int HW = g.H * g.W;
@@ -274,80 +334,107 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
         }
     }
 
-    // ---- epilogue / partial store.  C/D map: row(channel) = (r&3) + 8*(r>>2) + 4*half, col(point) = l31
-    const int64_t ohw = (int64_t)g.OH * g.OW;
-    const float ns = (!PARTIAL && e.noise) ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
-    float* yb = PARTIAL ? y + ((int64_t)(split * g.B + b) * g.O) * ohw : y + ((int64_t)b * g.O) * ohw;
+    // ---- segment done: a whole tile is finished here, a partial K range is parked for the fix-up kernel
+    if (!SK || (c_lo == 0 && c_hi == g.C)) {
+        store_tile<TR, FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
+    } else if constexpr (SK) {
+        const int slot = (tile == first_tile) ? 0 : 1;   // a worker has at most a leading and a trailing partial tile
+        float* slab = slabs + (((int64_t)b * g.G + worker) * 2 + slot) * ((int64_t)NACC * NTHREADS) + tid;
+        int k = 0;
 #pragma unroll
-    for (int fp = 0; fp < FP; ++fp) {
-        const int p = p0 + (wp * FP + fp) * 32 + l31;
-        if (p >= npts) continue;
-        const int pr = p / g.GW, pc = p - pr * g.GW;
-#pragma unroll
-        for (int ph = 0; ph < NPH; ++ph) {
-            int64_t pix;
-            if (TR) {
-                const int oy = 2 * pr + (ph >> 1), ox = 2 * pc + (ph & 1);
-                if (oy >= g.OH || ox >= g.OW) continue;
-                pix = (int64_t)oy * g.OW + ox;
-            } else pix = p;
+        for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
             for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (o >= g.O) continue;
-                    float v = acc[ph][fo][fp][r];
-                    if (!PARTIAL) v = epilogue(v, b, o, pix, ohw, g, e, ns);
-                    yb[(int64_t)o * ohw + pix] = v;
-                }
-        }
+                for (int fp = 0; fp < FP; ++fp)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r, ++k) slab[(int64_t)k * NTHREADS] = acc[ph][fo][fp][r];
     }
+  }   // segments of this worker
 }
 
-// Split-K second pass: y = epilogue(sum_s part[s]) in fixed order.
-__global__ __launch_bounds__(256) void conv_reduce_kernel(const float* __restrict__ part, float* __restrict__ y, Geo g, Epi e) {
-    const int64_t ohw = (int64_t)g.OH * g.OW, per_split = (int64_t)g.B * g.O * ohw;
+// Fix-up: tiles that were split between workers.  grid = (tile, batch, accumulator slice): a workgroup adds KZ accumulator
+// registers of every thread position over the tile's slabs in worker order and stores them through the epilogue.
+constexpr int KZ = 8;
+template <bool TR, int FO, int FP, int WO, int WP>
+__global__ __launch_bounds__(WO * WP * 64) void conv_fixup_kernel(const float* __restrict__ slabs, float* __restrict__ y, Geo g, Epi e) {
+    constexpr int NPH = TR ? 4 : 1;
+    constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
+    constexpr int NACC = NPH * FO * FP * 16;
+    const int tile = blockIdx.x, b = blockIdx.y, k0 = blockIdx.z * KZ, tid = threadIdx.x;
+    const int64_t U = (int64_t)g.T * g.C, t_begin = (int64_t)tile * g.C, t_end = t_begin + g.C;
+    int w_first = (int)((t_begin * g.G) / U);
+    while (w_first > 0 && range_begin(w_first, U, g.G) > t_begin) --w_first;
+    while (range_begin(w_first + 1, U, g.G) <= t_begin) ++w_first;
+    int w_last = w_first;
+    while (range_begin(w_last + 1, U, g.G) < t_end) ++w_last;
+    if (w_first == w_last) return;                       // the tile was finished by a single worker
+    const int64_t slab_floats = (int64_t)NACC * NTHREADS;
+    const float* base = slabs + ((int64_t)b * g.G) * 2 * slab_floats + (int64_t)k0 * NTHREADS + tid;
+    // only the first worker can hold this tile in its trailing slot (1); every later worker starts inside the tile (slot 0)
+    const int slot_first = (tile == (int)(range_begin(w_first, U, g.G) / g.C)) ? 0 : 1;
+    float acc[KZ];
+#pragma unroll
+    for (int k = 0; k < KZ; ++k) acc[k] = base[((int64_t)w_first * 2 + slot_first) * slab_floats + (int64_t)k * NTHREADS];
+    for (int w = w_first + 1; w <= w_last; ++w) {
+        const float* sl = base + ((int64_t)w * 2) * slab_floats;
+        float v[KZ];
+#pragma unroll
+        for (int k = 0; k < KZ; ++k) v[k] = sl[(int64_t)k * NTHREADS];
+#pragma unroll
+        for (int k = 0; k < KZ; ++k) acc[k] += v[k];
+    }
+    // decode (register index, thread) -> (channel, point) exactly as the MFMA kernel lays its accumulators out
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wo = wave / WP, wp = wave % WP;
+    const int o0 = (tile % g.TO) * BO, p0 = (tile / g.TO) * BP;
+    const int npts = g.GH * g.GW;
+    const int64_t ohw = (int64_t)g.OH * g.OW;
     const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_split; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        int s = 0;
-        for (; s + 8 <= g.S; s += 8) {    // 8 independent loads in flight, summed in split order
-            float t[8];
+    float* yb = y + ((int64_t)b * g.O) * ohw;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = part[(s + k) * per_split + i];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v += t[k];
+    for (int k = 0; k < KZ; ++k) {
+        const int kk = k0 + k, r = kk & 15, fp = (kk >> 4) % FP, fo = ((kk >> 4) / FP) % FO, ph = (kk >> 4) / (FP * FO);
+        const int p = p0 + (wp * FP + fp) * 32 + l31;
+        const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (p >= npts || o >= g.O) continue;
+        const int pr = p / g.GW, pc = p - pr * g.GW;
+        int64_t pix = p;
+        if (TR) {
+            const int oy = 2 * pr + (ph >> 1), ox = 2 * pc + (ph & 1);
+            if (oy >= g.OH || ox >= g.OW) continue;
+            pix = (int64_t)oy * g.OW + ox;
         }
-        for (; s < g.S; ++s) v += part[s * per_split + i];
-        const int64_t pix = i % ohw;
-        const int bo = (int)(i / ohw);
-        y[i] = epilogue(v, bo / g.O, bo % g.O, pix, ohw, g, e, ns);
+        yb[(int64_t)o * ohw + pix] = epilogue(acc[k], b, o, pix, ohw, g, e, ns);
     }
 }
 
 template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS>
 int launch_npos(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g_in, const Epi& e,
                 int worst, hipStream_t s) {
-    constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NT = KS * KS;
+    constexpr int BO = 32 * FO * WO, NT = KS * KS;
     Geo g = g_in;
-    g.patch_cap = (worst + 3) & ~3;                                  // keeps the second buffer 16-byte aligned
-    const int npts = g.GH * g.GW;
-    dim3 grid((npts + BP - 1) / BP, (g.O + BO - 1) / BO, g.B * g.S), block(WO * WP * 64);
+    g.patch_cap = (worst + 3) & ~3;
     const size_t lds = (size_t)(NT * CC * BO + CC * g.patch_cap) * sizeof(float);
     if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
-    if (g.S > 1) {
-        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, true>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, grid, block, lds, s, x, wk, styles, scratch, g, e);
-        const int64_t n = (int64_t)g.B * g.O * g.OH * g.OW;
-        hipLaunchKernelGGL(conv_reduce_kernel, dim3(ia::streaming_grid(n, 256)), dim3(256), 0, s, scratch, y, g, e);
-    } else {
+    if (g.G == g.T) {   // one whole tile per workgroup
         auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, false>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, grid, block, lds, s, x, wk, styles, y, g, e);
+        hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
+        return ia::check_launch("ia_conv2d_mfma");
     }
-    return ia::check_launch("ia_conv2d_mfma");
+    auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, true>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
+    int st = ia::check_launch("ia_conv2d_mfma");
+    if (st != IA_OK) return st;
+    const bool whole_tiles = ((int64_t)g.T * g.C) % g.G == 0 && (((int64_t)g.T * g.C) / g.G) % g.C == 0;
+    if (!whole_tiles) {   // some tiles were shared between workers
+        constexpr int NACC = (TR ? 4 : 1) * FO * FP * 16;
+        hipLaunchKernelGGL((conv_fixup_kernel<TR, FO, FP, WO, WP>), dim3(g.T, g.B, NACC / KZ), dim3(WO * WP * 64), 0, s, scratch, y, g, e);
+        st = ia::check_launch("ia_conv2d_mfma(fix-up)");
+    }
+    return st;
 }
 
 template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC>
@@ -384,22 +471,40 @@ void tile_dims(int O, int npts, int transposed, int* bo, int* bp, int* cc) {
 
 }  // namespace
 
+// Shared by the planner and the entry point: tile counts and the worker count for a layer.
+struct Plan { int bo, bp, cc, T, TO, C, G, nacc_threads; };
+static Plan make_plan(int B, int I, int O, int H, int W, int transposed) {
+    Plan p;
+    const int npts = transposed ? (H + 1) * (W + 1) : H * W;
+    tile_dims(O, npts, transposed, &p.bo, &p.bp, &p.cc);
+    p.TO = (O + p.bo - 1) / p.bo;
+    p.T = ((npts + p.bp - 1) / p.bp) * p.TO;
+    p.C = (I + p.cc - 1) / p.cc;
+    const int64_t U = (int64_t)p.T * p.C;
+    // two workgroups per CU over the whole launch (all batch elements); never more workers than units
+    const int64_t slots = 2 * ia::kNumCU;                           // two workgroups per CU
+    int64_t G;
+    if ((int64_t)p.T * B >= slots && (((int64_t)p.T * B) % slots == 0 || (int64_t)p.T * B >= 8 * slots)) {
+        G = p.T;                                                     // whole rounds of whole tiles: one tile per workgroup, no fix-up
+    } else {
+        G = (slots + B - 1) / B;                                     // stream-K: equal (tile, chunk) ranges
+        if (G > U / 2) G = U / 2;                                    // at least two K chunks per worker
+    }
+    if (G < 1) G = 1;
+    // when every worker would get >= one whole tile, round down to a divisor-friendly count only if it is exact
+    p.G = (int)G;
+    const int frags = (p.bo / 32) * (p.bp / 32) / 4;                 // fragments per wave with 4 waves
+    p.nacc_threads = (transposed ? 4 : 1) * frags * 16 * 256;       // floats per slab
+    return p;
+}
+
 extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int* h_ksplit,
                               size_t* h_scratch_bytes) {
     IA_REQUIRE(h_ksplit && h_scratch_bytes, "null output pointer");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
-    int bo, bp, cc;
-    const int npts = transposed ? (H + 1) * (W + 1) : H * W;
-    tile_dims(O, npts, transposed, &bo, &bp, &cc);
-    const int64_t blocks = (int64_t)((npts + bp - 1) / bp) * ((O + bo - 1) / bo) * B;
-    const int chunks = (I + cc - 1) / cc;
-    int s = 1;
-    // aim for >= 2 workgroups per CU, keep >= 2 chunks (16 channels x taps) of work per split
-    const int min_chunks = (npts <= kSmallPoints) ? 1 : 2;   // chunks of K left per split
-    while (blocks * s < 2 * ia::kNumCU && s * 2 * min_chunks <= chunks && s < 64) s *= 2;
-    *h_ksplit = s;
-    const int64_t oh = transposed ? 2 * H + 1 : H, ow = transposed ? 2 * W + 1 : W;
-    *h_scratch_bytes = s > 1 ? (size_t)s * B * O * oh * ow * sizeof(float) : 0;
+    const Plan p = make_plan(B, I, O, H, W, transposed);
+    *h_ksplit = p.G;
+    *h_scratch_bytes = (size_t)B * p.G * 2 * p.nacc_threads * sizeof(float);
     return IA_OK;
 }
 
@@ -413,7 +518,7 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
     IA_REQUIRE(ksize == 1 || ksize == 3, "kernel size must be 1 or 3");
     IA_REQUIRE(!transposed || ksize == 3, "the transposed form is 3x3 stride 2 only");
     IA_REQUIRE(act == IA_ACT_LINEAR || act == IA_ACT_LRELU, "conv epilogue supports linear and lrelu");
-    IA_REQUIRE(ksplit >= 1, "ksplit must be >= 1");
+    IA_REQUIRE(ksplit >= 1, "worker count must be >= 1");
     IA_REQUIRE(!transposed || (noise == nullptr && bias == nullptr && residual == nullptr && act == IA_ACT_LINEAR),
                "the transposed form only applies the demodulation; FIR + bias_act follow in ia_fir_bias_act");
     Geo g;
@@ -421,15 +526,16 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
     g.GH = transposed ? H + 1 : H; g.GW = transposed ? W + 1 : W;
     g.OH = transposed ? 2 * H + 1 : H; g.OW = transposed ? 2 * W + 1 : W;
     IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
-    int bo_, bp_, cc;
-    tile_dims(O, g.GH * g.GW, transposed, &bo_, &bp_, &cc);
-    const int chunks = (I + cc - 1) / cc;
-    if (ksplit > chunks) ksplit = chunks;
-    g.S = ksplit;
-    g.ci_per_split = ((chunks + ksplit - 1) / ksplit) * cc;
-    if (ksplit > 1) {
-        const size_t need = (size_t)ksplit * B * O * g.OH * g.OW * sizeof(float);
-        IA_REQUIRE(scratch && scratch_bytes >= need, "split-K needs %zu bytes of scratch, got %zu", need, scratch_bytes);
+    const Plan p = make_plan(B, I, O, H, W, transposed);
+    const int bp_ = p.bp;
+    g.T = p.T; g.TO = p.TO; g.C = p.C;
+    const int64_t U = (int64_t)p.T * p.C;
+    g.G = (int)(ksplit > U ? U : ksplit);
+    g.patch_cap = 0;
+    {
+        const size_t need = (size_t)B * g.G * 2 * p.nacc_threads * sizeof(float);
+        const bool whole_tiles = U % g.G == 0 && (U / g.G) % g.C == 0;
+        IA_REQUIRE(whole_tiles || (scratch && scratch_bytes >= need), "stream-K needs %zu bytes of scratch, got %zu", need, scratch_bytes);
     }
     Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp};
     hipStream_t s = (hipStream_t)stream;

@@ -68,7 +68,7 @@ _scratch = {}
 
 
 def _scratch_buffer(device, nbytes):
-    """Grow-only per-device scratch for split-K partial sums (caller-owned memory, as the ABI requires)."""
+    """Grow-only per-device scratch for the stream-K accumulator slabs (caller-owned memory, as the ABI requires)."""
     buf = _scratch.get(device)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
@@ -94,9 +94,8 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
         ksplit = plan_s.value
     oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (h, w)
     y = torch.empty(b, o, oh, ow, device=x.device, dtype=torch.float32)
-    scratch, nbytes = None, 0
-    if ksplit > 1:
-        nbytes = ksplit * b * o * oh * ow * 4
+    scratch, nbytes = None, plan_bytes.value
+    if nbytes:
         scratch = _scratch_buffer(x.device, nbytes)
     flops = 2.0 * b * h * w * i * o * ksize * ksize
     traffic = 4.0 * (x.numel() + wk.numel() + y.numel() + (residual.numel() if residual is not None else 0))
