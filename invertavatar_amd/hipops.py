@@ -68,11 +68,13 @@ _scratch = {}
 
 
 def _scratch_buffer(device, nbytes):
-    """Grow-only per-device scratch for the stream-K accumulator slabs (caller-owned memory, as the ABI requires)."""
-    buf = _scratch.get(device)
+    """Grow-only scratch for the stream-K accumulator slabs, one per (device, stream): launches on different streams may
+    overlap, so they must not share slabs (caller-owned memory, as the ABI requires)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _scratch.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
-        _scratch[device] = buf
+        _scratch[key] = buf
     return buf
 
 

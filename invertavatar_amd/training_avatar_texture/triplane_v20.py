@@ -79,6 +79,28 @@ class TriPlaneGenerator(torch.nn.Module):
         origins, dirs = self.ray_sampler(cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3), neural_rendering_resolution)
         return origins, dirs, neural_rendering_resolution
 
+    def _two_backbones(self, ws, update_emas, synthesis_kwargs):
+        """The texture and the static backbone are independent: on the device they run on two streams so that their
+        latency-bound low-resolution layers (a handful of workgroups each at batch 1) overlap."""
+        def tex():
+            return self.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
+
+        def sta():
+            return self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
+        if not (ws.is_cuda and not torch.is_grad_enabled()):
+            return tex(), sta()
+        if getattr(self, '_backbone_stream', None) is None or self._backbone_stream.device != ws.device:
+            object.__setattr__(self, '_backbone_stream', torch.cuda.Stream(device=ws.device))
+        main, side = torch.cuda.current_stream(ws.device), self._backbone_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            texture_feats = tex()
+        static_feats = sta()
+        main.wait_stream(side)
+        for t in texture_feats:
+            t.record_stream(main)
+        return texture_feats, static_feats
+
     def _start_mouth_fill(self, mesh_condition):
         """The mouth-hole fill depends only on the UV mask, and its flood is a one-workgroup, latency-bound kernel:
         start it on a side stream at the top of the frame so that it runs underneath the backbone convolutions."""
@@ -152,8 +174,7 @@ class TriPlaneGenerator(torch.nn.Module):
                   use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, ray_dist=None, **synthesis_kwargs):
         mouth = self._start_mouth_fill(mesh_condition)
         origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
-        texture_feats = self.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
-        static_feats = self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
+        texture_feats, static_feats = self._two_backbones(ws, update_emas, synthesis_kwargs)
         planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, mouth=mouth)
         image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist)
         out = {'image': image, 'image_raw': rgb, 'image_depth': depth}
