@@ -21,16 +21,34 @@ from ..training.networks_stylegan2 import (normalize_2nd_moment, modulated_conv2
 
 @persistence.persistent_class
 class SynthesisNetwork(_base.SynthesisNetwork):
-    def forward(self, ws, cond_list, return_list, feat_conditions=None, return_imgs=False, out_res=(32, 256), **block_kwargs):
+    def forward_head(self, ws, out_res=(32, 256), **block_kwargs):
+        """Blocks 4^2 .. out_res[0]^2, which never see `cond_list` (it is blended in AFTER the out_res[0] block): lets a caller
+        start them before the conditioning images exist.  Returns the state to pass as `_head=` to forward()."""
+        first = int(np.log2(out_res[0])) - 2
+        x = img = None
+        self._prepare_styles(ws)
+        for idx, (res, cur_ws) in enumerate(zip(self.block_resolutions, self._split_ws(ws))):
+            if idx > first:
+                break
+            x, img = getattr(self, f'b{res}')(x, img, cur_ws, None, **block_kwargs)
+        return x, img, first
+
+    def forward(self, ws, cond_list, return_list, feat_conditions=None, return_imgs=False, out_res=(32, 256), _head=None, **block_kwargs):
         assert not (return_list and return_imgs)
         first = int(np.log2(out_res[0])) - 2                       # index of the first tapped block (32^2)
         last = (self.img_resolution_log2 - 2) if len(out_res) == 1 else (int(np.log2(out_res[1])) - 2)
         x = img = None
         feats, imgs = [], []
-        self._prepare_styles(ws)
+        if _head is None:
+            self._prepare_styles(ws)
         for idx, (res, cur_ws) in enumerate(zip(self.block_resolutions, self._split_ws(ws))):
             cond = feat_conditions[res] if (feat_conditions is not None and res in feat_conditions.keys()) else None
-            x, img = getattr(self, f'b{res}')(x, img, cur_ws, cond, **block_kwargs)
+            if _head is not None and idx <= _head[2]:
+                if idx < _head[2]:
+                    continue
+                x, img = _head[0], _head[1]                         # resume after the pre-computed head
+            else:
+                x, img = getattr(self, f'b{res}')(x, img, cur_ws, cond, **block_kwargs)
             if idx < first:
                 continue
             if return_list:

@@ -101,6 +101,22 @@ class TriPlaneGenerator(torch.nn.Module):
             t.record_stream(main)
         return texture_feats, static_feats
 
+    def _start_face_head(self, ws, update_emas, synthesis_kwargs):
+        """The 4^2..32^2 blocks of the face backbone depend only on ws; run them on a third stream under the other backbones."""
+        if not (ws.is_cuda and not torch.is_grad_enabled()):
+            return None
+        if getattr(self, '_face_stream', None) is None or self._face_stream.device != ws.device:
+            object.__setattr__(self, '_face_stream', torch.cuda.Stream(device=ws.device))
+        main, side = torch.cuda.current_stream(ws.device), self._face_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            x, img, first = self.face_backbone.synthesis.forward_head(ws, update_emas=update_emas, **synthesis_kwargs)
+            done = torch.cuda.Event()
+            done.record(side)
+        x.record_stream(main)
+        img.record_stream(main)
+        return x, img, first, done
+
     def _start_mouth_fill(self, mesh_condition):
         """The mouth-hole fill depends only on the UV mask, and its flood is a one-workgroup, latency-bound kernel:
         start it on a side stream at the top of the frame so that it runs underneath the backbone convolutions."""
@@ -148,12 +164,17 @@ class TriPlaneGenerator(torch.nn.Module):
         planes[:, 0] = canvas * alpha + static_plane[:, 0] * (1 - alpha)
         return planes
 
-    def _planes(self, ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, all_levels=False, mouth=None):
+    def _planes(self, ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, all_levels=False, mouth=None,
+                face_head=None):
         static_for_raster, static_plane = self._split_static(static_feats)
         assert len(static_for_raster) == len(texture_feats), (len(static_for_raster), len(texture_feats))
         cond, full_alpha, _ = self.rasterize(texture_feats, mesh_condition['uvcoords_image'], static_for_raster, BBOX_256,
                                              levels=None if all_levels else N_COND_LEVELS_USED, _mouth=mouth)
-        stitch = self.face_backbone.synthesis(ws, cond, return_list=False, update_emas=update_emas, **synthesis_kwargs)
+        head = None
+        if face_head is not None:
+            torch.cuda.current_stream(ws.device).wait_event(face_head[3])
+            head = face_head[:3]
+        stitch = self.face_backbone.synthesis(ws, cond, return_list=False, update_emas=update_emas, _head=head, **synthesis_kwargs)
         return self._blend_planes(stitch, full_alpha, static_plane)
 
     def _render(self, ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist=None):
@@ -173,9 +194,11 @@ class TriPlaneGenerator(torch.nn.Module):
     def synthesis(self, ws, c, mesh_condition, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
                   use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, ray_dist=None, **synthesis_kwargs):
         mouth = self._start_mouth_fill(mesh_condition)
+        face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
         origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
         texture_feats, static_feats = self._two_backbones(ws, update_emas, synthesis_kwargs)
-        planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, mouth=mouth)
+        planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, mouth=mouth,
+                              face_head=face_head)
         image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist)
         out = {'image': image, 'image_raw': rgb, 'image_depth': depth}
         if return_featmap:
