@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=3)
     ap.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
+    ap.add_argument('--in-flight', type=int, default=1, help='frames in flight per rank (captured graphs on separate streams)')
     return ap.parse_args()
 
 
@@ -117,7 +118,8 @@ def cpu_baseline_leg(gen, ws, cams, uvs, jits, frames):
     from oracle import generator as OG
     sd = {k: v.detach().cpu() for k, v in gen.state_dict().items()}
     ws_c, cams_c, uvs_c, jits_c = ws.cpu(), cams.cpu(), uvs.cpu(), jits.cpu()
-    cores = torch.get_num_threads()
+    cores = min(torch.get_num_threads(), 32)     # the torch-CPU path stops scaling (and oversubscribes) beyond ~32 threads
+    torch.set_num_threads(cores)
     with torch.no_grad():
         OG.synthesis(sd, ws_c, cams_c[:1], uvs_c[:1], jits_c[:1].unsqueeze(-1), nrr=NRR)   # warm
         t0 = time.perf_counter()
@@ -159,6 +161,22 @@ def main():
             except Exception as exc:   # fall back to eager launches, and say so in the JSON line
                 graphed, launch_mode = None, f'eager (graph capture unavailable: {exc})'
         step = make_step(gen, ws, cams, uvs, jits, world, rank, graphed)
+        pipeline = None
+        if graphed is not None and args.in_flight > 1 and world == 1:
+            from invertavatar_amd.graphed import FramePipeline
+            pipeline = FramePipeline(gen, depth=args.in_flight, batch=FRAMES_PER_RANK, neural_rendering_resolution=NRR)
+            pipeline.capture(ws, cams[:1], uvs[:1], jits[:1])
+            out_p, ev, _ = pipeline.submit(ws, cams[1:2], uvs[1:2], jits[1:2])
+            pipeline.drain(); torch.cuda.synchronize()
+            err = (out_p['image'] - eager_step(1)).abs().max().item()
+            if not err <= 1e-5:
+                raise RuntimeError(f'pipelined replay differs from eager by {err}')
+            launch_mode += f'; {args.in_flight} frames in flight on separate streams'
+            n_frames_ = cams.shape[0]
+
+            def step(k, _p=pipeline):   # noqa: F811  (same work per step; consecutive steps overlap on the GPU)
+                i = k % n_frames_
+                return _p.submit(ws, cams[i:i + 1], uvs[i:i + 1], jits[i:i + 1])[0]['image']
 
         for k in range(args.warmup):
             step(k)
@@ -168,6 +186,8 @@ def main():
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(k)
+        if pipeline is not None:
+            pipeline.drain()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()

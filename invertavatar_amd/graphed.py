@@ -53,3 +53,49 @@ class GraphedSynthesis:
             self.capture()
         self.graph.replay()
         return self.out
+
+
+class FramePipeline:
+    """`depth` captured frames in flight: frame k is replayed on stream k % depth with its own static buffers, so the
+    latency-bound parts of consecutive frames (low-resolution layers, renderer sampling phases) fill each other's idle
+    compute units.  Results are returned in submission order; `submit` returns the output dict of the frame that was in
+    the slot before (already complete on the caller's stream), `drain` the rest."""
+
+    def __init__(self, generator, depth=2, batch=1, neural_rendering_resolution=128, **synthesis_kwargs):
+        self.slots = [GraphedSynthesis(generator, batch, neural_rendering_resolution, **synthesis_kwargs) for _ in range(depth)]
+        dev = next(generator.parameters()).device
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.pending = [None] * depth
+        self.k = 0
+
+    def capture(self, ws, c, uv, jitter):
+        """Capture every slot (each capture runs real frames, so valid inputs are required)."""
+        for slot in self.slots:
+            slot(ws, c, uv, jitter)
+        torch.cuda.synchronize()
+        return self
+
+    @torch.no_grad()
+    def submit(self, ws, c, uvcoords_image, jitter):
+        i = self.k % len(self.slots)
+        self.k += 1
+        slot, stream = self.slots[i], self.streams[i]
+        main = torch.cuda.current_stream()
+        done_prev = self.pending[i]
+        stream.wait_stream(main)                       # inputs produced on the caller's stream are ready
+        with torch.cuda.stream(stream):
+            slot.ws.copy_(ws.expand_as(slot.ws), non_blocking=True)
+            slot.c.copy_(c[:, -25:], non_blocking=True)
+            slot.uv.copy_(uvcoords_image, non_blocking=True)
+            slot.jitter.copy_(jitter.reshape(slot.jitter.shape), non_blocking=True)
+            slot.graph.replay()
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self.pending[i] = ev
+        return slot.out, ev, done_prev
+
+    def drain(self):
+        main = torch.cuda.current_stream()
+        for ev in self.pending:
+            if ev is not None:
+                main.wait_event(ev)
