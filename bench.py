@@ -92,7 +92,7 @@ def roofline_leg(step, frames=3):
     finally:
         hipops.PROFILE = None
     fam = {}
-    for name, flops, nbytes, e0, e1 in recs:
+    for name, flops, nbytes, e0, e1, _ in recs:
         key = 'conv2d_mfma' if name.startswith('conv2d_mfma') else name
         f = fam.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
         f['ms'] += e0.elapsed_time(e1); f['flops'] += flops; f['bytes'] += nbytes; f['launches'] += 1

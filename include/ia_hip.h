@@ -118,9 +118,12 @@ int ia_upfirdn2d_bias_act(const void* x, const float* f, const float* noise, con
  *   transposed = 1 : 3x3, stride 2, no padding = F.conv_transpose2d(x, w^T, stride=2);  y : [B, O, 2H+1, 2W+1];
  *                    only `demod` is applied (noise/bias/residual must be NULL, act linear) -- the FIR and the
  *                    tail follow in ia_upfirdn2d_bias_act
- *   ksplit   : number of stream-K workers per batch element (from ia_conv2d_plan): the (tile, K-chunk) units of the layer are
- *              cut into that many equal ranges; tiles shared between workers are summed by a deterministic fix-up pass that
- *              uses `scratch` (planned size)
+ *   ksplit   : number of stream-K workers per batch element (from ia_conv2d_plan; 0 when the plan has none).  Tiles that
+ *              fill whole rounds of the machine run one per workgroup; the (tile, K-chunk) units of the remaining tiles are
+ *              cut into `ksplit` equal ranges, and tiles shared between workers are summed in worker order by a
+ *              deterministic fix-up pass
+ *   scratch  : caller-owned accumulator slabs for that pass, `scratch_bytes` >= the planned size (NULL/0 when the plan needs
+ *              none).  Launches that may run concurrently must not share a scratch buffer.
  */
 int ia_conv2d_mfma(const float* x, const float* wk, const float* styles, const float* demod,
                    const float* noise, const float* noise_strength, const float* bias, const float* residual,
@@ -128,7 +131,7 @@ int ia_conv2d_mfma(const float* x, const float* wk, const float* styles, const f
                    int B, int I, int O, int H, int W, int ksize, int transposed,
                    int act, float alpha, float gain, float clamp, int ksplit, void* stream);
 
-/* Host-only planner for ia_conv2d_mfma: worker count that fills 256 CUs twice and the scratch the fix-up pass needs. */
+/* Host-only planner for ia_conv2d_mfma: stream-K worker count (0: none) and the scratch bytes the fix-up pass needs. */
 int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int* h_ksplit, size_t* h_scratch_bytes);
 
 /*

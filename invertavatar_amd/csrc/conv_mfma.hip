@@ -23,13 +23,16 @@
 //                          (= F.conv_transpose2d(x, w^T, stride 2)); the four output
 //                          phases of a point (m,n) share one input patch and live in four accumulators.
 //
-// Scheduling is stream-K: the work of a layer is the list of (tile, K-chunk) units in tile-major order; it is cut into
-// G equal contiguous ranges, one per persistent workgroup ("worker", G = 2 per CU).  A worker that owns a whole tile
-// applies the epilogue and stores it; a worker that owns only part of a tile's K range parks its accumulators in a
+// Scheduling.  Tiles that fill whole rounds of the machine (2 workgroups per CU) run one tile per workgroup.  The tiles
+// left over -- all of them for layers with fewer tiles than slots -- are stream-K: their (tile, K-chunk) units, in
+// tile-major order, are cut into G equal contiguous ranges, one per workgroup ("worker").  A worker that owns a whole
+// tile applies the epilogue and stores it; a worker that owns only part of a tile's K range parks its accumulators in a
 // caller-owned slab, and a fix-up kernel adds the slabs of such tiles in worker order (deterministic) and applies the
-// epilogue.  This balances layers whose tile count is not a multiple of the machine (e.g. the (H+1)x(W+1) point grids of
-// the transposed form: 524 equal workgroups on 512 slots ran as two rounds) and gives low-resolution layers, which have
-// only a handful of tiles, a fine-grained K split for free.
+// epilogue.  The hand-off is the kernel boundary: slabs written by workgroups on one XCD are read by workgroups on
+// another, and an in-kernel hand-off (write-through slabs + flags + one serial finisher per tile) measured slower than
+// this parallel fix-up for every layer of the model.  This balances layers whose tile count is not a multiple of the
+// machine (e.g. the (H+1)x(W+1) point grids of the transposed form: 524 equal workgroups on 512 slots ran as two rounds)
+// and gives low-resolution layers, which have only a handful of tiles, a fine-grained K split.
 #include "ia_common.h"
 
 namespace {
@@ -42,13 +45,14 @@ struct Geo {
     int B, I, O, H, W;     // input
     int GH, GW;            // point grid: conv H x W, transposed (H+1) x (W+1)
     int OH, OW;            // output image
-    int G;                 // stream-K workers per batch element
+    int G;                 // stream-K workers per batch element (0: none)
     int C;                 // K chunks per tile
     int TO, T;             // out-channel tiles, tiles in total (point tiles x out-channel tiles)
+    int T_dp;              // tiles [0, T_dp) run one per workgroup, tiles [T_dp, T) are stream-K
     int patch_cap;         // floats per channel reserved for the patch in LDS
 };
 
-// unit range of worker w: [range_begin(w), range_begin(w+1)) over U = T*C units
+// unit range of worker w: [range_begin(w), range_begin(w+1)) over U = (T - T_dp)*C units
 __host__ __device__ inline int64_t range_begin(int w, int64_t U, int G) { return ((int64_t)w * U) / G; }
 
 struct Epi {
@@ -148,8 +152,8 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
 
 // FO x FP fragments (32 channels x 32 points each) per wave, WO x WP waves per workgroup, CC in-channels per K chunk,
 // NPOS patch positions staged per thread (>= ceil(worst PSZ / threads), chosen by the host).
-// SK = false: classic mapping, workgroup = one whole tile (used when the tiles fill whole rounds of the machine);
-// SK = true: stream-K ranges with slab hand-off.
+// SK = false: workgroup = one whole tile (tiles [0, T_dp), whole rounds of the machine);
+// SK = true: stream-K ranges over tiles [T_dp, T) with slab hand-off.
 template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool SK>
 __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                                  const float* __restrict__ styles, float* __restrict__ y,
@@ -166,16 +170,18 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
     const int wo = wave / WP, wp = wave % WP;
     const int b = blockIdx.y, worker = blockIdx.x;
     const int npts = g.GH * g.GW;
-    const int64_t U = (int64_t)g.T * g.C;
+    const int64_t U = (int64_t)(g.T - g.T_dp) * g.C;
     const int64_t u_begin = SK ? range_begin(worker, U, g.G) : (int64_t)worker * g.C;
     const int64_t u_end = SK ? range_begin(worker + 1, U, g.G) : u_begin + g.C;
     const int first_tile = (int)(u_begin / g.C);
+    const int tile_base = SK ? g.T_dp : 0;
 
   for (int64_t u = u_begin; u < u_end;) {
     // ---- one segment: tile `tile`, K chunks [c_lo, c_hi)
-    const int tile = (int)(u / g.C), c_lo = (int)(u - (int64_t)tile * g.C);
+    const int tile_l = (int)(u / g.C), c_lo = (int)(u - (int64_t)tile_l * g.C);
     const int c_hi = (int)min((int64_t)g.C, (int64_t)c_lo + (u_end - u));
     u += c_hi - c_lo;
+    const int tile = tile_base + tile_l;
     const int o0 = (tile % g.TO) * BO;
     const int p0 = (tile / g.TO) * BP;
     const int p_last = min(p0 + BP, npts) - 1;
@@ -338,74 +344,74 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
     if (!SK || (c_lo == 0 && c_hi == g.C)) {
         store_tile<TR, FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
     } else if constexpr (SK) {
-        const int slot = (tile == first_tile) ? 0 : 1;   // a worker has at most a leading and a trailing partial tile
-        float* slab = slabs + (((int64_t)b * g.G + worker) * 2 + slot) * ((int64_t)NACC * NTHREADS) + tid;
-        int k = 0;
+        const int slot = (tile_l == first_tile) ? 0 : 1;   // a worker has at most a leading and a trailing partial tile
+        // slab layout: [NACC/4][NTHREADS] float4 (register quad q of thread t at (q*NTHREADS + t)*16 bytes)
+        float4* slab = reinterpret_cast<float4*>(slabs + (((int64_t)b * g.G + worker) * 2 + slot) * ((int64_t)NACC * NTHREADS)) + tid;
 #pragma unroll
-        for (int ph = 0; ph < NPH; ++ph)
-#pragma unroll
-            for (int fo = 0; fo < FO; ++fo)
-#pragma unroll
-                for (int fp = 0; fp < FP; ++fp)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r, ++k) slab[(int64_t)k * NTHREADS] = acc[ph][fo][fp][r];
+        for (int q = 0; q < NACC / 4; ++q) {
+            const int fr = q >> 2, r0 = (q & 3) * 4;
+            const f32x16& a = acc[fr / (FP * FO)][(fr / FP) % FO][fr % FP];
+            slab[(int64_t)q * NTHREADS] = make_float4(a[r0], a[r0 + 1], a[r0 + 2], a[r0 + 3]);
+        }
     }
   }   // segments of this worker
 }
 
-// Fix-up: tiles that were split between workers.  grid = (tile, batch, accumulator slice): a workgroup adds KZ accumulator
-// registers of every thread position over the tile's slabs in worker order and stores them through the epilogue.
-constexpr int KZ = 8;
+// Fix-up: stream-K tiles that were split between workers.  grid = (stream-K tile, batch, accumulator quad): a workgroup adds one
+// register quad (float4) of every thread position over the tile's slabs in worker order and stores it through the epilogue.
+// Loads of up to kFixBatch workers are in flight together (the adds keep the worker order).
+constexpr int kFixBatch = 8;
 template <bool TR, int FO, int FP, int WO, int WP>
 __global__ __launch_bounds__(WO * WP * 64) void conv_fixup_kernel(const float* __restrict__ slabs, float* __restrict__ y, Geo g, Epi e) {
     constexpr int NPH = TR ? 4 : 1;
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
     constexpr int NACC = NPH * FO * FP * 16;
-    const int tile = blockIdx.x, b = blockIdx.y, k0 = blockIdx.z * KZ, tid = threadIdx.x;
-    const int64_t U = (int64_t)g.T * g.C, t_begin = (int64_t)tile * g.C, t_end = t_begin + g.C;
+    const int tile_l = blockIdx.x, b = blockIdx.y, q = blockIdx.z, tid = threadIdx.x;
+    const int64_t U = (int64_t)(g.T - g.T_dp) * g.C, t_begin = (int64_t)tile_l * g.C, t_end = t_begin + g.C;
     int w_first = (int)((t_begin * g.G) / U);
     while (w_first > 0 && range_begin(w_first, U, g.G) > t_begin) --w_first;
     while (range_begin(w_first + 1, U, g.G) <= t_begin) ++w_first;
     int w_last = w_first;
     while (range_begin(w_last + 1, U, g.G) < t_end) ++w_last;
     if (w_first == w_last) return;                       // the tile was finished by a single worker
-    const int64_t slab_floats = (int64_t)NACC * NTHREADS;
-    const float* base = slabs + ((int64_t)b * g.G) * 2 * slab_floats + (int64_t)k0 * NTHREADS + tid;
+    const int64_t slab4 = (int64_t)NACC * NTHREADS / 4;
+    const float4* base = reinterpret_cast<const float4*>(slabs) + ((int64_t)b * g.G) * 2 * slab4 + (int64_t)q * NTHREADS + tid;
     // only the first worker can hold this tile in its trailing slot (1); every later worker starts inside the tile (slot 0)
-    const int slot_first = (tile == (int)(range_begin(w_first, U, g.G) / g.C)) ? 0 : 1;
-    float acc[KZ];
+    const int slot_first = (tile_l == (int)(range_begin(w_first, U, g.G) / g.C)) ? 0 : 1;
+    float4 acc = base[((int64_t)w_first * 2 + slot_first) * slab4];
+    for (int w = w_first + 1; w <= w_last; w += kFixBatch) {
+        float4 v[kFixBatch];
 #pragma unroll
-    for (int k = 0; k < KZ; ++k) acc[k] = base[((int64_t)w_first * 2 + slot_first) * slab_floats + (int64_t)k * NTHREADS];
-    for (int w = w_first + 1; w <= w_last; ++w) {
-        const float* sl = base + ((int64_t)w * 2) * slab_floats;
-        float v[KZ];
+        for (int j = 0; j < kFixBatch; ++j) v[j] = base[((int64_t)min(w + j, w_last) * 2) * slab4];
 #pragma unroll
-        for (int k = 0; k < KZ; ++k) v[k] = sl[(int64_t)k * NTHREADS];
-#pragma unroll
-        for (int k = 0; k < KZ; ++k) acc[k] += v[k];
+        for (int j = 0; j < kFixBatch; ++j)
+            if (w + j <= w_last) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
     }
     // decode (register index, thread) -> (channel, point) exactly as the MFMA kernel lays its accumulators out
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int wo = wave / WP, wp = wave % WP;
+    const int tile = g.T_dp + tile_l;
     const int o0 = (tile % g.TO) * BO, p0 = (tile / g.TO) * BP;
     const int npts = g.GH * g.GW;
     const int64_t ohw = (int64_t)g.OH * g.OW;
     const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
     float* yb = y + ((int64_t)b * g.O) * ohw;
+    const int fr = q >> 2, fp = fr % FP, fo = (fr / FP) % FO, ph = fr / (FP * FO);
+    const int p = p0 + (wp * FP + fp) * 32 + l31;
+    if (p >= npts) return;
+    const int pr = p / g.GW, pc = p - pr * g.GW;
+    int64_t pix = p;
+    if (TR) {
+        const int oy = 2 * pr + (ph >> 1), ox = 2 * pc + (ph & 1);
+        if (oy >= g.OH || ox >= g.OW) return;
+        pix = (int64_t)oy * g.OW + ox;
+    }
+    const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-    for (int k = 0; k < KZ; ++k) {
-        const int kk = k0 + k, r = kk & 15, fp = (kk >> 4) % FP, fo = ((kk >> 4) / FP) % FO, ph = (kk >> 4) / (FP * FO);
-        const int p = p0 + (wp * FP + fp) * 32 + l31;
+    for (int k = 0; k < 4; ++k) {
+        const int r = (q & 3) * 4 + k;
         const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (p >= npts || o >= g.O) continue;
-        const int pr = p / g.GW, pc = p - pr * g.GW;
-        int64_t pix = p;
-        if (TR) {
-            const int oy = 2 * pr + (ph >> 1), ox = 2 * pc + (ph & 1);
-            if (oy >= g.OH || ox >= g.OW) continue;
-            pix = (int64_t)oy * g.OW + ox;
-        }
-        yb[(int64_t)o * ohw + pix] = epilogue(acc[k], b, o, pix, ohw, g, e, ns);
+        if (o < g.O) yb[(int64_t)o * ohw + pix] = epilogue(vals[k], b, o, pix, ohw, g, e, ns);
     }
 }
 
@@ -417,22 +423,26 @@ int launch_npos(const float* x, const float* wk, const float* styles, float* y, 
     g.patch_cap = (worst + 3) & ~3;
     const size_t lds = (size_t)(NT * CC * BO + CC * g.patch_cap) * sizeof(float);
     if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
-    if (g.G == g.T) {   // one whole tile per workgroup
+    int st = IA_OK;
+    if (g.T_dp > 0) {   // whole rounds: one tile per workgroup
         auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, false>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
-        return ia::check_launch("ia_conv2d_mfma");
+        hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
+        st = ia::check_launch("ia_conv2d_mfma");
     }
-    auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, true>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
-    int st = ia::check_launch("ia_conv2d_mfma");
-    if (st != IA_OK) return st;
-    const bool whole_tiles = ((int64_t)g.T * g.C) % g.G == 0 && (((int64_t)g.T * g.C) / g.G) % g.C == 0;
-    if (!whole_tiles) {   // some tiles were shared between workers
-        constexpr int NACC = (TR ? 4 : 1) * FO * FP * 16;
-        hipLaunchKernelGGL((conv_fixup_kernel<TR, FO, FP, WO, WP>), dim3(g.T, g.B, NACC / KZ), dim3(WO * WP * 64), 0, s, scratch, y, g, e);
-        st = ia::check_launch("ia_conv2d_mfma(fix-up)");
+    if (st == IA_OK && g.T > g.T_dp) {   // the rest: stream-K, then the fix-up of the tiles that were shared
+        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, true>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
+        st = ia::check_launch("ia_conv2d_mfma(stream-K)");
+        const int64_t U = (int64_t)(g.T - g.T_dp) * g.C;
+        const bool whole_tiles = U % g.G == 0 && (U / g.G) % g.C == 0;
+        if (st == IA_OK && !whole_tiles) {
+            constexpr int NACC = (TR ? 4 : 1) * FO * FP * 16;
+            hipLaunchKernelGGL((conv_fixup_kernel<TR, FO, FP, WO, WP>), dim3(g.T - g.T_dp, g.B, NACC / 4), dim3(WO * WP * 64), 0, s,
+                               scratch, y, g, e);
+            st = ia::check_launch("ia_conv2d_mfma(fix-up)");
+        }
     }
     return st;
 }
@@ -471,8 +481,8 @@ void tile_dims(int O, int npts, int transposed, int* bo, int* bp, int* cc) {
 
 }  // namespace
 
-// Shared by the planner and the entry point: tile counts and the worker count for a layer.
-struct Plan { int bo, bp, cc, T, TO, C, G, nacc_threads; };
+// Shared by the planner and the entry point: tile counts and the split between whole rounds and stream-K.
+struct Plan { int bo, bp, cc, T, TO, C, T_dp, G, slab_floats; };
 static Plan make_plan(int B, int I, int O, int H, int W, int transposed) {
     Plan p;
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
@@ -480,23 +490,28 @@ static Plan make_plan(int B, int I, int O, int H, int W, int transposed) {
     p.TO = (O + p.bo - 1) / p.bo;
     p.T = ((npts + p.bp - 1) / p.bp) * p.TO;
     p.C = (I + p.cc - 1) / p.cc;
-    const int64_t U = (int64_t)p.T * p.C;
-    // two workgroups per CU over the whole launch (all batch elements); never more workers than units
-    const int64_t slots = 2 * ia::kNumCU;                           // two workgroups per CU
-    int64_t G;
-    if ((int64_t)p.T * B >= slots && (((int64_t)p.T * B) % slots == 0 || (int64_t)p.T * B >= 8 * slots)) {
-        G = p.T;                                                     // whole rounds of whole tiles: one tile per workgroup, no fix-up
+    const int slots = 2 * ia::kNumCU;                                // two workgroups per CU
+    const int Gb = slots / B > 0 ? slots / B : 1;                    // slots of one batch element
+    const int rounds = p.T / Gb, R = p.T - rounds * Gb;
+    if (R == 0 || rounds >= 8 || (rounds >= 1 && 4 * R >= 3 * Gb)) {
+        p.T_dp = p.T; p.G = 0;                                       // whole (or nearly whole) rounds of whole tiles
     } else {
-        G = (slots + B - 1) / B;                                     // stream-K: equal (tile, chunk) ranges
-        if (G > U / 2) G = U / 2;                                    // at least two K chunks per worker
+        p.T_dp = rounds * Gb;
+        const int64_t Ur = (int64_t)R * p.C;
+        // leftovers of a multi-round layer: at most an 8-way split per tile (a short tail);
+        // a layer smaller than the machine: as many workers as fit, at least two chunks each
+        const int per = rounds > 0 ? (p.C >= 8 ? p.C / 8 : 1) : 2;
+        int64_t G = Ur / per;
+        if (G > Gb) G = Gb;
+        if (G < 1) G = 1;
+        p.G = (int)G;
     }
-    if (G < 1) G = 1;
-    // when every worker would get >= one whole tile, round down to a divisor-friendly count only if it is exact
-    p.G = (int)G;
     const int frags = (p.bo / 32) * (p.bp / 32) / 4;                 // fragments per wave with 4 waves
-    p.nacc_threads = (transposed ? 4 : 1) * frags * 16 * 256;       // floats per slab
+    p.slab_floats = (transposed ? 4 : 1) * frags * 16 * 256;
     return p;
 }
+
+static size_t scratch_bytes_for(int B, int G, int slab_floats) { return (size_t)B * G * 2 * slab_floats * sizeof(float); }
 
 extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int* h_ksplit,
                               size_t* h_scratch_bytes) {
@@ -504,7 +519,7 @@ extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int 
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
     const Plan p = make_plan(B, I, O, H, W, transposed);
     *h_ksplit = p.G;
-    *h_scratch_bytes = (size_t)B * p.G * 2 * p.nacc_threads * sizeof(float);
+    *h_scratch_bytes = scratch_bytes_for(B, p.G, p.slab_floats);
     return IA_OK;
 }
 
@@ -518,7 +533,7 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
     IA_REQUIRE(ksize == 1 || ksize == 3, "kernel size must be 1 or 3");
     IA_REQUIRE(!transposed || ksize == 3, "the transposed form is 3x3 stride 2 only");
     IA_REQUIRE(act == IA_ACT_LINEAR || act == IA_ACT_LRELU, "conv epilogue supports linear and lrelu");
-    IA_REQUIRE(ksplit >= 1, "worker count must be >= 1");
+    IA_REQUIRE(ksplit >= 0, "worker count must be >= 0");
     IA_REQUIRE(!transposed || (noise == nullptr && bias == nullptr && residual == nullptr && act == IA_ACT_LINEAR),
                "the transposed form only applies the demodulation; FIR + bias_act follow in ia_fir_bias_act");
     Geo g;
@@ -528,15 +543,16 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
     IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
     const Plan p = make_plan(B, I, O, H, W, transposed);
     const int bp_ = p.bp;
-    g.T = p.T; g.TO = p.TO; g.C = p.C;
-    const int64_t U = (int64_t)p.T * p.C;
-    g.G = (int)(ksplit > U ? U : ksplit);
-    g.patch_cap = 0;
-    {
-        const size_t need = (size_t)B * g.G * 2 * p.nacc_threads * sizeof(float);
-        const bool whole_tiles = U % g.G == 0 && (U / g.G) % g.C == 0;
+    g.T = p.T; g.TO = p.TO; g.C = p.C; g.T_dp = p.T_dp; g.G = 0;
+    if (p.T_dp < p.T) {
+        IA_REQUIRE(ksplit >= 1, "this layer has stream-K tiles: pass the worker count from ia_conv2d_plan");
+        const int64_t Ur = (int64_t)(p.T - p.T_dp) * p.C;
+        g.G = (int)(ksplit > Ur ? Ur : ksplit);
+        const size_t need = scratch_bytes_for(B, g.G, p.slab_floats);
+        const bool whole_tiles = Ur % g.G == 0 && (Ur / g.G) % g.C == 0;
         IA_REQUIRE(whole_tiles || (scratch && scratch_bytes >= need), "stream-K needs %zu bytes of scratch, got %zu", need, scratch_bytes);
     }
+    g.patch_cap = 0;
     Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp};
     hipStream_t s = (hipStream_t)stream;
     if (bp_ == 32) {   // small images: 4 waves side by side over 128 out-channels, one 32-point fragment each

@@ -31,6 +31,14 @@ class GraphedSynthesis:
 
     def capture(self):
         # valid camera / inputs must be in the static buffers before capture (the warm-up runs execute real kernels)
+        from . import hipops
+        saved_tag, hipops.SCRATCH_TAG = hipops.SCRATCH_TAG, id(self)   # own stream-K scratch: graphs may replay concurrently
+        try:
+            return self._capture()
+        finally:
+            hipops.SCRATCH_TAG = saved_tag
+
+    def _capture(self):
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream), torch.no_grad():

@@ -12,13 +12,14 @@ from . import _lib
 ACT_ID = {'linear': 1, 'lrelu': 3}
 
 # Optional per-launch timing for bench.py's roofline leg: when PROFILE is a list, every fused stage appends
-# (kernel family, algorithmic FLOPs, algorithmic HBM bytes, start event, end event) recorded on the launch stream.
+# (kernel family, algorithmic FLOPs, algorithmic HBM bytes, start event, end event, shape note) recorded on the launch stream.
 PROFILE = None
 
 
 class _Timed:
-    def __init__(self, family, flops, nbytes):
+    def __init__(self, family, flops, nbytes, desc=''):
         self.args = (family, float(flops), float(nbytes))
+        self.desc = desc
 
     def __enter__(self):
         if PROFILE is not None:
@@ -30,7 +31,7 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append(self.args + (self.e0, self.e1))
+            PROFILE.append(self.args + (self.e0, self.e1, self.desc))
         return False
 
 
@@ -65,12 +66,15 @@ def modconv_demod(styles, wsq):
 
 
 _scratch = {}
+# Launch sequences that may run concurrently although they were issued on the same stream (two captured graphs replayed
+# on different streams) must not share scratch: each sets its own tag while it is being captured.
+SCRATCH_TAG = 0
 
 
 def _scratch_buffer(device, nbytes):
-    """Grow-only scratch for the stream-K accumulator slabs, one per (device, stream): launches on different streams may
-    overlap, so they must not share slabs (caller-owned memory, as the ABI requires)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    """Grow-only scratch for the stream-K accumulator slabs, one per (device, stream, tag): launches on different streams
+    may overlap, so they must not share slabs (caller-owned memory, as the ABI requires)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, SCRATCH_TAG)
     buf = _scratch.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
@@ -92,16 +96,20 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     lib = _lib.load()
     plan_s, plan_bytes = ctypes.c_int(0), ctypes.c_size_t(0)
     _lib.check(lib.ia_conv2d_plan(b, i, o, h, w, ksize, int(transposed), ctypes.byref(plan_s), ctypes.byref(plan_bytes)), 'ia_conv2d_plan')
+    nbytes = plan_bytes.value
     if ksplit is None:
         ksplit = plan_s.value
+    elif plan_s.value > 0 and ksplit != plan_s.value:   # caller-chosen worker count (tests): scale the slabs with it
+        nbytes = nbytes // plan_s.value * max(int(ksplit), 1)
     oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (h, w)
     y = torch.empty(b, o, oh, ow, device=x.device, dtype=torch.float32)
-    scratch, nbytes = None, plan_bytes.value
+    scratch = None
     if nbytes:
         scratch = _scratch_buffer(x.device, nbytes)
     flops = 2.0 * b * h * w * i * o * ksize * ksize
     traffic = 4.0 * (x.numel() + wk.numel() + y.numel() + (residual.numel() if residual is not None else 0))
-    with torch.cuda.device(x.device), _Timed('conv2d_mfma_t' if transposed else f'conv2d_mfma_k{ksize}', flops, traffic):
+    with torch.cuda.device(x.device), _Timed('conv2d_mfma_t' if transposed else f'conv2d_mfma_k{ksize}', flops, traffic,
+                                             f'B{b} I{i} O{o} {h}x{w} G{ksplit}'):
         st = lib.ia_conv2d_mfma(_p(x), _p(wk), _p(styles), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(residual),
                                 _p(y), _p(scratch), nbytes, b, i, o, h, w, ksize, int(transposed), ACT_ID[act], float(alpha),
                                 float(gain), float(-1 if clamp is None else clamp), int(ksplit), _lib.stream_ptr(x.device))

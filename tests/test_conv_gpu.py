@@ -58,7 +58,7 @@ def test_synthesis_layer(b, i, o, res, up):
     assert max_abs(got, ref) <= 3e-5 * max(scale, 1.0), (max_abs(got, ref), scale)
 
 
-@pytest.mark.parametrize('ksplit', [1, 2, 4, 8])
+@pytest.mark.parametrize('ksplit', [1, 2, 4, 8, 24, 64])
 def test_split_k_matches(ksplit):
     x, w, styles = rnd(1, 1, 64, 16, 16), rnd(2, 48, 64, 3, 3), rnd(3, 1, 64) * 0.3 + 1
     ref = _layer_ref(x, w, styles, None, 0, rnd(5, 48), 1, clamp=1.5)
@@ -67,6 +67,43 @@ def test_split_k_matches(ksplit):
     ref = _layer_ref(x, w, styles, None, 0, rnd(5, 48), 2)
     got = _layer_hip(x, w, styles, None, 0, rnd(5, 48), 2, ksplit=ksplit).cpu()
     assert max_abs(got, ref) <= 5e-5
+
+
+@pytest.mark.parametrize('transposed', [False, True])
+def test_whole_rounds_plus_stream_k_leftovers(transposed):
+    """B = 4 leaves 128 workgroup slots per batch element; 130 tiles = one whole round + 2 stream-K leftovers.
+    Checked against the device library convolution, twice (the flag header must come back zeroed), bit-identical."""
+    h, w, o = (127, 129, 64) if transposed else (128, 130, 128)
+    x = torch.randn(4, 16, h, w, device='cuda')
+    wt = torch.randn(o, 16, 3, 3, device='cuda') * 0.1
+    wk = hipops.pack_conv_weight(wt)
+    if transposed:
+        ref = torch.nn.functional.conv_transpose2d(x, wt.transpose(0, 1), stride=2)
+    else:
+        ref = torch.nn.functional.conv2d(x, wt, padding=1)
+    got = hipops.conv2d_mfma(x, wk, ksize=3, transposed=transposed)
+    again = hipops.conv2d_mfma(x, wk, ksize=3, transposed=transposed)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 5e-4          # library conv accumulates in a different order
+    assert torch.equal(got, again)
+
+
+def test_stream_k_is_deterministic_under_concurrency():
+    """The same layer on two streams at once (separate scratch per stream) and repeatedly: always the same bits."""
+    x = torch.randn(1, 256, 32, 32, device='cuda')
+    wk = hipops.pack_conv_weight(torch.randn(256, 256, 3, 3, device='cuda') * 0.05)
+    first = hipops.conv2d_mfma(x, wk, ksize=3)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(4):
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                outs.append(hipops.conv2d_mfma(x, wk, ksize=3))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(x, wk.reshape(3, 3, 256, 256).permute(3, 2, 0, 1), padding=1)
+    assert (first - ref).abs().max().item() <= 2e-3
+    assert all(torch.equal(first, o) for o in outs)
 
 
 @pytest.mark.parametrize('o', [3, 32, 96])
