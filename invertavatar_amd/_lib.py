@@ -57,9 +57,11 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        path = _build.LIB_PATH
-        if not os.path.exists(path):
-            path = _build.build()
+        path = os.environ.get('IA_HIP_LIB')          # explicit library (kernel experiments); otherwise the in-tree build
+        if not path:
+            path = _build.LIB_PATH
+            if not os.path.exists(path):
+                path = _build.build()
         lib = ctypes.CDLL(path)
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(lib, name)

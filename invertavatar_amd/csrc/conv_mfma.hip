@@ -112,8 +112,11 @@ __device__ __forceinline__ float epilogue(float v, int b, int o, int64_t pix, in
     return v;
 }
 
-// FO x FP fragments (32 channels x 32 points each) per wave, WO x WP waves per workgroup, CC in-channels per K chunk,
-// NPOS patch positions staged per thread (>= ceil(worst PSZ / threads), chosen by the host).
+// Which tile families stage through two LDS buffers: the transposed 64ch x 128pt tile does half the MFMAs of the conv tile
+// per staged chunk, so its two barriers per chunk cost twice as much; its stage is small enough for two per workgroup at
+// two workgroups per CU.
+__host__ __device__ constexpr bool double_buffered(bool tr, int fo, int fp) { return tr && fo * fp >= 2; }
+
 // Accumulator tile -> global memory.  C/D map of the 32x32 MFMA: row(channel) = (r&3) + 8*(r>>2) + 4*half, col(point) = l31.
 template <bool TR, int FO, int FP, int WO, int WP>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][FP], float* __restrict__ y, const Geo& g, const Epi& e,
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
     constexpr int PAD = TR ? 0 : KS / 2;
     constexpr int NACC = NPH * FO * FP * 16;           // accumulator registers per thread = floats per thread in a slab
+    constexpr bool DB = double_buffered(TR, FO, FP);   // two LDS stages: one barrier per chunk, commit overlaps the MFMAs
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -245,8 +249,9 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
         const int e_ = min(tid + k * NTHREADS, NT * CC * ROWV - 1);
         w_row[k] = e_ / ROWV; w_o4[k] = (e_ - w_row[k] * ROWV) * 4;
     }
+    const int stage_floats = NT * CC * BO + CC * g.patch_cap;
     float* w_lds = lds;                       // [NT*CC][BO]
-    float* p_lds = lds + NT * CC * BO;        // [CC][PSZ]
+    float* p_lds = lds + NT * CC * BO;        // [CC][PSZ]   (second stage, if any, stage_floats further on)
     float pv[NPOS][CC];                       // staged patch values     (global -> registers -> LDS)
     float sv[CC];                             // style * channel-tail mask of the staged chunk
     float4 wv[NWV];                           // staged weight vectors
@@ -277,20 +282,20 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
             }
         }
     };
-    auto commit = [&]() {   // registers -> LDS: style, zero padding and channel-tail masks folded into one multiply
+    auto commit = [&](int st_off) {   // registers -> LDS: style, zero padding and channel-tail masks folded into one multiply
 #pragma unroll
         for (int j = 0; j < NPOS; ++j) {
             const int pp = tid + j * NTHREADS;
             if (pp < PSZ) {
 #pragma unroll
-                for (int cc = 0; cc < CC; ++cc) p_lds[cc * PSZ + pp] = pv[j][cc] * (sv[cc] * gmask[j]);
+                for (int cc = 0; cc < CC; ++cc) p_lds[st_off + cc * PSZ + pp] = pv[j][cc] * (sv[cc] * gmask[j]);
             }
         }
 #pragma unroll
         for (int k = 0; k < NWV; ++k) {
             if (tid + k * NTHREADS < NT * CC * ROWV) {
                 // (weights of channels past ci_end need no mask: their patch rows are zeroed through sv[])
-                *(float4*)(w_lds + w_row[k] * BO + w_o4[k]) = wv[k];
+                *(float4*)(w_lds + st_off + w_row[k] * BO + w_o4[k]) = wv[k];
             }
         }
     };
@@ -301,11 +306,20 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
     static_assert(NSTEP_K % KP == 0, "chunk depth must be a multiple of the step depth");
 
     prefetch(ci_begin);
-    for (int ci0 = ci_begin; ci0 < ci_end; ci0 += CC) {
-        __syncthreads();                 // everyone is done reading the previous chunk
-        commit();
+    if constexpr (DB) {
+        __syncthreads();                 // (previous segment's readers are done)
+        commit(0);
         __syncthreads();
-        if (ci0 + CC < ci_end) prefetch(ci0 + CC);   // global loads of the next chunk fly behind the MFMAs below
+        if (ci_begin + CC < ci_end) prefetch(ci_begin + CC);
+    }
+    int st_cur = 0;                      // LDS stage the MFMAs of this chunk read (float offset)
+    for (int ci0 = ci_begin; ci0 < ci_end; ci0 += CC) {
+        if constexpr (!DB) {
+            __syncthreads();                 // everyone is done reading the previous chunk
+            commit(0);
+            __syncthreads();
+            if (ci0 + CC < ci_end) prefetch(ci0 + CC);   // global loads of the next chunk fly behind the MFMAs below
+        }
         // MFMA over the chunk: k-pair = channels (2cp, 2cp+1) of one tap; lane half picks the channel.  Operand reads
         // run one step ahead of the MFMAs that consume them (double-buffered registers) so the LDS latency hides
         // under the >= 256 MFMA cycles of a step.
@@ -315,9 +329,9 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
             for (int kk = 0; kk < KP; ++kk) {
                 const int kp = st * KP + kk, t = kp / (CC / 2), cp = kp % (CC / 2);
 #pragma unroll
-                for (int fo = 0; fo < FO; ++fo) a[kk][fo] = w_lds[(t * CC + 2 * cp + half) * BO + (wo * FO + fo) * 32 + l31];
+                for (int fo = 0; fo < FO; ++fo) a[kk][fo] = w_lds[st_cur + (t * CC + 2 * cp + half) * BO + (wo * FO + fo) * 32 + l31];
 #pragma unroll
-                for (int fp = 0; fp < FP; ++fp) bv[kk][fp] = p_lds[2 * cp * PSZ + base[fp] + toff[t]];
+                for (int fp = 0; fp < FP; ++fp) bv[kk][fp] = p_lds[st_cur + 2 * cp * PSZ + base[fp] + toff[t]];
             }
         };
         load_ops(0, a_buf[0], b_buf[0]);
@@ -337,6 +351,15 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
             }
             __builtin_amdgcn_sched_group_barrier(0x100, KP * (FO + FP), 0);   // next step's ds_reads first ...
             __builtin_amdgcn_sched_group_barrier(0x008, KP * FO * FP, 0);     // ... then this step's MFMAs
+        }
+        if constexpr (DB) {
+            // the next chunk (in registers since the last barrier) goes to the other stage while other waves may still
+            // be multiplying this one; a single barrier then publishes it and retires this stage
+            const int st_next = stage_floats - st_cur;
+            if (ci0 + CC < ci_end) commit(st_next);
+            __syncthreads();
+            if (ci0 + 2 * CC < ci_end) prefetch(ci0 + 2 * CC);
+            st_cur = st_next;
         }
     }
 
@@ -421,7 +444,7 @@ int launch_npos(const float* x, const float* wk, const float* styles, float* y, 
     constexpr int BO = 32 * FO * WO, NT = KS * KS;
     Geo g = g_in;
     g.patch_cap = (worst + 3) & ~3;
-    const size_t lds = (size_t)(NT * CC * BO + CC * g.patch_cap) * sizeof(float);
+    const size_t lds = (size_t)(NT * CC * BO + CC * g.patch_cap) * sizeof(float) * (double_buffered(TR, FO, FP) ? 2 : 1);
     if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
     int st = IA_OK;
     if (g.T_dp > 0) {   // whole rounds: one tile per workgroup
