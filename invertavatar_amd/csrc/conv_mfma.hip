@@ -34,10 +34,12 @@
 // machine (e.g. the (H+1)x(W+1) point grids of the transposed form: 524 equal workgroups on 512 slots ran as two rounds)
 // and gives low-resolution layers, which have only a handful of tiles, a fine-grained K split.
 #include "ia_common.h"
+#include <type_traits>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPatchFloats = 1024;  // per-channel LDS patch capacity (floats)
 
@@ -112,10 +114,11 @@ __device__ __forceinline__ float epilogue(float v, int b, int o, int64_t pix, in
     return v;
 }
 
-// Which tile families stage through two LDS buffers: the transposed 64ch x 128pt tile does half the MFMAs of the conv tile
-// per staged chunk, so its two barriers per chunk cost twice as much; its stage is small enough for two per workgroup at
-// two workgroups per CU.
-__host__ __device__ constexpr bool double_buffered(bool tr, int fo, int fp) { return tr && fo * fp >= 2; }
+// DB (two LDS stages) is used by the transposed 64ch x 128pt tile, which does half the MFMAs of the conv tile per staged
+// chunk, and by the 8-wave 128ch x 256pt tile, which is alone on its CU: one barrier per chunk, the next chunk is
+// committed to the other stage at the top of an iteration, and the loads of the chunk after that are spread over the MFMA
+// steps.  DB kernels require 16-byte aligned weight rows (O % 4 == 0); the host falls back to the single-stage form otherwise.
+__host__ __device__ constexpr bool db_family(bool tr, int fo, int fp, int waves) { return (tr && fo * fp >= 2) || waves == 8; }
 
 // Accumulator tile -> global memory.  C/D map of the 32x32 MFMA: row(channel) = (r&3) + 8*(r>>2) + 4*half, col(point) = l31.
 template <bool TR, int FO, int FP, int WO, int WP>
@@ -157,8 +160,8 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
 // NPOS patch positions staged per thread (>= ceil(worst PSZ / threads), chosen by the host).
 // SK = false: workgroup = one whole tile (tiles [0, T_dp), whole rounds of the machine);
 // SK = true: stream-K ranges over tiles [T_dp, T) with slab hand-off.
-template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool SK>
-__global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wk,
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool SK, bool DB>
+__global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                                  const float* __restrict__ styles, float* __restrict__ y,
                                                                  float* __restrict__ slabs, Geo g, Epi e) {
     constexpr int NT = KS * KS;
@@ -166,7 +169,6 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
     constexpr int PAD = TR ? 0 : KS / 2;
     constexpr int NACC = NPH * FO * FP * 16;           // accumulator registers per thread = floats per thread in a slab
-    constexpr bool DB = double_buffered(TR, FO, FP);   // two LDS stages: one barrier per chunk, commit overlaps the MFMAs
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -226,9 +228,12 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
     const int HW = g.H * g.W;
 
     // ---- staging plan, fixed for the whole K loop.
-    // Patch: thread owns up to NPOS positions of the window; per position the global offset and a 0/1 mask are
-    // computed once, then every chunk issues CC unconditional loads per position (no branches around loads).
-    int goff[NPOS]; float gmask[NPOS];
+    // Patch: thread owns up to NPOS positions of the window; per position the byte offset inside this batch element's
+    // channel plane is computed once (positions outside the image get an offset past the buffer, which the descriptor's
+    // bounds check turns into 0.0: zero padding without a mask); every chunk then issues CC unconditional loads per
+    // position with the channel offset in an SGPR.
+    constexpr int kOutside = 0x7ffffff0;
+    int goff[NPOS];
 #pragma unroll
     for (int j = 0; j < NPOS; ++j) {
         const int pp = tid + j * NTHREADS;
@@ -237,17 +242,20 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
         const int pr = (int)(((float)qq + 0.5f) * inv_pw), pc = qq - pr * PW;
         const int iy = win.r0[sg] + pr, ix = win.c0[sg] + pc;
         const bool ok = pp < PSZ && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-        goff[j] = ok ? iy * g.W + ix : 0;
-        gmask[j] = ok ? 1.f : 0.f;
+        goff[j] = ok ? (iy * g.W + ix) * 4 : kOutside;
     }
-    // Weights: NWV float4 per thread per chunk from the [tap][I][O] slab; rows = (tap, cc), o contiguous.
-    constexpr int ROWV = BO / 4, NWV = (NT * CC * ROWV + NTHREADS - 1) / NTHREADS;
-    const bool o_full = (g.O % 4) == 0 && (o0 + BO <= g.O);          // block-uniform fast path
-    int w_row[NWV], w_o4[NWV];                                        // this thread's slots of the weight slab
+    // Weights: NWV float4 per thread per chunk from the [tap][I][O] slab; slot e = tid + k*NTHREADS covers row
+    // (tap, cc) = e / ROWV and channels 4*(e % ROWV) ..+3 of the tile, and lands at float 4*e of the LDS slab.
+    constexpr int ROWV = BO / 4, NSLOT = NT * CC * ROWV, NWV = (NSLOT + NTHREADS - 1) / NTHREADS;
+    // o_vec: every weight row is 16-byte aligned and at least one float4 long, so the slab is fetched with
+    // unconditional, clamped float4 buffer loads (rows past O feed accumulator rows that are never stored; rows past
+    // the end of the tensor -- channel tail of the last tap -- read as zero through the bounds check).
+    const bool o_vec = (g.O % 4) == 0;
+    int w_off[NWV];                                                   // byte offset of the slot at channel 0 of a chunk
 #pragma unroll
     for (int k = 0; k < NWV; ++k) {
-        const int e_ = min(tid + k * NTHREADS, NT * CC * ROWV - 1);
-        w_row[k] = e_ / ROWV; w_o4[k] = (e_ - w_row[k] * ROWV) * 4;
+        const int e_ = min(tid + k * NTHREADS, NSLOT - 1), row = e_ / ROWV;
+        w_off[k] = (((row / CC) * g.I + (row % CC)) * g.O + min(o0 + (e_ - row * ROWV) * 4, max(g.O - 4, 0))) * 4;
     }
     const int stage_floats = NT * CC * BO + CC * g.patch_cap;
     float* w_lds = lds;                       // [NT*CC][BO]
@@ -255,47 +263,63 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
     float pv[NPOS][CC];                       // staged patch values     (global -> registers -> LDS)
     float sv[CC];                             // style * channel-tail mask of the staged chunk
     float4 wv[NWV];                           // staged weight vectors
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)((int64_t)g.I * HW * 4), 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)((int64_t)NT * g.I * g.O * 4), 0x00020000);
 
-    // All loads of a chunk are unconditional (addresses clamped, masks applied at commit) so that they issue
-    // back-to-back and one wait covers them; the chunk after next is in flight while the current one is multiplied.
-    auto prefetch = [&](int ci0) {
+    // All loads of a chunk are unconditional so that they can be issued anywhere; the chunk after next is in flight
+    // while the current one is multiplied.  No 64-bit address arithmetic in the K loop: per-thread byte offsets fixed
+    // for the tile (VGPR) + a per-chunk channel offset (SGPR for the patch, one v_add for the weights).
+    auto fetch_styles = [&](int ci0) {
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) {
             const int ci = ci0 + cc;
             const float sty = sb ? sb[min(ci, g.I - 1)] : 1.f;
             sv[cc] = ci < ci_end ? sty : 0.f;
         }
-#pragma unroll
-        for (int j = 0; j < NPOS; ++j)
-#pragma unroll
-            for (int cc = 0; cc < CC; ++cc) pv[j][cc] = xb[(int64_t)min(ci0 + cc, g.I - 1) * HW + goff[j]];
-#pragma unroll
-        for (int k = 0; k < NWV; ++k) {
-            const int tap = w_row[k] / CC, cc = w_row[k] % CC;
-            const float* src = wk + ((int64_t)tap * g.I + min(ci0 + cc, g.I - 1)) * g.O;
-            const int o = o0 + w_o4[k];
-            if (o_full) wv[k] = *(const float4*)(src + o);
-            else {   // ragged out-channel edge: clamped scalar loads, masked
-                const int last = g.O - 1;
-                wv[k] = make_float4(o < g.O ? src[min(o, last)] : 0.f, o + 1 < g.O ? src[min(o + 1, last)] : 0.f,
-                                    o + 2 < g.O ? src[min(o + 2, last)] : 0.f, o + 3 < g.O ? src[min(o + 3, last)] : 0.f);
-            }
+    };
+    constexpr int NLOAD = NPOS * CC + NWV;                            // loads per thread per chunk
+    auto fetch_one = [&](int idx, int ci0) {                          // idx is a compile-time constant after unrolling
+        if (idx < NPOS * CC) {
+            const int j = idx / CC, cc = idx % CC;
+            pv[j][cc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, goff[j], min(ci0 + cc, g.I - 1) * HW * 4, 0));
+        } else {
+            const int k = idx - NPOS * CC;
+            // (whole-vector bit_cast: element-wise bit_casts of an ext_vector were seen to be folded to element 0)
+            wv[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[k] + ci0 * g.O * 4, 0, 0));
         }
     };
-    auto commit = [&](int st_off) {   // registers -> LDS: style, zero padding and channel-tail masks folded into one multiply
+    auto prefetch = [&](int ci0) {
+        fetch_styles(ci0);
+        if (DB || o_vec) {
+#pragma unroll
+            for (int idx = 0; idx < NLOAD; ++idx) fetch_one(idx, ci0);
+            return;
+        }
+#pragma unroll
+        for (int idx = 0; idx < NPOS * CC; ++idx) fetch_one(idx, ci0);
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) {   // rows that are not 16-byte aligned: clamped scalar loads, masked
+            const int e_ = min(tid + k * NTHREADS, NSLOT - 1), row = e_ / ROWV;
+            const float* src = wk + ((int64_t)(row / CC) * g.I + min(ci0 + row % CC, g.I - 1)) * g.O;
+            const int o = o0 + (e_ - row * ROWV) * 4, last = g.O - 1;
+            wv[k] = make_float4(o < g.O ? src[min(o, last)] : 0.f, o + 1 < g.O ? src[min(o + 1, last)] : 0.f,
+                                o + 2 < g.O ? src[min(o + 2, last)] : 0.f, o + 3 < g.O ? src[min(o + 3, last)] : 0.f);
+        }
+    };
+    auto commit = [&](int st_off) {   // registers -> LDS: style and channel-tail masks folded into one multiply
 #pragma unroll
         for (int j = 0; j < NPOS; ++j) {
             const int pp = tid + j * NTHREADS;
             if (pp < PSZ) {
 #pragma unroll
-                for (int cc = 0; cc < CC; ++cc) p_lds[st_off + cc * PSZ + pp] = pv[j][cc] * (sv[cc] * gmask[j]);
+                for (int cc = 0; cc < CC; ++cc) p_lds[st_off + cc * PSZ + pp] = pv[j][cc] * sv[cc];
             }
         }
 #pragma unroll
         for (int k = 0; k < NWV; ++k) {
-            if (tid + k * NTHREADS < NT * CC * ROWV) {
+            if (tid + k * NTHREADS < NSLOT) {
                 // (weights of channels past ci_end need no mask: their patch rows are zeroed through sv[])
-                *(float4*)(w_lds + st_off + w_row[k] * BO + w_o4[k]) = wv[k];
+                *(float4*)(w_lds + st_off + (tid + k * NTHREADS) * 4) = wv[k];
             }
         }
     };
@@ -313,12 +337,21 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
         if (ci_begin + CC < ci_end) prefetch(ci_begin + CC);
     }
     int st_cur = 0;                      // LDS stage the MFMAs of this chunk read (float offset)
+    // DB kernels spread the global loads of the chunk after next over the first half of the MFMA steps (LPS per step)
+    // instead of issuing them in one burst: ~25 loads per thread from every workgroup at once back up the request path
+    // and hold the waves at VMEM issue while the MFMA pipe drains.
+    constexpr int LPS = (2 * NLOAD + NSTEP - 1) / NSTEP;
     for (int ci0 = ci_begin; ci0 < ci_end; ci0 += CC) {
-        if constexpr (!DB) {
+        if constexpr (DB) {
+            // the next chunk (in registers, loaded during the previous iteration) goes to the other stage, whose readers
+            // passed the barrier at the end of the previous iteration
+            if (ci0 + CC < ci_end) commit(stage_floats - st_cur);
+            fetch_styles(ci0 + 2 * CC);                        // (loads past the last chunk are clamped and unused)
+        } else {
             __syncthreads();                 // everyone is done reading the previous chunk
             commit(0);
             __syncthreads();
-            if (ci0 + CC < ci_end) prefetch(ci0 + CC);   // global loads of the next chunk fly behind the MFMAs below
+            if (ci0 + CC < ci_end) prefetch(ci0 + CC);         // global loads of the next chunk fly behind the MFMAs below
         }
         // MFMA over the chunk: k-pair = channels (2cp, 2cp+1) of one tap; lane half picks the channel.  Operand reads
         // run one step ahead of the MFMAs that consume them (double-buffered registers) so the LDS latency hides
@@ -338,6 +371,11 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
             if (st + 1 < NSTEP) load_ops(st + 1, a_buf[(st + 1) & 1], b_buf[(st + 1) & 1]);
+            if constexpr (DB) {
+#pragma unroll
+                for (int l = 0; l < LPS; ++l)
+                    if (st * LPS + l < NLOAD) fetch_one(st * LPS + l, ci0 + 2 * CC);
+            }
 #pragma unroll
             for (int kk = 0; kk < KP; ++kk) {
                 const int t = (st * KP + kk) / (CC / 2);
@@ -350,16 +388,12 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const float*
                                                                                acc[ph][fo][fp], 0, 0, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x100, KP * (FO + FP), 0);   // next step's ds_reads first ...
+            if (DB && st * LPS < NLOAD) __builtin_amdgcn_sched_group_barrier(0x020, LPS, 0);   // ... a few global loads ...
             __builtin_amdgcn_sched_group_barrier(0x008, KP * FO * FP, 0);     // ... then this step's MFMAs
         }
         if constexpr (DB) {
-            // the next chunk (in registers since the last barrier) goes to the other stage while other waves may still
-            // be multiplying this one; a single barrier then publishes it and retires this stage
-            const int st_next = stage_floats - st_cur;
-            if (ci0 + CC < ci_end) commit(st_next);
-            __syncthreads();
-            if (ci0 + 2 * CC < ci_end) prefetch(ci0 + 2 * CC);
-            st_cur = st_next;
+            __syncthreads();             // publishes the stage committed above and retires the one just read
+            st_cur = stage_floats - st_cur;
         }
     }
 
@@ -438,23 +472,23 @@ __global__ __launch_bounds__(WO * WP * 64) void conv_fixup_kernel(const float* _
     }
 }
 
-template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS>
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool DB>
 int launch_npos(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g_in, const Epi& e,
                 int worst, hipStream_t s) {
     constexpr int BO = 32 * FO * WO, NT = KS * KS;
     Geo g = g_in;
     g.patch_cap = (worst + 3) & ~3;
-    const size_t lds = (size_t)(NT * CC * BO + CC * g.patch_cap) * sizeof(float) * (double_buffered(TR, FO, FP) ? 2 : 1);
+    const size_t lds = (size_t)(NT * CC * BO + CC * g.patch_cap) * sizeof(float) * (DB ? 2 : 1);
     if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
     int st = IA_OK;
     if (g.T_dp > 0) {   // whole rounds: one tile per workgroup
-        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, false>;
+        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, false, DB>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma");
     }
     if (st == IA_OK && g.T > g.T_dp) {   // the rest: stream-K, then the fix-up of the tiles that were shared
-        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, true>;
+        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, true, DB>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma(stream-K)");
@@ -483,9 +517,16 @@ int launch(const float* x, const float* wk, const float* styles, float* y, float
     }
     if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d floats exceeds the LDS budget", worst);
     const int npos = (worst + NTHREADS - 1) / NTHREADS;
-    if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1>(x, wk, styles, y, scratch, g, e, worst, s);
-    if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2>(x, wk, styles, y, scratch, g, e, worst, s);
-    return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4>(x, wk, styles, y, scratch, g, e, worst, s);
+    if constexpr (db_family(TR, FO, FP, WO * WP)) {
+        if (g.O % 4 == 0) {
+            if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, true>(x, wk, styles, y, scratch, g, e, worst, s);
+            if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, true>(x, wk, styles, y, scratch, g, e, worst, s);
+            return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4, true>(x, wk, styles, y, scratch, g, e, worst, s);
+        }
+    }
+    if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, false>(x, wk, styles, y, scratch, g, e, worst, s);
+    if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, false>(x, wk, styles, y, scratch, g, e, worst, s);
+    return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4, false>(x, wk, styles, y, scratch, g, e, worst, s);
 }
 
 constexpr int kChunkConv = 8, kChunkTransposed = 8;
@@ -495,25 +536,44 @@ constexpr int kChunkConv = 8, kChunkTransposed = 8;
 // Images with <= kSmallPoints output points (4x4 .. 16x16) use a (128ch x 32pt) tile: the MFMA work of a chunk is fixed
 // by the tile, so a 128-point tile would spend 4 us per chunk on padding there.
 constexpr int kSmallPoints = 320;
-void tile_dims(int O, int npts, int transposed, int* bo, int* bp, int* cc) {
-    if (npts <= kSmallPoints && O > 32) { *bo = 128; *bp = 32; *cc = kChunkConv; }
+// Images with >= kWidePoints points use an 8-wave (128ch x 256pt) tile for 3x3 convolutions with wide outputs: one
+// workgroup per CU fetches the chunk's weight slab once instead of twice (the slab is 70 % of the staged bytes).
+constexpr int kWidePoints = 4096;
+
+int worst_patch(int npts, int GW, int bp, int ksize, bool tr) {
+    int worst = 0;
+    for (int q0 = 0; q0 < npts; q0 += bp) {
+        const int q1 = (q0 + bp < npts ? q0 + bp : npts) - 1;
+        const Window w = tile_window(q0, q1, GW, tr ? 0 : ksize / 2, tr);
+        if (w.PSZ > worst) worst = w.PSZ;
+    }
+    return worst;
+}
+
+void tile_dims(int O, int H, int W, int ksize, int transposed, int* bo, int* bp, int* cc, int* waves) {
+    const int npts = transposed ? (H + 1) * (W + 1) : H * W;
+    *waves = 4; *cc = kChunkConv;
+    if (npts <= kSmallPoints && O > 32) { *bo = 128; *bp = 32; }
     else if (transposed) { *bo = 64; *bp = 128; *cc = kChunkTransposed; }
-    else if (O <= 32) { *bo = 32; *bp = 256; *cc = kChunkConv; }
-    else { *bo = 128; *bp = 128; *cc = kChunkConv; }
+    else if (O <= 32) { *bo = 32; *bp = 256; }
+    else if (ksize == 3 && O >= 128 && O % 4 == 0 && npts >= kWidePoints && worst_patch(npts, W, 256, 3, false) <= kPatchFloats) {
+        *bo = 128; *bp = 256; *waves = 8;
+    }
+    else { *bo = 128; *bp = 128; }
 }
 
 }  // namespace
 
 // Shared by the planner and the entry point: tile counts and the split between whole rounds and stream-K.
-struct Plan { int bo, bp, cc, T, TO, C, T_dp, G, slab_floats; };
-static Plan make_plan(int B, int I, int O, int H, int W, int transposed) {
+struct Plan { int bo, bp, cc, waves, T, TO, C, T_dp, G, slab_floats; };
+static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transposed) {
     Plan p;
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
-    tile_dims(O, npts, transposed, &p.bo, &p.bp, &p.cc);
+    tile_dims(O, H, W, ksize, transposed, &p.bo, &p.bp, &p.cc, &p.waves);
     p.TO = (O + p.bo - 1) / p.bo;
     p.T = ((npts + p.bp - 1) / p.bp) * p.TO;
     p.C = (I + p.cc - 1) / p.cc;
-    const int slots = 2 * ia::kNumCU;                                // two workgroups per CU
+    const int slots = (p.waves == 8 ? 1 : 2) * ia::kNumCU;           // workgroups per CU of the tile family
     const int Gb = slots / B > 0 ? slots / B : 1;                    // slots of one batch element
     const int rounds = p.T / Gb, R = p.T - rounds * Gb;
     if (R == 0 || rounds >= 8 || (rounds >= 1 && 4 * R >= 3 * Gb)) {
@@ -529,8 +589,8 @@ static Plan make_plan(int B, int I, int O, int H, int W, int transposed) {
         if (G < 1) G = 1;
         p.G = (int)G;
     }
-    const int frags = (p.bo / 32) * (p.bp / 32) / 4;                 // fragments per wave with 4 waves
-    p.slab_floats = (transposed ? 4 : 1) * frags * 16 * 256;
+    const int frags = (p.bo / 32) * (p.bp / 32) / p.waves;           // fragments per wave
+    p.slab_floats = (transposed ? 4 : 1) * frags * 16 * p.waves * 64;
     return p;
 }
 
@@ -540,7 +600,7 @@ extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int 
                               size_t* h_scratch_bytes) {
     IA_REQUIRE(h_ksplit && h_scratch_bytes, "null output pointer");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
-    const Plan p = make_plan(B, I, O, H, W, transposed);
+    const Plan p = make_plan(B, I, O, H, W, ksize, transposed);
     *h_ksplit = p.G;
     *h_scratch_bytes = scratch_bytes_for(B, p.G, p.slab_floats);
     return IA_OK;
@@ -564,7 +624,7 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
     g.GH = transposed ? H + 1 : H; g.GW = transposed ? W + 1 : W;
     g.OH = transposed ? 2 * H + 1 : H; g.OW = transposed ? 2 * W + 1 : W;
     IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
-    const Plan p = make_plan(B, I, O, H, W, transposed);
+    const Plan p = make_plan(B, I, O, H, W, ksize, transposed);
     const int bp_ = p.bp;
     g.T = p.T; g.TO = p.TO; g.C = p.C; g.T_dp = p.T_dp; g.G = 0;
     if (p.T_dp < p.T) {
@@ -588,6 +648,7 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
         return ksize == 3 ? launch<3, false, 1, 2, 1, 4, kChunkConv>(x, wk, styles, y, scratch, g, e, s)
                           : launch<1, false, 1, 2, 1, 4, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
     }
+    if (p.waves == 8) return launch<3, false, 2, 2, 2, 4, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
     return ksize == 3 ? launch<3, false, 2, 2, 2, 2, kChunkConv>(x, wk, styles, y, scratch, g, e, s)
                       : launch<1, false, 2, 2, 2, 2, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
 }
