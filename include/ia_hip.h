@@ -213,6 +213,13 @@ int ia_blend_planes(const float* stitch, const float* full_alpha, const float* s
                     float* planes_cl, int B, int y0, int y1, int x0, int x1, void* stream);
 
 /*
+ * Paste of a rasterised condition over features or the skip image inside the face backbone
+ * (training_avatar_texture/networks_stylegan2_new.py:537-540):  y = cond[:, :C] * a + x * (1 - a),  a = cond[:, C:C+1].
+ *   cond : [B, C+1, H, W] float32 (last channel = alpha);  x, y : [B, C, H, W] float32;  H*W % 4 == 0.
+ */
+int ia_cond_blend(const float* cond, const float* x, float* y, int B, int C, int H, int W, void* stream);
+
+/*
  * All affine style vectors and demodulation coefficients of one synthesis network in two launches.
  * Replaces, per layer, FullyConnectedLayer.forward of `.affine` (training/networks_stylegan2.py:114-127, called at :318
  * and :353) and the demodulation reduction of modulated_conv2d (:60-64):

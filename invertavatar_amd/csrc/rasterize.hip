@@ -263,6 +263,31 @@ extern "C" int ia_rasterize_level(const float* tex_cl, const float* uv, const fl
     return ia::check_launch("ia_rasterize_level");
 }
 
+// y[b,c] = cond[b,c] * a + x[b,c] * (1 - a), a = cond[b,C]: the paste of a rasterised condition over the features / skip image
+// (networks_stylegan2_new.py:537-540), same operation order as the reference's four elementwise kernels.
+__global__ __launch_bounds__(256) void cond_blend_kernel(const float* __restrict__ cond, const float* __restrict__ x, float* __restrict__ y,
+                                                         int C, int64_t hw4, int64_t total4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int64_t pix4 = i % hw4, bc = i / hw4, b = bc / C, c = bc - b * C;
+    const float4 cv = reinterpret_cast<const float4*>(cond)[(b * (C + 1) + c) * hw4 + pix4];
+    const float4 av = reinterpret_cast<const float4*>(cond)[(b * (C + 1) + C) * hw4 + pix4];
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    float4 o;
+    o.x = cv.x * av.x + xv.x * (1.f - av.x); o.y = cv.y * av.y + xv.y * (1.f - av.y);
+    o.z = cv.z * av.z + xv.z * (1.f - av.z); o.w = cv.w * av.w + xv.w * (1.f - av.w);
+    reinterpret_cast<float4*>(y)[i] = o;
+}
+
+extern "C" int ia_cond_blend(const float* cond, const float* x, float* y, int B, int C, int H, int W, void* stream) {
+    IA_REQUIRE(cond && x && y, "null pointer argument");
+    IA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "empty tensor");
+    IA_REQUIRE(((int64_t)H * W) % 4 == 0, "H*W must be a multiple of 4");
+    const int64_t hw4 = (int64_t)H * W / 4, total4 = (int64_t)B * C * hw4;
+    hipLaunchKernelGGL(cond_blend_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cond, x, y, C, hw4, total4);
+    return ia::check_launch("ia_cond_blend");
+}
+
 extern "C" int ia_blend_planes(const float* stitch, const float* full_alpha, const float* static_planes, int64_t sta_batch_stride,
                                float* planes_cl, int B, int y0, int y1, int x0, int x1, void* stream) {
     IA_REQUIRE(stitch && full_alpha && static_planes && planes_cl, "null pointer argument");

@@ -201,11 +201,13 @@ def fill_mouth(alpha):
     return mouth
 
 
-def rasterize_level(tex, uvcoords_image, upper_alpha, sta, bbox, res):
+def rasterize_level(tex, uvcoords_image, upper_alpha, sta, bbox, res, tex_cl=None):
     """One level of TriPlaneGenerator.rasterize (see ia_rasterize_level).  tex [B,C,Rt,Rt]; sta NCHW (may be a channel
-    slice of a wider tensor as long as channels/rows are dense); returns [B, C+1, res, res]."""
+    slice of a wider tensor as long as channels/rows are dense); returns [B, C+1, res, res].  `tex_cl` is the level
+    already in channels-last order (channels_last_copy), if the caller made it ahead of time."""
     b, c, rt, _ = tex.shape
-    tex_cl = tex.permute(0, 2, 3, 1).contiguous()
+    if tex_cl is None:
+        tex_cl = channels_last_copy(tex)
     rs = sta.shape[-1]
     if not (sta.stride(3) == 1 and sta.stride(2) == rs and sta.stride(1) == rs * rs and sta.shape[1] >= c):
         sta = sta.contiguous()
@@ -217,6 +219,21 @@ def rasterize_level(tex, uvcoords_image, upper_alpha, sta, bbox, res):
                                             b, c, rt, rs, res, y0, y1, x0, x1, _lib.stream_ptr(tex.device))
     _lib.check(st, 'ia_rasterize_level')
     return out
+
+
+def cond_blend(cond, x):
+    """cond[:, :-1] * a + x * (1 - a) with a = cond[:, -1:] in one pass (see ia_cond_blend)."""
+    b, c, h, w = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        st = _lib.load().ia_cond_blend(_p(_f32c(cond, 'cond')), _p(_f32c(x, 'x')), _p(y), b, c, h, w, _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_cond_blend')
+    return y
+
+
+def channels_last_copy(t):
+    """[B,C,H,W] -> contiguous [B,H,W,C] (the layout ia_rasterize_level gathers from)."""
+    return t.permute(0, 2, 3, 1).contiguous()
 
 
 def blend_planes(stitch, full_alpha, static_planes, bbox):

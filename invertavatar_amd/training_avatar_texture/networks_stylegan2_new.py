@@ -19,6 +19,15 @@ from ..training.networks_stylegan2 import (normalize_2nd_moment, modulated_conv2
                                            MappingNetwork, SynthesisLayer, ToRGBLayer, SynthesisBlock)
 
 
+def _paste(cond, x, fused):
+    """cond[:, :-1] * a + x * (1 - a), a = cond[:, -1:] (reference :537-540)."""
+    if fused and cond.dtype == torch.float32 and (x.shape[2] * x.shape[3]) % 4 == 0:
+        from invertavatar_amd import hipops
+        return hipops.cond_blend(cond.contiguous(), x.contiguous())
+    a = cond[:, -1:]
+    return cond[:, :-1] * a + x * (1 - a)
+
+
 @persistence.persistent_class
 class SynthesisNetwork(_base.SynthesisNetwork):
     def forward_head(self, ws, out_res=(32, 256), **block_kwargs):
@@ -51,17 +60,19 @@ class SynthesisNetwork(_base.SynthesisNetwork):
                 x, img = getattr(self, f'b{res}')(x, img, cur_ws, cond, **block_kwargs)
             if idx < first:
                 continue
+            # On the device inference path nothing downstream writes x / img in place (every fused layer allocates its
+            # output), so the taps are returned without the reference's defensive clones, and the condition paste
+            # (four elementwise kernels in the reference, :537-540) is one launch.
+            fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
             if return_list:
                 if idx == first:
-                    feats.append(img.clone())
-                feats.append(x.clone())
+                    feats.append(img if fused else img.clone())
+                feats.append(x if fused else x.clone())
             if cond_list is not None:
                 if idx == first:   # face region copied straight into the skip image
-                    alpha = cond_list[0][:, -1:]
-                    img = cond_list[0][:, :-1] * alpha + img * (1 - alpha)
+                    img = _paste(cond_list[0], img, fused)
                 if idx < last:     # ... and into the features of the next block's input
-                    c = cond_list[1 + idx - first]
-                    x = c[:, :-1] * c[:, -1:] + x * (1 - c[:, -1:])
+                    x = _paste(cond_list[1 + idx - first], x, fused)
         if return_list:
             feats.append(img)
             return feats

@@ -95,10 +95,13 @@ class TriPlaneGenerator(torch.nn.Module):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             texture_feats = tex()
+            # the rasteriser gathers from channels-last copies; make them here, under the static backbone
+            tex_cl = [hipops.channels_last_copy(t) if t.dtype == torch.float32 else None for t in texture_feats[:N_COND_LEVELS_USED]]
         static_feats = sta()
         main.wait_stream(side)
-        for t in texture_feats:
+        for t in list(texture_feats) + [t for t in tex_cl if t is not None]:
             t.record_stream(main)
+        object.__setattr__(self, '_tex_cl', (texture_feats, tex_cl))
         return texture_feats, static_feats
 
     def _start_face_head(self, ws, update_emas, synthesis_kwargs):
@@ -117,10 +120,13 @@ class TriPlaneGenerator(torch.nn.Module):
         img.record_stream(main)
         return x, img, first, done
 
-    def _start_mouth_fill(self, mesh_condition):
+    def _start_mouth_fill(self, mesh_condition, rays=None):
         """The mouth-hole fill depends only on the UV mask, and its flood is a one-workgroup, latency-bound kernel:
-        start it on a side stream at the top of the frame so that it runs underneath the backbone convolutions."""
+        start it on a side stream at the top of the frame so that it runs underneath the backbone convolutions.
+        `rays` = (c, neural_rendering_resolution, ray_dist): the camera rays and the batch mean of |ray origin| depend
+        only on the cameras, so they are produced on the same side stream (self._side_rays)."""
         uv = mesh_condition['uvcoords_image']
+        object.__setattr__(self, '_side_rays', None)
         if not (uv.is_cuda and not torch.is_grad_enabled()):
             return None
         if getattr(self, '_side_stream', None) is None or self._side_stream.device != uv.device:
@@ -128,13 +134,30 @@ class TriPlaneGenerator(torch.nn.Module):
         main = torch.cuda.current_stream(uv.device)
         self._side_stream.wait_stream(main)
         with torch.cuda.stream(self._side_stream):
-            alpha = uv.float()[..., 2:].permute(0, 3, 1, 2).contiguous()
+            uv_c = uv.float().contiguous()
+            alpha = uv_c[..., 2:].permute(0, 3, 1, 2).contiguous()
             full_alpha, mouth = fill_mouth(alpha, blur_mouth_edge=False)
+            upper_c = self._upper_alpha(alpha, mouth).reshape(-1, uv.shape[1], uv.shape[2]).contiguous()
+            extra = ()
+            if rays is not None:
+                c, nrr, ray_dist = rays
+                origins, dirs, nrr = self._rays(c, nrr)
+                if ray_dist is None:
+                    ray_dist = torch.norm(origins, dim=-1).mean().reshape(1)     # (renderer.py:311), no host sync
+                object.__setattr__(self, '_side_rays', (origins, dirs, nrr, ray_dist))
+                extra = (origins, dirs, ray_dist)
             done = torch.cuda.Event()
             done.record(self._side_stream)
-        for t in (alpha, full_alpha, mouth):
+        for t in (uv_c, alpha, full_alpha, mouth, upper_c) + tuple(t for t in extra if torch.is_tensor(t)):
             t.record_stream(main)
-        return alpha, full_alpha, mouth, done
+        return alpha, full_alpha, mouth, done, uv_c, upper_c
+
+    @staticmethod
+    def _upper_alpha(alpha, mouth):
+        """Face alpha with the upper part of the mouth hole closed (reference :324-326)."""
+        upper = mouth.clone()
+        upper[:, :, :87] = 0
+        return torch.clamp(alpha + upper, min=0, max=1)
 
     @staticmethod
     def _split_static(static_feats):
@@ -193,9 +216,12 @@ class TriPlaneGenerator(torch.nn.Module):
     # ------------------------------------------------------------------ public synthesis entry points
     def synthesis(self, ws, c, mesh_condition, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
                   use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, ray_dist=None, **synthesis_kwargs):
-        mouth = self._start_mouth_fill(mesh_condition)
+        mouth = self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, ray_dist))
         face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
-        origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
+        if self._side_rays is not None:      # made on the side stream; joined with the mouth fill inside rasterize()
+            origins, dirs, nrr, ray_dist = self._side_rays
+        else:
+            origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
         texture_feats, static_feats = self._two_backbones(ws, update_emas, synthesis_kwargs)
         planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, mouth=mouth,
                               face_head=face_head)
@@ -246,24 +272,29 @@ class TriPlaneGenerator(torch.nn.Module):
         `levels` limits how many pyramid levels are produced (None = all, as the reference)."""
         uv = uvcoords_image if uvcoords_image.dtype == torch.float32 else uvcoords_image.float()
         grid, alpha = uv[..., :2], uv[..., 2:].permute(0, 3, 1, 2)
+        fused = uv.is_cuda and uv.shape[1:3] == (256, 256) and not torch.is_grad_enabled()
+        uv_c = upper_c = None
         if _mouth is not None:   # started on the side stream by synthesis(): join it here
-            alpha, full_alpha, mouth, done = _mouth
+            alpha, full_alpha, mouth, done, uv_c, upper_c = _mouth
             torch.cuda.current_stream(uv.device).wait_event(done)
+            upper_alpha = upper_c.unsqueeze(1)
         else:
             full_alpha, mouth = fill_mouth(alpha.clone(), blur_mouth_edge=False)
-        upper = mouth.clone()
-        upper[:, :, :87] = 0
-        upper_alpha = torch.clamp(alpha + upper, min=0, max=1)
+            upper_alpha = self._upper_alpha(alpha, mouth)
+            if fused:
+                uv_c, upper_c = uv.contiguous(), upper_alpha.reshape(-1, 256, 256).contiguous()
         out = []
         n = len(texture_feats) if levels is None else min(levels, len(texture_feats))
-        fused = uv.is_cuda and uv.shape[1:3] == (256, 256) and not torch.is_grad_enabled()
-        uv_c = uv.contiguous() if fused else None
-        upper_c = upper_alpha.reshape(-1, 256, 256).contiguous() if fused else None
-        for tex, sta in zip(texture_feats[:n], static_feats[:n]):
+        # channels-last copies made on the texture stream by _two_backbones (same list object => same frame)
+        cached = getattr(self, '_tex_cl', None)
+        tex_cl = cached[1] if (cached is not None and cached[0] is texture_feats) else [None] * n
+        object.__setattr__(self, '_tex_cl', None)
+        for k, (tex, sta) in enumerate(zip(texture_feats[:n], static_feats[:n])):
             res = tex.shape[2]
             y0, y1, x0, x1 = [round(v * res / 256) for v in bbox_256]
             if fused and res in (32, 64, 128) and tex.dtype == torch.float32 and sta.dtype == torch.float32:
-                out.append(hipops.rasterize_level(tex, uv_c, upper_c, sta, (y0, y1, x0, x1), res))
+                out.append(hipops.rasterize_level(tex, uv_c, upper_c, sta, (y0, y1, x0, x1), res,
+                                                  tex_cl=tex_cl[k] if k < len(tex_cl) else None))
                 continue
             rend = _aa_resize(F.grid_sample(tex, grid, align_corners=False), res)
             a = _aa_resize(alpha, res)

@@ -108,3 +108,14 @@ def test_filtered_lrelu_composition_on_device():
     y = filtered_lrelu.filtered_lrelu(x.cuda(), fu.cuda(), fu.cuda(), b.cuda(), up=2, down=2, padding=3)
     r = filtered_lrelu.filtered_lrelu(x, fu, fu, b, up=2, down=2, padding=3, impl='ref')
     assert max_abs(y.cpu(), r) <= 1e-5
+
+
+def test_cond_blend_is_the_reference_expression_bit_for_bit():
+    """ia_cond_blend = cond[:, :-1] * a + x * (1 - a), a = cond[:, -1:] (networks_stylegan2_new.py:537-540): same
+    operation order as the four elementwise kernels of the reference, so the bits must be identical."""
+    from invertavatar_amd import hipops
+    cond, x = rnd(1, 2, 33, 16, 24).cuda(), rnd(2, 2, 32, 16, 24).cuda()
+    cond[:, -1:] = cond[:, -1:].sigmoid()
+    a = cond[:, -1:]
+    ref = cond[:, :-1] * a + x * (1 - a)
+    assert torch.equal(hipops.cond_blend(cond, x), ref)
