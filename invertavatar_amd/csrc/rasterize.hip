@@ -50,16 +50,25 @@ struct RastParams {
     int by0, by1, bx0, bx1;   // crop of the static level that is resized to res
 };
 
-__global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
+__global__ __launch_bounds__(512) void rasterize_level_kernel(RastParams p) {
     __shared__ int4 s_idx[kMaxRows * kMaxCols];     // 4 texel indices (pre-multiplied by C) per source pixel
     __shared__ float4 s_w[kMaxRows * kMaxCols];     // 4 bilinear weights * row AA weight (0 for padding)
     __shared__ float4 s_wx[kMaxCols];               // column AA weight of each source column for the 4 output pixels
     __shared__ float s_alpha[kMaxRows * kMaxCols], s_upper[kMaxRows * kMaxCols];
     __shared__ float s_a[PXB], s_u[PXB];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // partial sums of the split walk
 
     const int tid = threadIdx.x;
-    const int xt = blockIdx.x * PXB, y = blockIdx.y, b = blockIdx.z;
     const int res = p.res;
+    // Workgroup -> output tile, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, so id % 8 picks the
+    // XCD and id / 8 the position inside that XCD's share; each XCD then owns a contiguous band of output rows and its
+    // L2 only has to hold the texels under that band (a 128^2 x 256-channel level is 16 MB, a band of it 2 MB).
+    const int xtiles = (res + PXB - 1) / PXB, per_img = xtiles * res, nblk = per_img * p.B;
+    const int per_xcd = (nblk + 7) / 8;
+    const int logical = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    if (logical >= nblk) return;
+    const int b = logical / per_img, rem = logical - b * per_img;
+    const int y = rem / xtiles, xt = (rem - y * xtiles) * PXB;
 
     // ---- AA footprint: rows of output row y, columns of output pixels xt .. xt+3
     int ylo, yhi; float yc, yinv, ytot;
@@ -136,17 +145,25 @@ __global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
     const int64_t rr = (int64_t)res * res;
     float* outb = p.out + (int64_t)b * (p.C + 1) * rr + (int64_t)y * res + xt;
     const bool vec_ok = (xt + PXB <= res) && (res % 4 == 0);
-    // each thread owns 4 consecutive channels (one 16-byte gather per texel) when C % 4 == 0, else one channel
+    // each thread owns 4 consecutive channels (one 16-byte gather per texel) when C % 4 == 0, else one channel;
+    // when the level has fewer channel groups than the workgroup has threads, the threads split the footprint's source
+    // pixels nsplit ways (every nsplit-th pixel) and the partial sums are added through LDS in split order: the walk
+    // over the footprint is a chain of dependent-latency gathers, so more walkers per output pixel is what makes it fast.
     const int CV = (p.C % 4 == 0) ? 4 : 1;
-    for (int c = tid * CV; c < p.C; c += blockDim.x * CV) {
-        float acc[4][PXB];
+    const int ncq = (p.C + CV - 1) / CV;
+    const int nsplit = (CV == 4 && ncq <= (int)blockDim.x) ? (int)blockDim.x / ncq : 1;
+    float* s_red = reinterpret_cast<float*>(s_dyn);                 // [nsplit][ncq][16]
+
+    // walk source pixels first, first + step, ... of the footprint for channels c .. c+CV-1
+    auto walk = [&](int c, int first, int step, float (&acc)[4][PXB]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < PXB; ++k) acc[j][k] = 0.f;
         const float* tc = texb + c;
         if (CV == 4) {
-            for (int i = 0; i < nsrc; ++i) {
+#pragma unroll 2
+            for (int i = first; i < nsrc; i += step) {
                 const int4 id = s_idx[i];
                 const float4 w = s_w[i];
                 const float4 wx = s_wx[i % ncols];
@@ -163,7 +180,7 @@ __global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
                 }
             }
         } else {
-            for (int i = 0; i < nsrc; ++i) {
+            for (int i = first; i < nsrc; i += step) {
                 const int4 id = s_idx[i];
                 const float4 w = s_w[i];
                 const float4 wx = s_wx[i % ncols];
@@ -172,23 +189,101 @@ __global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
                 acc[0][2] = fmaf(v, wx.z, acc[0][2]); acc[0][3] = fmaf(v, wx.w, acc[0][3]);
             }
         }
+    };
+    // Static crop: the (<= kSRows x kSCols) source window of the 4 output pixels and its separable AA weights are the same
+    // for every channel, so they are tabulated once (wide windows fall back to the direct double loop).
+    constexpr int kSRows = 3, kSCols = 6;
+    const int s_c0 = sxlo[0], s_nc = sxhi[PXB - 1] - sxlo[0], s_nr = syhi - sylo;
+    const bool s_tab = s_nr <= kSRows && s_nc <= kSCols && s_nc > 0;
+    float swy[kSRows], swx[PXB][kSCols];
+#pragma unroll
+    for (int r = 0; r < kSRows; ++r) swy[r] = (s_tab && r < s_nr) ? aa_weight(sylo + r, syc, syinv, sytot) : 0.f;
+#pragma unroll
+    for (int k = 0; k < PXB; ++k)
+#pragma unroll
+        for (int i = 0; i < kSCols; ++i) {
+            const int X = s_c0 + i;
+            swx[k][i] = (s_tab && X >= sxlo[k] && X < sxhi[k]) ? aa_weight(X, sxc[k], sxinv[k], sxtot[k]) : 0.f;
+        }
+    // blend with the resized static crop and store channels c .. c+CV-1 of the 4 output pixels
+    auto finish = [&](int c, const float (&acc)[4][PXB]) {
         for (int j = 0; j < CV; ++j) {
             const float* sc = p.sta + (int64_t)b * p.sta_bs + (int64_t)(c + j) * p.Rs * p.Rs;
             float o[PXB];
+            if (s_tab) {
+                float sv[PXB] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < PXB; ++k) {
-                float sv = 0.f;
-                for (int jj = sylo; jj < syhi; ++jj) {
-                    const float wj = aa_weight(jj, syc, syinv, sytot);
-                    for (int i = sxlo[k]; i < sxhi[k]; ++i)
-                        sv = fmaf(sc[(int64_t)(p.by0 + jj) * p.Rs + p.bx0 + i], wj * aa_weight(i, sxc[k], sxinv[k], sxtot[k]), sv);
+                for (int r = 0; r < kSRows; ++r) {
+                    if (r < s_nr) {
+                        const float* row = sc + (int64_t)(p.by0 + sylo + r) * p.Rs + p.bx0 + s_c0;
+                        float h[PXB] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < kSCols; ++i) {
+                            if (i < s_nc) {
+                                const float v = row[i];
+#pragma unroll
+                                for (int k = 0; k < PXB; ++k) h[k] = fmaf(v, swx[k][i], h[k]);
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < PXB; ++k) sv[k] = fmaf(h[k], swy[r], sv[k]);
+                    }
                 }
-                const float a = s_a[k];
-                o[k] = acc[j][k] * a + sv * (1.f - a);
+#pragma unroll
+                for (int k = 0; k < PXB; ++k) { const float a = s_a[k]; o[k] = acc[j][k] * a + sv[k] * (1.f - a); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PXB; ++k) {
+                    float sv = 0.f;
+                    for (int jj = sylo; jj < syhi; ++jj) {
+                        const float wj = aa_weight(jj, syc, syinv, sytot);
+                        for (int i = sxlo[k]; i < sxhi[k]; ++i)
+                            sv = fmaf(sc[(int64_t)(p.by0 + jj) * p.Rs + p.bx0 + i], wj * aa_weight(i, sxc[k], sxinv[k], sxtot[k]), sv);
+                    }
+                    const float a = s_a[k];
+                    o[k] = acc[j][k] * a + sv * (1.f - a);
+                }
             }
             float* dst = outb + (int64_t)(c + j) * rr;
             if (vec_ok) *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
             else for (int k = 0; k < PXB && xt + k < res; ++k) dst[k] = o[k];
+        }
+    };
+
+    float acc[4][PXB];
+    if (nsplit > 1) {
+        // The walk over the footprint is a chain of dependent-latency gathers, and a level has fewer channel groups than
+        // the workgroup has threads: the threads split the source pixels nsplit ways (every nsplit-th pixel) and the
+        // partial sums are added through LDS in split order.
+        const int sp = tid / ncq, cq = tid - sp * ncq;
+        const bool active = sp < nsplit;
+        if (active) {
+            walk(cq * CV, sp, nsplit, acc);
+            float* mine = s_red + ((int64_t)sp * ncq + cq) * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < PXB; ++k) mine[j * PXB + k] = acc[j][k];
+        }
+        __syncthreads();
+        if (sp == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < PXB; ++k) acc[j][k] = 0.f;
+            for (int q = 0; q < nsplit; ++q) {
+                const float* part = s_red + ((int64_t)q * ncq + cq) * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < PXB; ++k) acc[j][k] += part[j * PXB + k];
+            }
+            finish(cq * CV, acc);
+        }
+    } else {
+        for (int c = tid * CV; c < p.C; c += blockDim.x * CV) {
+            walk(c, 0, 1, acc);
+            finish(c, acc);
         }
     }
     if (tid < PXB && xt + tid < res) outb[(int64_t)p.C * rr + tid] = s_u[tid];
@@ -256,10 +351,17 @@ extern "C" int ia_rasterize_level(const float* tex_cl, const float* uv, const fl
     if (res > kSrc || kSrc % res != 0 || kSrc / res > kMaxScale || kSrc / res < 2)
         return ia::fail(IA_ERR_UNSUPPORTED, "rasterize level resolution %d: supported are 32, 64, 128 (256 -> res by 8, 4, 2)", res);
     RastParams p{tex_cl, uv, upper_alpha, sta, out, sta_batch_stride, B, C, tex_res, sta_res, res, by0, by1, bx0, bx1};
-    dim3 grid((res + PXB - 1) / PXB, res, B);
-    // 4 channels per thread: 128 threads cover 512 channels; narrow levels use one wave
-    const int threads = (C % 4 == 0) ? (C >= 512 ? 128 : 64) : 256;
-    hipLaunchKernelGGL(rasterize_level_kernel, grid, dim3(threads), 0, (hipStream_t)stream, p);
+    const int nblk = ((res + PXB - 1) / PXB) * res * B;
+    dim3 grid(((nblk + 7) / 8) * 8);
+    // 4 channels per thread; the footprint walk is split over the remaining threads of a 256-thread workgroup (512 threads
+    // for the coarse levels, whose footprint is 640 source pixels per workgroup)
+    int threads = 256;
+    if (C % 4 == 0 && res <= 32 && C / 4 <= 512) threads = 512;
+    if (res > 32) threads = (C % 4 == 0) ? (C >= 512 ? 128 : 64) : 256;   // finer levels: enough workgroups, no split
+    const int ncq = C % 4 == 0 ? C / 4 : C;
+    const int nsplit = (C % 4 == 0 && ncq <= threads) ? threads / ncq : 1;
+    const size_t red_bytes = nsplit > 1 ? (size_t)nsplit * ncq * 16 * sizeof(float) : 0;
+    hipLaunchKernelGGL(rasterize_level_kernel, grid, dim3(threads), red_bytes, (hipStream_t)stream, p);
     return ia::check_launch("ia_rasterize_level");
 }
 
