@@ -81,6 +81,20 @@ def make_step(gen, ws, cams, uvs, jits, world, rank, graphed=None):
     return step
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of the dominant kernel family from the committed PMC collection (rocprofv3 --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE, separate passes over this same command with --eager; tools/pmc_frame.sh).  Counters cannot be read
+    from inside this process, so the figure comes from profiles/; None when that file is absent or names another family."""
+    path = os.path.join(REPO, 'profiles', 'r01_pmc_frame_hbm_traffic.json')
+    if family != 'conv2d_mfma' or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as fh:
+            return round(json.load(fh)['_summary']['conv_family_per_logical_launch_mb'] * 1e6)
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def roofline_leg(step, frames=3):
     """Per-launch timing of every fused stage over `frames` extra frames; dominant family by total time."""
     hipops.PROFILE = []
@@ -100,7 +114,7 @@ def roofline_leg(step, frames=3):
     d = fam[dom]
     achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
     out = dict(bound='mfma', kernel=dom, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-               frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None, launches_per_frame=d['launches'] // frames,
+               frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom), launches_per_frame=d['launches'] // frames,
                avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2), algorithmic_gflop_per_frame=round(d['flops'] / frames / 1e9, 1))
     others = {}
     for k, f in fam.items():
