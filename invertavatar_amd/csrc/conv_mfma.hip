@@ -114,11 +114,11 @@ __device__ __forceinline__ float epilogue(float v, int b, int o, int64_t pix, in
     return v;
 }
 
-// DB (two LDS stages) is used by the transposed 64ch x 128pt tile, which does half the MFMAs of the conv tile per staged
-// chunk, and by the 8-wave 128ch x 256pt tile, which is alone on its CU: one barrier per chunk, the next chunk is
+// DB (two LDS stages) is used by the transposed 64ch x 64pt x 4-phase tile, which does a quarter of the MFMAs of the conv tile
+// per staged chunk, and by the 8-wave 128ch x 256pt tile, which is alone on its CU: one barrier per chunk, the next chunk is
 // committed to the other stage at the top of an iteration, and the loads of the chunk after that are spread over the MFMA
 // steps.  DB kernels require 16-byte aligned weight rows (O % 4 == 0); the host falls back to the single-stage form otherwise.
-__host__ __device__ constexpr bool db_family(bool tr, int fo, int fp, int waves) { return (tr && fo * fp >= 2) || waves == 8; }
+__host__ __device__ constexpr bool db_family(bool tr, int fo, int fp, int wo, int wp) { return (tr && wo == 2) || wo * wp == 8; }
 
 // Accumulator tile -> global memory.  C/D map of the 32x32 MFMA: row(channel) = (r&3) + 8*(r>>2) + 4*half, col(point) = l31.
 template <bool TR, int FO, int FP, int WO, int WP>
@@ -517,7 +517,7 @@ int launch(const float* x, const float* wk, const float* styles, float* y, float
     }
     if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d floats exceeds the LDS budget", worst);
     const int npos = (worst + NTHREADS - 1) / NTHREADS;
-    if constexpr (db_family(TR, FO, FP, WO * WP)) {
+    if constexpr (db_family(TR, FO, FP, WO, WP)) {
         if (g.O % 4 == 0) {
             if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, true>(x, wk, styles, y, scratch, g, e, worst, s);
             if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, true>(x, wk, styles, y, scratch, g, e, worst, s);
@@ -531,8 +531,10 @@ int launch(const float* x, const float* wk, const float* styles, float* y, float
 
 constexpr int kChunkConv = 8, kChunkTransposed = 8;
 
-// Tile family per layer shape: (32ch x 256pt) for narrow outputs, (128ch x 128pt) otherwise; the transposed form
-// uses (64ch x 128pt x 4 phases) with 16-channel chunks so that it does as many MFMAs per staged chunk as the conv.
+// Tile family per layer shape: (32ch x 256pt) for narrow outputs, (128ch x 128pt) for mid-sized layers, (128ch x 256pt,
+// 8 waves) for large 3x3 layers; the transposed form uses (64ch x 64pt x 4 phases): the small point tile gives the
+// (H+1)x(W+1) grids of the 32^2..128^2 layers enough tiles that most of them run whole (a 128-point tile left every tile
+// of those layers split between stream-K workers: 128 KB of accumulator slab per part).
 // Images with <= kSmallPoints output points (4x4 .. 16x16) use a (128ch x 32pt) tile: the MFMA work of a chunk is fixed
 // by the tile, so a 128-point tile would spend 4 us per chunk on padding there.
 constexpr int kSmallPoints = 320;
@@ -554,7 +556,7 @@ void tile_dims(int O, int H, int W, int ksize, int transposed, int* bo, int* bp,
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
     *waves = 4; *cc = kChunkConv;
     if (npts <= kSmallPoints && O > 32) { *bo = 128; *bp = 32; }
-    else if (transposed) { *bo = 64; *bp = 128; *cc = kChunkTransposed; }
+    else if (transposed) { *bo = 64; *bp = 64; *cc = kChunkTransposed; }
     else if (O <= 32) { *bo = 32; *bp = 256; }
     else if (ksize == 3 && O >= 128 && O % 4 == 0 && npts >= kWidePoints && worst_patch(npts, W, 256, 3, false) <= kPatchFloats) {
         *bo = 128; *bp = 256; *waves = 8;
@@ -643,7 +645,7 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
         return ksize == 3 ? launch<3, false, 1, 1, 4, 1, kChunkConv>(x, wk, styles, y, scratch, g, e, s)
                           : launch<1, false, 1, 1, 4, 1, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
     }
-    if (transposed) return launch<3, true, 1, 2, 2, 2, kChunkTransposed>(x, wk, styles, y, scratch, g, e, s);
+    if (transposed) return launch<3, true, 1, 1, 2, 2, kChunkTransposed>(x, wk, styles, y, scratch, g, e, s);
     if (O <= 32) {
         return ksize == 3 ? launch<3, false, 1, 2, 1, 4, kChunkConv>(x, wk, styles, y, scratch, g, e, s)
                           : launch<1, false, 1, 2, 1, 4, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
