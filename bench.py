@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--width', default='full', choices=['full', 'small'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-sr-fp16', action='store_true', help='skip the extra leg with the SR head on the fp16 MFMA')
     ap.add_argument('--cpu-frames', type=int, default=3)
     ap.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
     ap.add_argument('--in-flight', type=int, default=1, help='frames in flight per rank (captured graphs on separate streams)')
@@ -145,6 +146,37 @@ def cpu_baseline_leg(gen, ws, cams, uvs, jits, frames):
                 sample=f'{frames} frames of the same workload (B=1, nrr={NRR}, 512^2 out, fp32) after 1 warm-up frame')
 
 
+def sr_fp16_leg(gen, ws, cams, uvs, jits, args, eager_step):
+    """Same workload with the SR head as the reference deploys it (sr_num_fp16_res = 4, train_avatar_texture.py:215,365):
+    its six 3x3 convolutions run with fp16 operands / fp32 accumulation on the fp16 MFMA (ia_conv2d_mfma_h); backbones and
+    renderer stay fp32.  Reported beside the fp32 headline, never as `value`."""
+    from invertavatar_amd.graphed import GraphedSynthesis
+    from invertavatar_amd.training import networks_stylegan2 as sg2
+    gen16 = TriPlaneGenerator(**synthetic.generator_kwargs(args.width, sr_num_fp16_res=4)).eval().requires_grad_(False)
+    gen16.load_state_dict(gen.state_dict())
+    gen16 = gen16.cuda()
+    saved, sg2.FP16_BLOCKS_COMPUTE_FP32 = sg2.FP16_BLOCKS_COMPUTE_FP32, False
+    try:
+        graphed = GraphedSynthesis(gen16, batch=FRAMES_PER_RANK, neural_rendering_resolution=NRR)
+        img16 = graphed(ws, cams[:1], uvs[:1], jits[:1])['image'].clone()
+        err = (img16 - eager_step(0)).abs().max().item()
+        n = cams.shape[0]
+        for k in range(args.warmup):
+            graphed(ws, cams[k % n:k % n + 1], uvs[k % n:k % n + 1], jits[k % n:k % n + 1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            i = k % n
+            graphed(ws, cams[i:i + 1], uvs[i:i + 1], jits[i:i + 1])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        sg2.FP16_BLOCKS_COMPUTE_FP32 = saved
+    return dict(value=round(args.steps / dt, 3), unit='frames/s', ms_per_step=round(dt / args.steps * 1e3, 3),
+                dtype='f32 backbones + renderer, SR head: fp16 operands / f32 accumulate / f32 storage',
+                max_abs_rgb_vs_f32_run=float(f'{err:.3e}'))
+
+
 def main():
     args = parse()
     rank, world, _ = setup_distributed(args.gpus)
@@ -224,6 +256,8 @@ def main():
                        'launch': launch_mode},
         }
         if rank == 0 and world == 1:
+            if not args.no_sr_fp16:
+                result['sr_fp16'] = sr_fp16_leg(gen, ws, cams, uvs, jits, args, eager_step)
             if not args.no_roofline:
                 result['roofline'], result['kernels'] = roofline_leg(eager_step)
             if not args.no_cpu_baseline:

@@ -131,6 +131,22 @@ int ia_conv2d_mfma(const float* x, const float* wk, const float* styles, const f
                    int B, int I, int O, int H, int W, int ksize, int transposed,
                    int act, float alpha, float gain, float clamp, int ksplit, void* stream);
 
+/*
+ * ia_conv2d_mfma with fp16 operands on v_mfma_f32_32x32x8_f16 and fp32 accumulation: the arithmetic of the reference's
+ * fp16 blocks (modulated_conv2d with x.dtype == float16, training/networks_stylegan2.py:34-91; the SR head with
+ * sr_num_fp16_res > 0, training_avatar_texture/superresolution.py:209-216).  The style-scaled input and the weights are
+ * rounded to fp16, everything else (demodulation, noise, bias, activation, clamp, storage) stays fp32.
+ *   wk_h : weights as fp16, packed [ksize*ksize][I/4][O][4] (channel quads innermost), from the reference's [O, I, kh, kw]
+ * Same arguments, plan and scratch as ia_conv2d_mfma.  Covers 3x3 layers that run on the two-stage tiles (stride-1 layers
+ * with O >= 128 and >= 64^2 outputs; every stride-2 transposed layer) with I % 8 == 0 and O % 4 == 0; other shapes return
+ * IA_ERR_INVALID_ARG and the caller uses ia_conv2d_mfma.
+ */
+int ia_conv2d_mfma_h(const float* x, const void* wk_h, const float* styles, const float* demod,
+                     const float* noise, const float* noise_strength, const float* bias, const float* residual,
+                     float* y, float* scratch, size_t scratch_bytes,
+                     int B, int I, int O, int H, int W, int ksize, int transposed,
+                     int act, float alpha, float gain, float clamp, int ksplit, void* stream);
+
 /* Host-only planner for ia_conv2d_mfma: stream-K worker count (0: none) and the scratch bytes the fix-up pass needs. */
 int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int* h_ksplit, size_t* h_scratch_bytes);
 

@@ -40,6 +40,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPatchFloats = 1024;  // per-channel LDS patch capacity (floats)
 
@@ -160,7 +161,10 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
 // NPOS patch positions staged per thread (>= ceil(worst PSZ / threads), chosen by the host).
 // SK = false: workgroup = one whole tile (tiles [0, T_dp), whole rounds of the machine);
 // SK = true: stream-K ranges over tiles [T_dp, T) with slab hand-off.
-template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool SK, bool DB>
+// HM = true (DB kernels only): fp16 operands on v_mfma_f32_32x32x8_f16, fp32 accumulation -- the arithmetic of the reference's
+// fp16 blocks (training/networks_stylegan2.py:34-91 with x.dtype == float16; superresolution.py:209-216), activations kept
+// in fp32 in memory.  `wk` then points at the fp16 weights packed [tap][I/4][O][4] (pack_conv_weight_h).
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool SK, bool DB, bool HM>
 __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                                  const float* __restrict__ styles, float* __restrict__ y,
                                                                  float* __restrict__ slabs, Geo g, Epi e) {
@@ -246,7 +250,10 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
     }
     // Weights: NWV float4 per thread per chunk from the [tap][I][O] slab; slot e = tid + k*NTHREADS covers row
     // (tap, cc) = e / ROWV and channels 4*(e % ROWV) ..+3 of the tile, and lands at float 4*e of the LDS slab.
-    constexpr int ROWV = BO / 4, NSLOT = NT * CC * ROWV, NWV = (NSLOT + NTHREADS - 1) / NTHREADS;
+    // (HM: the fp16 slab of a chunk is [tap][2 channel quads][BO][4] halves; 16-byte slot e covers (tap, quad) = e / (BO/2)
+    // and out-channels 2*(e % (BO/2)), +1, and lands at byte 16*e of the LDS slab.)
+    constexpr int ROWV = HM ? BO / 2 : BO / 4, NSLOT = HM ? NT * 2 * ROWV : NT * CC * ROWV, NWV = (NSLOT + NTHREADS - 1) / NTHREADS;
+    static_assert(!HM || (DB && CC == 8), "the fp16 MFMA mode is built for the two-stage kernels with 8-channel chunks");
     // o_vec: every weight row is 16-byte aligned and at least one float4 long, so the slab is fetched with
     // unconditional, clamped float4 buffer loads (rows past O feed accumulator rows that are never stored; rows past
     // the end of the tensor -- channel tail of the last tap -- read as zero through the bounds check).
@@ -255,7 +262,10 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
 #pragma unroll
     for (int k = 0; k < NWV; ++k) {
         const int e_ = min(tid + k * NTHREADS, NSLOT - 1), row = e_ / ROWV;
-        w_off[k] = (((row / CC) * g.I + (row % CC)) * g.O + min(o0 + (e_ - row * ROWV) * 4, max(g.O - 4, 0))) * 4;
+        if constexpr (HM)   // halves: ((tap*(I/4) + quad)*O + o)*4, o = o0 + 2*(e % ROWV) clamped inside the tensor row
+            w_off[k] = ((((row >> 1) * (g.I / 4) + (row & 1)) * g.O + min(o0 + (e_ - row * ROWV) * 2, max(g.O - 2, 0))) * 4) * 2;
+        else
+            w_off[k] = (((row / CC) * g.I + (row % CC)) * g.O + min(o0 + (e_ - row * ROWV) * 4, max(g.O - 4, 0))) * 4;
     }
     const int stage_floats = NT * CC * BO + CC * g.patch_cap;
     float* w_lds = lds;                       // [NT*CC][BO]
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
     float sv[CC];                             // style * channel-tail mask of the staged chunk
     float4 wv[NWV];                           // staged weight vectors
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)((int64_t)g.I * HW * 4), 0x00020000);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)((int64_t)NT * g.I * g.O * 4), 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)((int64_t)NT * g.I * g.O * (HM ? 2 : 4)), 0x00020000);
 
     // All loads of a chunk are unconditional so that they can be issued anywhere; the chunk after next is in flight
     // while the current one is multiplied.  No 64-bit address arithmetic in the K loop: per-thread byte offsets fixed
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         } else {
             const int k = idx - NPOS * CC;
             // (whole-vector bit_cast: element-wise bit_casts of an ext_vector were seen to be folded to element 0)
-            wv[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[k] + ci0 * g.O * 4, 0, 0));
+            wv[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[k] + ci0 * g.O * (HM ? 2 : 4), 0, 0));
         }
     };
     auto prefetch = [&](int ci0) {
@@ -311,8 +321,19 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         for (int j = 0; j < NPOS; ++j) {
             const int pp = tid + j * NTHREADS;
             if (pp < PSZ) {
+                if constexpr (HM) {   // patch as [2 channel quads][PSZ][4] halves: one 8-byte store per quad
+                    h16x4* ph = reinterpret_cast<h16x4*>(lds + st_off + NT * BO * 4);
 #pragma unroll
-                for (int cc = 0; cc < CC; ++cc) p_lds[st_off + cc * PSZ + pp] = pv[j][cc] * sv[cc];
+                    for (int q = 0; q < 2; ++q) {
+                        h16x4 v;
+                        v[0] = (_Float16)(pv[j][4 * q] * sv[4 * q]);         v[1] = (_Float16)(pv[j][4 * q + 1] * sv[4 * q + 1]);
+                        v[2] = (_Float16)(pv[j][4 * q + 2] * sv[4 * q + 2]); v[3] = (_Float16)(pv[j][4 * q + 3] * sv[4 * q + 3]);
+                        ph[q * PSZ + pp] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < CC; ++cc) p_lds[st_off + cc * PSZ + pp] = pv[j][cc] * sv[cc];
+                }
             }
         }
 #pragma unroll
@@ -324,8 +345,10 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         }
     };
 
-    constexpr int NSTEP_K = NT * (CC / 2);                    // k-pairs per chunk
-    constexpr int KP = (FO * FP >= 4) ? 1 : (FO * FP == 2 ? 2 : 4);   // k-pairs per pipeline step: >= 4 MFMAs (256 cycles) per step
+    // fp32: a k-step is a channel pair of one tap (32x32x2); fp16: all 8 channels of one tap (32x32x8)
+    constexpr int NSTEP_K = HM ? NT : NT * (CC / 2);          // k-steps per chunk
+    constexpr int KP = HM ? ((FO * FP >= 4) ? 1 : 3)          // k-steps per pipeline step
+                          : ((FO * FP >= 4) ? 1 : (FO * FP == 2 ? 2 : 4));   // fp32: >= 4 MFMAs (256 cycles) per step
     constexpr int NSTEP = NSTEP_K / KP;
     static_assert(NSTEP_K % KP == 0, "chunk depth must be a multiple of the step depth");
 
@@ -356,15 +379,26 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         // MFMA over the chunk: k-pair = channels (2cp, 2cp+1) of one tap; lane half picks the channel.  Operand reads
         // run one step ahead of the MFMAs that consume them (double-buffered registers) so the LDS latency hides
         // under the >= 256 MFMA cycles of a step.
-        float a_buf[2][KP][FO], b_buf[2][KP][FP];
-        auto load_ops = [&](int st, float (&a)[KP][FO], float (&bv)[KP][FP]) {
+        using op_t = std::conditional_t<HM, h16x4, float>;
+        op_t a_buf[2][KP][FO], b_buf[2][KP][FP];
+        auto load_ops = [&](int st, op_t (&a)[KP][FO], op_t (&bv)[KP][FP]) {
 #pragma unroll
             for (int kk = 0; kk < KP; ++kk) {
-                const int kp = st * KP + kk, t = kp / (CC / 2), cp = kp % (CC / 2);
+                if constexpr (HM) {
+                    const int t = st * KP + kk;
+                    const h16x4* wh = reinterpret_cast<const h16x4*>(lds + st_cur);
+                    const h16x4* ph = reinterpret_cast<const h16x4*>(lds + st_cur + NT * BO * 4);
 #pragma unroll
-                for (int fo = 0; fo < FO; ++fo) a[kk][fo] = w_lds[st_cur + (t * CC + 2 * cp + half) * BO + (wo * FO + fo) * 32 + l31];
+                    for (int fo = 0; fo < FO; ++fo) a[kk][fo] = wh[(t * 2 + half) * BO + (wo * FO + fo) * 32 + l31];
 #pragma unroll
-                for (int fp = 0; fp < FP; ++fp) bv[kk][fp] = p_lds[st_cur + 2 * cp * PSZ + base[fp] + toff[t]];
+                    for (int fp = 0; fp < FP; ++fp) bv[kk][fp] = ph[base[fp] + toff[t]];
+                } else {
+                    const int kp = st * KP + kk, t = kp / (CC / 2), cp = kp % (CC / 2);
+#pragma unroll
+                    for (int fo = 0; fo < FO; ++fo) a[kk][fo] = w_lds[st_cur + (t * CC + 2 * cp + half) * BO + (wo * FO + fo) * 32 + l31];
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp) bv[kk][fp] = p_lds[st_cur + 2 * cp * PSZ + base[fp] + toff[t]];
+                }
             }
         };
         load_ops(0, a_buf[0], b_buf[0]);
@@ -378,14 +412,19 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
             }
 #pragma unroll
             for (int kk = 0; kk < KP; ++kk) {
-                const int t = (st * KP + kk) / (CC / 2);
+                const int t = HM ? st * KP + kk : (st * KP + kk) / (CC / 2);
                 const int ph = TR ? (((t / KS) & 1) * 2 + ((t % KS) & 1)) : 0;
 #pragma unroll
                 for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
-                    for (int fp = 0; fp < FP; ++fp)
-                        acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][fp],
-                                                                               acc[ph][fo][fp], 0, 0, 0);
+                    for (int fp = 0; fp < FP; ++fp) {
+                        if constexpr (HM)
+                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x8f16(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][fp],
+                                                                                   acc[ph][fo][fp], 0, 0, 0);
+                        else
+                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][fp],
+                                                                                   acc[ph][fo][fp], 0, 0, 0);
+                    }
             }
             __builtin_amdgcn_sched_group_barrier(0x100, KP * (FO + FP), 0);   // next step's ds_reads first ...
             if (DB && st * LPS < NLOAD) __builtin_amdgcn_sched_group_barrier(0x020, LPS, 0);   // ... a few global loads ...
@@ -472,7 +511,7 @@ __global__ __launch_bounds__(WO * WP * 64) void conv_fixup_kernel(const float* _
     }
 }
 
-template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool DB>
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool DB, bool HM = false>
 int launch_npos(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g_in, const Epi& e,
                 int worst, hipStream_t s) {
     constexpr int BO = 32 * FO * WO, NT = KS * KS;
@@ -482,13 +521,13 @@ int launch_npos(const float* x, const float* wk, const float* styles, float* y, 
     if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
     int st = IA_OK;
     if (g.T_dp > 0) {   // whole rounds: one tile per workgroup
-        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, false, DB>;
+        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, false, DB, HM>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma");
     }
     if (st == IA_OK && g.T > g.T_dp) {   // the rest: stream-K, then the fix-up of the tiles that were shared
-        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, true, DB>;
+        auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, true, DB, HM>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma(stream-K)");
@@ -504,7 +543,7 @@ int launch_npos(const float* x, const float* wk, const float* styles, float* y, 
     return st;
 }
 
-template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC>
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, bool HM = false>
 int launch(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g, const Epi& e, hipStream_t s) {
     constexpr int BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
     const int npts = g.GH * g.GW, ntiles = (npts + BP - 1) / BP;
@@ -517,7 +556,11 @@ int launch(const float* x, const float* wk, const float* styles, float* y, float
     }
     if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d floats exceeds the LDS budget", worst);
     const int npos = (worst + NTHREADS - 1) / NTHREADS;
-    if constexpr (db_family(TR, FO, FP, WO, WP)) {
+    if constexpr (HM) {
+        if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, true, true>(x, wk, styles, y, scratch, g, e, worst, s);
+        if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, true, true>(x, wk, styles, y, scratch, g, e, worst, s);
+        return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4, true, true>(x, wk, styles, y, scratch, g, e, worst, s);
+    } else if constexpr (db_family(TR, FO, FP, WO, WP)) {
         if (g.O % 4 == 0) {
             if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, true>(x, wk, styles, y, scratch, g, e, worst, s);
             if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, true>(x, wk, styles, y, scratch, g, e, worst, s);
@@ -608,11 +651,12 @@ extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int 
     return IA_OK;
 }
 
-extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styles, const float* demod,
-                              const float* noise, const float* noise_strength, const float* bias, const float* residual,
-                              float* y, float* scratch, size_t scratch_bytes,
-                              int B, int I, int O, int H, int W, int ksize, int transposed,
-                              int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
+static int conv2d_entry(const float* x, const void* wk_any, const float* styles, const float* demod,
+                        const float* noise, const float* noise_strength, const float* bias, const float* residual,
+                        float* y, float* scratch, size_t scratch_bytes,
+                        int B, int I, int O, int H, int W, int ksize, int transposed,
+                        int act, float alpha, float gain, float clamp, int ksplit, void* stream, bool half_ops) {
+    const float* wk = static_cast<const float*>(wk_any);
     IA_REQUIRE(x && wk && y, "x, wk and y must be device pointers");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
     IA_REQUIRE(ksize == 1 || ksize == 3, "kernel size must be 1 or 3");
@@ -640,6 +684,13 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
     g.patch_cap = 0;
     Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp};
     hipStream_t s = (hipStream_t)stream;
+    if (half_ops) {
+        const bool wide = p.waves == 8;
+        IA_REQUIRE(ksize == 3 && (wide || (transposed && p.bo == 64 && p.bp == 64)) && I % 8 == 0 && O % 4 == 0,
+                   "the fp16-operand form covers 3x3 layers on the two-stage tiles (large stride-1 layers, stride-2 transposed) with I %% 8 == 0, O %% 4 == 0");
+        if (transposed) return launch<3, true, 1, 1, 2, 2, kChunkTransposed, true>(x, wk, styles, y, scratch, g, e, s);
+        return launch<3, false, 2, 2, 2, 4, kChunkConv, true>(x, wk, styles, y, scratch, g, e, s);
+    }
     if (bp_ == 32) {   // small images: 4 waves side by side over 128 out-channels, one 32-point fragment each
         if (transposed) return launch<3, true, 1, 1, 4, 1, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
         return ksize == 3 ? launch<3, false, 1, 1, 4, 1, kChunkConv>(x, wk, styles, y, scratch, g, e, s)
@@ -653,6 +704,24 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
     if (p.waves == 8) return launch<3, false, 2, 2, 2, 4, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
     return ksize == 3 ? launch<3, false, 2, 2, 2, 2, kChunkConv>(x, wk, styles, y, scratch, g, e, s)
                       : launch<1, false, 2, 2, 2, 2, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
+}
+
+extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styles, const float* demod,
+                              const float* noise, const float* noise_strength, const float* bias, const float* residual,
+                              float* y, float* scratch, size_t scratch_bytes,
+                              int B, int I, int O, int H, int W, int ksize, int transposed,
+                              int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
+    return conv2d_entry(x, wk, styles, demod, noise, noise_strength, bias, residual, y, scratch, scratch_bytes, B, I, O, H, W, ksize,
+                        transposed, act, alpha, gain, clamp, ksplit, stream, false);
+}
+
+extern "C" int ia_conv2d_mfma_h(const float* x, const void* wk_h, const float* styles, const float* demod,
+                                const float* noise, const float* noise_strength, const float* bias, const float* residual,
+                                float* y, float* scratch, size_t scratch_bytes,
+                                int B, int I, int O, int H, int W, int ksize, int transposed,
+                                int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
+    return conv2d_entry(x, wk_h, styles, demod, noise, noise_strength, bias, residual, y, scratch, scratch_bytes, B, I, O, H, W, ksize,
+                        transposed, act, alpha, gain, clamp, ksplit, stream, true);
 }
 
 // d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + 1e-8): demodulation coefficients of the modulated conv

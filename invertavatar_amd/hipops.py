@@ -51,6 +51,23 @@ def pack_conv_weight(w):
     return w.detach().permute(2, 3, 1, 0).reshape(kh * kw, i, o).contiguous()
 
 
+def pack_conv_weight_h(w):
+    """[O, I, kh, kw] -> fp16 [kh*kw, I/4, O, 4] (channel quads innermost): the layout ia_conv2d_mfma_h reads."""
+    o, i, kh, kw = w.shape
+    if i % 4:
+        raise RuntimeError('fp16 packing needs in_channels % 4 == 0')
+    return w.detach().permute(2, 3, 1, 0).reshape(kh * kw, i // 4, 4, o).permute(0, 1, 3, 2).contiguous().to(torch.float16)
+
+
+def conv_h_supported(i, o, h, w, ksize, transposed):
+    """Shapes ia_conv2d_mfma_h covers (see include/ia_hip.h)."""
+    if ksize != 3 or i % 8 or o % 4:
+        return False
+    if transposed:
+        return (h + 1) * (w + 1) > 320
+    return o >= 128 and h * w >= 4096 and w <= 512
+
+
 def weight_sq_sum(w):
     """wsq[o, i] = sum over taps of w^2: the static half of the demodulation reduction."""
     return w.detach().float().square().sum(dim=[2, 3]).contiguous()
@@ -84,10 +101,18 @@ def _scratch_buffer(device, nbytes):
 
 def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None, bias=None, residual=None,
                 ksize=3, transposed=False, act='linear', alpha=0.2, gain=1.0, clamp=None, ksplit=None):
-    """One fused StyleGAN2 convolution (see ia_conv2d_mfma in include/ia_hip.h)."""
-    _f32c(x, 'x'); _f32c(wk, 'wk')
+    """One fused StyleGAN2 convolution (see ia_conv2d_mfma in include/ia_hip.h).  A float16 `wk` (pack_conv_weight_h)
+    selects the fp16-operand form ia_conv2d_mfma_h."""
+    _f32c(x, 'x')
     b, i, h, w = x.shape
-    taps, wi, o = wk.shape
+    half_ops = wk.dtype == torch.float16
+    if half_ops:
+        if not (wk.is_cuda and wk.is_contiguous() and wk.dim() == 4 and wk.shape[3] == 4):
+            raise RuntimeError('wk must be a contiguous fp16 [taps, I/4, O, 4] device tensor')
+        taps, wi, o = wk.shape[0], wk.shape[1] * 4, wk.shape[2]
+    else:
+        _f32c(wk, 'wk')
+        taps, wi, o = wk.shape
     if taps != ksize * ksize or wi != i:
         raise RuntimeError(f'packed weight {tuple(wk.shape)} does not match ksize {ksize}, in-channels {i}')
     for name, t in (('styles', styles), ('demod', demod), ('noise', noise), ('bias', bias), ('residual', residual)):
@@ -109,8 +134,9 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     flops = 2.0 * b * h * w * i * o * ksize * ksize
     traffic = 4.0 * (x.numel() + wk.numel() + y.numel() + (residual.numel() if residual is not None else 0))
     with torch.cuda.device(x.device), _Timed('conv2d_mfma_t' if transposed else f'conv2d_mfma_k{ksize}', flops, traffic,
-                                             f'B{b} I{i} O{o} {h}x{w} G{ksplit}'):
-        st = lib.ia_conv2d_mfma(_p(x), _p(wk), _p(styles), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(residual),
+                                             f'B{b} I{i} O{o} {h}x{w} G{ksplit}' + (' f16' if half_ops else '')):
+        fn = lib.ia_conv2d_mfma_h if half_ops else lib.ia_conv2d_mfma
+        st = fn(_p(x), _p(wk), _p(styles), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(residual),
                                 _p(y), _p(scratch), nbytes, b, i, o, h, w, ksize, int(transposed), ACT_ID[act], float(alpha),
                                 float(gain), float(-1 if clamp is None else clamp), int(ksplit), _lib.stream_ptr(x.device))
     _lib.check(st, 'ia_conv2d_mfma')

@@ -25,8 +25,10 @@ from ..torch_utils import misc, persistence
 from ..torch_utils.ops import bias_act, conv2d_resample, fma, upfirdn2d
 from .. import hipops
 
-# Blocks built with use_fp16 run their convolutions in fp32 on this backend (a superset of the
-# reference's fp16 precision); an fp16-MFMA convolution is a later-round item.
+# Blocks built with use_fp16 (the reference's fp16 blocks: SR head with sr_num_fp16_res > 0) keep their activations in
+# fp32 on this backend; FP16_BLOCKS_COMPUTE_FP32 = False additionally runs their 3x3 convolutions with fp16 operands and
+# fp32 accumulation on the fp16 MFMA (ia_conv2d_mfma_h) -- the arithmetic precision of the reference's fp16 path without
+# its fp16 storage rounding.  True (default) computes them entirely in fp32, a superset of the reference's precision.
 FP16_BLOCKS_COMPUTE_FP32 = True
 
 
@@ -42,6 +44,7 @@ class _PackedWeights:
         self.key = None
         self.wk = None
         self.wsq = None
+        self.wk_h = None
 
     def get(self, weight, scale=1.0):
         key = (weight.data_ptr(), weight._version, weight.device, weight.dtype, scale)
@@ -49,8 +52,16 @@ class _PackedWeights:
             w32 = weight.detach().float() * scale if scale != 1.0 else weight.detach().float()
             self.wk = hipops.pack_conv_weight(w32)
             self.wsq = hipops.weight_sq_sum(w32)
+            self.wk_h = None
             self.key = key
         return self.wk, self.wsq
+
+    def get_half(self, weight):
+        """fp16 packing for ia_conv2d_mfma_h (made on first use)."""
+        self.get(weight)
+        if self.wk_h is None:
+            self.wk_h = hipops.pack_conv_weight_h(weight.detach().float())
+        return self.wk_h
 
 
 def _on_device(x):
@@ -293,9 +304,11 @@ class SynthesisLayer(torch.nn.Module):
         self._packed = _PackedWeights()
         self._pre = None   # (styles, demod) computed for this call by the owning network's StylePlan
 
-    def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp, demod=None):
+    def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp, demod=None, half_ops=False):
         """conv + demod + noise + bias + lrelu + clamp on the MFMA path (one or two launches)."""
         wk, wsq = self._packed.get(self.weight)
+        if half_ops and hipops.conv_h_supported(self.in_channels, self.out_channels, x.shape[2], x.shape[3], 3, self.up == 2):
+            wk = self._packed.get_half(self.weight)
         styles = styles.float().contiguous()
         if demod is None:
             demod = hipops.modconv_demod(styles, wsq)
@@ -320,7 +333,7 @@ class SynthesisLayer(torch.nn.Module):
         return hipops.upfirdn2d_bias_act(t, self.resample_filter, nz, ns, bias, up=1, pad0=(1, 1), out_hw=(res, res),
                                          fir_gain=4.0, act=self.activation, act_gain=act_gain, clamp=act_clamp)
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, half_ops=False):
         assert noise_mode in ['random', 'const', 'none']
         in_res = self.resolution // self.up
         misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
@@ -330,7 +343,7 @@ class SynthesisLayer(torch.nn.Module):
         if (_on_device(x) and self.activation in hipops.ACT_ID and self.weight.shape[2] == 3 and self.up in (1, 2)
                 and not _needs_autograd(x, w, self.weight, self.bias)):
             styles, demod = pre if pre is not None else (self.affine(w), None)
-            return self._fused_device_forward(x, styles, noise_mode, act_gain, act_clamp, demod).to(x.dtype)
+            return self._fused_device_forward(x, styles, noise_mode, act_gain, act_clamp, demod, half_ops).to(x.dtype)
         styles = self.affine(w)
         noise = None
         if self.use_noise and noise_mode == 'random':
@@ -431,8 +444,10 @@ class SynthesisBlock(torch.nn.Module):
         _ = update_emas
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
         w_iter = iter(ws.unbind(dim=1))
-        if ws.device.type != 'cuda' or FP16_BLOCKS_COMPUTE_FP32:
-            force_fp32 = True
+        half_ops = self.use_fp16 and not force_fp32 and ws.device.type == 'cuda' and not FP16_BLOCKS_COMPUTE_FP32
+        force_fp32 = True      # storage stays fp32 on this backend (CPU: as the reference, :437)
+        if half_ops:
+            layer_kwargs = dict(layer_kwargs, half_ops=True)
         dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
         fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
         if fused_modconv is None:

@@ -129,3 +129,28 @@ def test_conv_linearity_at_full_size():
     reft = torch.nn.functional.conv_transpose2d(a, w.transpose(0, 1), stride=2)
     got = hipops.conv2d_mfma(a, wk, ksize=3, transposed=True)
     assert got.shape == reft.shape and (got - reft).abs().max().item() <= 2e-3
+
+
+@pytest.mark.parametrize('transposed', [False, True])
+def test_fp16_operand_form_is_exact_on_fp16_rounded_operands(transposed):
+    """ia_conv2d_mfma_h rounds the style-scaled input and the weights to fp16 and accumulates in fp32: on operands that are
+    already fp16 numbers it must agree with the fp32 library convolution up to summation order."""
+    i, o, h, w = (16, 64, 33, 33) if transposed else (32, 128, 64, 64)
+    x = (torch.randn(2, i, h, w, device='cuda')).half().float()
+    wt = (torch.randn(o, i, 3, 3, device='cuda') * 0.1).half().float()
+    wk_h = hipops.pack_conv_weight_h(wt)
+    assert hipops.conv_h_supported(i, o, h, w, 3, transposed)
+    got = hipops.conv2d_mfma(x, wk_h, ksize=3, transposed=transposed)
+    if transposed:
+        ref = torch.nn.functional.conv_transpose2d(x, wt.transpose(0, 1), stride=2)
+    else:
+        ref = torch.nn.functional.conv2d(x, wt, padding=1)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-4
+    # and with styles: x * s is rounded to fp16 before the product (relative 2^-11 per term)
+    s = torch.rand(2, i, device='cuda') + 0.5
+    got = hipops.conv2d_mfma(x, wk_h, styles=s, ksize=3, transposed=transposed)
+    xs = (x * s[:, :, None, None]).half().float()
+    ref = (torch.nn.functional.conv_transpose2d(xs, wt.transpose(0, 1), stride=2) if transposed
+           else torch.nn.functional.conv2d(xs, wt, padding=1))
+    assert (got - ref).abs().max().item() <= 1e-3    # a tie in the fp16 rounding of one x*s flips an operand by one fp16 ulp

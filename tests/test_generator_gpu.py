@@ -81,6 +81,33 @@ def test_full_width_generator_vs_reference(golden):
     assert abs(out['image'].abs().mean().item() - gld['image_mean_abs']) <= 1e-4
 
 
+TOL_RGB_FP16_SR = 2e-2   # fp16 operands (11-bit mantissa) in the 6 SR convolutions; the reference's own fp16 path also stores fp16
+
+
+def test_full_width_generator_with_fp16_sr_head(golden):
+    """sr_num_fp16_res = 4 (the reference's deployed SR precision, train_avatar_texture.py:215,365) with the SR convolutions
+    on the fp16 MFMA (FP16_BLOCKS_COMPUTE_FP32 = False): everything up to the SR head is untouched (fp32 path, same bits as
+    the fp32 run), the image stays within the fp16-operand tolerance of the reference's fp32 CPU output."""
+    from invertavatar_amd.training import networks_stylegan2 as sg2
+    gld = golden('generator_full.npz')
+    g = TriPlaneGenerator(**synthetic.generator_kwargs('full', sr_num_fp16_res=4)).eval().requires_grad_(False)
+    synthetic.fill_parameters(g)
+    g = g.cuda()
+    ws, c, uv, jit, nrr = _inputs(gld)
+    saved, sg2.FP16_BLOCKS_COMPUTE_FP32 = sg2.FP16_BLOCKS_COMPUTE_FP32, False
+    try:
+        with torch.no_grad():
+            out = g.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=nrr, noise_mode='const', evaluation=True,
+                              return_featmap=True, jitter=jit)
+    finally:
+        sg2.FP16_BLOCKS_COMPUTE_FP32 = saved
+    assert max_abs(out['feature_image'].cpu(), gld['feature_image']) <= 5e-4
+    err = max_abs(out['image'].cpu()[..., ::4, ::4], gld['image_sub4'])
+    print(f'full generator, fp16 SR head: max|dRGB| = {err:.2e}')
+    assert err <= TOL_RGB_FP16_SR
+    assert abs(out['image'].abs().mean().item() - gld['image_mean_abs']) <= 2e-3
+
+
 def test_fill_mouth_known_answers_on_device(golden):
     from invertavatar_amd.training_avatar_texture.volumetric_rendering.renderer import fill_mouth
     g = golden('renderer.npz')
