@@ -147,6 +147,23 @@ int ia_conv2d_mfma_h(const float* x, const void* wk_h, const float* styles, cons
                      int B, int I, int O, int H, int W, int ksize, int transposed,
                      int act, float alpha, float gain, float clamp, int ksplit, void* stream);
 
+/*
+ * ia_conv2d_mfma with fp32-equivalent products formed from fp16 pairs on v_mfma_f32_32x32x8_f16 (fp32 accumulation):
+ * every operand v is split as hi = fp16(v), lo = fp16(v - hi) -- 22 mantissa bits together -- and a*b is taken as
+ * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi.  The dropped a_lo*b_lo is <= 2^-22 |a*b|, the size of fp32's own rounding, so the
+ * result is an fp32 convolution (measured against an fp64 convolution it is as close as ia_conv2d_mfma) at 3/16 of the fp32
+ * MFMA's cycles.  Range: |w| < 65504; x * style saturates at +-65504 (StyleGAN2 activations are O(1)-O(100); the reference
+ * clamps its fp16 blocks at 256); operand values below 3e-8 lose their low part.
+ *   wk_split : fp16 [2 (hi, lo * 2^11)][ksize*ksize][I/4][O][4]  (low parts are kept scaled so that they are normal fp16
+ *              numbers; their products are accumulated separately and folded in with 2^-11)
+ * Same arguments, plan, scratch and shape coverage as ia_conv2d_mfma_h.
+ */
+int ia_conv2d_mfma_s(const float* x, const void* wk_split, const float* styles, const float* demod,
+                     const float* noise, const float* noise_strength, const float* bias, const float* residual,
+                     float* y, float* scratch, size_t scratch_bytes,
+                     int B, int I, int O, int H, int W, int ksize, int transposed,
+                     int act, float alpha, float gain, float clamp, int ksplit, void* stream);
+
 /* Host-only planner for ia_conv2d_mfma: stream-K worker count (0: none) and the scratch bytes the fix-up pass needs. */
 int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int* h_ksplit, size_t* h_scratch_bytes);
 

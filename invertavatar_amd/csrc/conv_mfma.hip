@@ -43,6 +43,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPatchFloats = 1024;  // per-channel LDS patch capacity (floats)
+// The low parts of the hi/lo fp16 split are stored scaled by 2^11 so that they are normal fp16 numbers (the MFMA flushes
+// fp16 denormals): their products go to a second accumulator that is folded in with 2^-11 at the end of the K loop.
+constexpr float kLoScale = 2048.f;
 
 struct Geo {
     int B, I, O, H, W;     // input
@@ -161,10 +164,14 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
 // NPOS patch positions staged per thread (>= ceil(worst PSZ / threads), chosen by the host).
 // SK = false: workgroup = one whole tile (tiles [0, T_dp), whole rounds of the machine);
 // SK = true: stream-K ranges over tiles [T_dp, T) with slab hand-off.
-// HM = true (DB kernels only): fp16 operands on v_mfma_f32_32x32x8_f16, fp32 accumulation -- the arithmetic of the reference's
+// HM = 2 (DB kernels only): fp32-equivalent products from fp16 pairs.  Every operand value v is split as hi = fp16(v),
+// lo = fp16(v - hi) (22 mantissa bits together) and a*b is taken as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
+// v_mfma_f32_32x32x8_f16 with fp32 accumulation: the dropped term a_lo*b_lo is 2^-22 of the product, the size of fp32's own
+// rounding, at 3/16 of the fp32 MFMA's cycles.  `wk` = [2 (hi, lo)][tap][I/4][O][4] halves (pack_conv_weight_split).
+// HM = 1 (DB kernels only): fp16 operands on v_mfma_f32_32x32x8_f16, fp32 accumulation -- the arithmetic of the reference's
 // fp16 blocks (training/networks_stylegan2.py:34-91 with x.dtype == float16; superresolution.py:209-216), activations kept
 // in fp32 in memory.  `wk` then points at the fp16 weights packed [tap][I/4][O][4] (pack_conv_weight_h).
-template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool SK, bool DB, bool HM>
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool SK, bool DB, int HM>
 __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                                  const float* __restrict__ styles, float* __restrict__ y,
                                                                  float* __restrict__ slabs, Geo g, Epi e) {
@@ -225,6 +232,17 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
             for (int fp = 0; fp < FP; ++fp)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] = 0.f;
+    f32x16 acc2[HM == 2 ? NPH : 1][HM == 2 ? FO : 1][HM == 2 ? FP : 1];   // hi*lo + lo*hi products (scaled by kLoScale)
+    if constexpr (HM == 2) {
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[ph][fo][fp][r] = 0.f;
+    }
 
     const int ci_begin = c_lo * CC, ci_end = min(c_hi * CC, g.I);
     const float* xb = x + (int64_t)b * g.I * g.H * g.W;
@@ -252,7 +270,8 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
     // (tap, cc) = e / ROWV and channels 4*(e % ROWV) ..+3 of the tile, and lands at float 4*e of the LDS slab.
     // (HM: the fp16 slab of a chunk is [tap][2 channel quads][BO][4] halves; 16-byte slot e covers (tap, quad) = e / (BO/2)
     // and out-channels 2*(e % (BO/2)), +1, and lands at byte 16*e of the LDS slab.)
-    constexpr int ROWV = HM ? BO / 2 : BO / 4, NSLOT = HM ? NT * 2 * ROWV : NT * CC * ROWV, NWV = (NSLOT + NTHREADS - 1) / NTHREADS;
+    constexpr int NPL = HM == 2 ? 2 : 1;                              // operand planes (hi, lo)
+    constexpr int ROWV = HM ? BO / 2 : BO / 4, NSLOT = HM ? NPL * NT * 2 * ROWV : NT * CC * ROWV, NWV = (NSLOT + NTHREADS - 1) / NTHREADS;
     static_assert(!HM || (DB && CC == 8), "the fp16 MFMA mode is built for the two-stage kernels with 8-channel chunks");
     // o_vec: every weight row is 16-byte aligned and at least one float4 long, so the slab is fetched with
     // unconditional, clamped float4 buffer loads (rows past O feed accumulator rows that are never stored; rows past
@@ -262,8 +281,10 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
 #pragma unroll
     for (int k = 0; k < NWV; ++k) {
         const int e_ = min(tid + k * NTHREADS, NSLOT - 1), row = e_ / ROWV;
-        if constexpr (HM)   // halves: ((tap*(I/4) + quad)*O + o)*4, o = o0 + 2*(e % ROWV) clamped inside the tensor row
-            w_off[k] = ((((row >> 1) * (g.I / 4) + (row & 1)) * g.O + min(o0 + (e_ - row * ROWV) * 2, max(g.O - 2, 0))) * 4) * 2;
+        if constexpr (HM != 0) {   // halves: (plane*NT*I/4 + (tap*(I/4) + quad))*O + o)*4, o = o0 + 2*(e % ROWV) clamped inside the row
+            const int pl = row / (NT * 2), rw = row - pl * NT * 2;
+            w_off[k] = ((((pl * NT + (rw >> 1)) * (g.I / 4) + (rw & 1)) * g.O + min(o0 + (e_ - row * ROWV) * 2, max(g.O - 2, 0))) * 4) * 2;
+        }
         else
             w_off[k] = (((row / CC) * g.I + (row % CC)) * g.O + min(o0 + (e_ - row * ROWV) * 4, max(g.O - 4, 0))) * 4;
     }
@@ -274,7 +295,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
     float sv[CC];                             // style * channel-tail mask of the staged chunk
     float4 wv[NWV];                           // staged weight vectors
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)((int64_t)g.I * HW * 4), 0x00020000);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)((int64_t)NT * g.I * g.O * (HM ? 2 : 4)), 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)((int64_t)NT * g.I * g.O * (HM == 2 ? 4 : (HM ? 2 : 4))), 0x00020000);
 
     // All loads of a chunk are unconditional so that they can be issued anywhere; the chunk after next is in flight
     // while the current one is multiplied.  No 64-bit address arithmetic in the K loop: per-thread byte offsets fixed
@@ -321,14 +342,19 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         for (int j = 0; j < NPOS; ++j) {
             const int pp = tid + j * NTHREADS;
             if (pp < PSZ) {
-                if constexpr (HM) {   // patch as [2 channel quads][PSZ][4] halves: one 8-byte store per quad
-                    h16x4* ph = reinterpret_cast<h16x4*>(lds + st_off + NT * BO * 4);
+                if constexpr (HM != 0) {   // patch as [plane][2 channel quads][PSZ][4] halves: one 8-byte store per quad
+                    h16x4* ph = reinterpret_cast<h16x4*>(lds + st_off + NPL * NT * BO * 4);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        h16x4 v;
-                        v[0] = (_Float16)(pv[j][4 * q] * sv[4 * q]);         v[1] = (_Float16)(pv[j][4 * q + 1] * sv[4 * q + 1]);
-                        v[2] = (_Float16)(pv[j][4 * q + 2] * sv[4 * q + 2]); v[3] = (_Float16)(pv[j][4 * q + 3] * sv[4 * q + 3]);
-                        ph[q * PSZ + pp] = v;
+                        h16x4 hi, lo;
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const float v = fminf(fmaxf(pv[j][4 * q + c4] * sv[4 * q + c4], -65504.f), 65504.f);   // fp16 range: saturate, never inf
+                            hi[c4] = (_Float16)v;
+                            lo[c4] = (_Float16)((v - (float)hi[c4]) * kLoScale);
+                        }
+                        ph[q * PSZ + pp] = hi;
+                        if constexpr (HM == 2) ph[(2 + q) * PSZ + pp] = lo;
                     }
                 } else {
 #pragma unroll
@@ -379,19 +405,22 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         // MFMA over the chunk: k-pair = channels (2cp, 2cp+1) of one tap; lane half picks the channel.  Operand reads
         // run one step ahead of the MFMAs that consume them (double-buffered registers) so the LDS latency hides
         // under the >= 256 MFMA cycles of a step.
-        using op_t = std::conditional_t<HM, h16x4, float>;
-        op_t a_buf[2][KP][FO], b_buf[2][KP][FP];
-        auto load_ops = [&](int st, op_t (&a)[KP][FO], op_t (&bv)[KP][FP]) {
+        using op_t = std::conditional_t<HM != 0, h16x4, float>;
+        op_t a_buf[2][KP][FO * NPL], b_buf[2][KP][FP * NPL];
+        auto load_ops = [&](int st, op_t (&a)[KP][FO * NPL], op_t (&bv)[KP][FP * NPL]) {
 #pragma unroll
             for (int kk = 0; kk < KP; ++kk) {
-                if constexpr (HM) {
+                if constexpr (HM != 0) {
                     const int t = st * KP + kk;
                     const h16x4* wh = reinterpret_cast<const h16x4*>(lds + st_cur);
-                    const h16x4* ph = reinterpret_cast<const h16x4*>(lds + st_cur + NT * BO * 4);
+                    const h16x4* ph = reinterpret_cast<const h16x4*>(lds + st_cur + NPL * NT * BO * 4);
 #pragma unroll
-                    for (int fo = 0; fo < FO; ++fo) a[kk][fo] = wh[(t * 2 + half) * BO + (wo * FO + fo) * 32 + l31];
+                    for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-                    for (int fp = 0; fp < FP; ++fp) bv[kk][fp] = ph[base[fp] + toff[t]];
+                        for (int fo = 0; fo < FO; ++fo) a[kk][pl * FO + fo] = wh[((pl * NT + t) * 2 + half) * BO + (wo * FO + fo) * 32 + l31];
+#pragma unroll
+                        for (int fp = 0; fp < FP; ++fp) bv[kk][pl * FP + fp] = ph[pl * 2 * PSZ + base[fp] + toff[t]];
+                    }
                 } else {
                     const int kp = st * KP + kk, t = kp / (CC / 2), cp = kp % (CC / 2);
 #pragma unroll
@@ -418,7 +447,14 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
                 for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
                     for (int fp = 0; fp < FP; ++fp) {
-                        if constexpr (HM)
+                        if constexpr (HM == 2) {
+                            acc2[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x8f16(a_buf[st & 1][kk][FO + fo], b_buf[st & 1][kk][fp],
+                                                                                    acc2[ph][fo][fp], 0, 0, 0);
+                            acc2[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x8f16(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][FP + fp],
+                                                                                    acc2[ph][fo][fp], 0, 0, 0);
+                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x8f16(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][fp],
+                                                                                   acc[ph][fo][fp], 0, 0, 0);
+                        } else if constexpr (HM == 1)
                             acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x8f16(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][fp],
                                                                                    acc[ph][fo][fp], 0, 0, 0);
                         else
@@ -426,9 +462,9 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
                                                                                    acc[ph][fo][fp], 0, 0, 0);
                     }
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, KP * (FO + FP), 0);   // next step's ds_reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x100, KP * (FO + FP) * NPL, 0);   // next step's ds_reads first ...
             if (DB && st * LPS < NLOAD) __builtin_amdgcn_sched_group_barrier(0x020, LPS, 0);   // ... a few global loads ...
-            __builtin_amdgcn_sched_group_barrier(0x008, KP * FO * FP, 0);     // ... then this step's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, KP * FO * FP * (HM == 2 ? 3 : 1), 0);     // ... then this step's MFMAs
         }
         if constexpr (DB) {
             __syncthreads();             // publishes the stage committed above and retires the one just read
@@ -436,6 +472,16 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         }
     }
 
+    if constexpr (HM == 2) {   // fold the scaled low-part products in
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] = fmaf(acc2[ph][fo][fp][r], 1.0f / kLoScale, acc[ph][fo][fp][r]);
+    }
     // ---- segment done: a whole tile is finished here, a partial K range is parked for the fix-up kernel
     if (!SK || (c_lo == 0 && c_hi == g.C)) {
         store_tile<TR, FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
@@ -511,7 +557,7 @@ __global__ __launch_bounds__(WO * WP * 64) void conv_fixup_kernel(const float* _
     }
 }
 
-template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool DB, bool HM = false>
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool DB, int HM = 0>
 int launch_npos(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g_in, const Epi& e,
                 int worst, hipStream_t s) {
     constexpr int BO = 32 * FO * WO, NT = KS * KS;
@@ -543,7 +589,7 @@ int launch_npos(const float* x, const float* wk, const float* styles, float* y, 
     return st;
 }
 
-template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, bool HM = false>
+template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int HM = 0>
 int launch(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g, const Epi& e, hipStream_t s) {
     constexpr int BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
     const int npts = g.GH * g.GW, ntiles = (npts + BP - 1) / BP;
@@ -556,10 +602,10 @@ int launch(const float* x, const float* wk, const float* styles, float* y, float
     }
     if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d floats exceeds the LDS budget", worst);
     const int npos = (worst + NTHREADS - 1) / NTHREADS;
-    if constexpr (HM) {
-        if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, true, true>(x, wk, styles, y, scratch, g, e, worst, s);
-        if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, true, true>(x, wk, styles, y, scratch, g, e, worst, s);
-        return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4, true, true>(x, wk, styles, y, scratch, g, e, worst, s);
+    if constexpr (HM != 0) {
+        if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, true, HM>(x, wk, styles, y, scratch, g, e, worst, s);
+        if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, true, HM>(x, wk, styles, y, scratch, g, e, worst, s);
+        return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4, true, HM>(x, wk, styles, y, scratch, g, e, worst, s);
     } else if constexpr (db_family(TR, FO, FP, WO, WP)) {
         if (g.O % 4 == 0) {
             if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, true>(x, wk, styles, y, scratch, g, e, worst, s);
@@ -655,7 +701,7 @@ static int conv2d_entry(const float* x, const void* wk_any, const float* styles,
                         const float* noise, const float* noise_strength, const float* bias, const float* residual,
                         float* y, float* scratch, size_t scratch_bytes,
                         int B, int I, int O, int H, int W, int ksize, int transposed,
-                        int act, float alpha, float gain, float clamp, int ksplit, void* stream, bool half_ops) {
+                        int act, float alpha, float gain, float clamp, int ksplit, void* stream, int half_ops) {
     const float* wk = static_cast<const float*>(wk_any);
     IA_REQUIRE(x && wk && y, "x, wk and y must be device pointers");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
@@ -688,8 +734,12 @@ static int conv2d_entry(const float* x, const void* wk_any, const float* styles,
         const bool wide = p.waves == 8;
         IA_REQUIRE(ksize == 3 && (wide || (transposed && p.bo == 64 && p.bp == 64)) && I % 8 == 0 && O % 4 == 0,
                    "the fp16-operand form covers 3x3 layers on the two-stage tiles (large stride-1 layers, stride-2 transposed) with I %% 8 == 0, O %% 4 == 0");
-        if (transposed) return launch<3, true, 1, 1, 2, 2, kChunkTransposed, true>(x, wk, styles, y, scratch, g, e, s);
-        return launch<3, false, 2, 2, 2, 4, kChunkConv, true>(x, wk, styles, y, scratch, g, e, s);
+        if (half_ops == 2) {
+            if (transposed) return launch<3, true, 1, 1, 2, 2, kChunkTransposed, 2>(x, wk, styles, y, scratch, g, e, s);
+            return launch<3, false, 2, 2, 2, 4, kChunkConv, 2>(x, wk, styles, y, scratch, g, e, s);
+        }
+        if (transposed) return launch<3, true, 1, 1, 2, 2, kChunkTransposed, 1>(x, wk, styles, y, scratch, g, e, s);
+        return launch<3, false, 2, 2, 2, 4, kChunkConv, 1>(x, wk, styles, y, scratch, g, e, s);
     }
     if (bp_ == 32) {   // small images: 4 waves side by side over 128 out-channels, one 32-point fragment each
         if (transposed) return launch<3, true, 1, 1, 4, 1, kChunkConv>(x, wk, styles, y, scratch, g, e, s);
@@ -712,7 +762,7 @@ extern "C" int ia_conv2d_mfma(const float* x, const float* wk, const float* styl
                               int B, int I, int O, int H, int W, int ksize, int transposed,
                               int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
     return conv2d_entry(x, wk, styles, demod, noise, noise_strength, bias, residual, y, scratch, scratch_bytes, B, I, O, H, W, ksize,
-                        transposed, act, alpha, gain, clamp, ksplit, stream, false);
+                        transposed, act, alpha, gain, clamp, ksplit, stream, 0);
 }
 
 extern "C" int ia_conv2d_mfma_h(const float* x, const void* wk_h, const float* styles, const float* demod,
@@ -721,7 +771,16 @@ extern "C" int ia_conv2d_mfma_h(const float* x, const void* wk_h, const float* s
                                 int B, int I, int O, int H, int W, int ksize, int transposed,
                                 int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
     return conv2d_entry(x, wk_h, styles, demod, noise, noise_strength, bias, residual, y, scratch, scratch_bytes, B, I, O, H, W, ksize,
-                        transposed, act, alpha, gain, clamp, ksplit, stream, true);
+                        transposed, act, alpha, gain, clamp, ksplit, stream, 1);
+}
+
+extern "C" int ia_conv2d_mfma_s(const float* x, const void* wk_split, const float* styles, const float* demod,
+                                const float* noise, const float* noise_strength, const float* bias, const float* residual,
+                                float* y, float* scratch, size_t scratch_bytes,
+                                int B, int I, int O, int H, int W, int ksize, int transposed,
+                                int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
+    return conv2d_entry(x, wk_split, styles, demod, noise, noise_strength, bias, residual, y, scratch, scratch_bytes, B, I, O, H, W, ksize,
+                        transposed, act, alpha, gain, clamp, ksplit, stream, 2);
 }
 
 // d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + 1e-8): demodulation coefficients of the modulated conv

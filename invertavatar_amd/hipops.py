@@ -59,6 +59,14 @@ def pack_conv_weight_h(w):
     return w.detach().permute(2, 3, 1, 0).reshape(kh * kw, i // 4, 4, o).permute(0, 1, 3, 2).contiguous().to(torch.float16)
 
 
+def pack_conv_weight_split(w):
+    """[O, I, kh, kw] -> fp16 [2, kh*kw, I/4, O, 4]: hi = fp16(w) and lo = fp16((w - hi) * 2^11), the layout ia_conv2d_mfma_s reads."""
+    w = w.detach().float()
+    hi = w.to(torch.float16)
+    lo = ((w - hi.float()) * 2048.0).to(torch.float16)      # scaled by 2^11: normal fp16 numbers (kLoScale in conv_mfma.hip)
+    return torch.stack([pack_conv_weight_h(hi), pack_conv_weight_h(lo)]).contiguous()
+
+
 def conv_h_supported(i, o, h, w, ksize, transposed):
     """Shapes ia_conv2d_mfma_h covers (see include/ia_hip.h)."""
     if ksize != 3 or i % 8 or o % 4:
@@ -106,10 +114,11 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     _f32c(x, 'x')
     b, i, h, w = x.shape
     half_ops = wk.dtype == torch.float16
+    split = half_ops and wk.dim() == 5
     if half_ops:
-        if not (wk.is_cuda and wk.is_contiguous() and wk.dim() == 4 and wk.shape[3] == 4):
-            raise RuntimeError('wk must be a contiguous fp16 [taps, I/4, O, 4] device tensor')
-        taps, wi, o = wk.shape[0], wk.shape[1] * 4, wk.shape[2]
+        if not (wk.is_cuda and wk.is_contiguous() and wk.dim() in (4, 5) and wk.shape[-1] == 4 and (not split or wk.shape[0] == 2)):
+            raise RuntimeError('wk must be a contiguous fp16 [taps, I/4, O, 4] (or [2, taps, I/4, O, 4] hi/lo) device tensor')
+        taps, wi, o = wk.shape[-4], wk.shape[-3] * 4, wk.shape[-2]
     else:
         _f32c(wk, 'wk')
         taps, wi, o = wk.shape
@@ -134,8 +143,8 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     flops = 2.0 * b * h * w * i * o * ksize * ksize
     traffic = 4.0 * (x.numel() + wk.numel() + y.numel() + (residual.numel() if residual is not None else 0))
     with torch.cuda.device(x.device), _Timed('conv2d_mfma_t' if transposed else f'conv2d_mfma_k{ksize}', flops, traffic,
-                                             f'B{b} I{i} O{o} {h}x{w} G{ksplit}' + (' f16' if half_ops else '')):
-        fn = lib.ia_conv2d_mfma_h if half_ops else lib.ia_conv2d_mfma
+                                             f'B{b} I{i} O{o} {h}x{w} G{ksplit}' + (' f16x3' if split else (' f16' if half_ops else ''))):
+        fn = lib.ia_conv2d_mfma_s if split else (lib.ia_conv2d_mfma_h if half_ops else lib.ia_conv2d_mfma)
         st = fn(_p(x), _p(wk), _p(styles), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(residual),
                                 _p(y), _p(scratch), nbytes, b, i, o, h, w, ksize, int(transposed), ACT_ID[act], float(alpha),
                                 float(gain), float(-1 if clamp is None else clamp), int(ksplit), _lib.stream_ptr(x.device))

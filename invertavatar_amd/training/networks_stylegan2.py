@@ -31,6 +31,11 @@ from .. import hipops
 # its fp16 storage rounding.  True (default) computes them entirely in fp32, a superset of the reference's precision.
 FP16_BLOCKS_COMPUTE_FP32 = True
 
+# fp32 layers: where the shape allows (hipops.conv_h_supported), the 3x3 convolutions form their fp32 products from hi/lo
+# fp16 pairs on the fp16 MFMA (ia_conv2d_mfma_s): as accurate against an fp64 convolution as the fp32 MFMA form
+# (tests/test_conv_gpu.py) and twice as fast.  False keeps every layer on v_mfma_f32_32x32x2_f32.
+SPLIT_FP16_PRODUCTS = True
+
 
 @misc.profiled_function
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
@@ -55,6 +60,14 @@ class _PackedWeights:
             self.wk_h = None
             self.key = key
         return self.wk, self.wsq
+
+    def get_split(self, weight):
+        """hi/lo fp16 packing for ia_conv2d_mfma_s (made on first use)."""
+        self.get(weight)
+        if getattr(self, 'wk_s', None) is None or self.wk_s_key != self.key:
+            self.wk_s = hipops.pack_conv_weight_split(weight.detach().float())
+            self.wk_s_key = self.key
+        return self.wk_s
 
     def get_half(self, weight):
         """fp16 packing for ia_conv2d_mfma_h (made on first use)."""
@@ -307,8 +320,9 @@ class SynthesisLayer(torch.nn.Module):
     def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp, demod=None, half_ops=False):
         """conv + demod + noise + bias + lrelu + clamp on the MFMA path (one or two launches)."""
         wk, wsq = self._packed.get(self.weight)
-        if half_ops and hipops.conv_h_supported(self.in_channels, self.out_channels, x.shape[2], x.shape[3], 3, self.up == 2):
-            wk = self._packed.get_half(self.weight)
+        if (half_ops or SPLIT_FP16_PRODUCTS) and hipops.conv_h_supported(self.in_channels, self.out_channels, x.shape[2], x.shape[3], 3,
+                                                                        self.up == 2):
+            wk = self._packed.get_half(self.weight) if half_ops else self._packed.get_split(self.weight)
         styles = styles.float().contiguous()
         if demod is None:
             demod = hipops.modconv_demod(styles, wsq)

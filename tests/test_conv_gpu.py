@@ -154,3 +154,26 @@ def test_fp16_operand_form_is_exact_on_fp16_rounded_operands(transposed):
     ref = (torch.nn.functional.conv_transpose2d(xs, wt.transpose(0, 1), stride=2) if transposed
            else torch.nn.functional.conv2d(xs, wt, padding=1))
     assert (got - ref).abs().max().item() <= 1e-3    # a tie in the fp16 rounding of one x*s flips an operand by one fp16 ulp
+
+
+@pytest.mark.parametrize('transposed', [False, True])
+def test_split_fp16_form_is_an_fp32_convolution(transposed):
+    """ia_conv2d_mfma_s (hi + lo fp16 pairs, three products, fp32 accumulation) against an fp64 convolution: its error must
+    be of the size of the fp32 MFMA form's own error (both are dominated by fp32 accumulation), far below the fp16 form's."""
+    i, o, h, w = (64, 64, 65, 65) if transposed else (128, 128, 64, 64)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(1, i, h, w, device='cuda', generator=g) * 3
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g)
+    s = torch.rand(1, i, device='cuda', generator=g) + 0.5
+    xs = (x * s[:, :, None, None]).double()
+    ref = (torch.nn.functional.conv_transpose2d(xs, wt.double().transpose(0, 1), stride=2) if transposed
+           else torch.nn.functional.conv2d(xs, wt.double(), padding=1))
+    scale = ref.abs().max().item()
+    err = {}
+    for name, wk in (('f32', hipops.pack_conv_weight(wt)), ('split', hipops.pack_conv_weight_split(wt)), ('f16', hipops.pack_conv_weight_h(wt))):
+        got = hipops.conv2d_mfma(x, wk, styles=s, ksize=3, transposed=transposed)
+        err[name] = (got.double() - ref).abs().max().item() / scale
+    print(f'relative max error vs fp64: {err}')
+    assert err['f32'] <= 2e-6
+    assert err['split'] <= 3 * max(err['f32'], 3e-7)
+    assert err['f16'] >= 20 * err['split']

@@ -6,7 +6,7 @@ from invertavatar_amd import hipops
 for i, o, r, tr in [(32, 256, 128, 1), (256, 256, 256, 0), (256, 128, 256, 1), (128, 128, 512, 0), (512, 512, 64, 0), (256, 128, 128, 1)]:
     x = torch.randn(1, i, r, r, device='cuda')
     w = torch.randn(o, i, 3, 3, device='cuda')
-    for name, wk in (('f32', hipops.pack_conv_weight(w)), ('f16', hipops.pack_conv_weight_h(w))):
+    for name, wk in (('f32', hipops.pack_conv_weight(w)), ('f16', hipops.pack_conv_weight_h(w)), ('f16x3', hipops.pack_conv_weight_split(w))):
         fn = lambda: hipops.conv2d_mfma(x, wk, ksize=3, transposed=bool(tr))
         for _ in range(3): fn()
         torch.cuda.synchronize()
