@@ -7,7 +7,7 @@ mkdir -p $repo/gpurun_out/pmc_frame
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   timeout 280 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- \
-      python $repo/bench.py --steps 2 --warmup 1 --eager --no-cpu-baseline --no-roofline > /tmp/pmc_$c.log 2>&1
+      python $repo/bench.py --steps 2 --warmup 1 --eager --no-cpu-baseline --no-roofline --no-sr-fp16 > /tmp/pmc_$c.log 2>&1
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)
   if [ -z "$f" ]; then tail -5 /tmp/pmc_$c.log; else cp $f $repo/gpurun_out/pmc_frame/${c}_counter_collection.csv; fi
 done
