@@ -123,7 +123,7 @@ def roofline_leg(step, frames=3):
         # Most of the family's time is in the split form: price it against the matrix pipe it runs on.  Executed fp16 MFMA
         # FLOPs = 3 x the algorithmic fp32 FLOPs of those launches; peak = dense fp16 MFMA (MI355X_MICROARCH.md).
         executed = 3.0 * split['flops'] / (split['ms'] * 1e-3) / 1e12
-        out = dict(bound='mfma', kernel='conv2d_mfma (3x3 layers >= 64^2: fp32 products from fp16 hi/lo pairs, 3 x v_mfma_f32_32x32x8_f16)',
+        out = dict(bound='mfma', kernel='conv2d_mfma (3x3 layers >= 64^2: fp32 products from fp16 hi/lo pairs, 3 x v_mfma_f32_32x32x16_f16)',
                    achieved=round(executed, 2), peak=PEAK_FP16_MFMA_TFLOPS, unit='TFLOP/s', frac=round(executed / PEAK_FP16_MFMA_TFLOPS, 4),
                    traffic=pmc_traffic(dom), launches_per_frame=split['launches'] // frames,
                    avg_launch_us=round(split['ms'] * 1e3 / split['launches'], 2),

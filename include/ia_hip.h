@@ -132,11 +132,11 @@ int ia_conv2d_mfma(const float* x, const float* wk, const float* styles, const f
                    int act, float alpha, float gain, float clamp, int ksplit, void* stream);
 
 /*
- * ia_conv2d_mfma with fp16 operands on v_mfma_f32_32x32x8_f16 and fp32 accumulation: the arithmetic of the reference's
+ * ia_conv2d_mfma with fp16 operands on v_mfma_f32_32x32x16_f16 and fp32 accumulation: the arithmetic of the reference's
  * fp16 blocks (modulated_conv2d with x.dtype == float16, training/networks_stylegan2.py:34-91; the SR head with
  * sr_num_fp16_res > 0, training_avatar_texture/superresolution.py:209-216).  The style-scaled input and the weights are
  * rounded to fp16, everything else (demodulation, noise, bias, activation, clamp, storage) stays fp32.
- *   wk_h : weights as fp16, packed [ksize*ksize][I/4][O][4] (channel quads innermost), from the reference's [O, I, kh, kw]
+ *   wk_h : weights as fp16, packed [ksize*ksize][I/8][O][8] (channel octets innermost), from the reference's [O, I, kh, kw]
  * Same arguments, plan and scratch as ia_conv2d_mfma.  Covers 3x3 layers that run on the two-stage tiles (stride-1 layers
  * with O >= 128 and >= 64^2 outputs; every stride-2 transposed layer) with I % 8 == 0 and O % 4 == 0; other shapes return
  * IA_ERR_INVALID_ARG and the caller uses ia_conv2d_mfma.
@@ -148,13 +148,13 @@ int ia_conv2d_mfma_h(const float* x, const void* wk_h, const float* styles, cons
                      int act, float alpha, float gain, float clamp, int ksplit, void* stream);
 
 /*
- * ia_conv2d_mfma with fp32-equivalent products formed from fp16 pairs on v_mfma_f32_32x32x8_f16 (fp32 accumulation):
+ * ia_conv2d_mfma with fp32-equivalent products formed from fp16 pairs on v_mfma_f32_32x32x16_f16 (fp32 accumulation):
  * every operand v is split as hi = fp16(v), lo = fp16(v - hi) -- 22 mantissa bits together -- and a*b is taken as
  * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi.  The dropped a_lo*b_lo is <= 2^-22 |a*b|, the size of fp32's own rounding, so the
  * result is an fp32 convolution (measured against an fp64 convolution it is as close as ia_conv2d_mfma) at 3/16 of the fp32
  * MFMA's cycles.  Range: |w| < 65504; x * style saturates at +-65504 (StyleGAN2 activations are O(1)-O(100); the reference
  * clamps its fp16 blocks at 256); operand values below 3e-8 lose their low part.
- *   wk_split : fp16 [2 (hi, lo * 2^11)][ksize*ksize][I/4][O][4]  (low parts are kept scaled so that they are normal fp16
+ *   wk_split : fp16 [2 (hi, lo * 2^11)][ksize*ksize][I/8][O][8]  (low parts are kept scaled so that they are normal fp16
  *              numbers; their products are accumulated separately and folded in with 2^-11)
  * Same arguments, plan, scratch and shape coverage as ia_conv2d_mfma_h.
  */

@@ -41,11 +41,20 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kPatchFloats = 1024;  // per-channel LDS patch capacity (floats)
 // The low parts of the hi/lo fp16 split are stored scaled by 2^11 so that they are normal fp16 numbers (the MFMA flushes
 // fp16 denormals): their products go to a second accumulator that is folded in with 2^-11 at the end of the K loop.
 constexpr float kLoScale = 2048.f;
+// fp16 forms: one k-step of v_mfma_f32_32x32x16_f16 = 8 channels of TWO taps (lanes 0-31 carry the first tap of the pair,
+// lanes 32-63 the second).  The nine taps make five pairs; the odd tap out pairs with an all-zero tap (index 9).  In the
+// transposed form both taps of a pair must feed the same output phase: phase 0 owns taps {0,2,6,8}, phase 1 {1,7},
+// phase 2 {3,5}, phase 3 {4}.
+constexpr int kPairs = 5, kZeroTap = 9;
+__host__ __device__ constexpr int pair_t0(bool tr, int s) { return tr ? (s == 0 ? 0 : s == 1 ? 6 : s == 2 ? 1 : s == 3 ? 3 : 4) : 2 * s; }
+__host__ __device__ constexpr int pair_t1(bool tr, int s) { return tr ? (s == 0 ? 2 : s == 1 ? 8 : s == 2 ? 7 : s == 3 ? 5 : kZeroTap) : (s == 4 ? kZeroTap : 2 * s + 1); }
+__host__ __device__ constexpr int pair_phase(bool tr, int s) { return tr ? (s < 2 ? 0 : s - 1) : 0; }
 
 struct Geo {
     int B, I, O, H, W;     // input
@@ -166,9 +175,9 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
 // SK = true: stream-K ranges over tiles [T_dp, T) with slab hand-off.
 // HM = 2 (DB kernels only): fp32-equivalent products from fp16 pairs.  Every operand value v is split as hi = fp16(v),
 // lo = fp16(v - hi) (22 mantissa bits together) and a*b is taken as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
-// v_mfma_f32_32x32x8_f16 with fp32 accumulation: the dropped term a_lo*b_lo is 2^-22 of the product, the size of fp32's own
-// rounding, at 3/16 of the fp32 MFMA's cycles.  `wk` = [2 (hi, lo)][tap][I/4][O][4] halves (pack_conv_weight_split).
-// HM = 1 (DB kernels only): fp16 operands on v_mfma_f32_32x32x8_f16, fp32 accumulation -- the arithmetic of the reference's
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation: the dropped term a_lo*b_lo is 2^-22 of the product, the size of fp32's own
+// rounding.  `wk` = [2 (hi, lo)][tap][I/8][O][8] halves (pack_conv_weight_split).
+// HM = 1 (DB kernels only): fp16 operands on v_mfma_f32_32x32x16_f16, fp32 accumulation -- the arithmetic of the reference's
 // fp16 blocks (training/networks_stylegan2.py:34-91 with x.dtype == float16; superresolution.py:209-216), activations kept
 // in fp32 in memory.  `wk` then points at the fp16 weights packed [tap][I/4][O][4] (pack_conv_weight_h).
 template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool SK, bool DB, int HM>
@@ -208,13 +217,14 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
     const float inv_pw = 1.0f / (float)PW;
 
     // per-lane patch offset of each point fragment (points past the grid alias the last valid one)
-    int base[FP];
+    int base[FP], bpos[FP];
 #pragma unroll
     for (int fp = 0; fp < FP; ++fp) {
         const int p = min(p0 + (wp * FP + fp) * 32 + l31, p_last);
         const int r = p / g.GW, c = p - r * g.GW;
         const int sg = (r == r_split) ? 1 : 0;
         base[fp] = sg * seg1_off + (r - PAD - win.r0[sg]) * PW + (c - PAD - win.c0[sg]) + half * PSZ;
+        bpos[fp] = base[fp] - half * PSZ;       // (fp16 forms: the lane half picks the tap of a pair, not a channel)
     }
     int toff[NT];
 #pragma unroll
@@ -268,11 +278,12 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
     }
     // Weights: NWV float4 per thread per chunk from the [tap][I][O] slab; slot e = tid + k*NTHREADS covers row
     // (tap, cc) = e / ROWV and channels 4*(e % ROWV) ..+3 of the tile, and lands at float 4*e of the LDS slab.
-    // (HM: the fp16 slab of a chunk is [tap][2 channel quads][BO][4] halves; 16-byte slot e covers (tap, quad) = e / (BO/2)
-    // and out-channels 2*(e % (BO/2)), +1, and lands at byte 16*e of the LDS slab.)
+    // (fp16 forms: the slab of a chunk is [plane][tap][BO][8 channels] halves; 16-byte slot e = (plane*NT + tap)*BO + o.  In
+    // LDS every plane has one more, all-zero, tap: slot e lands at 16-byte index e + plane*BO.)
     constexpr int NPL = HM == 2 ? 2 : 1;                              // operand planes (hi, lo)
-    constexpr int ROWV = HM ? BO / 2 : BO / 4, NSLOT = HM ? NPL * NT * 2 * ROWV : NT * CC * ROWV, NWV = (NSLOT + NTHREADS - 1) / NTHREADS;
-    static_assert(!HM || (DB && CC == 8), "the fp16 MFMA mode is built for the two-stage kernels with 8-channel chunks");
+    constexpr int NTP = NT + 1;
+    constexpr int ROWV = HM ? BO : BO / 4, NSLOT = HM ? NPL * NT * BO : NT * CC * ROWV, NWV = (NSLOT + NTHREADS - 1) / NTHREADS;
+    static_assert(!HM || (DB && CC == 8 && NT == 9), "the fp16 MFMA forms are built for the two-stage 3x3 kernels with 8-channel chunks");
     // o_vec: every weight row is 16-byte aligned and at least one float4 long, so the slab is fetched with
     // unconditional, clamped float4 buffer loads (rows past O feed accumulator rows that are never stored; rows past
     // the end of the tensor -- channel tail of the last tap -- read as zero through the bounds check).
@@ -281,21 +292,19 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
 #pragma unroll
     for (int k = 0; k < NWV; ++k) {
         const int e_ = min(tid + k * NTHREADS, NSLOT - 1), row = e_ / ROWV;
-        if constexpr (HM != 0) {   // halves: (plane*NT*I/4 + (tap*(I/4) + quad))*O + o)*4, o = o0 + 2*(e % ROWV) clamped inside the row
-            const int pl = row / (NT * 2), rw = row - pl * NT * 2;
-            w_off[k] = ((((pl * NT + (rw >> 1)) * (g.I / 4) + (rw & 1)) * g.O + min(o0 + (e_ - row * ROWV) * 2, max(g.O - 2, 0))) * 4) * 2;
-        }
+        if constexpr (HM != 0)     // bytes: (((plane*NT + tap)*(I/8) + octet)*O + o)*16, o clamped inside the tensor row
+            w_off[k] = ((row * (g.I / 8)) * g.O + min(o0 + (e_ - row * ROWV), g.O - 1)) * 16;
         else
             w_off[k] = (((row / CC) * g.I + (row % CC)) * g.O + min(o0 + (e_ - row * ROWV) * 4, max(g.O - 4, 0))) * 4;
     }
-    const int stage_floats = NT * CC * BO + CC * g.patch_cap;
+    const int stage_floats = HM ? NPL * NTP * BO * 4 + NPL * 4 * g.patch_cap : NT * CC * BO + CC * g.patch_cap;
     float* w_lds = lds;                       // [NT*CC][BO]
     float* p_lds = lds + NT * CC * BO;        // [CC][PSZ]   (second stage, if any, stage_floats further on)
     float pv[NPOS][CC];                       // staged patch values     (global -> registers -> LDS)
     float sv[CC];                             // style * channel-tail mask of the staged chunk
     float4 wv[NWV];                           // staged weight vectors
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)((int64_t)g.I * HW * 4), 0x00020000);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)((int64_t)NT * g.I * g.O * (HM == 2 ? 4 : (HM ? 2 : 4))), 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)((int64_t)NT * g.I * g.O * (HM == 2 ? 4 : (HM ? 2 : 4))), 0x00020000);   // bytes of all planes
 
     // All loads of a chunk are unconditional so that they can be issued anywhere; the chunk after next is in flight
     // while the current one is multiplied.  No 64-bit address arithmetic in the K loop: per-thread byte offsets fixed
@@ -342,20 +351,17 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         for (int j = 0; j < NPOS; ++j) {
             const int pp = tid + j * NTHREADS;
             if (pp < PSZ) {
-                if constexpr (HM != 0) {   // patch as [plane][2 channel quads][PSZ][4] halves: one 8-byte store per quad
-                    h16x4* ph = reinterpret_cast<h16x4*>(lds + st_off + NPL * NT * BO * 4);
+                if constexpr (HM != 0) {   // patch as [plane][PSZ][8 channels] halves: one 16-byte store per plane
+                    h16x8* ph = reinterpret_cast<h16x8*>(lds + st_off + NPL * NTP * BO * 4);
+                    h16x8 hi, lo;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        h16x4 hi, lo;
-#pragma unroll
-                        for (int c4 = 0; c4 < 4; ++c4) {
-                            const float v = fminf(fmaxf(pv[j][4 * q + c4] * sv[4 * q + c4], -65504.f), 65504.f);   // fp16 range: saturate, never inf
-                            hi[c4] = (_Float16)v;
-                            lo[c4] = (_Float16)((v - (float)hi[c4]) * kLoScale);
-                        }
-                        ph[q * PSZ + pp] = hi;
-                        if constexpr (HM == 2) ph[(2 + q) * PSZ + pp] = lo;
+                    for (int cc = 0; cc < 8; ++cc) {
+                        const float v = fminf(fmaxf(pv[j][cc] * sv[cc], -65504.f), 65504.f);   // fp16 range: saturate, never inf
+                        hi[cc] = (_Float16)v;
+                        lo[cc] = (_Float16)((v - (float)hi[cc]) * kLoScale);
                     }
+                    ph[pp] = hi;
+                    if constexpr (HM == 2) ph[PSZ + pp] = lo;
                 } else {
 #pragma unroll
                     for (int cc = 0; cc < CC; ++cc) p_lds[st_off + cc * PSZ + pp] = pv[j][cc] * sv[cc];
@@ -366,21 +372,27 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         for (int k = 0; k < NWV; ++k) {
             if (tid + k * NTHREADS < NSLOT) {
                 // (weights of channels past ci_end need no mask: their patch rows are zeroed through sv[])
-                *(float4*)(w_lds + st_off + (tid + k * NTHREADS) * 4) = wv[k];
+                const int e_ = tid + k * NTHREADS;
+                *(float4*)(w_lds + st_off + (HM == 2 && e_ >= NT * BO ? e_ + BO : e_) * 4) = wv[k];
             }
         }
     };
 
-    // fp32: a k-step is a channel pair of one tap (32x32x2); fp16: all 8 channels of one tap (32x32x8)
-    constexpr int NSTEP_K = HM ? NT : NT * (CC / 2);          // k-steps per chunk
-    constexpr int KP = HM ? ((FO * FP >= 4) ? 1 : 3)          // k-steps per pipeline step
-                          : ((FO * FP >= 4) ? 1 : (FO * FP == 2 ? 2 : 4));   // fp32: >= 4 MFMAs (256 cycles) per step
+    // fp32: a k-step is a channel pair of one tap (32x32x2); fp16: the 8 channels of a pair of taps (32x32x16)
+    constexpr int NSTEP_K = HM ? kPairs : NT * (CC / 2);      // k-steps per chunk
+    constexpr int KP = HM ? 1 : ((FO * FP >= 4) ? 1 : (FO * FP == 2 ? 2 : 4));   // k-steps per pipeline step (fp32: >= 4 MFMAs)
     constexpr int NSTEP = NSTEP_K / KP;
     static_assert(NSTEP_K % KP == 0, "chunk depth must be a multiple of the step depth");
 
     prefetch(ci_begin);
     if constexpr (DB) {
         __syncthreads();                 // (previous segment's readers are done)
+        if constexpr (HM != 0) {         // the all-zero tap of every plane, in both stages (never overwritten by commit)
+            for (int i = tid; i < 2 * NPL * BO; i += NTHREADS) {
+                const int stg = i / (NPL * BO), r = i - stg * NPL * BO, pl = r / BO, o = r - pl * BO;
+                *(float4*)(lds + stg * stage_floats + ((pl * NTP + NT) * BO + o) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         commit(0);
         __syncthreads();
         if (ci_begin + CC < ci_end) prefetch(ci_begin + CC);
@@ -405,21 +417,26 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         // MFMA over the chunk: k-pair = channels (2cp, 2cp+1) of one tap; lane half picks the channel.  Operand reads
         // run one step ahead of the MFMAs that consume them (double-buffered registers) so the LDS latency hides
         // under the >= 256 MFMA cycles of a step.
-        using op_t = std::conditional_t<HM != 0, h16x4, float>;
-        op_t a_buf[2][KP][FO * NPL], b_buf[2][KP][FP * NPL];
+        using op_t = std::conditional_t<HM != 0, h16x8, float>;
+        // (the wide fp16-pair tile keeps two accumulator sets: its operand registers are single-buffered to stay inside 256 VGPRs)
+        constexpr int OB = (HM == 2 && FO * FP >= 4) ? 1 : 2;
+        op_t a_buf[OB][KP][FO * NPL], b_buf[OB][KP][FP * NPL];
         auto load_ops = [&](int st, op_t (&a)[KP][FO * NPL], op_t (&bv)[KP][FP * NPL]) {
 #pragma unroll
             for (int kk = 0; kk < KP; ++kk) {
                 if constexpr (HM != 0) {
-                    const int t = st * KP + kk;
-                    const h16x4* wh = reinterpret_cast<const h16x4*>(lds + st_cur);
-                    const h16x4* ph = reinterpret_cast<const h16x4*>(lds + st_cur + NPL * NT * BO * 4);
+                    const int sidx = st * KP + kk;
+                    const int tap = half ? pair_t1(TR, sidx) : pair_t0(TR, sidx);        // this lane half's tap of the pair
+                    const int tof = pair_t1(TR, sidx) == kZeroTap ? (half ? 0 : toff[pair_t0(TR, sidx)])
+                                                                  : (half ? toff[pair_t1(TR, sidx)] : toff[pair_t0(TR, sidx)]);
+                    const h16x8* wh = reinterpret_cast<const h16x8*>(lds + st_cur);
+                    const h16x8* ph = reinterpret_cast<const h16x8*>(lds + st_cur + NPL * NTP * BO * 4);
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-                        for (int fo = 0; fo < FO; ++fo) a[kk][pl * FO + fo] = wh[((pl * NT + t) * 2 + half) * BO + (wo * FO + fo) * 32 + l31];
+                        for (int fo = 0; fo < FO; ++fo) a[kk][pl * FO + fo] = wh[(pl * NTP + tap) * BO + (wo * FO + fo) * 32 + l31];
 #pragma unroll
-                        for (int fp = 0; fp < FP; ++fp) bv[kk][pl * FP + fp] = ph[pl * 2 * PSZ + base[fp] + toff[t]];
+                        for (int fp = 0; fp < FP; ++fp) bv[kk][pl * FP + fp] = ph[pl * PSZ + bpos[fp] + tof];
                     }
                 } else {
                     const int kp = st * KP + kk, t = kp / (CC / 2), cp = kp % (CC / 2);
@@ -433,7 +450,8 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         load_ops(0, a_buf[0], b_buf[0]);
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
-            if (st + 1 < NSTEP) load_ops(st + 1, a_buf[(st + 1) & 1], b_buf[(st + 1) & 1]);
+            const int cur = OB == 2 ? (st & 1) : 0;
+            if (OB == 2 && st + 1 < NSTEP) load_ops(st + 1, a_buf[(st + 1) & 1], b_buf[(st + 1) & 1]);
             if constexpr (DB) {
 #pragma unroll
                 for (int l = 0; l < LPS; ++l)
@@ -441,30 +459,33 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
             }
 #pragma unroll
             for (int kk = 0; kk < KP; ++kk) {
-                const int t = HM ? st * KP + kk : (st * KP + kk) / (CC / 2);
-                const int ph = TR ? (((t / KS) & 1) * 2 + ((t % KS) & 1)) : 0;
+                const int t = HM ? st * KP + kk : (st * KP + kk) / (CC / 2);   // fp16 forms: pair index
+                const int ph = HM ? pair_phase(TR, t) : (TR ? (((t / KS) & 1) * 2 + ((t % KS) & 1)) : 0);
 #pragma unroll
                 for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
                     for (int fp = 0; fp < FP; ++fp) {
                         if constexpr (HM == 2) {
-                            acc2[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x8f16(a_buf[st & 1][kk][FO + fo], b_buf[st & 1][kk][fp],
-                                                                                    acc2[ph][fo][fp], 0, 0, 0);
-                            acc2[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x8f16(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][FP + fp],
-                                                                                    acc2[ph][fo][fp], 0, 0, 0);
-                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x8f16(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][fp],
-                                                                                   acc[ph][fo][fp], 0, 0, 0);
+                            acc2[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[cur][kk][FO + fo], b_buf[cur][kk][fp],
+                                                                                      acc2[ph][fo][fp], 0, 0, 0);
+                            acc2[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[cur][kk][fo], b_buf[cur][kk][FP + fp],
+                                                                                      acc2[ph][fo][fp], 0, 0, 0);
+                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[cur][kk][fo], b_buf[cur][kk][fp],
+                                                                                     acc[ph][fo][fp], 0, 0, 0);
                         } else if constexpr (HM == 1)
-                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x8f16(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][fp],
-                                                                                   acc[ph][fo][fp], 0, 0, 0);
+                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[cur][kk][fo], b_buf[cur][kk][fp],
+                                                                                     acc[ph][fo][fp], 0, 0, 0);
                         else
-                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_buf[st & 1][kk][fo], b_buf[st & 1][kk][fp],
+                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_buf[cur][kk][fo], b_buf[cur][kk][fp],
                                                                                    acc[ph][fo][fp], 0, 0, 0);
                     }
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, KP * (FO + FP) * NPL, 0);   // next step's ds_reads first ...
-            if (DB && st * LPS < NLOAD) __builtin_amdgcn_sched_group_barrier(0x020, LPS, 0);   // ... a few global loads ...
-            __builtin_amdgcn_sched_group_barrier(0x008, KP * FO * FP * (HM == 2 ? 3 : 1), 0);     // ... then this step's MFMAs
+            if (OB == 1 && st + 1 < NSTEP) load_ops(st + 1, a_buf[0], b_buf[0]);   // after the MFMAs that read these registers were issued
+            if constexpr (OB == 2) {
+                __builtin_amdgcn_sched_group_barrier(0x100, KP * (FO + FP) * NPL, 0);   // next step's ds_reads first ...
+                if (DB && st * LPS < NLOAD) __builtin_amdgcn_sched_group_barrier(0x020, LPS, 0);   // ... a few global loads ...
+                __builtin_amdgcn_sched_group_barrier(0x008, KP * FO * FP * (HM == 2 ? 3 : 1), 0);     // ... then this step's MFMAs
+            }
         }
         if constexpr (DB) {
             __syncthreads();             // publishes the stage committed above and retires the one just read
@@ -563,7 +584,9 @@ int launch_npos(const float* x, const float* wk, const float* styles, float* y, 
     constexpr int BO = 32 * FO * WO, NT = KS * KS;
     Geo g = g_in;
     g.patch_cap = (worst + 3) & ~3;
-    const size_t lds = (size_t)(NT * CC * BO + CC * g.patch_cap) * sizeof(float) * (DB ? 2 : 1);
+    constexpr int NPL = HM == 2 ? 2 : 1;
+    const size_t stage = HM ? (size_t)NPL * (NT + 1) * BO * 4 + (size_t)NPL * 4 * g.patch_cap : (size_t)NT * CC * BO + (size_t)CC * g.patch_cap;
+    const size_t lds = stage * sizeof(float) * (DB ? 2 : 1);
     if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
     int st = IA_OK;
     if (g.T_dp > 0) {   // whole rounds: one tile per workgroup

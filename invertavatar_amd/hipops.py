@@ -52,15 +52,15 @@ def pack_conv_weight(w):
 
 
 def pack_conv_weight_h(w):
-    """[O, I, kh, kw] -> fp16 [kh*kw, I/4, O, 4] (channel quads innermost): the layout ia_conv2d_mfma_h reads."""
+    """[O, I, kh, kw] -> fp16 [kh*kw, I/8, O, 8] (channel octets innermost): the layout ia_conv2d_mfma_h reads."""
     o, i, kh, kw = w.shape
-    if i % 4:
-        raise RuntimeError('fp16 packing needs in_channels % 4 == 0')
-    return w.detach().permute(2, 3, 1, 0).reshape(kh * kw, i // 4, 4, o).permute(0, 1, 3, 2).contiguous().to(torch.float16)
+    if i % 8:
+        raise RuntimeError('fp16 packing needs in_channels % 8 == 0')
+    return w.detach().permute(2, 3, 1, 0).reshape(kh * kw, i // 8, 8, o).permute(0, 1, 3, 2).contiguous().to(torch.float16)
 
 
 def pack_conv_weight_split(w):
-    """[O, I, kh, kw] -> fp16 [2, kh*kw, I/4, O, 4]: hi = fp16(w) and lo = fp16((w - hi) * 2^11), the layout ia_conv2d_mfma_s reads."""
+    """[O, I, kh, kw] -> fp16 [2, kh*kw, I/8, O, 8]: hi = fp16(w) and lo = fp16((w - hi) * 2^11), the layout ia_conv2d_mfma_s reads."""
     w = w.detach().float()
     hi = w.to(torch.float16)
     lo = ((w - hi.float()) * 2048.0).to(torch.float16)      # scaled by 2^11: normal fp16 numbers (kLoScale in conv_mfma.hip)
@@ -116,9 +116,9 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     half_ops = wk.dtype == torch.float16
     split = half_ops and wk.dim() == 5
     if half_ops:
-        if not (wk.is_cuda and wk.is_contiguous() and wk.dim() in (4, 5) and wk.shape[-1] == 4 and (not split or wk.shape[0] == 2)):
-            raise RuntimeError('wk must be a contiguous fp16 [taps, I/4, O, 4] (or [2, taps, I/4, O, 4] hi/lo) device tensor')
-        taps, wi, o = wk.shape[-4], wk.shape[-3] * 4, wk.shape[-2]
+        if not (wk.is_cuda and wk.is_contiguous() and wk.dim() in (4, 5) and wk.shape[-1] == 8 and (not split or wk.shape[0] == 2)):
+            raise RuntimeError('wk must be a contiguous fp16 [taps, I/8, O, 8] (or [2, taps, I/8, O, 8] hi/lo) device tensor')
+        taps, wi, o = wk.shape[-4], wk.shape[-3] * 8, wk.shape[-2]
     else:
         _f32c(wk, 'wk')
         taps, wi, o = wk.shape
