@@ -138,7 +138,7 @@ int ia_conv2d_mfma(const float* x, const float* wk, const float* styles, const f
  * rounded to fp16, everything else (demodulation, noise, bias, activation, clamp, storage) stays fp32.
  *   wk_h : weights as fp16, packed [ksize*ksize][I/8][O][8] (channel octets innermost), from the reference's [O, I, kh, kw]
  * Same arguments, plan and scratch as ia_conv2d_mfma.  Covers 3x3 layers that run on the two-stage tiles (stride-1 layers
- * with O >= 128 and >= 64^2 outputs; every stride-2 transposed layer) with I % 8 == 0 and O % 4 == 0; other shapes return
+ * with O >= 128 and >= 32^2 outputs; every stride-2 transposed layer) with I % 8 == 0 and O % 4 == 0; other shapes return
  * IA_ERR_INVALID_ARG and the caller uses ia_conv2d_mfma.
  */
 int ia_conv2d_mfma_h(const float* x, const void* wk_h, const float* styles, const float* demod,

@@ -652,7 +652,7 @@ constexpr int kChunkConv = 8, kChunkTransposed = 8;
 constexpr int kSmallPoints = 320;
 // Images with >= kWidePoints points use an 8-wave (128ch x 256pt) tile for 3x3 convolutions with wide outputs: one
 // workgroup per CU fetches the chunk's weight slab once instead of twice (the slab is 70 % of the staged bytes).
-constexpr int kWidePoints = 4096;
+constexpr int kWidePoints = 1024;
 
 int worst_patch(int npts, int GW, int bp, int ksize, bool tr) {
     int worst = 0;

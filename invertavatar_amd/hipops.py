@@ -73,7 +73,7 @@ def conv_h_supported(i, o, h, w, ksize, transposed):
         return False
     if transposed:
         return (h + 1) * (w + 1) > 320
-    return o >= 128 and h * w >= 4096 and w <= 512
+    return o >= 128 and h * w >= 1024 and w <= 512
 
 
 def weight_sq_sum(w):
