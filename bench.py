@@ -123,7 +123,7 @@ def roofline_leg(step, frames=3):
         # Most of the family's time is in the split form: price it against the matrix pipe it runs on.  Executed fp16 MFMA
         # FLOPs = 3 x the algorithmic fp32 FLOPs of those launches; peak = dense fp16 MFMA (MI355X_MICROARCH.md).
         executed = 3.0 * split['flops'] / (split['ms'] * 1e-3) / 1e12
-        out = dict(bound='mfma', kernel='conv2d_mfma (3x3 layers >= 64^2: fp32 products from fp16 hi/lo pairs, 3 x v_mfma_f32_32x32x16_f16)',
+        out = dict(bound='mfma', kernel='conv2d_mfma (3x3 layers >= 32^2: fp32 products from fp16 hi/lo pairs, 3 x v_mfma_f32_32x32x16_f16)',
                    achieved=round(executed, 2), peak=PEAK_FP16_MFMA_TFLOPS, unit='TFLOP/s', frac=round(executed / PEAK_FP16_MFMA_TFLOPS, 4),
                    traffic=pmc_traffic(dom), launches_per_frame=split['launches'] // frames,
                    avg_launch_us=round(split['ms'] * 1e3 / split['launches'], 2),
@@ -189,6 +189,50 @@ def f32_mfma_only_leg(gen, ws, cams, uvs, jits, args, eager_step):
     err = (img - eager_step(0)).abs().max().item()
     return dict(value=round(args.steps / dt, 3), unit='frames/s', ms_per_step=round(dt / args.steps * 1e3, 3),
                 max_abs_rgb_vs_headline_run=float(f'{err:.3e}'))
+
+
+def drive_loop_leg(gen, ws, cams, uvs, jits, args):
+    """The drive loop of eval_seq.py:212 / BASELINE configs[2]: the texture and static features of the identity are computed
+    once (inversion result) and every drive frame is `synthesis_withTexture` = rasterize + face backbone + renderer + SR."""
+    with torch.no_grad():
+        tex = gen.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        sta = gen.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        c_s, uv_s, jit_s = cams[:1].clone(), uvs[:1].clone(), jits[:1].clone()
+
+        def call():
+            return gen.synthesis_withTexture(ws, tex, c_s, {'uvcoords_image': uv_s}, static_feats=sta, neural_rendering_resolution=NRR,
+                                             noise_mode='const', evaluation=True, jitter=jit_s)['image']
+        ref = gen.synthesis(ws, cams[:1], {'uvcoords_image': uvs[:1]}, neural_rendering_resolution=NRR, noise_mode='const',
+                            evaluation=True, jitter=jits[:1])['image']
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                img = call()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        err = (img - ref).abs().max().item()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = call()
+        n = cams.shape[0]
+
+        def step(k):
+            i = k % n
+            c_s.copy_(cams[i:i + 1]); uv_s.copy_(uvs[i:i + 1]); jit_s.copy_(jits[i:i + 1])
+            graph.replay()
+            return out
+        for k in range(args.warmup):
+            step(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dict(value=round(args.steps / dt, 3), unit='frames/s', ms_per_step=round(dt / args.steps * 1e3, 3),
+                workload='synthesis_withTexture per drive frame, texture + static backbone features cached (eval_seq.py:212)',
+                max_abs_rgb_vs_full_synthesis=float(f'{err:.3e}'))
 
 
 def sr_fp16_leg(gen, ws, cams, uvs, jits, args, eager_step):
@@ -292,7 +336,7 @@ def main():
             'metric': 'frames/sec (512^2 out, 128^2 neural render)', 'value': round(world * FRAMES_PER_RANK * args.steps / dt, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (3x3 convolutions >= 64^2 form their f32 products from fp16 hi/lo pairs on the f16 MFMA, f32 accumulate; '
+            'dtype': 'f32 (3x3 convolutions >= 32^2 form their f32 products from fp16 hi/lo pairs on the f16 MFMA, f32 accumulate; '
                      'all other arithmetic f32)', 'data': 'synthetic',
             'config': {'workload': 'TriPlaneGenerator.synthesis, reenact_avatar_next3d single-seed render (BASELINE configs[1]): '
                                    '512^2 out, neural_rendering_resolution=128, 1 frame per rank per step, all three backbones + '
@@ -305,6 +349,7 @@ def main():
             if not args.no_sr_fp16:
                 result['f32_mfma_only'] = f32_mfma_only_leg(gen, ws, cams, uvs, jits, args, eager_step)
                 result['sr_fp16'] = sr_fp16_leg(gen, ws, cams, uvs, jits, args, eager_step)
+                result['drive_loop'] = drive_loop_leg(gen, ws, cams, uvs, jits, args)
             if not args.no_roofline:
                 result['roofline'], result['kernels'] = roofline_leg(eager_step)
             if not args.no_cpu_baseline:

@@ -234,11 +234,19 @@ class TriPlaneGenerator(torch.nn.Module):
     def synthesis_withTexture(self, ws, texture_feats, c, mesh_condition, static_feats=None, neural_rendering_resolution=None,
                               update_emas=False, cache_backbone=False, use_cached_backbone=False, evaluation=False, jitter=None,
                               **synthesis_kwargs):
-        origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
+        # same orchestration as synthesis(): mouth fill + rays on the side stream, face-backbone head on its own stream
+        mouth = self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, None))
+        face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
+        ray_dist = None
+        if self._side_rays is not None:
+            origins, dirs, nrr, ray_dist = self._side_rays
+        else:
+            origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
         if static_feats is None:
             static_feats = self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
-        planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs)
-        image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs)
+        planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, mouth=mouth,
+                              face_head=face_head)
+        image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist)
         return {'image': image, 'image_raw': rgb, 'image_depth': depth, 'feature_image': feature_image, 'triplane': planes}
 
     def synthesis_withCondition(self, ws, c, mesh_condition, gt_texture_feats=None, gt_static_feats=None, texture_feats_conditions=None,
