@@ -150,3 +150,20 @@ def test_rasterize_and_blend_kernels_vs_oracle():
         planes = g._blend_planes(stitch.cuda(), full, plane_dev)
         assert planes.shape == ref_planes.shape and max_abs(planes.cpu(), ref_planes) <= 2e-5
         assert planes.permute(0, 1, 3, 4, 2).is_contiguous()
+
+
+def test_drive_loop_equals_full_synthesis(small):
+    """synthesis_withTexture with the backbones' own features (the eval_seq.py:212 drive loop) must reproduce synthesis()
+    bit for bit: same kernels, only the stream orchestration differs."""
+    g = small
+    ws = g.mapping(synthetic.latent(3, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14)
+    c, uv, jit = synthetic.camera_labels([7]).cuda(), synthetic.uv_conditions([7]).cuda(), synthetic.jitter([7], 64 * 64).cuda()
+    with torch.no_grad():
+        full = g.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=64, noise_mode='const', evaluation=True, jitter=jit)
+        tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        drive = g.synthesis_withTexture(ws, tex, c, {'uvcoords_image': uv}, static_feats=sta, neural_rendering_resolution=64,
+                                        noise_mode='const', evaluation=True, jitter=jit)
+    torch.cuda.synchronize()
+    assert torch.equal(full['image'], drive['image'])
+    assert torch.equal(full['image_depth'], drive['image_depth'])
