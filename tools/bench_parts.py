@@ -1,0 +1,48 @@
+"""Stand-alone graph-replay times of the parts of a frame (each alone on the GPU)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from invertavatar_amd import synthetic
+from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+
+gen = TriPlaneGenerator(**synthetic.generator_kwargs('full')).eval().requires_grad_(False)
+synthetic.fill_parameters(gen)
+gen = gen.cuda()
+
+
+def timeit(name, fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        g.replay()
+    torch.cuda.synchronize()
+    print(f'{name:28s} {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms', flush=True)
+    return out
+
+
+with torch.no_grad():
+    ws = gen.mapping(synthetic.latent(0, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14)
+    cams, uvs = synthetic.camera_labels([0]).cuda(), synthetic.uv_conditions([0]).cuda()
+    jit = synthetic.jitter([0], 128 * 128).squeeze(-1).cuda()
+    tex = timeit('texture backbone', lambda: gen.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const'))
+    sta = timeit('static backbone', lambda: gen.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const'))
+    timeit('face head (4..32)', lambda: gen.face_backbone.synthesis.forward_head(ws, noise_mode='const'))
+    timeit('both backbones (2 streams)', lambda: gen._two_backbones(ws, False, dict(noise_mode='const')))
+    full = timeit('synthesis', lambda: gen.synthesis(ws, cams, {'uvcoords_image': uvs}, neural_rendering_resolution=128,
+                                                     noise_mode='const', evaluation=True, jitter=jit))
+    timeit('synthesis_withTexture', lambda: gen.synthesis_withTexture(ws, tex, cams, {'uvcoords_image': uvs}, static_feats=sta,
+                                                                      neural_rendering_resolution=128, noise_mode='const',
+                                                                      evaluation=True, jitter=jit))
+    planes = gen.synthesis(ws, cams, {'uvcoords_image': uvs}, neural_rendering_resolution=128, noise_mode='const', evaluation=True,
+                           jitter=jit, return_featmap=True)['triplane']
+    o, d, nrr = gen._rays(cams, 128)
+    timeit('render + SR', lambda: gen._render(ws, planes, o, d, nrr, True, jit, dict(noise_mode='const')))
