@@ -60,11 +60,108 @@ __global__ __launch_bounds__(kThreads) void fill_mouth_kernel(const float* __res
     }
 }
 
+// ---- 256 x 256 masks (the generator's UV maps): bit-parallel flood.
+// The label image is kept as two 256 x 256 bit matrices (passable P, reached R), row-major AND column-major, 64 pixels per
+// 64-bit word.  Carrying the fill along a whole line is then integer arithmetic: with X = R & P, the multi-word sum P + X
+// ripples a carry from every reached pixel to the end of its run of passable pixels, so ((P + X) ^ P) & P | X is the line
+// filled towards higher indices; the other direction is the same on bit-reversed words.  One thread owns one row (then
+// one column); between the row pass and the column pass R is transposed with one ballot per pixel column.  A round costs
+// ~10 us instead of ~100 us of byte-wise LDS sweeps; results are identical (the 4-connected component is unique).
+constexpr int kN = 256, kNW = kN / 64;
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void fill_line(const u64 (&P)[kNW], u64 (&R)[kNW]) {
+    u64 X[kNW], F[kNW];
+    unsigned carry = 0;
+#pragma unroll
+    for (int w = 0; w < kNW; ++w) {            // towards higher bit indices
+        X[w] = R[w] & P[w];
+        const u64 s1 = P[w] + X[w], s2 = s1 + carry;
+        carry = (s1 < P[w]) | (s2 < s1);
+        F[w] = ((s2 ^ P[w]) & P[w]) | X[w];
+    }
+    carry = 0;
+#pragma unroll
+    for (int w = kNW - 1; w >= 0; --w) {       // towards lower bit indices: the same on the reversed line
+        const u64 p = __brevll(P[w]), x = __brevll(F[w]);
+        const u64 s1 = p + x, s2 = s1 + carry;
+        carry = (s1 < p) | (s2 < s1);
+        R[w] = __brevll(((s2 ^ p) & p) | x);
+    }
+}
+
+// dst[c][wave] = bit c of the 64 rows of this wave (src row words in registers): 256 x 256 bit transpose.
+__device__ __forceinline__ void transpose_bits(const u64 (&r)[kNW], u64* dst, int wave, int lane) {
+#pragma unroll
+    for (int w = 0; w < kNW; ++w)
+        for (int bit = 0; bit < 64; ++bit) {
+            const u64 word = __ballot((r[w] >> bit) & 1ull);
+            if (lane == 0) dst[(w * 64 + bit) * kNW + wave] = word;
+        }
+}
+
+__global__ __launch_bounds__(kN) void fill_mouth256_kernel(const float* __restrict__ alpha, float* __restrict__ mouth) {
+    __shared__ u64 Prow[kN * kNW], Pcol[kN * kNW], Rrow[kN * kNW], Rcol[kN * kNW];
+    __shared__ int changed;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* a = alpha + (int64_t)blockIdx.x * kN * kN;
+    float* m = mouth + (int64_t)blockIdx.x * kN * kN;
+    const float seed = a[0] * 255.f;
+    for (int wd = wave; wd < kN * kNW; wd += kN / 64) {          // one 64-pixel word per wave iteration (coalesced reads)
+        const float v = a[wd * 64 + lane] * 255.f;
+        const u64 word = __ballot(v >= seed && v <= seed + 254.f);
+        if (lane == 0) Prow[wd] = word;
+    }
+    __syncthreads();
+    u64 P[kNW], R[kNW], Pc[kNW];
+#pragma unroll
+    for (int w = 0; w < kNW; ++w) { P[w] = Prow[tid * kNW + w]; R[w] = 0; }
+    if (tid == 0) R[0] = 1ull;                                    // the seed pixel (0,0) is passable by definition
+    transpose_bits(P, Pcol, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kNW; ++w) Pc[w] = Pcol[tid * kNW + w];
+    for (int round = 0; round < 2 * kN; ++round) {
+        if (tid == 0) changed = 0;
+        u64 before[kNW];
+#pragma unroll
+        for (int w = 0; w < kNW; ++w) before[w] = R[w];
+        fill_line(P, R);                                          // along the row this thread owns
+        transpose_bits(R, Rcol, wave, lane);
+        __syncthreads();
+        u64 C[kNW];
+#pragma unroll
+        for (int w = 0; w < kNW; ++w) C[w] = Rcol[tid * kNW + w];
+        fill_line(Pc, C);                                         // along the column this thread owns
+        transpose_bits(C, Rrow, wave, lane);
+        __syncthreads();
+        bool diff = false;
+#pragma unroll
+        for (int w = 0; w < kNW; ++w) { R[w] = Rrow[tid * kNW + w]; diff |= R[w] != before[w]; }
+        if (diff) changed = 1;
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int w = 0; w < kNW; ++w) Rrow[tid * kNW + w] = R[w];
+    __syncthreads();
+    for (int wd = wave; wd < kN * kNW; wd += kN / 64) {
+        const int i = wd * 64 + lane;
+        const bool reached = (Rrow[wd] >> lane) & 1ull;
+        m[i] = reached ? 0.f : (255.f - a[i] * 255.f) / 255.f;
+    }
+}
+
 }  // namespace
 
 extern "C" int ia_fill_mouth(const float* alpha, float* mouth, int B, int H, int W, void* stream) {
     IA_REQUIRE(alpha && mouth, "null pointer argument");
     IA_REQUIRE(B > 0 && H > 0 && W > 0, "empty tensor");
+    if (H == kN && W == kN) {
+        hipLaunchKernelGGL(fill_mouth256_kernel, dim3(B), dim3(kN), 0, (hipStream_t)stream, alpha, mouth);
+        return ia::check_launch("ia_fill_mouth");
+    }
     const size_t lds = (size_t)H * (W + 4);
     if (lds > 150 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "mask %dx%d does not fit the LDS label image", H, W);
     (void)hipFuncSetAttribute((const void*)fill_mouth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

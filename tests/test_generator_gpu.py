@@ -120,6 +120,18 @@ def test_fill_mouth_known_answers_on_device(golden):
     cpu_full, cpu_mouth = fill_mouth(m.clone(), blur_mouth_edge=False)
     dev_full, dev_mouth = fill_mouth(m.cuda(), blur_mouth_edge=False)
     assert torch.equal(dev_mouth.cpu(), cpu_mouth) and torch.equal(dev_full.cpu(), cpu_full)
+    # the bit-parallel 256^2 kernel on a face-like disc with a mouth hole, on salt-and-pepper noise and on fractional alphas
+    import numpy as np
+    yy, xx = torch.meshgrid(torch.arange(256), torch.arange(256), indexing='ij')
+    disc = ((xx - 128) ** 2 + (yy - 120) ** 2 < 90 ** 2).float()
+    disc[150:170, 100:156] = 0.0
+    noise = torch.from_numpy((np.random.RandomState(3).rand(256, 256) > 0.6).astype(np.float32))
+    noise[0, 0] = 0.0
+    soft = torch.from_numpy(np.random.RandomState(4).rand(256, 256).astype(np.float32)) * disc
+    big = torch.stack([disc, noise, soft])[:, None]
+    cpu_full, cpu_mouth = fill_mouth(big.clone(), blur_mouth_edge=False)
+    dev_full, dev_mouth = fill_mouth(big.cuda(), blur_mouth_edge=False)
+    assert torch.equal(dev_mouth.cpu(), cpu_mouth) and torch.equal(dev_full.cpu(), cpu_full)
 
 
 def test_rasterize_and_blend_kernels_vs_oracle():
