@@ -149,6 +149,32 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
         const int p = p0 + (wp * FP + fp) * 32 + l31;
         if (p >= npts) continue;
         const int pr = p / g.GW, pc = p - pr * g.GW;
+        if constexpr (TR) {
+            // the two horizontal phases of a point are adjacent output pixels: one 8-byte store per (row phase, channel), so
+            // that a half-wave writes 64 consecutive floats instead of every other one twice
+            const int ox = 2 * pc;
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int oy = 2 * pr + py;
+                if (oy >= g.OH) continue;
+                const int64_t pix = (int64_t)oy * g.OW + ox;
+                const bool pair = ox + 1 < g.OW;
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (o >= g.O) continue;
+                        float* dst = yb + (int64_t)o * ohw + pix;
+                        const float v0 = epilogue(acc[2 * py][fo][fp][r], b, o, pix, ohw, g, e, ns);
+                        if (pair) {
+                            const float v1 = epilogue(acc[2 * py + 1][fo][fp][r], b, o, pix + 1, ohw, g, e, ns);
+                            __builtin_memcpy(dst, &(const float2&)make_float2(v0, v1), 8);     // (rows of odd width: 4-byte aligned only)
+                        } else dst[0] = v0;
+                    }
+            }
+            continue;
+        }
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             int64_t pix;
