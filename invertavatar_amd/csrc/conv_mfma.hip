@@ -547,7 +547,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
 }
 
 // Fix-up: stream-K tiles that were split between workers.  grid = (stream-K tile, batch, accumulator quad): a workgroup adds one
-// register quad (float4) of every thread position over the tile's slabs in worker order and stores it through the epilogue.
+// register quad (float4; a pair of them in the transposed form) of every thread position over the tile's slabs in worker order and stores it through the epilogue.
 // Loads of up to kFixBatch workers are in flight together (the adds keep the worker order).
 constexpr int kFixBatch = 8;
 template <bool TR, int FO, int FP, int WO, int WP>
@@ -555,7 +555,14 @@ __global__ __launch_bounds__(WO * WP * 64) void conv_fixup_kernel(const float* _
     constexpr int NPH = TR ? 4 : 1;
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
     constexpr int NACC = NPH * FO * FP * 16;
-    const int tile_l = blockIdx.x, b = blockIdx.y, q = blockIdx.z, tid = threadIdx.x;
+    // (transposed form: blockIdx.z enumerates quads of ROW phases; the thread sums the quads of both horizontal phases and
+    // stores them as 8-byte pairs of adjacent output pixels, like store_tile)
+    constexpr int NQ = TR ? 2 : 1;
+    const int tile_l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int zq = blockIdx.z, rq = zq & 3, frp = zq >> 2, fp = frp % FP, fo = (frp / FP) % FO, pyh = frp / (FP * FO);
+    int q[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) q[h] = ((((TR ? 2 * pyh + h : 0) * FO + fo) * FP + fp) << 2) + rq;
     const int64_t U = (int64_t)(g.T - g.T_dp) * g.C, t_begin = (int64_t)tile_l * g.C, t_end = t_begin + g.C;
     int w_first = (int)((t_begin * g.G) / U);
     while (w_first > 0 && range_begin(w_first, U, g.G) > t_begin) --w_first;
@@ -564,17 +571,25 @@ __global__ __launch_bounds__(WO * WP * 64) void conv_fixup_kernel(const float* _
     while (range_begin(w_last + 1, U, g.G) < t_end) ++w_last;
     if (w_first == w_last) return;                       // the tile was finished by a single worker
     const int64_t slab4 = (int64_t)NACC * NTHREADS / 4;
-    const float4* base = reinterpret_cast<const float4*>(slabs) + ((int64_t)b * g.G) * 2 * slab4 + (int64_t)q * NTHREADS + tid;
+    const float4* base = reinterpret_cast<const float4*>(slabs) + ((int64_t)b * g.G) * 2 * slab4 + tid;
     // only the first worker can hold this tile in its trailing slot (1); every later worker starts inside the tile (slot 0)
     const int slot_first = (tile_l == (int)(range_begin(w_first, U, g.G) / g.C)) ? 0 : 1;
-    float4 acc = base[((int64_t)w_first * 2 + slot_first) * slab4];
-    for (int w = w_first + 1; w <= w_last; w += kFixBatch) {
-        float4 v[kFixBatch];
+    constexpr int FB = kFixBatch / NQ;
+    float4 acc[NQ];
 #pragma unroll
-        for (int j = 0; j < kFixBatch; ++j) v[j] = base[((int64_t)min(w + j, w_last) * 2) * slab4];
+    for (int h = 0; h < NQ; ++h) acc[h] = base[((int64_t)w_first * 2 + slot_first) * slab4 + (int64_t)q[h] * NTHREADS];
+    for (int w = w_first + 1; w <= w_last; w += FB) {
+        float4 v[FB][NQ];
 #pragma unroll
-        for (int j = 0; j < kFixBatch; ++j)
-            if (w + j <= w_last) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+        for (int j = 0; j < FB; ++j)
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) v[j][h] = base[((int64_t)min(w + j, w_last) * 2) * slab4 + (int64_t)q[h] * NTHREADS];
+#pragma unroll
+        for (int j = 0; j < FB; ++j)
+            if (w + j <= w_last) {
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) { acc[h].x += v[j][h].x; acc[h].y += v[j][h].y; acc[h].z += v[j][h].z; acc[h].w += v[j][h].w; }
+            }
     }
     // decode (register index, thread) -> (channel, point) exactly as the MFMA kernel lays its accumulators out
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -585,22 +600,30 @@ __global__ __launch_bounds__(WO * WP * 64) void conv_fixup_kernel(const float* _
     const int64_t ohw = (int64_t)g.OH * g.OW;
     const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
     float* yb = y + ((int64_t)b * g.O) * ohw;
-    const int fr = q >> 2, fp = fr % FP, fo = (fr / FP) % FO, ph = fr / (FP * FO);
     const int p = p0 + (wp * FP + fp) * 32 + l31;
     if (p >= npts) return;
     const int pr = p / g.GW, pc = p - pr * g.GW;
     int64_t pix = p;
+    bool pair = false;
     if (TR) {
-        const int oy = 2 * pr + (ph >> 1), ox = 2 * pc + (ph & 1);
-        if (oy >= g.OH || ox >= g.OW) return;
+        const int oy = 2 * pr + pyh, ox = 2 * pc;
+        if (oy >= g.OH) return;
         pix = (int64_t)oy * g.OW + ox;
+        pair = ox + 1 < g.OW;
     }
-    const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
+    const float v0[4] = {acc[0].x, acc[0].y, acc[0].z, acc[0].w};
+    const float v1[4] = {acc[NQ - 1].x, acc[NQ - 1].y, acc[NQ - 1].z, acc[NQ - 1].w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int r = (q & 3) * 4 + k;
+        const int r = rq * 4 + k;
         const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o < g.O) yb[(int64_t)o * ohw + pix] = epilogue(vals[k], b, o, pix, ohw, g, e, ns);
+        if (o >= g.O) continue;
+        float* dst = yb + (int64_t)o * ohw + pix;
+        const float a0 = epilogue(v0[k], b, o, pix, ohw, g, e, ns);
+        if (TR && pair) {
+            const float a1 = epilogue(v1[k], b, o, pix + 1, ohw, g, e, ns);
+            __builtin_memcpy(dst, &(const float2&)make_float2(a0, a1), 8);
+        } else dst[0] = a0;
     }
 }
 
@@ -630,7 +653,7 @@ int launch_npos(const float* x, const float* wk, const float* styles, float* y, 
         const bool whole_tiles = U % g.G == 0 && (U / g.G) % g.C == 0;
         if (st == IA_OK && !whole_tiles) {
             constexpr int NACC = (TR ? 4 : 1) * FO * FP * 16;
-            hipLaunchKernelGGL((conv_fixup_kernel<TR, FO, FP, WO, WP>), dim3(g.T - g.T_dp, g.B, NACC / 4), dim3(WO * WP * 64), 0, s,
+            hipLaunchKernelGGL((conv_fixup_kernel<TR, FO, FP, WO, WP>), dim3(g.T - g.T_dp, g.B, NACC / (TR ? 8 : 4)), dim3(WO * WP * 64), 0, s,
                                scratch, y, g, e);
             st = ia::check_launch("ia_conv2d_mfma(fix-up)");
         }
