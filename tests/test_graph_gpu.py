@@ -1,0 +1,71 @@
+"""The launch modes bench.py times (hipGraph replay, frames in flight) against eager calls of the same frames: replaying
+a captured frame with new inputs must give the bits of an eager call -- same kernels, same order of additions."""
+import pytest
+import torch
+
+from invertavatar_amd import synthetic
+from invertavatar_amd.graphed import FramePipeline, GraphedSynthesis
+from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(width, nrr, frames):
+    g = TriPlaneGenerator(**synthetic.generator_kwargs(width)).eval().requires_grad_(False)
+    synthetic.fill_parameters(g)
+    g = g.cuda()
+    with torch.no_grad():
+        ws = g.mapping(synthetic.latent(0, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14)
+    cams, uvs = synthetic.camera_labels(frames).cuda(), synthetic.uv_conditions(frames).cuda()
+    jits = synthetic.jitter(frames, nrr * nrr).squeeze(-1).cuda()
+
+    def eager(i):
+        with torch.no_grad():
+            out = g.synthesis(ws, cams[i:i + 1], {'uvcoords_image': uvs[i:i + 1]}, neural_rendering_resolution=nrr, noise_mode='const',
+                              evaluation=True, jitter=jits[i:i + 1])
+        return out['image'].clone(), out['image_depth'].clone()
+    return g, ws, cams, uvs, jits, eager
+
+
+def test_graph_replay_is_the_eager_frame_bit_for_bit():
+    frames = [0, 37, 120, 201]
+    g, ws, cams, uvs, jits, eager = _setup('small', 64, frames)
+    want = [eager(i) for i in range(len(frames))]
+    graphed = GraphedSynthesis(g, batch=1, neural_rendering_resolution=64)
+    for i in (0, 1, 2, 3, 1, 0):   # captured on frame 0; later replays see other cameras / expressions, then come back
+        out = graphed(ws, cams[i:i + 1], uvs[i:i + 1], jits[i:i + 1])
+        torch.cuda.synchronize()
+        assert torch.equal(out['image'], want[i][0]), i
+        assert torch.equal(out['image_depth'], want[i][1]), i
+    assert not torch.equal(want[0][0], want[2][0])   # (the frames do differ)
+
+
+def test_frames_in_flight_return_their_own_results():
+    frames = [3, 60, 150, 230, 90]
+    g, ws, cams, uvs, jits, eager = _setup('small', 64, frames)
+    want = [eager(i)[0] for i in range(len(frames))]
+    pipe = FramePipeline(g, depth=2, batch=1, neural_rendering_resolution=64).capture(ws, cams[:1], uvs[:1], jits[:1])
+    got = []
+    for i in range(len(frames)):
+        out, ev, _ = pipe.submit(ws, cams[i:i + 1], uvs[i:i + 1], jits[i:i + 1])
+        ev.synchronize()              # the slot's output buffer is rewritten two submits later: take it now
+        got.append(out['image'].clone())
+    pipe.drain()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), i
+
+
+def test_bench_workload_replay_equals_eager():
+    """BASELINE configs[1]: full-width model, 128^2 neural render, 512^2 out, B = 1 -- the frame bench.py times."""
+    frames = [0, 16]
+    g, ws, cams, uvs, jits, eager = _setup('full', 128, frames)
+    want = [eager(i) for i in range(2)]
+    graphed = GraphedSynthesis(g, batch=1, neural_rendering_resolution=128)
+    for i in (0, 1, 0):
+        out = graphed(ws, cams[i:i + 1], uvs[i:i + 1], jits[i:i + 1])
+        torch.cuda.synchronize()
+        assert out['image'].shape == (1, 3, 512, 512)
+        assert torch.equal(out['image'], want[i][0]), i
+        assert torch.equal(out['image_depth'], want[i][1]), i
+    assert torch.isfinite(want[0][0]).all() and want[0][0].abs().mean().item() > 1e-3
