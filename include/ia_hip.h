@@ -152,13 +152,17 @@ int ia_conv2d_mfma_h(const float* x, const void* wk_h, const float* styles, cons
  * every operand v is split as hi = fp16(v), lo = fp16(v - hi) -- 22 mantissa bits together -- and a*b is taken as
  * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi.  The dropped a_lo*b_lo is <= 2^-22 |a*b|, the size of fp32's own rounding, so the
  * result is an fp32 convolution (measured against an fp64 convolution it is as close as ia_conv2d_mfma) at 3/16 of the fp32
- * MFMA's cycles.  Range: |w| < 65504; x * style saturates at +-65504 (StyleGAN2 activations are O(1)-O(100); the reference
- * clamps its fp16 blocks at 256); operand values below 3e-8 lose their low part.
- *   wk_split : fp16 [2 (hi, lo * 2^11)][ksize*ksize][I/8][O][8]  (low parts are kept scaled so that they are normal fp16
- *              numbers; their products are accumulated separately and folded in with 2^-11)
- * Same arguments, plan, scratch and shape coverage as ia_conv2d_mfma_h.
+ * MFMA's cycles.  The MFMA flushes fp16 denormals, so every factor is kept a normal number: the weights are scaled by
+ * 2^wk_exp at pack time (wk_exp chosen per layer so that max|w| * 2^wk_exp <= 32768), the low parts of the activations by
+ * 2^11, and the high part of a weight is multiplied by 2^-11 (exact) where it meets an activation's low part -- all three
+ * products then carry the factor 2^wk_exp and go to ONE fp32 accumulator, which is multiplied by 2^-wk_exp at the end.
+ * Range: x * style saturates at +-65504 (StyleGAN2 activations are O(1)-O(100); the reference clamps its fp16 blocks at
+ * 256); weights below 2^(-3-wk_exp) lose the a_hi*b_lo correction, activations below 6e-5 are taken as zero.
+ *   wk_split : fp16 [2 (hi, lo)][ksize*ksize][I/8][O][8] of w * 2^wk_exp
+ *   wk_exp   : the power of two above
+ * Other arguments, plan, scratch and shape coverage as ia_conv2d_mfma_h.
  */
-int ia_conv2d_mfma_s(const float* x, const void* wk_split, const float* styles, const float* demod,
+int ia_conv2d_mfma_s(const float* x, const void* wk_split, int wk_exp, const float* styles, const float* demod,
                      const float* noise, const float* noise_strength, const float* bias, const float* residual,
                      float* y, float* scratch, size_t scratch_bytes,
                      int B, int I, int O, int H, int W, int ksize, int transposed,

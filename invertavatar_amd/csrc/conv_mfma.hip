@@ -44,8 +44,8 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kPatchFloats = 1024;  // per-channel LDS patch capacity (floats)
-// The low parts of the hi/lo fp16 split are stored scaled by 2^11 so that they are normal fp16 numbers (the MFMA flushes
-// fp16 denormals): their products go to a second accumulator that is folded in with 2^-11 at the end of the K loop.
+// The low parts of the activations' hi/lo fp16 split are scaled by 2^11 so that they are normal fp16 numbers (the MFMA
+// flushes fp16 denormals); the weight's high part is multiplied by 2^-11 where it meets one (see HM = 2 below).
 constexpr float kLoScale = 2048.f;
 // fp16 forms: one k-step of v_mfma_f32_32x32x16_f16 = 8 channels of TWO taps (lanes 0-31 carry the first tap of the pair,
 // lanes 32-63 the second).  The nine taps make five pairs; the odd tap out pairs with an all-zero tap (index 9).  In the
@@ -65,6 +65,7 @@ struct Geo {
     int TO, T;             // out-channel tiles, tiles in total (point tiles x out-channel tiles)
     int T_dp;              // tiles [0, T_dp) run one per workgroup, tiles [T_dp, T) are stream-K
     int patch_cap;         // floats per channel reserved for the patch in LDS
+    float acc_scale;       // fp16-pair form: 2^-wk_exp, takes the accumulators back from the scale of the packed weights
 };
 
 // unit range of worker w: [range_begin(w), range_begin(w+1)) over U = (T - T_dp)*C units
@@ -202,7 +203,11 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
 // HM = 2 (DB kernels only): fp32-equivalent products from fp16 pairs.  Every operand value v is split as hi = fp16(v),
 // lo = fp16(v - hi) (22 mantissa bits together) and a*b is taken as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
 // v_mfma_f32_32x32x16_f16 with fp32 accumulation: the dropped term a_lo*b_lo is 2^-22 of the product, the size of fp32's own
-// rounding.  `wk` = [2 (hi, lo)][tap][I/8][O][8] halves (pack_conv_weight_split).
+// rounding.  The MFMA flushes fp16 denormals, so the factors are kept normal: weights arrive scaled by 2^wk_exp (hi and lo of
+// w * 2^wk_exp, pack_conv_weight_split), the low part of an activation is scaled by 2^11 at commit, and the weight's high part
+// is multiplied by 2^-11 (exact, one v_pk_mul_f16 per register pair) where it meets it.  All three products then carry 2^wk_exp
+// and accumulate in ONE register set, scaled back by g.acc_scale = 2^-wk_exp before the epilogue / the slab hand-off.
+// `wk` = [2 (hi, lo)][tap][I/8][O][8] halves.
 // HM = 1 (DB kernels only): fp16 operands on v_mfma_f32_32x32x16_f16, fp32 accumulation -- the arithmetic of the reference's
 // fp16 blocks (training/networks_stylegan2.py:34-91 with x.dtype == float16; superresolution.py:209-216), activations kept
 // in fp32 in memory.  `wk` then points at the fp16 weights packed [tap][I/4][O][4] (pack_conv_weight_h).
@@ -268,17 +273,6 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
             for (int fp = 0; fp < FP; ++fp)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] = 0.f;
-    f32x16 acc2[HM == 2 ? NPH : 1][HM == 2 ? FO : 1][HM == 2 ? FP : 1];   // hi*lo + lo*hi products (scaled by kLoScale)
-    if constexpr (HM == 2) {
-#pragma unroll
-        for (int ph = 0; ph < NPH; ++ph)
-#pragma unroll
-            for (int fo = 0; fo < FO; ++fo)
-#pragma unroll
-                for (int fp = 0; fp < FP; ++fp)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[ph][fo][fp][r] = 0.f;
-    }
 
     const int ci_begin = c_lo * CC, ci_end = min(c_hi * CC, g.I);
     const float* xb = x + (int64_t)b * g.I * g.H * g.W;
@@ -306,9 +300,9 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
     // (tap, cc) = e / ROWV and channels 4*(e % ROWV) ..+3 of the tile, and lands at float 4*e of the LDS slab.
     // (fp16 forms: the slab of a chunk is [plane][tap][BO][8 channels] halves; 16-byte slot e = (plane*NT + tap)*BO + o.  In
     // LDS every plane has one more, all-zero, tap: slot e lands at 16-byte index e + plane*BO.)
-    constexpr int NPL = HM == 2 ? 2 : 1;                              // operand planes (hi, lo)
+    constexpr int NPA = HM == 2 ? 2 : 1, NPB = NPA;                   // operand planes: weights (hi, lo) at the packed scale, patch (hi, lo*2^11)
     constexpr int NTP = NT + 1;
-    constexpr int ROWV = HM ? BO : BO / 4, NSLOT = HM ? NPL * NT * BO : NT * CC * ROWV, NWV = (NSLOT + NTHREADS - 1) / NTHREADS;
+    constexpr int ROWV = HM ? BO : BO / 4, NSLOT = HM ? NPA * NT * BO : NT * CC * ROWV, NWV = (NSLOT + NTHREADS - 1) / NTHREADS;
     static_assert(!HM || (DB && CC == 8 && NT == 9), "the fp16 MFMA forms are built for the two-stage 3x3 kernels with 8-channel chunks");
     // o_vec: every weight row is 16-byte aligned and at least one float4 long, so the slab is fetched with
     // unconditional, clamped float4 buffer loads (rows past O feed accumulator rows that are never stored; rows past
@@ -323,14 +317,14 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         else
             w_off[k] = (((row / CC) * g.I + (row % CC)) * g.O + min(o0 + (e_ - row * ROWV) * 4, max(g.O - 4, 0))) * 4;
     }
-    const int stage_floats = HM ? NPL * NTP * BO * 4 + NPL * 4 * g.patch_cap : NT * CC * BO + CC * g.patch_cap;
+    const int stage_floats = HM ? NPA * NTP * BO * 4 + NPB * 4 * g.patch_cap : NT * CC * BO + CC * g.patch_cap;
     float* w_lds = lds;                       // [NT*CC][BO]
     float* p_lds = lds + NT * CC * BO;        // [CC][PSZ]   (second stage, if any, stage_floats further on)
     float pv[NPOS][CC];                       // staged patch values     (global -> registers -> LDS)
     float sv[CC];                             // style * channel-tail mask of the staged chunk
     float4 wv[NWV];                           // staged weight vectors
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)((int64_t)g.I * HW * 4), 0x00020000);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)((int64_t)NT * g.I * g.O * (HM == 2 ? 4 : (HM ? 2 : 4))), 0x00020000);   // bytes of all planes
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)((int64_t)NT * g.I * g.O * (HM ? 2 * NPA : 4)), 0x00020000);   // bytes of all planes
 
     // All loads of a chunk are unconditional so that they can be issued anywhere; the chunk after next is in flight
     // while the current one is multiplied.  No 64-bit address arithmetic in the K loop: per-thread byte offsets fixed
@@ -378,7 +372,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
             const int pp = tid + j * NTHREADS;
             if (pp < PSZ) {
                 if constexpr (HM != 0) {   // patch as [plane][PSZ][8 channels] halves: one 16-byte store per plane
-                    h16x8* ph = reinterpret_cast<h16x8*>(lds + st_off + NPL * NTP * BO * 4);
+                    h16x8* ph = reinterpret_cast<h16x8*>(lds + st_off + NPA * NTP * BO * 4);
                     h16x8 hi, lo;
 #pragma unroll
                     for (int cc = 0; cc < 8; ++cc) {
@@ -399,7 +393,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
             if (tid + k * NTHREADS < NSLOT) {
                 // (weights of channels past ci_end need no mask: their patch rows are zeroed through sv[])
                 const int e_ = tid + k * NTHREADS;
-                *(float4*)(w_lds + st_off + (HM == 2 && e_ >= NT * BO ? e_ + BO : e_) * 4) = wv[k];
+                *(float4*)(w_lds + st_off + (HM ? e_ + (e_ / (NT * BO)) * BO : e_) * 4) = wv[k];
             }
         }
     };
@@ -414,8 +408,8 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
     if constexpr (DB) {
         __syncthreads();                 // (previous segment's readers are done)
         if constexpr (HM != 0) {         // the all-zero tap of every plane, in both stages (never overwritten by commit)
-            for (int i = tid; i < 2 * NPL * BO; i += NTHREADS) {
-                const int stg = i / (NPL * BO), r = i - stg * NPL * BO, pl = r / BO, o = r - pl * BO;
+            for (int i = tid; i < 2 * NPA * BO; i += NTHREADS) {
+                const int stg = i / (NPA * BO), r = i - stg * NPA * BO, pl = r / BO, o = r - pl * BO;
                 *(float4*)(lds + stg * stage_floats + ((pl * NTP + NT) * BO + o) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -444,10 +438,9 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         // run one step ahead of the MFMAs that consume them (double-buffered registers) so the LDS latency hides
         // under the >= 256 MFMA cycles of a step.
         using op_t = std::conditional_t<HM != 0, h16x8, float>;
-        // (the wide fp16-pair tile keeps two accumulator sets: its operand registers are single-buffered to stay inside 256 VGPRs)
-        constexpr int OB = (HM == 2 && FO * FP >= 4) ? 1 : 2;
-        op_t a_buf[OB][KP][FO * NPL], b_buf[OB][KP][FP * NPL];
-        auto load_ops = [&](int st, op_t (&a)[KP][FO * NPL], op_t (&bv)[KP][FP * NPL]) {
+        constexpr int OB = 2;
+        op_t a_buf[OB][KP][FO * NPA], b_buf[OB][KP][FP * NPB];
+        auto load_ops = [&](int st, op_t (&a)[KP][FO * NPA], op_t (&bv)[KP][FP * NPB]) {
 #pragma unroll
             for (int kk = 0; kk < KP; ++kk) {
                 if constexpr (HM != 0) {
@@ -456,14 +449,15 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
                     const int tof = pair_t1(TR, sidx) == kZeroTap ? (half ? 0 : toff[pair_t0(TR, sidx)])
                                                                   : (half ? toff[pair_t1(TR, sidx)] : toff[pair_t0(TR, sidx)]);
                     const h16x8* wh = reinterpret_cast<const h16x8*>(lds + st_cur);
-                    const h16x8* ph = reinterpret_cast<const h16x8*>(lds + st_cur + NPL * NTP * BO * 4);
+                    const h16x8* ph = reinterpret_cast<const h16x8*>(lds + st_cur + NPA * NTP * BO * 4);
 #pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) {
+                    for (int pl = 0; pl < NPA; ++pl)
 #pragma unroll
                         for (int fo = 0; fo < FO; ++fo) a[kk][pl * FO + fo] = wh[(pl * NTP + tap) * BO + (wo * FO + fo) * 32 + l31];
 #pragma unroll
+                    for (int pl = 0; pl < NPB; ++pl)
+#pragma unroll
                         for (int fp = 0; fp < FP; ++fp) bv[kk][pl * FP + fp] = ph[pl * PSZ + bpos[fp] + tof];
-                    }
                 } else {
                     const int kp = st * KP + kk, t = kp / (CC / 2), cp = kp % (CC / 2);
 #pragma unroll
@@ -491,11 +485,11 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
                 for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
                     for (int fp = 0; fp < FP; ++fp) {
-                        if constexpr (HM == 2) {
-                            acc2[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[cur][kk][FO + fo], b_buf[cur][kk][fp],
-                                                                                      acc2[ph][fo][fp], 0, 0, 0);
-                            acc2[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[cur][kk][fo], b_buf[cur][kk][FP + fp],
-                                                                                      acc2[ph][fo][fp], 0, 0, 0);
+                        if constexpr (HM == 2) {   // lo*hi, (hi*2^-11)*(lo*2^11), hi*hi: all at the scale of the packed weights
+                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[cur][kk][FO + fo], b_buf[cur][kk][fp],
+                                                                                     acc[ph][fo][fp], 0, 0, 0);
+                            acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[cur][kk][fo] * (_Float16)(1.0f / kLoScale), b_buf[cur][kk][FP + fp],
+                                                                                     acc[ph][fo][fp], 0, 0, 0);
                             acc[ph][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[cur][kk][fo], b_buf[cur][kk][fp],
                                                                                      acc[ph][fo][fp], 0, 0, 0);
                         } else if constexpr (HM == 1)
@@ -508,7 +502,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
             }
             if (OB == 1 && st + 1 < NSTEP) load_ops(st + 1, a_buf[0], b_buf[0]);   // after the MFMAs that read these registers were issued
             if constexpr (OB == 2) {
-                __builtin_amdgcn_sched_group_barrier(0x100, KP * (FO + FP) * NPL, 0);   // next step's ds_reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x100, KP * (FO * NPA + FP * NPB), 0);   // next step's ds_reads first ...
                 if (DB && st * LPS < NLOAD) __builtin_amdgcn_sched_group_barrier(0x020, LPS, 0);   // ... a few global loads ...
                 __builtin_amdgcn_sched_group_barrier(0x008, KP * FO * FP * (HM == 2 ? 3 : 1), 0);     // ... then this step's MFMAs
             }
@@ -519,7 +513,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
         }
     }
 
-    if constexpr (HM == 2) {   // fold the scaled low-part products in
+    if constexpr (HM == 2) {   // back from the scale of the packed weights (a power of two: exact)
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
@@ -527,7 +521,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
 #pragma unroll
                 for (int fp = 0; fp < FP; ++fp)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] = fmaf(acc2[ph][fo][fp][r], 1.0f / kLoScale, acc[ph][fo][fp][r]);
+                    for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] *= g.acc_scale;
     }
     // ---- segment done: a whole tile is finished here, a partial K range is parked for the fix-up kernel
     if (!SK || (c_lo == 0 && c_hi == g.C)) {
@@ -633,8 +627,8 @@ int launch_npos(const float* x, const float* wk, const float* styles, float* y, 
     constexpr int BO = 32 * FO * WO, NT = KS * KS;
     Geo g = g_in;
     g.patch_cap = (worst + 3) & ~3;
-    constexpr int NPL = HM == 2 ? 2 : 1;
-    const size_t stage = HM ? (size_t)NPL * (NT + 1) * BO * 4 + (size_t)NPL * 4 * g.patch_cap : (size_t)NT * CC * BO + (size_t)CC * g.patch_cap;
+    constexpr int NPA = HM == 2 ? 2 : 1, NPB = NPA;
+    const size_t stage = HM ? (size_t)NPA * (NT + 1) * BO * 4 + (size_t)NPB * 4 * g.patch_cap : (size_t)NT * CC * BO + (size_t)CC * g.patch_cap;
     const size_t lds = stage * sizeof(float) * (DB ? 2 : 1);
     if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
     int st = IA_OK;
@@ -773,7 +767,7 @@ static int conv2d_entry(const float* x, const void* wk_any, const float* styles,
                         const float* noise, const float* noise_strength, const float* bias, const float* residual,
                         float* y, float* scratch, size_t scratch_bytes,
                         int B, int I, int O, int H, int W, int ksize, int transposed,
-                        int act, float alpha, float gain, float clamp, int ksplit, void* stream, int half_ops) {
+                        int act, float alpha, float gain, float clamp, int ksplit, void* stream, int half_ops, int wk_exp = 0) {
     const float* wk = static_cast<const float*>(wk_any);
     IA_REQUIRE(x && wk && y, "x, wk and y must be device pointers");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
@@ -800,6 +794,7 @@ static int conv2d_entry(const float* x, const void* wk_any, const float* styles,
         IA_REQUIRE(whole_tiles || (scratch && scratch_bytes >= need), "stream-K needs %zu bytes of scratch, got %zu", need, scratch_bytes);
     }
     g.patch_cap = 0;
+    g.acc_scale = ldexpf(1.f, -wk_exp);
     Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp};
     hipStream_t s = (hipStream_t)stream;
     if (half_ops) {
@@ -846,13 +841,14 @@ extern "C" int ia_conv2d_mfma_h(const float* x, const void* wk_h, const float* s
                         transposed, act, alpha, gain, clamp, ksplit, stream, 1);
 }
 
-extern "C" int ia_conv2d_mfma_s(const float* x, const void* wk_split, const float* styles, const float* demod,
+extern "C" int ia_conv2d_mfma_s(const float* x, const void* wk_split, int wk_exp, const float* styles, const float* demod,
                                 const float* noise, const float* noise_strength, const float* bias, const float* residual,
                                 float* y, float* scratch, size_t scratch_bytes,
                                 int B, int I, int O, int H, int W, int ksize, int transposed,
                                 int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
+    IA_REQUIRE(wk_exp >= -14 && wk_exp <= 30, "wk_exp is the power of two the weights were scaled by at pack time");
     return conv2d_entry(x, wk_split, styles, demod, noise, noise_strength, bias, residual, y, scratch, scratch_bytes, B, I, O, H, W, ksize,
-                        transposed, act, alpha, gain, clamp, ksplit, stream, 2);
+                        transposed, act, alpha, gain, clamp, ksplit, stream, 2, wk_exp);
 }
 
 // d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + 1e-8): demodulation coefficients of the modulated conv

@@ -4,6 +4,7 @@ Each function allocates its output with torch (device memory is plumbing), passe
 pointers to libia_hip.so on torch's current stream and raises on any non-zero status.
 None of them has a CPU path: they are only ever called with device tensors."""
 import ctypes
+import math
 
 import torch
 
@@ -60,11 +61,18 @@ def pack_conv_weight_h(w):
 
 
 def pack_conv_weight_split(w):
-    """[O, I, kh, kw] -> fp16 [2, kh*kw, I/8, O, 8]: hi = fp16(w) and lo = fp16((w - hi) * 2^11), the layout ia_conv2d_mfma_s reads."""
+    """[O, I, kh, kw] -> fp16 [2, kh*kw, I/8, O, 8]: hi = fp16(w * 2^e) and lo = fp16(w * 2^e - hi), the layout ia_conv2d_mfma_s
+    reads.  e (returned as the tensor attribute `wk_exp`) is the largest power of two with max|w| * 2^e <= 32768: it keeps the
+    low parts, and the high parts times 2^-11, normal fp16 numbers (the MFMA flushes denormals)."""
     w = w.detach().float()
-    hi = w.to(torch.float16)
-    lo = ((w - hi.float()) * 2048.0).to(torch.float16)      # scaled by 2^11: normal fp16 numbers (kLoScale in conv_mfma.hip)
-    return torch.stack([pack_conv_weight_h(hi), pack_conv_weight_h(lo)]).contiguous()
+    top = float(w.abs().max())
+    e = 0 if not (top > 0.0 and math.isfinite(top)) else max(-14, min(30, math.floor(math.log2(32768.0 / top))))
+    ws = w * (2.0 ** e)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    out = torch.stack([pack_conv_weight_h(hi), pack_conv_weight_h(lo)]).contiguous()
+    out.wk_exp = int(e)
+    return out
 
 
 def conv_h_supported(i, o, h, w, ksize, transposed):
@@ -118,6 +126,8 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     if half_ops:
         if not (wk.is_cuda and wk.is_contiguous() and wk.dim() in (4, 5) and wk.shape[-1] == 8 and (not split or wk.shape[0] == 2)):
             raise RuntimeError('wk must be a contiguous fp16 [taps, I/8, O, 8] (or [2, taps, I/8, O, 8] hi/lo) device tensor')
+        if split and not hasattr(wk, 'wk_exp'):
+            raise RuntimeError('hi/lo weights must come from pack_conv_weight_split (they carry their scale as .wk_exp)')
         taps, wi, o = wk.shape[-4], wk.shape[-3] * 8, wk.shape[-2]
     else:
         _f32c(wk, 'wk')
@@ -145,7 +155,8 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     with torch.cuda.device(x.device), _Timed('conv2d_mfma_t' if transposed else f'conv2d_mfma_k{ksize}', flops, traffic,
                                              f'B{b} I{i} O{o} {h}x{w} G{ksplit}' + (' f16x3' if split else (' f16' if half_ops else ''))):
         fn = lib.ia_conv2d_mfma_s if split else (lib.ia_conv2d_mfma_h if half_ops else lib.ia_conv2d_mfma)
-        st = fn(_p(x), _p(wk), _p(styles), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(residual),
+        head = (_p(x), _p(wk), int(wk.wk_exp)) if split else (_p(x), _p(wk))
+        st = fn(*head, _p(styles), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(residual),
                                 _p(y), _p(scratch), nbytes, b, i, o, h, w, ksize, int(transposed), ACT_ID[act], float(alpha),
                                 float(gain), float(-1 if clamp is None else clamp), int(ksplit), _lib.stream_ptr(x.device))
     _lib.check(st, 'ia_conv2d_mfma')
