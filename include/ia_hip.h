@@ -157,7 +157,8 @@ int ia_conv2d_mfma_h(const float* x, const void* wk_h, const float* styles, cons
  * 2^11, and the high part of a weight is multiplied by 2^-11 (exact) where it meets an activation's low part -- all three
  * products then carry the factor 2^wk_exp and go to ONE fp32 accumulator, which is multiplied by 2^-wk_exp at the end.
  * Range: x * style saturates at +-65504 (StyleGAN2 activations are O(1)-O(100); the reference clamps its fp16 blocks at
- * 256); weights below 2^(-3-wk_exp) lose the a_hi*b_lo correction, activations below 6e-5 are taken as zero.
+ * 256); weights below 2^(-3-wk_exp) lose the a_hi*b_lo correction, activations below 2^-14 = 6.1e-5 are carried by their
+ * (scaled) low part alone, i.e. with 11 mantissa bits.
  *   wk_split : fp16 [2 (hi, lo)][ksize*ksize][I/8][O][8] of w * 2^wk_exp
  *   wk_exp   : the power of two above
  * Other arguments, plan, scratch and shape coverage as ia_conv2d_mfma_h.

@@ -377,7 +377,8 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
 #pragma unroll
                     for (int cc = 0; cc < 8; ++cc) {
                         const float v = fminf(fmaxf(pv[j][cc] * sv[cc], -65504.f), 65504.f);   // fp16 range: saturate, never inf
-                        hi[cc] = (_Float16)v;
+                        // (a denormal high part would be flushed by the MFMA: below 2^-14 the value rides in the scaled low part)
+                        hi[cc] = (HM == 2 && fabsf(v) < 6.103515625e-5f) ? (_Float16)0.f : (_Float16)v;
                         lo[cc] = (_Float16)((v - (float)hi[cc]) * kLoScale);
                     }
                     ph[pp] = hi;

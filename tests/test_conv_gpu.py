@@ -177,3 +177,26 @@ def test_split_fp16_form_is_an_fp32_convolution(transposed):
     assert err['f32'] <= 2e-6
     assert err['split'] <= 3 * max(err['f32'], 3e-7)
     assert err['f16'] >= 20 * err['split']
+
+
+@pytest.mark.parametrize('wscale', [1e-5, 1.0, 3e3])
+def test_split_fp16_form_over_the_operand_range(wscale):
+    """The fp16-pair form keeps every factor a normal fp16 number by powers of two (weights packed at 2^wk_exp, low parts of
+    the activations at 2^11), so its accuracy must not depend on the scale of the weights, and input channels whose
+    style-scaled activations fall below fp16's normal range (2^-14) must still contribute (they ride in the low part)."""
+    i, o, h, w = 128, 128, 64, 64
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.randn(1, i, h, w, device='cuda', generator=g) * 3
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g) * wscale
+    s = torch.rand(1, i, device='cuda', generator=g) + 0.5
+    s[:, ::2] *= 2e-5                                                   # every other channel: activations ~ 6e-5 and below
+    xs = (x * s[:, :, None, None]).double()
+    ref = torch.nn.functional.conv2d(xs, wt.double(), padding=1)
+    tiny_only = torch.nn.functional.conv2d(xs[:, ::2], wt.double()[:, ::2], padding=1)
+    scale = ref.abs().max().item()
+    got = hipops.conv2d_mfma(x, hipops.pack_conv_weight_split(wt), styles=s, ksize=3)
+    err = (got.double() - ref).abs().max().item() / scale
+    share = tiny_only.abs().max().item() / scale
+    print(f'weights x {wscale:g}: relative max error vs fp64 {err:.2e}; the tiny channels alone are {share:.1e} of the output')
+    assert share > 15 * 1e-6      # (dropping them would show)
+    assert err <= 1e-6
