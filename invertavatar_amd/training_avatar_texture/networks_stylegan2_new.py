@@ -42,7 +42,8 @@ class SynthesisNetwork(_base.SynthesisNetwork):
             x, img = getattr(self, f'b{res}')(x, img, cur_ws, None, **block_kwargs)
         return x, img, first
 
-    def forward(self, ws, cond_list, return_list, feat_conditions=None, return_imgs=False, out_res=(32, 256), _head=None, **block_kwargs):
+    def forward(self, ws, cond_list, return_list, feat_conditions=None, return_imgs=False, out_res=(32, 256), _head=None, _tap=None,
+                **block_kwargs):
         assert not (return_list and return_imgs)
         first = int(np.log2(out_res[0])) - 2                       # index of the first tapped block (32^2)
         last = (self.img_resolution_log2 - 2) if len(out_res) == 1 else (int(np.log2(out_res[1])) - 2)
@@ -68,6 +69,8 @@ class SynthesisNetwork(_base.SynthesisNetwork):
                 if idx == first:
                     feats.append(img if fused else img.clone())
                 feats.append(x if fused else x.clone())
+                if _tap is not None and len(feats) == _tap[0]:
+                    _tap[1](feats)      # the first _tap[0] taps exist: the caller may let their consumer start (triplane_v20)
             if cond_list is not None:
                 if idx == first:   # face region copied straight into the skip image
                     img = _paste(cond_list[0], img, fused)

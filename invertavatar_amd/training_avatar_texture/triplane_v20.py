@@ -79,30 +79,54 @@ class TriPlaneGenerator(torch.nn.Module):
         origins, dirs = self.ray_sampler(cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3), neural_rendering_resolution)
         return origins, dirs, neural_rendering_resolution
 
-    def _two_backbones(self, ws, update_emas, synthesis_kwargs):
-        """The texture and the static backbone are independent: on the device they run on two streams so that their
-        latency-bound low-resolution layers (a handful of workgroups each at batch 1) overlap."""
-        def tex():
-            return self.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
+    def _two_backbones(self, ws, update_emas, synthesis_kwargs, partial=False):
+        """The texture and the static backbone are independent: on the device they run on two streams of their own so that their
+        latency-bound low-resolution layers (a handful of workgroups each at batch 1) overlap.
 
-        def sta():
-            return self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
+        partial=True (synthesis): the rasteriser and the face backbone consume only the first N_COND_LEVELS_USED taps (up to
+        128^2) of both networks, so the caller's stream waits for an event recorded right after those and the 256^2 blocks
+        keep running under the rasteriser and the face backbone; the caller joins the streams returned as `pending`
+        (texture stream, static stream) where the last taps are consumed (_planes: static, before the plane blend; synthesis:
+        texture, at the end of the frame)."""
+        def tex(**kw):
+            return self.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **kw, **synthesis_kwargs)
+
+        def sta(**kw):
+            return self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **kw, **synthesis_kwargs)
         if not (ws.is_cuda and not torch.is_grad_enabled()):
-            return tex(), sta()
-        if getattr(self, '_backbone_stream', None) is None or self._backbone_stream.device != ws.device:
-            object.__setattr__(self, '_backbone_stream', torch.cuda.Stream(device=ws.device))
-        main, side = torch.cuda.current_stream(ws.device), self._backbone_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            texture_feats = tex()
-            # the rasteriser gathers from channels-last copies; make them here, under the static backbone
-            tex_cl = [hipops.channels_last_copy(t) if t.dtype == torch.float32 else None for t in texture_feats[:N_COND_LEVELS_USED]]
-        static_feats = sta()
-        main.wait_stream(side)
-        for t in list(texture_feats) + [t for t in tex_cl if t is not None]:
+            return tex(), sta(), None
+        for name in ('_backbone_stream', '_static_stream'):
+            if getattr(self, name, None) is None or getattr(self, name).device != ws.device:
+                object.__setattr__(self, name, torch.cuda.Stream(device=ws.device))
+        main, t_stream, s_stream = torch.cuda.current_stream(ws.device), self._backbone_stream, self._static_stream
+        box = {}
+
+        def make_cl(feats):   # the rasteriser gathers from channels-last copies; make them on the texture stream
+            box['tex_cl'] = [hipops.channels_last_copy(t) if t.dtype == torch.float32 else None for t in feats[:N_COND_LEVELS_USED]]
+        ev_tex, ev_sta = torch.cuda.Event(), torch.cuda.Event()
+        t_stream.wait_stream(main)
+        with torch.cuda.stream(t_stream):
+            if partial:
+                texture_feats = tex(_tap=(N_COND_LEVELS_USED, lambda feats: (make_cl(feats), ev_tex.record(t_stream))))
+            else:
+                texture_feats = tex()
+                make_cl(texture_feats)
+        if partial:
+            s_stream.wait_stream(main)
+            with torch.cuda.stream(s_stream):
+                static_feats = sta(_tap=(N_COND_LEVELS_USED, lambda feats: ev_sta.record(s_stream)))
+            main.wait_event(ev_tex)
+            main.wait_event(ev_sta)
+            pending = (t_stream, s_stream)
+        else:
+            static_feats = sta()
+            main.wait_stream(t_stream)
+            pending = None
+        tex_cl = box['tex_cl']
+        for t in list(texture_feats) + [t for t in tex_cl if t is not None] + (list(static_feats) if partial else []):
             t.record_stream(main)
         object.__setattr__(self, '_tex_cl', (texture_feats, tex_cl))
-        return texture_feats, static_feats
+        return texture_feats, static_feats, pending
 
     def _start_face_head(self, ws, update_emas, synthesis_kwargs):
         """The 4^2..32^2 blocks of the face backbone depend only on ws; run them on a third stream under the other backbones."""
@@ -188,7 +212,7 @@ class TriPlaneGenerator(torch.nn.Module):
         return planes
 
     def _planes(self, ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, all_levels=False, mouth=None,
-                face_head=None):
+                face_head=None, pending=None):
         static_for_raster, static_plane = self._split_static(static_feats)
         assert len(static_for_raster) == len(texture_feats), (len(static_for_raster), len(texture_feats))
         cond, full_alpha, _ = self.rasterize(texture_feats, mesh_condition['uvcoords_image'], static_for_raster, BBOX_256,
@@ -198,6 +222,8 @@ class TriPlaneGenerator(torch.nn.Module):
             torch.cuda.current_stream(ws.device).wait_event(face_head[3])
             head = face_head[:3]
         stitch = self.face_backbone.synthesis(ws, cond, return_list=False, update_emas=update_emas, _head=head, **synthesis_kwargs)
+        if pending is not None:      # the static backbone's 256^2 taps (the planes) are consumed from here on
+            torch.cuda.current_stream(ws.device).wait_stream(pending[1])
         return self._blend_planes(stitch, full_alpha, static_plane)
 
     def _render(self, ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist=None):
@@ -222,10 +248,12 @@ class TriPlaneGenerator(torch.nn.Module):
             origins, dirs, nrr, ray_dist = self._side_rays
         else:
             origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
-        texture_feats, static_feats = self._two_backbones(ws, update_emas, synthesis_kwargs)
+        texture_feats, static_feats, pending = self._two_backbones(ws, update_emas, synthesis_kwargs, partial=True)
         planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, mouth=mouth,
-                              face_head=face_head)
+                              face_head=face_head, pending=pending)
         image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist)
+        if pending is not None:      # the texture backbone's 256^2 block (not consumed by this frame's image) ends with the frame
+            torch.cuda.current_stream(ws.device).wait_stream(pending[0])
         out = {'image': image, 'image_raw': rgb, 'image_depth': depth}
         if return_featmap:
             out.update(feature_image=feature_image, triplane=planes, texture=texture_feats)
