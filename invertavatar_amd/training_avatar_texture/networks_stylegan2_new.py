@@ -69,8 +69,8 @@ class SynthesisNetwork(_base.SynthesisNetwork):
                 if idx == first:
                     feats.append(img if fused else img.clone())
                 feats.append(x if fused else x.clone())
-                if _tap is not None and len(feats) == _tap[0]:
-                    _tap[1](feats)      # the first _tap[0] taps exist: the caller may let their consumer start (triplane_v20)
+                if _tap is not None and len(feats) in _tap[0]:
+                    _tap[1](feats)      # len(feats) taps exist: the caller may let their consumer start (triplane_v20)
             if cond_list is not None:
                 if idx == first:   # face region copied straight into the skip image
                     img = _paste(cond_list[0], img, fused)

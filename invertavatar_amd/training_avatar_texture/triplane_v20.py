@@ -32,6 +32,22 @@ BBOX_256 = [57, 185, 64, 192]   # face region of the frontal plane, in 256^2 pix
 N_COND_LEVELS_USED = 4          # cond_list entries the face backbone consumes
 
 
+class _LazyLevels:
+    """cond_list whose entry k is produced (rasterised) the first time the face backbone reads it."""
+
+    def __init__(self, n, make):
+        self._n, self._make, self._have = n, make, {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, k):
+        if k not in self._have:
+            self._have[k] = self._make(k)
+        return self._have[k]
+
+
+
 def _aa_resize(x, size):
     return F.interpolate(x, size=(size, size), mode='bilinear', antialias=True)
 
@@ -83,11 +99,12 @@ class TriPlaneGenerator(torch.nn.Module):
         """The texture and the static backbone are independent: on the device they run on two streams of their own so that their
         latency-bound low-resolution layers (a handful of workgroups each at batch 1) overlap.
 
-        partial=True (synthesis): the rasteriser and the face backbone consume only the first N_COND_LEVELS_USED taps (up to
-        128^2) of both networks, so the caller's stream waits for an event recorded right after those and the 256^2 blocks
-        keep running under the rasteriser and the face backbone; the caller joins the streams returned as `pending`
-        (texture stream, static stream) where the last taps are consumed (_planes: static, before the plane blend; synthesis:
-        texture, at the end of the frame)."""
+        partial=True (synthesis): the rasteriser consumes the taps level by level (32^2, 64^2, 128^2) and the face backbone
+        consumes the rasterised levels block by block, so nothing waits for whole networks: both backbones record an event
+        after every tap (`pending[2]`, `pending[3]`: tap count -> event) and _planes rasterises level k when the face
+        backbone asks for it.  The 256^2 blocks are not consumed by the rasteriser at all; the caller joins the streams
+        (`pending[0]` texture, `pending[1]` static) where the last taps are consumed (_planes: static, before the plane
+        blend; synthesis: texture, at the end of the frame)."""
         def tex(**kw):
             return self.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **kw, **synthesis_kwargs)
 
@@ -99,30 +116,34 @@ class TriPlaneGenerator(torch.nn.Module):
             if getattr(self, name, None) is None or getattr(self, name).device != ws.device:
                 object.__setattr__(self, name, torch.cuda.Stream(device=ws.device))
         main, t_stream, s_stream = torch.cuda.current_stream(ws.device), self._backbone_stream, self._static_stream
-        box = {}
+        tex_cl = [None] * N_COND_LEVELS_USED
+        counts = tuple(range(2, N_COND_LEVELS_USED + 1))       # taps 0 and 1 (image and features at 32^2) appear together
+        ev_tex, ev_sta = {n: torch.cuda.Event() for n in counts}, {n: torch.cuda.Event() for n in counts}
 
         def make_cl(feats):   # the rasteriser gathers from channels-last copies; make them on the texture stream
-            box['tex_cl'] = [hipops.channels_last_copy(t) if t.dtype == torch.float32 else None for t in feats[:N_COND_LEVELS_USED]]
-        ev_tex, ev_sta = torch.cuda.Event(), torch.cuda.Event()
+            for k, t in enumerate(feats[:N_COND_LEVELS_USED]):
+                if tex_cl[k] is None and t.dtype == torch.float32:
+                    tex_cl[k] = hipops.channels_last_copy(t)
+
+        def tap_tex(feats):
+            make_cl(feats)
+            ev_tex[len(feats)].record(t_stream)
         t_stream.wait_stream(main)
         with torch.cuda.stream(t_stream):
             if partial:
-                texture_feats = tex(_tap=(N_COND_LEVELS_USED, lambda feats: (make_cl(feats), ev_tex.record(t_stream))))
+                texture_feats = tex(_tap=(counts, tap_tex))
             else:
                 texture_feats = tex()
                 make_cl(texture_feats)
         if partial:
             s_stream.wait_stream(main)
             with torch.cuda.stream(s_stream):
-                static_feats = sta(_tap=(N_COND_LEVELS_USED, lambda feats: ev_sta.record(s_stream)))
-            main.wait_event(ev_tex)
-            main.wait_event(ev_sta)
-            pending = (t_stream, s_stream)
+                static_feats = sta(_tap=(counts, lambda feats: ev_sta[len(feats)].record(s_stream)))
+            pending = (t_stream, s_stream, ev_tex, ev_sta)
         else:
             static_feats = sta()
             main.wait_stream(t_stream)
             pending = None
-        tex_cl = box['tex_cl']
         for t in list(texture_feats) + [t for t in tex_cl if t is not None] + (list(static_feats) if partial else []):
             t.record_stream(main)
         object.__setattr__(self, '_tex_cl', (texture_feats, tex_cl))
@@ -215,8 +236,25 @@ class TriPlaneGenerator(torch.nn.Module):
                 face_head=None, pending=None):
         static_for_raster, static_plane = self._split_static(static_feats)
         assert len(static_for_raster) == len(texture_feats), (len(static_for_raster), len(texture_feats))
-        cond, full_alpha, _ = self.rasterize(texture_feats, mesh_condition['uvcoords_image'], static_for_raster, BBOX_256,
-                                             levels=None if all_levels else N_COND_LEVELS_USED, _mouth=mouth)
+        if pending is not None and not all_levels:
+            # level k is rasterised when the face backbone asks for it, after the events of the taps it reads (taps 0 and 1 are
+            # both 32^2 and come with the first event)
+            main = torch.cuda.current_stream(ws.device)
+            prep = self._raster_prep(mesh_condition['uvcoords_image'], mouth)
+            full_alpha = prep['full_alpha']
+
+            def level(k):
+                need = max(2, k + 1)
+                main.wait_event(pending[2][need])
+                main.wait_event(pending[3][need])
+                return self._raster_level(k, texture_feats[k], static_for_raster[k], BBOX_256, prep)
+            cond = _LazyLevels(N_COND_LEVELS_USED, level)
+        else:
+            if pending is not None:
+                for st in pending[:2]:
+                    torch.cuda.current_stream(ws.device).wait_stream(st)
+            cond, full_alpha, _ = self.rasterize(texture_feats, mesh_condition['uvcoords_image'], static_for_raster, BBOX_256,
+                                                 levels=None if all_levels else N_COND_LEVELS_USED, _mouth=mouth)
         head = None
         if face_head is not None:
             torch.cuda.current_stream(ws.device).wait_event(face_head[3])
@@ -306,6 +344,13 @@ class TriPlaneGenerator(torch.nn.Module):
         uvcoords_image [B,H,W,3] = (u, v, mask).  Returns (list of [B, C_k+1, res_k, res_k], full_alpha, mouth_masks);
         the extra channel is the face alpha with the upper part of the mouth hole closed (:324-326).
         `levels` limits how many pyramid levels are produced (None = all, as the reference)."""
+        prep = self._raster_prep(uvcoords_image, _mouth)
+        n = len(texture_feats) if levels is None else min(levels, len(texture_feats))
+        out = [self._raster_level(k, tex, sta, bbox_256, prep) for k, (tex, sta) in enumerate(zip(texture_feats[:n], static_feats[:n]))]
+        return out, prep['full_alpha'], prep['mouth']
+
+    def _raster_prep(self, uvcoords_image, _mouth=None):
+        """Per-frame inputs of the rasteriser: UV grid, face alpha, filled mouth (joined here if it was started on the side stream)."""
         uv = uvcoords_image if uvcoords_image.dtype == torch.float32 else uvcoords_image.float()
         grid, alpha = uv[..., :2], uv[..., 2:].permute(0, 3, 1, 2)
         fused = uv.is_cuda and uv.shape[1:3] == (256, 256) and not torch.is_grad_enabled()
@@ -319,24 +364,24 @@ class TriPlaneGenerator(torch.nn.Module):
             upper_alpha = self._upper_alpha(alpha, mouth)
             if fused:
                 uv_c, upper_c = uv.contiguous(), upper_alpha.reshape(-1, 256, 256).contiguous()
-        out = []
-        n = len(texture_feats) if levels is None else min(levels, len(texture_feats))
         # channels-last copies made on the texture stream by _two_backbones (same list object => same frame)
         cached = getattr(self, '_tex_cl', None)
-        tex_cl = cached[1] if (cached is not None and cached[0] is texture_feats) else [None] * n
         object.__setattr__(self, '_tex_cl', None)
-        for k, (tex, sta) in enumerate(zip(texture_feats[:n], static_feats[:n])):
-            res = tex.shape[2]
-            y0, y1, x0, x1 = [round(v * res / 256) for v in bbox_256]
-            if fused and res in (32, 64, 128) and tex.dtype == torch.float32 and sta.dtype == torch.float32:
-                out.append(hipops.rasterize_level(tex, uv_c, upper_c, sta, (y0, y1, x0, x1), res,
-                                                  tex_cl=tex_cl[k] if k < len(tex_cl) else None))
-                continue
-            rend = _aa_resize(F.grid_sample(tex, grid, align_corners=False), res)
-            a = _aa_resize(alpha, res)
-            s = _aa_resize(sta[:, :, y0:y1, x0:x1], res)
-            out.append(torch.cat([rend * a + s * (1 - a), _aa_resize(upper_alpha, res)], dim=1))
-        return out, full_alpha, mouth
+        return dict(grid=grid, alpha=alpha, full_alpha=full_alpha, mouth=mouth, upper_alpha=upper_alpha, uv_c=uv_c, upper_c=upper_c,
+                    fused=fused, cached=cached)
+
+    def _raster_level(self, k, tex, sta, bbox_256, prep):
+        """One pyramid level: texture sampled through the UV map, AA-resized, blended over the static features' bbox crop."""
+        res = tex.shape[2]
+        y0, y1, x0, x1 = [round(v * res / 256) for v in bbox_256]
+        if prep['fused'] and res in (32, 64, 128) and tex.dtype == torch.float32 and sta.dtype == torch.float32:
+            cached = prep['cached']
+            cl = cached[1][k] if (cached is not None and k < len(cached[0]) and cached[0][k] is tex and k < len(cached[1])) else None
+            return hipops.rasterize_level(tex, prep['uv_c'], prep['upper_c'], sta, (y0, y1, x0, x1), res, tex_cl=cl)
+        rend = _aa_resize(F.grid_sample(tex, prep['grid'], align_corners=False), res)
+        a = _aa_resize(prep['alpha'], res)
+        s = _aa_resize(sta[:, :, y0:y1, x0:x1], res)
+        return torch.cat([rend * a + s * (1 - a), _aa_resize(prep['upper_alpha'], res)], dim=1)
 
     def visualize_mesh_condition(self, mesh_condition, to_imgs=False):
         uv = mesh_condition['uvcoords_image'].clone().permute(0, 3, 1, 2)
