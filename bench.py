@@ -97,16 +97,29 @@ def pmc_traffic(family):
         return None
 
 
-def roofline_leg(step, frames=3):
-    """Per-launch timing of every fused stage over `frames` extra frames; dominant family by total time."""
+def _profiled_frames(step, frames, single_stream):
+    from invertavatar_amd.training_avatar_texture import triplane_v20
+    saved, triplane_v20.SINGLE_STREAM = triplane_v20.SINGLE_STREAM, single_stream
     hipops.PROFILE = []
     try:
         for k in range(frames):
             step(1000 + k)
         torch.cuda.synchronize()
-        recs = hipops.PROFILE
+        return hipops.PROFILE
     finally:
         hipops.PROFILE = None
+        triplane_v20.SINGLE_STREAM = saved
+
+
+def roofline_leg(step, frames=3):
+    """Per-launch HIP-event timing of every fused stage over `frames` extra eager frames; dominant family by total time.
+    The kernels are timed with the frame's launches in program order on ONE stream (triplane_v20.SINGLE_STREAM), i.e. without
+    neighbours from the other streams of a frame stretching them -- the same condition rocprofv3 imposes on the committed
+    kernel stats; `in_frame_avg_launch_us` is the same average with the five streams of a normal frame running."""
+    _profiled_frames(step, 1, True)                     # (the first single-stream frame allocates that path's buffers)
+    recs = _profiled_frames(step, frames, True)
+    in_frame = [e0.elapsed_time(e1) for name, _, _, e0, e1, desc in _profiled_frames(step, frames, False)
+                if name.startswith('conv2d_mfma') and desc.endswith('f16x3')]
     fam = {}
     split = dict(ms=0.0, flops=0.0, launches=0)     # conv launches whose products are fp16 hi/lo pairs (3 MFMAs per k-step)
     for name, flops, nbytes, e0, e1, desc in recs:
@@ -127,6 +140,7 @@ def roofline_leg(step, frames=3):
                    achieved=round(executed, 2), peak=PEAK_FP16_MFMA_TFLOPS, unit='TFLOP/s', frac=round(executed / PEAK_FP16_MFMA_TFLOPS, 4),
                    traffic=pmc_traffic(dom), launches_per_frame=split['launches'] // frames,
                    avg_launch_us=round(split['ms'] * 1e3 / split['launches'], 2),
+                   in_frame_avg_launch_us=round(sum(in_frame) * 1e3 / max(len(in_frame), 1), 2),
                    algorithmic_gflop_per_frame=round(split['flops'] / frames / 1e9, 1),
                    algorithmic_f32_tflops=round(split['flops'] / (split['ms'] * 1e-3) / 1e12, 2),
                    whole_conv_family=dict(algorithmic_f32_tflops=round(achieved, 2), launches_per_frame=d['launches'] // frames,

@@ -30,6 +30,8 @@ from .volumetric_rendering.ray_sampler import RaySampler, RaySampler_zxc  # noqa
 
 BBOX_256 = [57, 185, 64, 192]   # face region of the frontal plane, in 256^2 pixels (triplane_v20.py:114)
 N_COND_LEVELS_USED = 4          # cond_list entries the face backbone consumes
+SINGLE_STREAM = False           # True: no side streams (every launch of a frame in program order on the caller's stream); used by
+                                # bench.py to time kernels without neighbours from other streams
 
 
 class _LazyLevels:
@@ -110,7 +112,7 @@ class TriPlaneGenerator(torch.nn.Module):
 
         def sta(**kw):
             return self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **kw, **synthesis_kwargs)
-        if not (ws.is_cuda and not torch.is_grad_enabled()):
+        if not (ws.is_cuda and not torch.is_grad_enabled()) or SINGLE_STREAM:
             return tex(), sta(), None
         for name in ('_backbone_stream', '_static_stream'):
             if getattr(self, name, None) is None or getattr(self, name).device != ws.device:
@@ -151,7 +153,7 @@ class TriPlaneGenerator(torch.nn.Module):
 
     def _start_face_head(self, ws, update_emas, synthesis_kwargs):
         """The 4^2..32^2 blocks of the face backbone depend only on ws; run them on a third stream under the other backbones."""
-        if not (ws.is_cuda and not torch.is_grad_enabled()):
+        if not (ws.is_cuda and not torch.is_grad_enabled()) or SINGLE_STREAM:
             return None
         if getattr(self, '_face_stream', None) is None or self._face_stream.device != ws.device:
             object.__setattr__(self, '_face_stream', torch.cuda.Stream(device=ws.device))
@@ -172,7 +174,7 @@ class TriPlaneGenerator(torch.nn.Module):
         only on the cameras, so they are produced on the same side stream (self._side_rays)."""
         uv = mesh_condition['uvcoords_image']
         object.__setattr__(self, '_side_rays', None)
-        if not (uv.is_cuda and not torch.is_grad_enabled()):
+        if not (uv.is_cuda and not torch.is_grad_enabled()) or SINGLE_STREAM:
             return None
         if getattr(self, '_side_stream', None) is None or self._side_stream.device != uv.device:
             object.__setattr__(self, '_side_stream', torch.cuda.Stream(device=uv.device))
