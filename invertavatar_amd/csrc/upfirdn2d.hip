@@ -156,6 +156,93 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T* __restrict__ x, 
     }
 }
 
+// The same tile and the same arithmetic for the 4x4 filter at up = 1 (the FIR that follows every stride-2 transposed convolution:
+// the heavy case), with the global loads of the next tile in flight while the current one is filtered: a workgroup walks
+// kPipeTiles tiles through two LDS images, one barrier per tile.  (In the one-tile kernel the load phase, the LDS reads and
+// the stores of a workgroup never overlap; only other workgroups of the CU fill in.)
+constexpr int kPipeTiles = 4;
+template <class T, bool TAIL>
+__global__ __launch_bounds__(256) void upfirdn2d_tiled_pipe(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ y,
+                                                           Geo g, int64_t fs0, int64_t fs1, int flip, Tail tail) {
+    constexpr int FS = 4;
+    constexpr int IH = TH + FS, IW = TW + FS, IWP = IW + 1, NLD = (IH * IW + 255) / 256;
+    __shared__ float k_lds[FS * FS];
+    __shared__ float in_lds[2][IH * IWP];
+
+    const int tiles_x = (g.out_w + TW - 1) / TW;
+    const int64_t plane = blockIdx.y;
+    const T* xp = x + plane * (int64_t)g.in_h * g.in_w;
+    T* yp = y + plane * (int64_t)g.out_h * g.out_w;
+    stage_filter(k_lds, f, FS, FS, fs0, fs1, flip, g.gain);
+
+    // per-thread slots of the input image of a tile (fixed for all tiles): LDS offset and (row, column) inside the image
+    int l_off[NLD], l_r[NLD], l_c[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = threadIdx.x + j * 256;
+        l_r[j] = i / IW; l_c[j] = i - l_r[j] * IW;
+        l_off[j] = i < IH * IW ? l_r[j] * IWP + l_c[j] : -1;
+    }
+    float v[NLD];
+    auto fetch = [&](int tile) {
+        const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+        const int iy0 = oy0 - g.pady0, ix0 = ox0 - g.padx0;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int iy = iy0 + l_r[j], ix = ix0 + l_c[j];
+            const bool ok = l_off[j] >= 0 && iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w;
+            v[j] = ok ? (float)ia::Num<T>::load(xp + (int64_t)iy * g.in_w + ix) : 0.f;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (l_off[j] >= 0) in_lds[buf][l_off[j]] = v[j];
+    };
+    const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * RPT;
+    float t_bias = 0.f, t_ns = 0.f;
+    if (TAIL) {
+        if (tail.bias) t_bias = (float)ia::Num<T>::load((const T*)tail.bias + (plane % g.c));
+        if (tail.noise) t_ns = tail.noise_strength ? *tail.noise_strength : 1.f;
+    }
+    const int tile0 = blockIdx.x * kPipeTiles;
+    fetch(tile0);
+    commit(0);
+    __syncthreads();
+    float kf[FS * FS];
+#pragma unroll
+    for (int i = 0; i < FS * FS; ++i) kf[i] = k_lds[i];
+#pragma unroll 1
+    for (int t = 0; t < kPipeTiles; ++t) {
+        const int tile = tile0 + t, buf = t & 1;
+        if (t + 1 < kPipeTiles) fetch(tile + 1);                 // in flight under the filter below
+        const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+        const int ox = ox0 + tx;
+        if (ox < g.out_w) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int oy = oy0 + ty + r;
+                if (oy >= g.out_h) break;
+                float acc = 0.f;
+#pragma unroll
+                for (int a = 0; a < FS; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < FS; ++bb) acc = fmaf(in_lds[buf][(ty + r + a) * IWP + tx + bb], kf[a * FS + bb], acc);
+                if (TAIL) {
+                    if (tail.noise) acc = fmaf(tail.noise[(int64_t)oy * g.out_w + ox], t_ns, acc);
+                    acc += t_bias;
+                    if (tail.act == IA_ACT_LRELU) acc = acc > 0.f ? acc : acc * tail.alpha;
+                    acc *= tail.gain;
+                    if (tail.clamp >= 0.f) acc = fminf(fmaxf(acc, -tail.clamp), tail.clamp);
+                }
+                ia::Num<T>::store(yp + (int64_t)oy * g.out_w + ox, acc);
+            }
+        }
+        if (t + 1 < kPipeTiles) commit(buf ^ 1);                 // (its last readers passed the barrier of the previous tile)
+        __syncthreads();
+    }
+}
+
 template <class T>
 bool tiled_eligible(const Geo& g) {
     const bool nchw = g.xs[3] == 1 && g.xs[2] == g.in_w && g.xs[1] == (int64_t)g.in_h * g.in_w &&
@@ -169,6 +256,11 @@ template <class T, bool TAIL>
 int launch_tiled(const void* x, const float* f, void* y, const Geo& g, int64_t fs0, int64_t fs1, int flip, const Tail& tail,
                  hipStream_t s) {
     dim3 grid(((g.out_w + TW - 1) / TW) * ((g.out_h + TH - 1) / TH), g.n * g.c);
+    if (g.upx == 1 && grid.x % kPipeTiles == 0 && grid.x >= 64) {
+        hipLaunchKernelGGL((upfirdn2d_tiled_pipe<T, TAIL>), dim3(grid.x / kPipeTiles, grid.y), dim3(256), 0, s, (const T*)x, f, (T*)y, g, fs0, fs1,
+                           flip, tail);
+        return ia::check_launch(TAIL ? "ia_upfirdn2d_bias_act" : "ia_upfirdn2d(tiled)");
+    }
     if (g.upx == 1) hipLaunchKernelGGL((upfirdn2d_tiled<T, 1, 4, TAIL>), grid, dim3(256), 0, s, (const T*)x, f, (T*)y, g, fs0, fs1, flip, tail);
     else hipLaunchKernelGGL((upfirdn2d_tiled<T, 2, 4, TAIL>), grid, dim3(256), 0, s, (const T*)x, f, (T*)y, g, fs0, fs1, flip, tail);
     return ia::check_launch(TAIL ? "ia_upfirdn2d_bias_act" : "ia_upfirdn2d(tiled)");
