@@ -37,6 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NS = 48;            // coarse samples == importance samples (depth_resolution[_importance])
 constexpr int NM = 2 * NS;        // merged
 constexpr int WAVES = 4;          // rays per workgroup pass
+constexpr int kEarlyPlanes = 1;   // planes whose texels are prefetched one sample group ahead (the third is loaded at use: registers)
 
 struct Params {
     const float* planes;          // [B][3][PH][PW][32] channels-last fp32
@@ -117,6 +118,56 @@ __device__ __forceinline__ void gather_features(const float* __restrict__ planes
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) f[c] = (acc[0][c] + acc[1][c] + acc[2][c]) * (1.f / 3.f);   // mean over planes (<= 1 ulp from x / 3)
+}
+
+// The same gather in two halves, so that the loads of the NEXT group of samples fly under the decoder of the current one:
+// gather_issue computes the 12 texel addresses / bilinear weights and issues the 24 float4 loads (taps outside the plane read
+// a clamped, valid texel with weight 0: fmaf(v, 0, acc) == acc, so the sum is the bits of gather_features), gather_reduce
+// is the accumulation in the same order.
+template <int P0, int P1>
+__device__ __forceinline__ void gather_issue(const float* __restrict__ planes_b, int PH, int PW, int q, float x, float y, float z,
+                                             float4 (&raw)[24], float (&wgt)[12]) {
+#pragma unroll
+    for (int p = P0; p < P1; ++p) {
+        const float gx = (p == 2) ? z : x;
+        const float gy = (p == 0) ? y : (p == 1 ? z : x);
+        const float ix = (gx + 1.f) * (0.5f * (float)PW) - 0.5f;
+        const float iy = (gy + 1.f) * (0.5f * (float)PH) - 0.5f;
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float fx = ix - x0f, fy = iy - y0f;
+        const int x0 = (int)fminf(fmaxf(x0f, -2.f), (float)PW + 1.f), y0 = (int)fminf(fmaxf(y0f, -2.f), (float)PH + 1.f);
+        const float* pl = planes_b + (int64_t)p * PH * PW * 32 + 8 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+            const bool ok = xi >= 0 && xi < PW && yi >= 0 && yi < PH;
+            wgt[p * 4 + t] = ok ? ((t & 1) ? fx : 1.f - fx) * ((t >> 1) ? fy : 1.f - fy) : 0.f;
+            const int xc = min(max(xi, 0), PW - 1), yc = min(max(yi, 0), PH - 1);
+            const float4* src = (const float4*)(pl + ((int64_t)yc * PW + xc) * 32);
+            raw[(p * 4 + t) * 2] = src[0];
+            raw[(p * 4 + t) * 2 + 1] = src[1];
+        }
+    }
+}
+
+__device__ __forceinline__ void gather_reduce(const float4 (&raw)[24], const float (&wgt)[12], float (&f)[8]) {
+    float acc[3][8];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[p][c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 a = raw[(p * 4 + t) * 2], b = raw[(p * 4 + t) * 2 + 1];
+            const float w = wgt[p * 4 + t];
+            acc[p][0] = fmaf(a.x, w, acc[p][0]); acc[p][1] = fmaf(a.y, w, acc[p][1]);
+            acc[p][2] = fmaf(a.z, w, acc[p][2]); acc[p][3] = fmaf(a.w, w, acc[p][3]);
+            acc[p][4] = fmaf(b.x, w, acc[p][4]); acc[p][5] = fmaf(b.y, w, acc[p][5]);
+            acc[p][6] = fmaf(b.z, w, acc[p][6]); acc[p][7] = fmaf(b.w, w, acc[p][7]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] = (acc[0][c] + acc[1][c] + acc[2][c]) * (1.f / 3.f);
 }
 
 // Layer 1 (32 -> 64, softplus) on MFMA.  In: f[8] = channels 8q..8q+7 of this lane's sample.
@@ -277,12 +328,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void render_rays_kernel(Params p) {
         // ---- coarse pass: density only
         if (lane < NS) tc[lane] = linspace_at(t_start, t_end, t_step, lane, NS) + p.jitter[(int64_t)ray * NS + lane] * t_delta;
         wave_sync();
+        float4 raw[24]; float wgt[12];
+        {
+            const float t = tc[s];
+            gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+        }
 #pragma unroll 1
         for (int g = 0; g < NS / 16; ++g) {
-            const float t = tc[16 * g + s];
             float f[8]; f32x4 h[4];
-            gather_features(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale,
-                            (oz + t * dz) * p.box_scale, f);
+            asm volatile("" ::: "memory");   // decoder weights are re-read from LDS every group: their registers hold the prefetched texels
+            {
+                const float t = tc[16 * g + s];
+                gather_issue<kEarlyPlanes, 3>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+            }
+            gather_reduce(raw, wgt, f);
+            if (g + 1 < NS / 16) {      // next group's loads fly under this group's decoder
+                const float t = tc[16 * (g + 1) + s];
+                gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+            }
             decoder_hidden(lds, lane, q, f, h);
             const float sg = decoder_sigma(lds, q, h);
             if (q == 0) sc[16 * g + s] = sg;
@@ -331,12 +394,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void render_rays_kernel(Params p) {
         float prev_t = 0.f, prev_sg = 0.f, prev_c[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) prev_c[c] = 0.f;
+        {
+            const float t = tm[s];
+            gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+        }
 #pragma unroll 1
         for (int g = 0; g < NM / 16; ++g) {
             const float t = tm[16 * g + s];
             float f[8]; f32x4 h[4], col[2];
-            gather_features(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale,
-                            (oz + t * dz) * p.box_scale, f);
+            asm volatile("" ::: "memory");
+            gather_issue<kEarlyPlanes, 3>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+            gather_reduce(raw, wgt, f);
+            if (g + 1 < NM / 16) {
+                const float tn = tm[16 * (g + 1) + s];
+                gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * p.box_scale, raw, wgt);
+            }
             decoder_hidden(lds, lane, q, f, h);
             const float sg = decoder_sigma(lds, q, h);
             decoder_rgb(lds, lane, q, h, col);
