@@ -239,17 +239,32 @@ class TriPlaneGenerator(torch.nn.Module):
         static_for_raster, static_plane = self._split_static(static_feats)
         assert len(static_for_raster) == len(texture_feats), (len(static_for_raster), len(texture_feats))
         if pending is not None and not all_levels:
-            # level k is rasterised when the face backbone asks for it, after the events of the taps it reads (taps 0 and 1 are
-            # both 32^2 and come with the first event)
+            # The rasteriser runs on a stream of its own: level k is launched there as soon as the events of the taps it reads exist
+            # (taps 0 and 1 are both 32^2 and come with the first event), under the face backbone's previous block; the face
+            # backbone only waits for level k's event when it reads cond_list[k].
             main = torch.cuda.current_stream(ws.device)
-            prep = self._raster_prep(mesh_condition['uvcoords_image'], mouth)
+            if getattr(self, '_raster_stream', None) is None or self._raster_stream.device != ws.device:
+                object.__setattr__(self, '_raster_stream', torch.cuda.Stream(device=ws.device))
+            rs = self._raster_stream
+            rs.wait_stream(main)
+            levels, done = [], []
+            with torch.cuda.stream(rs):
+                prep = self._raster_prep(mesh_condition['uvcoords_image'], mouth)      # (joins the mouth fill on this stream)
+                for k in range(N_COND_LEVELS_USED):
+                    need = max(2, k + 1)
+                    rs.wait_event(pending[2][need])
+                    rs.wait_event(pending[3][need])
+                    levels.append(self._raster_level(k, texture_feats[k], static_for_raster[k], BBOX_256, prep))
+                    ev = torch.cuda.Event()
+                    ev.record(rs)
+                    done.append(ev)
             full_alpha = prep['full_alpha']
+            for t in levels:
+                t.record_stream(main)
 
             def level(k):
-                need = max(2, k + 1)
-                main.wait_event(pending[2][need])
-                main.wait_event(pending[3][need])
-                return self._raster_level(k, texture_feats[k], static_for_raster[k], BBOX_256, prep)
+                main.wait_event(done[k])
+                return levels[k]
             cond = _LazyLevels(N_COND_LEVELS_USED, level)
         else:
             if pending is not None:
