@@ -169,8 +169,9 @@ int ia_conv2d_mfma_s(const float* x, const void* wk_split, int wk_exp, const flo
                      int B, int I, int O, int H, int W, int ksize, int transposed,
                      int act, float alpha, float gain, float clamp, int ksplit, void* stream);
 
-/* Host-only planner for ia_conv2d_mfma: stream-K worker count (0: none) and the scratch bytes the fix-up pass needs. */
-int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int* h_ksplit, size_t* h_scratch_bytes);
+/* Host-only planner for ia_conv2d_mfma (form 0), ia_conv2d_mfma_h (form 1) and ia_conv2d_mfma_s (form 2): stream-K worker count
+ * (0: none) and the scratch bytes the fix-up pass needs.  The tile family, and with it the plan, depends on the form. */
+int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int* h_ksplit, size_t* h_scratch_bytes);
 
 /*
  * Demodulation coefficients demod[b,o] = rsqrt(sum_i styles[b,i]^2 * wsq[o,i] + 1e-8) with

@@ -673,16 +673,18 @@ int launch(const float* x, const float* wk, const float* styles, float* y, float
         if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, true, HM>(x, wk, styles, y, scratch, g, e, worst, s);
         if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, true, HM>(x, wk, styles, y, scratch, g, e, worst, s);
         return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4, true, HM>(x, wk, styles, y, scratch, g, e, worst, s);
-    } else if constexpr (db_family(TR, FO, FP, WO, WP)) {
-        if (g.O % 4 == 0) {
-            if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, true>(x, wk, styles, y, scratch, g, e, worst, s);
-            if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, true>(x, wk, styles, y, scratch, g, e, worst, s);
-            return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4, true>(x, wk, styles, y, scratch, g, e, worst, s);
+    } else {
+        if constexpr (db_family(TR, FO, FP, WO, WP)) {
+            if (g.O % 4 == 0) {
+                if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, true>(x, wk, styles, y, scratch, g, e, worst, s);
+                if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, true>(x, wk, styles, y, scratch, g, e, worst, s);
+                return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4, true>(x, wk, styles, y, scratch, g, e, worst, s);
+            }
         }
+        if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, false>(x, wk, styles, y, scratch, g, e, worst, s);
+        if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, false>(x, wk, styles, y, scratch, g, e, worst, s);
+        return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4, false>(x, wk, styles, y, scratch, g, e, worst, s);
     }
-    if (npos <= 1) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 1, false>(x, wk, styles, y, scratch, g, e, worst, s);
-    if (npos <= 2) return launch_npos<KS, TR, FO, FP, WO, WP, CC, 2, false>(x, wk, styles, y, scratch, g, e, worst, s);
-    return launch_npos<KS, TR, FO, FP, WO, WP, CC, 4, false>(x, wk, styles, y, scratch, g, e, worst, s);
 }
 
 constexpr int kChunkConv = 8, kChunkTransposed = 8;
@@ -697,6 +699,7 @@ constexpr int kSmallPoints = 320;
 // Images with >= kWidePoints points use an 8-wave (128ch x 256pt) tile for 3x3 convolutions with wide outputs: one
 // workgroup per CU fetches the chunk's weight slab once instead of twice (the slab is 70 % of the staged bytes).
 constexpr int kWidePoints = 1024;
+constexpr int kWideTransposedPoints = 32768;   // (H+1)(W+1): the 256^2 -> 512^2 layers
 
 int worst_patch(int npts, int GW, int bp, int ksize, bool tr) {
     int worst = 0;
@@ -708,11 +711,15 @@ int worst_patch(int npts, int GW, int bp, int ksize, bool tr) {
     return worst;
 }
 
-void tile_dims(int O, int H, int W, int ksize, int transposed, int* bo, int* bp, int* cc, int* waves) {
+void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo, int* bp, int* cc, int* waves) {
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
     *waves = 4; *cc = kChunkConv;
     if (npts <= kSmallPoints && O > 32) { *bo = 128; *bp = 32; }
-    else if (transposed) { *bo = 64; *bp = 64; *cc = kChunkTransposed; }
+    else if (transposed) {
+        // fp16-pair form on large images: two point fragments per wave (64ch x 128pt x 4 phases) -- one accumulator set leaves
+        // the registers for it, and a k-step then reads 7 operand fragments for 6 MFMAs instead of 4 for 3
+        *bo = 64; *bp = (form == 2 && O % 4 == 0 && npts >= kWideTransposedPoints) ? 128 : 64; *cc = kChunkTransposed;
+    }
     else if (O <= 32) { *bo = 32; *bp = 256; }
     else if (ksize == 3 && O >= 128 && O % 4 == 0 && npts >= kWidePoints && worst_patch(npts, W, 256, 3, false) <= kPatchFloats) {
         *bo = 128; *bp = 256; *waves = 8;
@@ -724,10 +731,10 @@ void tile_dims(int O, int H, int W, int ksize, int transposed, int* bo, int* bp,
 
 // Shared by the planner and the entry point: tile counts and the split between whole rounds and stream-K.
 struct Plan { int bo, bp, cc, waves, T, TO, C, T_dp, G, slab_floats; };
-static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transposed) {
+static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int form) {
     Plan p;
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
-    tile_dims(O, H, W, ksize, transposed, &p.bo, &p.bp, &p.cc, &p.waves);
+    tile_dims(O, H, W, ksize, transposed, form, &p.bo, &p.bp, &p.cc, &p.waves);
     p.TO = (O + p.bo - 1) / p.bo;
     p.T = ((npts + p.bp - 1) / p.bp) * p.TO;
     p.C = (I + p.cc - 1) / p.cc;
@@ -754,11 +761,12 @@ static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transpos
 
 static size_t scratch_bytes_for(int B, int G, int slab_floats) { return (size_t)B * G * 2 * slab_floats * sizeof(float); }
 
-extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int* h_ksplit,
+extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int* h_ksplit,
                               size_t* h_scratch_bytes) {
     IA_REQUIRE(h_ksplit && h_scratch_bytes, "null output pointer");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
-    const Plan p = make_plan(B, I, O, H, W, ksize, transposed);
+    IA_REQUIRE(form >= 0 && form <= 2, "form: 0 = ia_conv2d_mfma, 1 = ia_conv2d_mfma_h, 2 = ia_conv2d_mfma_s");
+    const Plan p = make_plan(B, I, O, H, W, ksize, transposed, form);
     *h_ksplit = p.G;
     *h_scratch_bytes = scratch_bytes_for(B, p.G, p.slab_floats);
     return IA_OK;
@@ -783,7 +791,7 @@ static int conv2d_entry(const float* x, const void* wk_any, const float* styles,
     g.GH = transposed ? H + 1 : H; g.GW = transposed ? W + 1 : W;
     g.OH = transposed ? 2 * H + 1 : H; g.OW = transposed ? 2 * W + 1 : W;
     IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
-    const Plan p = make_plan(B, I, O, H, W, ksize, transposed);
+    const Plan p = make_plan(B, I, O, H, W, ksize, transposed, half_ops);
     const int bp_ = p.bp;
     g.T = p.T; g.TO = p.TO; g.C = p.C; g.T_dp = p.T_dp; g.G = 0;
     if (p.T_dp < p.T) {
@@ -800,9 +808,10 @@ static int conv2d_entry(const float* x, const void* wk_any, const float* styles,
     hipStream_t s = (hipStream_t)stream;
     if (half_ops) {
         const bool wide = p.waves == 8;
-        IA_REQUIRE(ksize == 3 && (wide || (transposed && p.bo == 64 && p.bp == 64)) && I % 8 == 0 && O % 4 == 0,
+        IA_REQUIRE(ksize == 3 && (wide || (transposed && p.bo == 64)) && I % 8 == 0 && O % 4 == 0,
                    "the fp16-operand form covers 3x3 layers on the two-stage tiles (large stride-1 layers, stride-2 transposed) with I %% 8 == 0, O %% 4 == 0");
         if (half_ops == 2) {
+            if (transposed && p.bp == 128) return launch<3, true, 1, 2, 2, 2, kChunkTransposed, 2>(x, wk, styles, y, scratch, g, e, s);
             if (transposed) return launch<3, true, 1, 1, 2, 2, kChunkTransposed, 2>(x, wk, styles, y, scratch, g, e, s);
             return launch<3, false, 2, 2, 2, 4, kChunkConv, 2>(x, wk, styles, y, scratch, g, e, s);
         }

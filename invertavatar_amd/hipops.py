@@ -139,7 +139,8 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
             _f32c(t, name)
     lib = _lib.load()
     plan_s, plan_bytes = ctypes.c_int(0), ctypes.c_size_t(0)
-    _lib.check(lib.ia_conv2d_plan(b, i, o, h, w, ksize, int(transposed), ctypes.byref(plan_s), ctypes.byref(plan_bytes)), 'ia_conv2d_plan')
+    form = 2 if split else (1 if half_ops else 0)
+    _lib.check(lib.ia_conv2d_plan(b, i, o, h, w, ksize, int(transposed), form, ctypes.byref(plan_s), ctypes.byref(plan_bytes)), 'ia_conv2d_plan')
     nbytes = plan_bytes.value
     if ksplit is None:
         ksplit = plan_s.value

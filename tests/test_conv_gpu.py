@@ -200,3 +200,20 @@ def test_split_fp16_form_over_the_operand_range(wscale):
     print(f'weights x {wscale:g}: relative max error vs fp64 {err:.2e}; the tiny channels alone are {share:.1e} of the output')
     assert share > 15 * 1e-6      # (dropping them would show)
     assert err <= 1e-6
+
+
+def test_split_fp16_form_large_transposed_tile():
+    """Point grids of >= 32768 points (the 256^2 -> 512^2 layers) take the 64ch x 128pt x 4-phase tile of the fp16-pair form:
+    same arithmetic, two point fragments per wave; checked against an fp64 transposed convolution on an odd-sized image whose
+    tiles straddle rows, with stream-K leftovers (B = 2)."""
+    i, o, h, w = 32, 64, 201, 187
+    g = torch.Generator(device='cuda').manual_seed(13)
+    x = torch.randn(2, i, h, w, device='cuda', generator=g) * 2
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g)
+    s = torch.rand(2, i, device='cuda', generator=g) + 0.5
+    ref = torch.nn.functional.conv_transpose2d((x * s[:, :, None, None]).double(), wt.double().transpose(0, 1), stride=2)
+    got = hipops.conv2d_mfma(x, hipops.pack_conv_weight_split(wt), styles=s, ksize=3, transposed=True)
+    assert got.shape == ref.shape
+    err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f'large transposed fp16-pair tile: relative max error vs fp64 {err:.2e}')
+    assert err <= 1e-6
