@@ -69,3 +69,25 @@ def test_bench_workload_replay_equals_eager():
         assert torch.equal(out['image'], want[i][0]), i
         assert torch.equal(out['image_depth'], want[i][1]), i
     assert torch.isfinite(want[0][0]).all() and want[0][0].abs().mean().item() > 1e-3
+
+
+def test_back_to_back_frames_do_not_interfere():
+    """Eager frames and graph replays issued without a host sync in between (the side streams of frame k+1 are forked while
+    frame k is still running) give the bits of frames run one at a time."""
+    frames = list(range(0, 240, 20))
+    g, ws, cams, uvs, jits, eager = _setup('small', 64, frames)
+    want = [eager(i)[0] for i in range(len(frames))]
+    torch.cuda.synchronize()
+    got = []
+    with torch.no_grad():
+        for k in range(36):
+            i = (k * 5) % len(frames)
+            out = g.synthesis(ws, cams[i:i + 1], {'uvcoords_image': uvs[i:i + 1]}, neural_rendering_resolution=64, noise_mode='const',
+                              evaluation=True, jitter=jits[i:i + 1])
+            got.append((i, out['image']))
+    graphed = GraphedSynthesis(g, batch=1, neural_rendering_resolution=64)
+    for k in range(60):
+        i = (k * 7) % len(frames)
+        got.append((i, graphed(ws, cams[i:i + 1], uvs[i:i + 1], jits[i:i + 1])['image'].clone()))
+    torch.cuda.synchronize()
+    assert sum(int(not torch.equal(a, want[i])) for i, a in got) == 0
