@@ -37,10 +37,22 @@ class _TwoBlockHead(torch.nn.Module):
         if isinstance(self.block0, SynthesisBlock) and isinstance(self.block1, SynthesisBlock):
             self._style_batcher_obj.prepare([self.block0, self.block1], [0, 0], ws3.to(torch.float32))
 
+    def hoist_styles(self, ws):
+        """The head's styles depend only on ws: a caller that knows ws long before the rendered features exist (triplane_v20:
+        at the top of the frame, on a side stream) can have them computed then; forward() with the same ws object uses them."""
+        w3 = _last_w(ws)
+        self._prepare_styles(w3)
+        object.__setattr__(self, '_hoisted', (ws, w3))
+
     def forward(self, rgb, x, ws, **block_kwargs):
-        ws = _last_w(ws)
+        hoisted = getattr(self, '_hoisted', None)
+        object.__setattr__(self, '_hoisted', None)
+        if hoisted is not None and hoisted[0] is ws:
+            ws = hoisted[1]
+        else:
+            ws = _last_w(ws)
+            self._prepare_styles(ws)
         x, rgb = _fit(x, rgb, self.input_resolution, self.sr_antialias)
-        self._prepare_styles(ws)
         x, rgb = self.block0(x, rgb, ws, **block_kwargs)
         x, rgb = self.block1(x, rgb, ws, **block_kwargs)
         return rgb

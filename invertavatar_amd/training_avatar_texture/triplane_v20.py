@@ -161,6 +161,8 @@ class TriPlaneGenerator(torch.nn.Module):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             x, img, first = self.face_backbone.synthesis.forward_head(ws, update_emas=update_emas, **synthesis_kwargs)
+            if hasattr(self.superresolution, 'hoist_styles'):      # three small launches off the render -> SR chain
+                self.superresolution.hoist_styles(ws)
             done = torch.cuda.Event()
             done.record(side)
         x.record_stream(main)
