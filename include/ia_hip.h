@@ -284,6 +284,18 @@ int ia_styles_demod(const float* ws, int B, int num_ws, int w_dim, const int64_t
  */
 int ia_ray_sampler(const float* cam, int cam_stride, float* rays_o, float* rays_d, int B, int resolution, int normalize, void* stream);
 
+/*
+ * Output side: float image batch -> uint8 picture grid, one pass.
+ * Replaces layout_grid(img, grid_w, grid_h, float_to_uint8=True, chw_to_hwc) of the reference's scripts
+ * (reenact_avatar_next3d.py:117-131): (img * 127.5 + 128).clamp(0, 255).to(uint8), frames tiled row-major into a
+ * grid_h x grid_w mosaic, channels moved last when chw_to_hwc != 0.
+ *   img : [B, C, H, W] float32 contiguous, B == grid_w * grid_h, C in {1, 3, 4}, W % 4 == 0
+ *   out : uint8, [grid_h*H, grid_w*W, C] (chw_to_hwc) or [C, grid_h*H, grid_w*W]; grid_w = 1 gives the batch of
+ *         HWC frames [B, H, W, C] that is all-gathered between GPUs / handed to the encoder
+ * Bit-exact with the reference's torch expression (one multiply, one add, clamp, truncation).
+ */
+int ia_layout_grid_u8(const float* img, uint8_t* out, int B, int C, int H, int W, int grid_w, int grid_h, int chw_to_hwc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

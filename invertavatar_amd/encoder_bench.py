@@ -1,0 +1,48 @@
+"""BASELINE configs[2] as a timed flow: encoder + tri-plane render on a 32-frame synthetic clip (eval_seq.py pattern):
+encode -> AR_eval_forward groups (ConvGRU state carried) -> 32 drive frames via synthesis_withTexture.  Used by bench.py's
+`encoder` leg (outside the headline's timed region); per-stage times are HIP-event times."""
+import time
+
+import torch
+
+from . import eval_seq, synthetic
+from .encoder_inversion.models.uvnet import inversionNet
+
+NRR = 128
+
+
+def encoder_leg(gen, n_sources=8, n_drive=32):
+    net = inversionNet(generator=gen, encoding_triplane=True, encoding_texture=True).requires_grad_(False)
+    synthetic.fill_encoder_parameters(net)
+    net = net.cuda()
+    was_training = gen.training
+    eval_seq.set_eval_seq_modes(net)
+    gen.neural_rendering_resolution = NRR
+    try:
+        src_frames = [int(round(k * 32 / n_sources)) for k in range(n_sources)]
+        images = torch.cat([synthetic.source_frames(7 + k // 4, 4)[k % 4:k % 4 + 1] for k in range(n_sources)]).cuda()
+        uvs = synthetic.source_uv(17, src_frames).cuda()
+        cams, uvc = synthetic.camera_labels(src_frames).cuda(), synthetic.uv_conditions(src_frames).cuda()
+        drive = list(range(40, 40 + n_drive))
+        d_c, d_uv = synthetic.camera_labels(drive).cuda(), synthetic.uv_conditions(drive).cuda()
+
+        def run():
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            ws, res, _ = eval_seq.few_shot_inversion(net, images, uvs, cams, uvc)
+            ev[1].record()
+            imgs, _ = eval_seq.drive_sequence(net, ws, res, d_c, d_uv, neural_rendering_resolution=NRR)
+            ev[2].record()
+            torch.cuda.synchronize()
+            return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), imgs
+        run()                                         # warm-up (allocations, MIOpen kernel selection)
+        t0 = time.perf_counter()
+        inv_ms, drive_ms, imgs = run()
+        wall = time.perf_counter() - t0
+        ok = bool(torch.isfinite(imgs).all().item())
+    finally:
+        gen.train(was_training)
+    return dict(workload=f'BASELINE configs[2]: encode + {n_sources // 4} AR_eval_forward groups of 4 sources (ConvGRU) + {n_drive} drive frames '
+                         '(synthesis_withTexture, B=1 per call), eager launches, generator in train() mode as eval_seq.py leaves it',
+                inversion_ms=round(inv_ms, 2), drive_ms=round(drive_ms, 2), drive_frames_per_s=round(n_drive / (drive_ms * 1e-3), 2),
+                clip_frames_per_s=round(n_drive / wall, 2), finite=ok)

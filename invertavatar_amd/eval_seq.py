@@ -1,0 +1,92 @@
+"""Few-shot inversion + reenactment harness: counterpart of the reference's eval_seq.py:77-219 (``run_video_animation``) for
+BASELINE configs[2] and [4].
+
+The flow of the script, restated:
+  1. module modes (:91-97): the whole inversion network in train() mode (train-mode BatchNorm in the recurrent up-path,
+     non-fused modulated convolutions in the generator), except the IR-SE50 trunks of both UNets (``input_layer``, ``body``);
+  2. ``ws = G.encode(first source frame)``; texture / static features of that identity (:168-171);
+  3. sources in groups of four through ``AR_eval_forward`` with the ConvGRU states carried from group to group; groups are
+     interleaved (``[idx::num_iter]``, :183-186) unless `sequential_sampling`; <= 4 sources are one group, 1 or 2 sources are
+     repeated to fill it (:141-150);
+  4. drive loop (:206-219): ``synthesis_withTexture(ws, texture, c, v, static_feats=static, noise_mode='const',
+     evaluation=True)`` per drive frame, mosaics [ground truth | rendered] through ``layout_grid``.
+
+Inputs are tensors (the datasets, FaceVerse and video writer of the script are outside this build's scope)."""
+import torch
+
+from .output import layout_grid
+
+
+def set_eval_seq_modes(net):
+    """Module modes exactly as eval_seq.py:91-97 leaves them."""
+    net.train()
+    for unet in (net.unet_encoder.triplane_unet, net.unet_encoder.texture_unet):
+        unet.input_layer.eval()
+        unet.body.eval()
+    return net
+
+
+def fill_group(t, n_src):
+    """1 or 2 sources are repeated to a group of four (:141-150); 3 is not a case the script supports."""
+    if n_src >= 4:
+        return t
+    assert n_src in (1, 2), n_src
+    return torch.cat([t] * (4 // n_src), dim=0)
+
+
+@torch.no_grad()
+def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=False, hook=None, chain_results=False):
+    """images [S,3,512,512] in [-1,1], uvs [S,6,256,256] (x['uv']), cams [S,25], uvcoords [S,256,256,3].  S in {1, 2, 4} or a
+    multiple of 4.  `hook(group_index)` may return a context manager entered around each AR_eval_forward (tests pin the
+    renderer's random draws with it).  chain_results=True feeds each group the features updated by the previous one instead of
+    the e4e features (a variant the golden fixture encoder_fewshot.npz was recorded with).  Returns (ws, {'w','texture','static'}, r_list)."""
+    s = images.shape[0]
+    assert s in (1, 2, 4) or s % 4 == 0, f'{s} source frames: the script pads to a multiple of 4 first (:135-136)'
+    images, uvs, cams, uvcoords = (fill_group(t, s) for t in (images, uvs, cams, uvcoords))
+    g = net.generator
+    ws = net.encode(images[:1])
+    tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
+    sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
+    results, r_list = {'w': ws, 'texture': tex, 'static': sta}, [None, None]
+    num_iter = max(images.shape[0] // 4, 1)
+    updated = results
+    for idx in range(num_iter):
+        sel = slice(4 * idx, 4 * (idx + 1)) if sequential_sampling else slice(idx, None, num_iter)
+        ctx = hook(idx) if hook is not None else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            # (every group starts from the e4e features: the script passes e4e_results=e4e_results each time, :187)
+            updated, r_list = net.AR_eval_forward({'image': images[sel], 'uv': uvs[sel]}, cams[sel], {'uvcoords_image': uvcoords[sel]},
+                                                  ws, r_list, e4e_results=updated if chain_results else results, return_fake=False)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+    return ws, updated, r_list
+
+
+@torch.no_grad()
+def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=None, neural_rendering_resolution=None):
+    """Drive loop (:206-219) over cams [F,25] / uvcoords [F,256,256,3] in calls of `batch` frames (the script uses 1).
+    Returns (images [F,3,H,W], mosaics or None): mosaics are the uint8 [gt | rendered] pictures when `gt` [F,3,H,W] is given."""
+    g = net.generator
+    n = cams.shape[0]
+    imgs, mosaics = [], ([] if gt is not None else None)
+    for lo in range(0, n, batch):
+        hi = min(lo + batch, n)
+        b = hi - lo
+        ws_b = ws.expand(b, -1, -1)
+        tex = [t.expand(b, -1, -1, -1) for t in results['texture']]
+        sta = [t.expand(b, -1, -1, -1) for t in results['static']]
+        kw = {}
+        if jitter is not None:
+            kw['jitter'] = jitter[lo:hi]
+        if neural_rendering_resolution is not None:
+            kw['neural_rendering_resolution'] = neural_rendering_resolution
+        out = g.synthesis_withTexture(ws_b, tex, cams[lo:hi], {'uvcoords_image': uvcoords[lo:hi]}, noise_mode='const', static_feats=sta,
+                                      evaluation=True, **kw)
+        imgs.append(out['image'])
+        if gt is not None:
+            for k in range(b):
+                mosaics.append(layout_grid(torch.cat([gt[lo + k:lo + k + 1, :3], out['image'][k:k + 1]], dim=0), grid_w=2, grid_h=1))
+    return torch.cat(imgs, 0), mosaics

@@ -32,6 +32,8 @@ def render_sharded(generator, ws, c, mesh_condition, rank=0, world_size=1, jitte
     ws [N or 1, num_ws, w_dim], c [N, 25+], mesh_condition['uvcoords_image'] [N,256,256,3], jitter [N,R,48] or None.
     Returns the full [N,3,H,W] batch on every rank (gather=True) or this rank's block."""
     n = c.shape[0]
+    if n < world_size:      # every rank sees the same n: all of them raise, none is left waiting in the collective
+        raise ValueError(f'render_sharded: {n} frames cannot be sharded over {world_size} ranks (every rank needs >= 1 frame)')
     lo, hi = shard_range(n, rank, world_size)
     dist = global_ray_dist(c)
     ws_local = ws[lo:hi] if ws.shape[0] == n else ws.expand(hi - lo, -1, -1)

@@ -10,7 +10,7 @@ import torch
 
 
 class GraphedSynthesis:
-    def __init__(self, generator, batch=1, neural_rendering_resolution=128, warmup=3, **synthesis_kwargs):
+    def __init__(self, generator, batch=1, neural_rendering_resolution=128, warmup=3, with_ray_dist=False, **synthesis_kwargs):
         self.g = generator
         self.nrr = neural_rendering_resolution
         self.kwargs = dict(noise_mode='const', evaluation=True)
@@ -21,22 +21,23 @@ class GraphedSynthesis:
         self.c = torch.zeros(batch, 25, device=dev)
         self.uv = torch.zeros(batch, 256, 256, 3, device=dev)
         self.jitter = torch.zeros(batch, self.nrr * self.nrr, 48, device=dev)
+        # batch-global mean |ray origin| (renderer.py:311) as an input: a rank that renders one shard of a larger batch gets the
+        # value of the WHOLE batch from its caller (frame_parallel.global_ray_dist) instead of the mean over its own frames
+        self.ray_dist = torch.zeros(1, device=dev) if with_ray_dist else None
         self.graph = None
         self.out = None
         self._warmup = warmup
+        self._scratch = {}
 
     def _call(self):
         return self.g.synthesis(self.ws, self.c, {'uvcoords_image': self.uv}, neural_rendering_resolution=self.nrr,
-                                jitter=self.jitter, **self.kwargs)
+                                jitter=self.jitter, ray_dist=self.ray_dist, **self.kwargs)
 
     def capture(self):
         # valid camera / inputs must be in the static buffers before capture (the warm-up runs execute real kernels)
         from . import hipops
-        saved_tag, hipops.SCRATCH_TAG = hipops.SCRATCH_TAG, id(self)   # own stream-K scratch: graphs may replay concurrently
-        try:
+        with hipops.scratch_owner(self._scratch):     # own stream-K scratch: graphs may replay concurrently; freed with self
             return self._capture()
-        finally:
-            hipops.SCRATCH_TAG = saved_tag
 
     def _capture(self):
         stream = torch.cuda.Stream()
@@ -52,7 +53,11 @@ class GraphedSynthesis:
         return self
 
     @torch.no_grad()
-    def __call__(self, ws, c, uvcoords_image, jitter):
+    def __call__(self, ws, c, uvcoords_image, jitter, ray_dist=None):
+        if (ray_dist is None) != (self.ray_dist is None):
+            raise ValueError('ray_dist must be passed exactly when the graph was built with with_ray_dist=True')
+        if ray_dist is not None:
+            self.ray_dist.copy_(ray_dist.reshape(1))
         self.ws.copy_(ws.expand_as(self.ws))
         self.c.copy_(c[:, -25:])
         self.uv.copy_(uvcoords_image)
@@ -66,8 +71,9 @@ class GraphedSynthesis:
 class FramePipeline:
     """`depth` captured frames in flight: frame k is replayed on stream k % depth with its own static buffers, so the
     latency-bound parts of consecutive frames (low-resolution layers, renderer sampling phases) fill each other's idle
-    compute units.  Results are returned in submission order; `submit` returns the output dict of the frame that was in
-    the slot before (already complete on the caller's stream), `drain` the rest."""
+    compute units.  `submit` returns (out, event, previous): `out` is the slot's STATIC output dict -- valid once `event` has
+    completed and until the slot is replayed again (`depth` submissions later), so consume or copy it before then; `previous`
+    is the event of the frame that occupied the slot before.  `drain` makes the caller's stream wait for everything in flight."""
 
     def __init__(self, generator, depth=2, batch=1, neural_rendering_resolution=128, **synthesis_kwargs):
         self.slots = [GraphedSynthesis(generator, batch, neural_rendering_resolution, **synthesis_kwargs) for _ in range(depth)]

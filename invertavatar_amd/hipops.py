@@ -3,6 +3,8 @@
 Each function allocates its output with torch (device memory is plumbing), passes raw
 pointers to libia_hip.so on torch's current stream and raises on any non-zero status.
 None of them has a CPU path: they are only ever called with device tensors."""
+import contextlib
+import contextvars
 import ctypes
 import math
 
@@ -98,20 +100,34 @@ def modconv_demod(styles, wsq):
     return d
 
 
-_scratch = {}
-# Launch sequences that may run concurrently although they were issued on the same stream (two captured graphs replayed
-# on different streams) must not share scratch: each sets its own tag while it is being captured.
-SCRATCH_TAG = 0
+# Stream-K accumulator slabs (caller-owned memory, as the ABI requires).  Launches on different streams may overlap, so a slab
+# is keyed by (device, stream).  A captured graph may be replayed on any stream, concurrently with eager launches or with other
+# graphs, so each GraphedSynthesis brings its OWN registry (scratch_owner) for the duration of its capture; the registry dies
+# with the graph object.  The default registry serves eager launches.
+_default_scratch = {}
+_scratch_registry = contextvars.ContextVar('ia_scratch_registry', default=None)
+
+
+@contextlib.contextmanager
+def scratch_owner(registry):
+    """Route the scratch allocations of the launches issued inside the block to `registry` (a dict the caller keeps alive)."""
+    token = _scratch_registry.set(registry)
+    try:
+        yield registry
+    finally:
+        _scratch_registry.reset(token)
 
 
 def _scratch_buffer(device, nbytes):
-    """Grow-only scratch for the stream-K accumulator slabs, one per (device, stream, tag): launches on different streams
-    may overlap, so they must not share slabs (caller-owned memory, as the ABI requires)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream, SCRATCH_TAG)
-    buf = _scratch.get(key)
+    """Grow-only scratch for the stream-K accumulator slabs, one per (device, stream) of the active registry."""
+    reg = _scratch_registry.get()
+    if reg is None:
+        reg = _default_scratch
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = reg.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
-        _scratch[key] = buf
+        reg[key] = buf
     return buf
 
 
@@ -212,7 +228,7 @@ def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_mult
                    order=torch.empty(b, r, 96, device=dev, dtype=torch.int32), w_coarse=torch.empty(b, r, 47, device=dev),
                    sigma_coarse=torch.empty(b, r, 48, device=dev))
     # algorithmic work: 2 passes x 48 samples x (32*64 + 64*33) MACs per ray; planes + rays in, 34 floats out
-    flops = 2.0 * b * r * 96 * 2 * (32 * 64 + 64 * 33)
+    flops = b * r * 96 * 2.0 * (32 * 64 + 64 * 33)
     traffic = 4.0 * (planes_cl.numel() + 2 * rays_o.numel() + jitter.numel() + b * r * 34)
     with torch.cuda.device(dev), _Timed('render_rays', flops, traffic):
         st = lib.ia_render_rays(_p(planes_cl), _p(rays_o), _p(rays_d), _p(jitter), _p(dist), _p(w0), _p(b0), _p(w1), _p(b1),

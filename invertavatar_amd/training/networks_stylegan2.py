@@ -23,7 +23,7 @@ import torch
 
 from ..torch_utils import misc, persistence
 from ..torch_utils.ops import bias_act, conv2d_resample, fma, upfirdn2d
-from .. import hipops
+from .. import _runtime, hipops
 
 # Blocks built with use_fp16 (the reference's fp16 blocks: SR head with sr_num_fp16_res > 0) keep their activations in
 # fp32 on this backend; FP16_BLOCKS_COMPUTE_FP32 = False additionally runs their 3x3 convolutions with fp16 operands and
@@ -42,7 +42,7 @@ def normalize_2nd_moment(x, dim=1, eps=1e-8):
     return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
 
 
-class _PackedWeights:
+class _PackedWeights(_runtime.DeviceCache):
     """Per-layer cache of the kernel-side weight layouts, rebuilt when the parameter changes."""
 
     def __init__(self):
@@ -105,51 +105,67 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     misc.assert_shape(x, [batch, in_ch, None, None])
     misc.assert_shape(styles, [batch, in_ch])
 
-    if (_hip_conv_ok(x, weight, up, down) and padding == kh // 2 and flip_weight == (up == 1)
-            and (noise is None or noise.ndim <= 2 or noise.shape[0] == 1) and not _needs_autograd(x, weight, styles, noise)):
+    noise_ok = noise is None or noise.numel() == (x.shape[2] * up) * (x.shape[3] * up)   # a per-pixel table the kernel can index
+    if (_hip_conv_ok(x, weight, up, down) and padding == kh // 2 and flip_weight == (up == 1) and noise_ok
+            and (up == 1 or resample_filter is not None) and not _needs_autograd(x, weight, styles, noise)):
         w32 = weight.float()
         wk = hipops.pack_conv_weight(w32)
         styles = styles.float().contiguous()
         demod = hipops.modconv_demod(styles, hipops.weight_sq_sum(w32)) if demodulate else None
         x = x.contiguous()
+        nz = None if noise is None else noise.reshape(-1).float().contiguous()
         if up == 1:
-            nz = None if noise is None else noise.reshape(-1).float().contiguous()
             return hipops.conv2d_mfma(x, wk, styles, demod, noise=nz, ksize=kh)
         t = hipops.conv2d_mfma(x, wk, styles, demod, ksize=3, transposed=True)
-        nz = None if noise is None else noise.reshape(-1).float().contiguous()
         return hipops.upfirdn2d_bias_act(t, resample_filter, noise=nz, up=1, pad0=(1, 1),
                                          out_hw=(x.shape[2] * 2, x.shape[3] * 2), fir_gain=4.0)
 
-    # torch formulations (CPU tensors and shapes without a kernel)
+    # torch formulations (CPU tensors, autograd, and shapes without a kernel)
     if x.dtype == torch.float16 and demodulate:
+        # fp16 head-room: both factors are brought to unit max-norm first; the demodulation cancels the scales again
         weight = weight * (1 / np.sqrt(in_ch * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
         styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
-    w = dcoefs = None
-    if demodulate or fused_modconv:
-        w = weight.unsqueeze(0) * styles.reshape(batch, 1, -1, 1, 1)
+    resample = dict(f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
+    if fused_modconv:
+        return _modconv_sample_weights(x, weight, styles, noise, demodulate, resample)
+    return _modconv_scaled_input(x, weight, styles, noise, demodulate, resample)
+
+
+def _modulated_weights(weight, styles):
+    """[B, O, I, kh, kw]: the shared weight with every input channel scaled by the sample's style."""
+    return weight[None] * styles[:, None, :, None, None]
+
+
+def _demod_coefficients(weight, styles):
+    """[B, O]: 1 / l2-norm of each sample's modulated filter (training/networks_stylegan2.py:63-64)."""
+    return (_modulated_weights(weight, styles).square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+
+
+def _modconv_scaled_input(x, weight, styles, noise, demodulate, resample):
+    """Styles applied to the activations, one shared weight, demodulation on the output (the reference's training-time
+    route, :70-79)."""
+    batch = x.shape[0]
+    dtype = x.dtype
+    y = conv2d_resample.conv2d_resample(x=x * styles.to(dtype).reshape(batch, -1, 1, 1), w=weight.to(dtype), **resample)
+    d = _demod_coefficients(weight, styles).to(dtype).reshape(batch, -1, 1, 1) if demodulate else None
+    if d is not None and noise is not None:
+        return fma.fma(y, d, noise.to(dtype))
+    if d is not None:
+        return y * d
+    return y if noise is None else y.add_(noise.to(dtype))
+
+
+def _modconv_sample_weights(x, weight, styles, noise, demodulate, resample):
+    """Per-sample weights (modulated, then demodulated) run as ONE grouped convolution with the batch folded into the
+    channel axis (the reference's inference-time route, :81-91)."""
+    batch, _, h, w_ = x.shape
+    wb = _modulated_weights(weight, styles)
     if demodulate:
-        dcoefs = (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
-    if not fused_modconv:
-        x = x * styles.to(x.dtype).reshape(batch, -1, 1, 1)
-        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
-                                            flip_weight=flip_weight)
-        if demodulate and noise is not None:
-            x = fma.fma(x, dcoefs.to(x.dtype).reshape(batch, -1, 1, 1), noise.to(x.dtype))
-        elif demodulate:
-            x = x * dcoefs.to(x.dtype).reshape(batch, -1, 1, 1)
-        elif noise is not None:
-            x = x.add_(noise.to(x.dtype))
-        return x
-    if demodulate:
-        w = w * dcoefs.reshape(batch, -1, 1, 1, 1)
-    x = x.reshape(1, -1, *x.shape[2:])
-    w = w.reshape(-1, in_ch, kh, kw)
-    x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
-                                        groups=batch, flip_weight=flip_weight)
-    x = x.reshape(batch, -1, *x.shape[2:])
-    if noise is not None:
-        x = x.add_(noise)
-    return x
+        wb = wb * _demod_coefficients(weight, styles).reshape(batch, -1, 1, 1, 1)
+    y = conv2d_resample.conv2d_resample(x=x.reshape(1, -1, h, w_), w=wb.reshape(-1, *weight.shape[1:]).to(x.dtype), groups=batch,
+                                        **resample)
+    y = y.reshape(batch, -1, *y.shape[2:])
+    return y if noise is None else y.add_(noise)
 
 
 @persistence.persistent_class
@@ -260,32 +276,34 @@ class MappingNetwork(torch.nn.Module):
         if num_ws is not None and w_avg_beta is not None:
             self.register_buffer('w_avg', torch.zeros([w_dim]))
 
+    def _embed_inputs(self, z, c):
+        """Unit-second-moment latent, concatenated with the unit-second-moment embedding of the label (:233-243)."""
+        parts = []
+        if self.z_dim > 0:
+            misc.assert_shape(z, [None, self.z_dim])
+            parts.append(normalize_2nd_moment(z.to(torch.float32)))
+        if self.c_dim > 0:
+            misc.assert_shape(c, [None, self.c_dim])
+            parts.append(normalize_2nd_moment(self.embed(c.to(torch.float32))))
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
-        x = None
-        with torch.autograd.profiler.record_function('input'):
-            if self.z_dim > 0:
-                misc.assert_shape(z, [None, self.z_dim])
-                x = normalize_2nd_moment(z.to(torch.float32))
-            if self.c_dim > 0:
-                misc.assert_shape(c, [None, self.c_dim])
-                y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
-                x = torch.cat([x, y], dim=1) if x is not None else y
+        w = self._embed_inputs(z, c)
         for idx in range(self.num_layers):
-            x = getattr(self, f'fc{idx}')(x)
-        if update_emas and self.w_avg_beta is not None:
-            with torch.autograd.profiler.record_function('update_w_avg'):
-                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
-        if self.num_ws is not None:
-            with torch.autograd.profiler.record_function('broadcast'):
-                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
-        if truncation_psi != 1:
-            with torch.autograd.profiler.record_function('truncate'):
-                assert self.w_avg_beta is not None
-                if self.num_ws is None or truncation_cutoff is None:
-                    x = self.w_avg.lerp(x, truncation_psi)
-                else:
-                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
-        return x
+            w = getattr(self, f'fc{idx}')(w)
+        if update_emas and self.w_avg_beta is not None:     # running mean of w (training only)
+            self.w_avg.copy_(w.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:                         # one copy of w per synthesis layer
+            w = w.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:                             # truncation trick: pull (the first `cutoff` rows) towards w_avg
+            if self.w_avg_beta is None:
+                raise AssertionError('truncation needs the w_avg buffer')
+            if self.num_ws is None or truncation_cutoff is None:
+                w = self.w_avg.lerp(w, truncation_psi)
+            else:
+                head = w[:, :truncation_cutoff]
+                w[:, :truncation_cutoff] = self.w_avg.lerp(head, truncation_psi)
+        return w
 
     def extra_repr(self):
         return f'z_dim={self.z_dim:d}, c_dim={self.c_dim:d}, w_dim={self.w_dim:d}, num_ws={self.num_ws:d}'
@@ -515,7 +533,7 @@ def _modulated_layers(block):
     return out
 
 
-class _StyleBatcher:
+class _StyleBatcher(_runtime.DeviceCache):
     """Computes the styles / demodulation coefficients of all layers of a list of blocks in two launches
     (``ia_styles_demod``) and parks them on the layers for the forward pass that follows."""
 

@@ -5,6 +5,7 @@ tensors the blocks run on the fused MFMA convolution path of ``training.networks
 import numpy as np
 import torch
 
+from .. import _runtime
 from ..torch_utils import misc, persistence
 from ..torch_utils.ops import upfirdn2d
 from ..training.networks_stylegan2 import Conv2dLayer, SynthesisBlock, SynthesisLayer, ToRGBLayer, _StyleBatcher
@@ -32,21 +33,22 @@ class _TwoBlockHead(torch.nn.Module):
         return sr_num_fp16_res > 0
 
     def _prepare_styles(self, ws3):
-        if not hasattr(self, '_style_batcher_obj'):
-            object.__setattr__(self, '_style_batcher_obj', _StyleBatcher())
+        rt = _runtime.state(self)          # (runtime state lives outside the module: deepcopy / pickle see parameters only)
+        if not hasattr(rt, 'style_batcher'):
+            rt.style_batcher = _StyleBatcher()
         if isinstance(self.block0, SynthesisBlock) and isinstance(self.block1, SynthesisBlock):
-            self._style_batcher_obj.prepare([self.block0, self.block1], [0, 0], ws3.to(torch.float32))
+            rt.style_batcher.prepare([self.block0, self.block1], [0, 0], ws3.to(torch.float32))
 
     def hoist_styles(self, ws):
         """The head's styles depend only on ws: a caller that knows ws long before the rendered features exist (triplane_v20:
         at the top of the frame, on a side stream) can have them computed then; forward() with the same ws object uses them."""
         w3 = _last_w(ws)
         self._prepare_styles(w3)
-        object.__setattr__(self, '_hoisted', (ws, w3))
+        _runtime.state(self).hoisted = (ws, w3)
 
     def forward(self, rgb, x, ws, **block_kwargs):
-        hoisted = getattr(self, '_hoisted', None)
-        object.__setattr__(self, '_hoisted', None)
+        rt = _runtime.state(self)
+        hoisted, rt.hoisted = getattr(rt, 'hoisted', None), None
         if hoisted is not None and hoisted[0] is ws:
             ws = hoisted[1]
         else:

@@ -21,7 +21,7 @@ the stratified-sampling noise can be injected (``jitter=``) for reproducible eva
 import torch
 import torch.nn.functional as F
 
-from .. import dnnlib, hipops
+from .. import _runtime, dnnlib, hipops
 from ..torch_utils import persistence
 from ..training.networks_stylegan2 import FullyConnectedLayer
 from .networks_stylegan2_new import Generator as StyleGAN2Backbone_cond
@@ -32,6 +32,30 @@ BBOX_256 = [57, 185, 64, 192]   # face region of the frontal plane, in 256^2 pix
 N_COND_LEVELS_USED = 4          # cond_list entries the face backbone consumes
 SINGLE_STREAM = False           # True: no side streams (every launch of a frame in program order on the caller's stream); used by
                                 # bench.py to time kernels without neighbours from other streams
+
+
+class _FrameState:
+    """Per-generator orchestration state of the device path (side streams, tensors handed between the stages of ONE frame).
+    It lives outside the module (invertavatar_amd._runtime) so that copy.deepcopy / pickle / torch.save of a generator that has
+    already rendered see parameters and buffers only."""
+
+    def __init__(self):
+        self.streams = {}
+        self.side_rays = None
+        self.tex_cl = None
+
+    def stream(self, name, device):
+        st = self.streams.get(name)
+        if st is None or st.device != device:
+            st = self.streams[name] = torch.cuda.Stream(device=device)
+        return st
+
+
+def _state(gen):
+    holder = _runtime.state(gen)
+    if not hasattr(holder, 'frame'):
+        holder.frame = _FrameState()
+    return holder.frame
 
 
 class _LazyLevels:
@@ -114,10 +138,8 @@ class TriPlaneGenerator(torch.nn.Module):
             return self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **kw, **synthesis_kwargs)
         if not (ws.is_cuda and not torch.is_grad_enabled()) or SINGLE_STREAM:
             return tex(), sta(), None
-        for name in ('_backbone_stream', '_static_stream'):
-            if getattr(self, name, None) is None or getattr(self, name).device != ws.device:
-                object.__setattr__(self, name, torch.cuda.Stream(device=ws.device))
-        main, t_stream, s_stream = torch.cuda.current_stream(ws.device), self._backbone_stream, self._static_stream
+        st = _state(self)
+        main, t_stream, s_stream = torch.cuda.current_stream(ws.device), st.stream('texture', ws.device), st.stream('static', ws.device)
         tex_cl = [None] * N_COND_LEVELS_USED
         counts = tuple(range(2, N_COND_LEVELS_USED + 1))       # taps 0 and 1 (image and features at 32^2) appear together
         ev_tex, ev_sta = {n: torch.cuda.Event() for n in counts}, {n: torch.cuda.Event() for n in counts}
@@ -148,16 +170,14 @@ class TriPlaneGenerator(torch.nn.Module):
             pending = None
         for t in list(texture_feats) + [t for t in tex_cl if t is not None] + (list(static_feats) if partial else []):
             t.record_stream(main)
-        object.__setattr__(self, '_tex_cl', (texture_feats, tex_cl))
+        st.tex_cl = (texture_feats, tex_cl)
         return texture_feats, static_feats, pending
 
     def _start_face_head(self, ws, update_emas, synthesis_kwargs):
         """The 4^2..32^2 blocks of the face backbone depend only on ws; run them on a third stream under the other backbones."""
         if not (ws.is_cuda and not torch.is_grad_enabled()) or SINGLE_STREAM:
             return None
-        if getattr(self, '_face_stream', None) is None or self._face_stream.device != ws.device:
-            object.__setattr__(self, '_face_stream', torch.cuda.Stream(device=ws.device))
-        main, side = torch.cuda.current_stream(ws.device), self._face_stream
+        main, side = torch.cuda.current_stream(ws.device), _state(self).stream('face_head', ws.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             x, img, first = self.face_backbone.synthesis.forward_head(ws, update_emas=update_emas, **synthesis_kwargs)
@@ -173,16 +193,15 @@ class TriPlaneGenerator(torch.nn.Module):
         """The mouth-hole fill depends only on the UV mask, and its flood is a one-workgroup, latency-bound kernel:
         start it on a side stream at the top of the frame so that it runs underneath the backbone convolutions.
         `rays` = (c, neural_rendering_resolution, ray_dist): the camera rays and the batch mean of |ray origin| depend
-        only on the cameras, so they are produced on the same side stream (self._side_rays)."""
+        only on the cameras, so they are produced on the same side stream (_FrameState.side_rays)."""
         uv = mesh_condition['uvcoords_image']
-        object.__setattr__(self, '_side_rays', None)
+        st = _state(self)
+        st.side_rays = None
         if not (uv.is_cuda and not torch.is_grad_enabled()) or SINGLE_STREAM:
             return None
-        if getattr(self, '_side_stream', None) is None or self._side_stream.device != uv.device:
-            object.__setattr__(self, '_side_stream', torch.cuda.Stream(device=uv.device))
-        main = torch.cuda.current_stream(uv.device)
-        self._side_stream.wait_stream(main)
-        with torch.cuda.stream(self._side_stream):
+        main, side = torch.cuda.current_stream(uv.device), st.stream('mouth', uv.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
             uv_c = uv.float().contiguous()
             alpha = uv_c[..., 2:].permute(0, 3, 1, 2).contiguous()
             full_alpha, mouth = fill_mouth(alpha, blur_mouth_edge=False)
@@ -193,10 +212,10 @@ class TriPlaneGenerator(torch.nn.Module):
                 origins, dirs, nrr = self._rays(c, nrr)
                 if ray_dist is None:
                     ray_dist = torch.norm(origins, dim=-1).mean().reshape(1)     # (renderer.py:311), no host sync
-                object.__setattr__(self, '_side_rays', (origins, dirs, nrr, ray_dist))
+                st.side_rays = (origins, dirs, nrr, ray_dist)
                 extra = (origins, dirs, ray_dist)
             done = torch.cuda.Event()
-            done.record(self._side_stream)
+            done.record(side)
         for t in (uv_c, alpha, full_alpha, mouth, upper_c) + tuple(t for t in extra if torch.is_tensor(t)):
             t.record_stream(main)
         return alpha, full_alpha, mouth, done, uv_c, upper_c
@@ -245,9 +264,7 @@ class TriPlaneGenerator(torch.nn.Module):
             # (taps 0 and 1 are both 32^2 and come with the first event), under the face backbone's previous block; the face
             # backbone only waits for level k's event when it reads cond_list[k].
             main = torch.cuda.current_stream(ws.device)
-            if getattr(self, '_raster_stream', None) is None or self._raster_stream.device != ws.device:
-                object.__setattr__(self, '_raster_stream', torch.cuda.Stream(device=ws.device))
-            rs = self._raster_stream
+            rs = _state(self).stream('raster', ws.device)
             rs.wait_stream(main)
             levels, done = [], []
             with torch.cuda.stream(rs):
@@ -301,8 +318,9 @@ class TriPlaneGenerator(torch.nn.Module):
                   use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, ray_dist=None, **synthesis_kwargs):
         mouth = self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, ray_dist))
         face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
-        if self._side_rays is not None:      # made on the side stream; joined with the mouth fill inside rasterize()
-            origins, dirs, nrr, ray_dist = self._side_rays
+        side_rays = _state(self).side_rays
+        if side_rays is not None:            # made on the side stream; joined with the mouth fill inside rasterize()
+            origins, dirs, nrr, ray_dist = side_rays
         else:
             origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
         texture_feats, static_feats, pending = self._two_backbones(ws, update_emas, synthesis_kwargs, partial=True)
@@ -323,8 +341,9 @@ class TriPlaneGenerator(torch.nn.Module):
         mouth = self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, None))
         face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
         ray_dist = None
-        if self._side_rays is not None:
-            origins, dirs, nrr, ray_dist = self._side_rays
+        side_rays = _state(self).side_rays
+        if side_rays is not None:
+            origins, dirs, nrr, ray_dist = side_rays
         else:
             origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
         if static_feats is None:
@@ -384,8 +403,8 @@ class TriPlaneGenerator(torch.nn.Module):
             if fused:
                 uv_c, upper_c = uv.contiguous(), upper_alpha.reshape(-1, 256, 256).contiguous()
         # channels-last copies made on the texture stream by _two_backbones (same list object => same frame)
-        cached = getattr(self, '_tex_cl', None)
-        object.__setattr__(self, '_tex_cl', None)
+        st = _state(self)
+        cached, st.tex_cl = st.tex_cl, None
         return dict(grid=grid, alpha=alpha, full_alpha=full_alpha, mouth=mouth, upper_alpha=upper_alpha, uv_c=uv_c, upper_c=upper_c,
                     fused=fused, cached=cached)
 

@@ -34,13 +34,7 @@ def encoder_inputs(nrr=32):
     return data, dict(c=synthetic.camera_labels(drive), uvcoords=synthetic.uv_conditions(drive), jitter=synthetic.jitter(drive, nrr * nrr))
 
 
-def set_eval_seq_modes(net):
-    """eval_seq.py:92-97: everything in train() mode except the trunks of the two UNets."""
-    net.train()
-    for unet in (net.unet_encoder.triplane_unet, net.unet_encoder.texture_unet):
-        unet.input_layer.eval()
-        unet.body.eval()
-    return net
+from invertavatar_amd.eval_seq import set_eval_seq_modes  # noqa: E402,F401  (module modes of eval_seq.py:92-97)
 
 
 def build_inversion_net(width='full'):
@@ -54,23 +48,17 @@ def build_inversion_net(width='full'):
 
 
 def run_few_shot(net, device, nrr=32):
+    """encode -> two AR_eval_forward groups with carried GRU state -> one drive frame, through the product's eval_seq harness
+    (sequential groups: the fixture's two groups are given in the order they are consumed)."""
+    from invertavatar_amd import eval_seq
     net.generator.neural_rendering_resolution = nrr
     groups, drive = encoder_inputs(nrr)
-    to = lambda t: t.to(device)
-    g = net.generator
-    with torch.no_grad():
-        ws = net.encode(to(groups[0]['image'][:1]))
-        tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
-        sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
-        res, r_list = {'w': ws, 'texture': tex, 'static': sta}, [None, None]
-        for grp in groups:
-            with fixed_randomness(grp['jitter']):
-                res, r_list = net.AR_eval_forward({'image': to(grp['image']), 'uv': to(grp['uv'])}, to(grp['c']),
-                                                  {'uvcoords_image': to(grp['uvcoords'])}, ws, r_list, res)
-        with fixed_randomness(drive['jitter']):
-            out = g.synthesis_withTexture(ws, res['texture'], to(drive['c']), {'uvcoords_image': to(drive['uvcoords'])},
-                                          noise_mode='const', static_feats=res['static'], evaluation=True)
-    return ws, res, r_list, out['image']
+    cat = lambda key: torch.cat([g[key] for g in groups]).to(device)
+    ws, res, r_list = eval_seq.few_shot_inversion(net, cat('image'), cat('uv'), cat('c'), cat('uvcoords'), sequential_sampling=True, chain_results=True,
+                                                  hook=lambda idx: fixed_randomness(groups[idx]['jitter']))
+    with fixed_randomness(drive['jitter']):
+        image, _ = eval_seq.drive_sequence(net, ws, res, drive['c'].to(device), drive['uvcoords'].to(device))
+    return ws, res, r_list, image
 
 
 def compare_with_fixture(gld, ws, res, r_list, image, tol):

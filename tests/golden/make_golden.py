@@ -227,6 +227,90 @@ def gen_generator(width):
     npz(f'generator_{width}.npz', **arrays)
 
 
+def block_means(t, k=32):
+    """Mean of every k x k block: a position-sensitive checksum of a full-resolution image."""
+    return torch.nn.functional.avg_pool2d(t.double(), k).float()
+
+
+def gen_generator_bench():
+    """The configuration bench.py times (BASELINE configs[1]): full width, nrr = 128, 512^2 out, B = 1 per call, plus one
+    B = 2 call (batch-global `dist`, renderer.py:311: the coupling config 4's sharding must reproduce)."""
+    g = build_reference_generator('full')
+    nrr, frames = 128, [0, 17]
+    ws1 = g.mapping(synthetic.latent(0, 1), synthetic.conditioning_camera(), truncation_psi=0.7, truncation_cutoff=14)
+    arrays = dict(frames=np.array(frames), nrr=nrr, ws=ws1)
+
+    def record(tag, out):
+        img = out['image']
+        arrays[f'{tag}_image_sub4'] = sub4(img)
+        arrays[f'{tag}_image_crop'] = img[..., 224:288, 224:288]
+        arrays[f'{tag}_image_block_means'] = block_means(img)
+        arrays[f'{tag}_image_raw'] = out['image_raw']
+        arrays[f'{tag}_image_depth_sub2'] = out['image_depth'][..., ::2, ::2]
+    for k in frames:
+        jit = synthetic.jitter([k], nrr * nrr)
+        with injected_jitter(jit):
+            out = g.synthesis(ws1, synthetic.camera_labels([k]), {'uvcoords_image': synthetic.uv_conditions([k])},
+                              neural_rendering_resolution=nrr, noise_mode='const', evaluation=True)
+        record(f'f{k}', out)
+    jit = synthetic.jitter(frames, nrr * nrr)
+    with injected_jitter(jit):
+        out = g.synthesis(ws1.repeat(2, 1, 1), synthetic.camera_labels(frames), {'uvcoords_image': synthetic.uv_conditions(frames)},
+                          neural_rendering_resolution=nrr, noise_mode='const', evaluation=True)
+    record('b2', out)
+    npz('generator_full_nrr128.npz', **arrays)
+
+
+def import_reference_script(name):
+    """Import one of the reference's top-level scripts (reenact_avatar_next3d.py, eval_seq.py) for its helpers.  Modules the
+    scripts import at the top but the container lacks (imageio, torchvision.utils, the FaceVerse / pytorch3d renderer, the
+    dataset classes' cv2 use) are stubbed as empty modules: only pure-torch helpers are called."""
+    import importlib
+    for mod in ('imageio', 'torchvision.utils', 'data_preprocess', 'data_preprocess.FaceVerse', 'data_preprocess.FaceVerse.renderer'):
+        if mod not in sys.modules:
+            sys.modules[mod] = types.ModuleType(mod)
+    sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+    sys.modules['data_preprocess.FaceVerse.renderer'].Faceverse_manager = object
+    return importlib.import_module(name)
+
+
+def gen_harness():
+    """H1 (reenact_avatar_next3d.py:146-219) on the reduced-width generator: seeds -> z -> mapping(psi 0.7, cutoff 14) with the
+    script's conditioning camera -> per drive frame one synthesis per seed -> the script's own layout_grid (uint8 HWC mosaic
+    [target | seed 0 | seed 1]).  Also layout_grid alone on a seeded batch in every mode."""
+    R = import_reference_script('reenact_avatar_next3d')
+    from training_avatar_texture.camera_utils import LookAtPoseSampler, FOV_to_intrinsics
+    arrays = {}
+    x = rnd(77, 6, 3, 8, 12) * 1.2
+    arrays['grid_in'] = x
+    arrays['grid_3x2_hwc'] = R.layout_grid(x, grid_w=3, grid_h=2)
+    arrays['grid_6x1_chw'] = R.layout_grid(x, grid_w=None, grid_h=1, chw_to_hwc=False)
+    arrays['grid_1x6_hwc'] = R.layout_grid(x, grid_w=1, grid_h=6)
+    assert R.parse_range('1,2,5-7') == [1, 2, 5, 6, 7] and R.parse_tuple('4x2') == (4, 2) and R.parse_tuple('0,1') == (0, 1)
+    g = build_reference_generator('small')
+    seeds, frames, nrr, psi, cutoff = [0, 3], [5, 60], 32, 0.7, 14
+    g.neural_rendering_resolution = nrr
+    intr = FOV_to_intrinsics(18.837)
+    pose = LookAtPoseSampler.sample(np.pi / 2, np.pi / 2, torch.tensor(g.rendering_kwargs['avg_camera_pivot']), radius=g.rendering_kwargs['avg_camera_radius'])
+    cond = torch.cat([pose.reshape(-1, 16), intr.reshape(-1, 9)], 1)
+    ws = [g.mapping(torch.from_numpy(np.random.RandomState(sd).randn(1, g.z_dim)), cond, truncation_psi=psi, truncation_cutoff=cutoff)
+          for sd in seeds]
+    arrays.update(seeds=np.array(seeds), frames=np.array(frames), nrr=nrr, psi=psi, cutoff=cutoff, cond=cond, ws=torch.cat(ws))
+    mosaics = []
+    for k in frames:
+        imgs = [synthetic.source_frames(1000 + k, 1)[0]]
+        for w in ws:
+            with injected_jitter(synthetic.jitter([k], nrr * nrr)):
+                imgs.append(g.synthesis(w, synthetic.camera_labels([k]), {'uvcoords_image': synthetic.uv_conditions([k])}, noise_mode='const',
+                                        evaluation=True)['image'][0])
+        mosaics.append(R.layout_grid(torch.stack(imgs), grid_w=3, grid_h=1))
+    m = np.stack(mosaics)
+    arrays['mosaic_sub4'] = m[:, ::4, ::4]
+    arrays['mosaic_crop'] = m[:, 192:320, 512 + 192:512 + 320]
+    arrays['mosaic_sum'] = m.astype(np.int64).sum(axis=(1, 2))
+    npz('harness.npz', **arrays)
+
+
 @contextlib.contextmanager
 def fixed_randomness(jit, u_seed=99):
     """Pin both noise sources of the renderer: the stratified jitter (torch.rand_like, renderer.py:406) and the uniform
@@ -328,7 +412,7 @@ def gen_names():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='ops,camera,renderer,small,full,names,encoder')
+    ap.add_argument('--only', default='ops,camera,renderer,small,full,bench,harness,names,encoder')
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -340,6 +424,8 @@ def main():
         if 'renderer' in todo: gen_renderer()
         if 'small' in todo: gen_generator('small')
         if 'full' in todo: gen_generator('full')
+        if 'bench' in todo: gen_generator_bench()
+        if 'harness' in todo: gen_harness()
         if 'names' in todo: gen_names()
         if 'encoder' in todo: gen_encoder()
 

@@ -169,13 +169,16 @@ def test_split_fp16_form_is_an_fp32_convolution(transposed):
     ref = (torch.nn.functional.conv_transpose2d(xs, wt.double().transpose(0, 1), stride=2) if transposed
            else torch.nn.functional.conv2d(xs, wt.double(), padding=1))
     scale = ref.abs().max().item()
-    err = {}
+    err, rms = {}, {}
     for name, wk in (('f32', hipops.pack_conv_weight(wt)), ('split', hipops.pack_conv_weight_split(wt)), ('f16', hipops.pack_conv_weight_h(wt))):
         got = hipops.conv2d_mfma(x, wk, styles=s, ksize=3, transposed=transposed)
         err[name] = (got.double() - ref).abs().max().item() / scale
-    print(f'relative max error vs fp64: {err}')
+        rms[name] = (got.double() - ref).square().mean().sqrt().item() / scale
+    print(f'relative max error vs fp64: {err}; rms: {rms}')
     assert err['f32'] <= 2e-6
-    assert err['split'] <= 3 * max(err['f32'], 3e-7)
+    # the pair form keeps 22 operand bits and rounds once per 16-deep MFMA instead of once per product, so it is
+    # at least as accurate as the fp32 MFMA chain, in the maximum and in the mean
+    assert err['split'] <= err['f32'] and rms['split'] <= rms['f32']
     assert err['f16'] >= 20 * err['split']
 
 

@@ -67,3 +67,12 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
     d_all = frame_parallel.global_ray_dist(c).item()
     d_half = frame_parallel.global_ray_dist(c[:2]).item()
     assert abs(d_all - d_half) > 1e-2
+
+
+def test_fewer_frames_than_ranks_is_refused_on_every_rank():
+    import pytest
+    from invertavatar_amd import frame_parallel
+    c = synthetic.camera_labels([0, 1])
+    for rank in range(4):
+        with pytest.raises(ValueError, match='cannot be sharded'):
+            frame_parallel.render_sharded(None, None, c, {'uvcoords_image': None}, rank=rank, world_size=4)

@@ -70,3 +70,25 @@ def test_cpu_synthesis_matches_reference(golden, small_generator):
         out = g.synthesis_withTexture(ws, tex, c, {'uvcoords_image': uv}, static_feats=sta, neural_rendering_resolution=nrr,
                                       noise_mode='const', evaluation=True, jitter=jit)
     assert max_abs(out['image'][..., ::4, ::4], gld['image_withtexture_sub4']) <= 1e-4
+
+
+def test_generator_copies_and_pickles_after_a_forward_pass(small_generator):
+    """copy.deepcopy / pickle / torch.save of a generator that has already rendered (the calls the reference's scripts make,
+    reenact_avatar_next3d.py:158): orchestration state lives outside the module, so only parameters and buffers travel."""
+    import copy, io, pickle
+    g = small_generator
+    frames, nrr = [3], 32
+    with torch.no_grad():
+        ws = g.mapping(synthetic.latent(0, 1), synthetic.conditioning_camera(), truncation_psi=0.7, truncation_cutoff=14)
+        args = (ws, synthetic.camera_labels(frames), {'uvcoords_image': synthetic.uv_conditions(frames)})
+        kw = dict(neural_rendering_resolution=nrr, noise_mode='const', evaluation=True, jitter=synthetic.jitter(frames, nrr * nrr))
+        ref = g.synthesis(*args, **kw)['image']
+        g2 = copy.deepcopy(g)
+        g3 = pickle.loads(pickle.dumps(g))
+        buf = io.BytesIO()
+        torch.save(g, buf)
+        buf.seek(0)
+        g4 = torch.load(buf, weights_only=False)
+        for other in (g2, g3, g4):
+            assert torch.equal(other.synthesis(*args, **kw)['image'], ref)
+    assert not any(k.startswith('_') and 'stream' in k for k in vars(g))

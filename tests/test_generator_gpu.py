@@ -65,10 +65,10 @@ def test_small_generator_train_mode_and_with_texture(golden, small):
     assert max_abs(out['image'].cpu()[..., ::4, ::4], gld['image_withtexture_sub4']) <= TOL_RGB
 
 
-def test_full_width_generator_vs_reference(golden):
+def test_full_width_generator_vs_reference(golden, full):
     """BASELINE model (88.3 M parameters) at 64^2 neural render against the reference's CPU output."""
     gld = golden('generator_full.npz')
-    g = _build('full')
+    g = full
     ws, c, uv, jit, nrr = _inputs(gld)
     with torch.no_grad():
         out = g.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=nrr, noise_mode='const', evaluation=True,
@@ -79,6 +79,49 @@ def test_full_width_generator_vs_reference(golden):
     print(f'full generator max|dRGB| = {err:.2e}')
     assert err <= TOL_RGB
     assert abs(out['image'].abs().mean().item() - gld['image_mean_abs']) <= 1e-4
+
+
+@pytest.fixture(scope='module')
+def full():
+    return _build('full')
+
+
+def _check_bench_frame(out, gld, tag, sl=slice(None)):
+    img = out['image'][sl].cpu()
+    errs = dict(sub4=max_abs(img[..., ::4, ::4], gld[f'{tag}_image_sub4'][sl]), crop=max_abs(img[..., 224:288, 224:288], gld[f'{tag}_image_crop'][sl]),
+                blocks=max_abs(torch.nn.functional.avg_pool2d(img.double(), 32).float(), gld[f'{tag}_image_block_means'][sl]),
+                raw=max_abs(out['image_raw'][sl].cpu(), gld[f'{tag}_image_raw'][sl]),
+                depth=max_abs(out['image_depth'][sl].cpu()[..., ::2, ::2], gld[f'{tag}_image_depth_sub2'][sl]))
+    print(f'{tag}: max|d| vs reference at nrr 128: {errs}')
+    assert errs['sub4'] <= TOL_RGB and errs['crop'] <= TOL_RGB and errs['raw'] <= TOL_RGB
+    assert errs['blocks'] <= 1e-4          # every 32x32 block of the full 512^2 image (position-sensitive checksum)
+    assert errs['depth'] <= 1e-3
+    return errs
+
+
+def test_bench_configuration_vs_reference(golden, full):
+    """The configuration bench.py times (BASELINE configs[1]: full width, nrr = 128, 512^2 out, B = 1) against outputs of the
+    reference generated by tests/golden/make_golden.py:gen_generator_bench: sub-sampled image, full-resolution crop, block
+    means of the whole image, raw render and depth."""
+    gld = golden('generator_full_nrr128.npz')
+    nrr, ws = gld['nrr'], gld['ws'].cuda()
+    for k in gld['frames'].tolist():
+        with torch.no_grad():
+            out = full.synthesis(ws, synthetic.camera_labels([k]).cuda(), {'uvcoords_image': synthetic.uv_conditions([k]).cuda()},
+                                 neural_rendering_resolution=nrr, noise_mode='const', evaluation=True,
+                                 jitter=synthetic.jitter([k], nrr * nrr).cuda())
+        _check_bench_frame(out, gld, f'f{k}')
+
+
+def test_bench_configuration_batched_vs_reference(golden, full):
+    """B = 2 in one call at the bench configuration: the batch-global `dist` (renderer.py:311) couples the frames."""
+    gld = golden('generator_full_nrr128.npz')
+    nrr, frames = gld['nrr'], gld['frames'].tolist()
+    with torch.no_grad():
+        out = full.synthesis(gld['ws'].cuda().repeat(2, 1, 1), synthetic.camera_labels(frames).cuda(),
+                             {'uvcoords_image': synthetic.uv_conditions(frames).cuda()}, neural_rendering_resolution=nrr,
+                             noise_mode='const', evaluation=True, jitter=synthetic.jitter(frames, nrr * nrr).cuda())
+    _check_bench_frame(out, gld, 'b2')
 
 
 TOL_RGB_FP16_SR = 2e-2   # fp16 operands (11-bit mantissa) in the 6 SR convolutions; the reference's own fp16 path also stores fp16

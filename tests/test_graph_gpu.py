@@ -91,3 +91,46 @@ def test_back_to_back_frames_do_not_interfere():
         got.append((i, graphed(ws, cams[i:i + 1], uvs[i:i + 1], jits[i:i + 1])['image'].clone()))
     torch.cuda.synchronize()
     assert sum(int(not torch.equal(a, want[i])) for i, a in got) == 0
+
+
+def test_generator_copies_and_pickles_after_a_device_forward_pass():
+    """streams / per-frame tensors must not live in the module: deepcopy, pickle and torch.save of a generator that
+    has rendered on the device work and the copies render the same bits."""
+    import copy, io, pickle
+    g = TriPlaneGenerator(**synthetic.generator_kwargs('small')).eval().requires_grad_(False)
+    synthetic.fill_parameters(g)
+    g = g.cuda()
+    frames, nrr = [3], 32
+    with torch.no_grad():
+        ws = g.mapping(synthetic.latent(0, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14)
+        args = (ws, synthetic.camera_labels(frames).cuda(), {'uvcoords_image': synthetic.uv_conditions(frames).cuda()})
+        kw = dict(neural_rendering_resolution=nrr, noise_mode='const', evaluation=True, jitter=synthetic.jitter(frames, nrr * nrr).cuda())
+        ref = g.synthesis(*args, **kw)['image']
+        buf = io.BytesIO()
+        torch.save(g, buf)
+        buf.seek(0)
+        for other in (copy.deepcopy(g), pickle.loads(pickle.dumps(g)), torch.load(buf, weights_only=False)):
+            assert torch.equal(other.synthesis(*args, **kw)['image'], ref)
+
+
+def test_config4_shard_of_eight_frames_full_width():
+    """BASELINE configs[3] as one rank sees it: 8 full-width frames in ONE synthesis call (batch-global `dist` passed in) against
+    the same 8 frames rendered one per call with that `dist`; and the captured graph of the 8-frame call against the eager call
+    (bit for bit).  Between batch sizes the stream-K split of the convolutions differs (ia_conv2d_plan depends on B), so the
+    frames agree to fp32 summation-order level, not bitwise."""
+    from invertavatar_amd import frame_parallel
+    nrr, frames = 128, list(range(16, 24))
+    g, ws, cams, uvs, jits, _ = _setup('full', nrr, frames)
+    dist = frame_parallel.global_ray_dist(synthetic.camera_labels(list(range(64))).cuda())     # of a B = 64 batch
+    with torch.no_grad():
+        call = lambda sl: g.synthesis(ws, cams[sl], {'uvcoords_image': uvs[sl]}, neural_rendering_resolution=nrr, noise_mode='const',   # noqa: E731
+                                      evaluation=True, jitter=jits[sl], ray_dist=dist)['image']
+        batched = call(slice(0, 8)).clone()
+        for i in range(8):
+            single = call(slice(i, i + 1))
+            assert (batched[i:i + 1] - single).abs().max().item() <= 2e-5, i
+        graphed = GraphedSynthesis(g, batch=8, neural_rendering_resolution=nrr, with_ray_dist=True)
+        replay = graphed(ws, cams, uvs, jits, dist)['image'].clone()
+        assert torch.equal(replay, batched)
+        replay2 = graphed(ws, cams.flip(0), uvs.flip(0), jits.flip(0), dist)['image']
+        assert torch.equal(replay2, call(slice(0, 8)).flip(0)) or (replay2 - batched.flip(0)).abs().max().item() <= 2e-5

@@ -188,3 +188,21 @@ def test_generator_small_trainmode_and_withtexture(golden, small_state):
     sta = OG.synthesis_network(OG.sub(small_state, 'backbone.synthesis'), ws, return_list=True)
     out = OG.synthesis(small_state, ws, c, uv, jit, nrr=nrr, texture_feats=tex, static_feats=sta)
     assert max_abs(out['image'][..., ::4, ::4], g['image_withtexture_sub4']) <= 1e-4
+
+
+def test_oracle_at_the_bench_configuration(golden):
+    """The oracle at BASELINE configs[1] (full width, nrr = 128, 512^2 out) against the reference's output for one frame: this is
+    the checker bench.py's max_abs_rgb_vs_oracle is measured against."""
+    from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+    gld = golden('generator_full_nrr128.npz')
+    k, nrr = gld['frames'].tolist()[0], gld['nrr']
+    gen = TriPlaneGenerator(**synthetic.generator_kwargs('full'))
+    sd = synthetic.fill_parameters({n: t.detach() for n, t in gen.state_dict().items()})
+    del gen
+    with torch.no_grad():
+        out = OG.synthesis(sd, gld['ws'], synthetic.camera_labels([k]), synthetic.uv_conditions([k]), synthetic.jitter([k], nrr * nrr), nrr=nrr)
+    img = out['image']
+    assert max_abs(img[..., ::4, ::4], gld[f'f{k}_image_sub4']) <= 1e-4
+    assert max_abs(img[..., 224:288, 224:288], gld[f'f{k}_image_crop']) <= 1e-4
+    assert max_abs(out['image_raw'], gld[f'f{k}_image_raw']) <= 1e-4
+    assert max_abs(torch.nn.functional.avg_pool2d(img.double(), 32).float(), gld[f'f{k}_image_block_means']) <= 1e-5
