@@ -95,7 +95,7 @@ class Workload:
             self.dists.append(frame_parallel.global_ray_dist(cams_all))          # batch-global, from the FULL camera batch
 
     def eager(self, gen, s):
-        return gen.synthesis(self.ws, self.cams[s], {'uvcoords_image': self.uvs[s]}, neural_rendering_resolution=NRR, noise_mode='const',
+        return gen.synthesis(self.ws.expand(self.per_rank, -1, -1), self.cams[s], {'uvcoords_image': self.uvs[s]}, neural_rendering_resolution=NRR, noise_mode='const',
                              evaluation=True, jitter=self.jits[s], ray_dist=self.dists[s] if self.world > 1 else None)
 
     def replay(self, graphed, s):
@@ -325,6 +325,43 @@ def drive_loop_leg(gen, wl, args):
                 max_abs_rgb_vs_full_synthesis=float(f'{err:.3e}'))
 
 
+def extra_legs(result, gen, wl, args):
+    """Variants reported beside the headline (never as `value`); a failing variant is recorded, it does not lose the headline."""
+    def guarded(name, fn):
+        try:
+            result[name] = fn()
+        except Exception as exc:   # noqa: BLE001
+            result[name] = f'failed: {type(exc).__name__}: {exc}'
+    headline_img = wl.eager(gen, 0)['image'].clone()
+
+    def f32_only():
+        r, img = variant_leg(gen, wl, args, SPLIT_FP16_PRODUCTS=False)
+        r['max_abs_rgb_vs_headline_run'] = float(f'{(img - headline_img).abs().max().item():.3e}')
+        return r
+
+    def sr_fp16():
+        gen16 = sr_fp16_generator(gen, args.width)
+        r, img = variant_leg(gen16, wl, args, FP16_BLOCKS_COMPUTE_FP32=False)
+        r.update(dtype='f32 backbones + renderer, SR head: fp16 operands / f32 accumulate',
+                 max_abs_rgb_vs_f32_run=float(f'{(img - headline_img).abs().max().item():.3e}'))
+        return r
+
+    def batch8():
+        wl8 = Workload(gen, FRAMES_PER_RANK_SHARDED, 0, 1, n_sets=2)
+        r, _ = variant_leg(gen, wl8, args, batch=FRAMES_PER_RANK_SHARDED)
+        r['workload'] = 'one rank\'s share of BASELINE configs[3]: 8 frames per synthesis call on one GPU'
+        return r
+
+    def encoder():
+        from invertavatar_amd.encoder_bench import encoder_leg
+        return encoder_leg(gen)
+    guarded('f32_mfma_only', f32_only)
+    guarded('sr_fp16', sr_fp16)
+    guarded('drive_loop', lambda: drive_loop_leg(gen, wl, args))
+    guarded('batch8', batch8)
+    guarded('encoder', encoder)
+
+
 def sr_fp16_generator(gen, width):
     gen16 = TriPlaneGenerator(**synthetic.generator_kwargs(width, sr_num_fp16_res=4)).eval().requires_grad_(False)
     gen16.load_state_dict(gen.state_dict())
@@ -418,23 +455,7 @@ def main():
             el = time.perf_counter() - t_s
             result['sustained'] = dict(value=round(n / el, 3), unit='frames/s', steps=n, seconds=round(el, 2))
             if not args.no_extra:
-                result['f32_mfma_only'], img32 = variant_leg(gen, wl, args, SPLIT_FP16_PRODUCTS=False)
-                result['f32_mfma_only']['max_abs_rgb_vs_headline_run'] = float(f"{(img32 - wl.eager(gen, 0)['image']).abs().max().item():.3e}")
-                gen16 = sr_fp16_generator(gen, args.width)
-                result['sr_fp16'], img16 = variant_leg(gen16, wl, args, FP16_BLOCKS_COMPUTE_FP32=False)
-                result['sr_fp16'].update(dtype='f32 backbones + renderer, SR head: fp16 operands / f32 accumulate',
-                                         max_abs_rgb_vs_f32_run=float(f"{(img16 - wl.eager(gen, 0)['image']).abs().max().item():.3e}"))
-                del gen16
-                result['drive_loop'] = drive_loop_leg(gen, wl, args)
-                wl8 = Workload(gen, FRAMES_PER_RANK_SHARDED, 0, 1, n_sets=2)
-                result['batch8'], _ = variant_leg(gen, wl8, args, batch=FRAMES_PER_RANK_SHARDED)
-                result['batch8']['workload'] = 'one rank\'s share of BASELINE configs[3]: 8 frames per synthesis call on one GPU'
-                del wl8
-                try:
-                    from invertavatar_amd.encoder_bench import encoder_leg
-                    result['encoder'] = encoder_leg(gen)
-                except Exception as exc:   # noqa: BLE001
-                    result['encoder'] = f'failed: {type(exc).__name__}: {exc}'
+                extra_legs(result, gen, wl, args)
             if not args.no_roofline:
                 result['roofline'], result['kernels'] = roofline_leg(gen, wl)
             if not args.no_cpu_baseline:

@@ -285,6 +285,30 @@ int ia_styles_demod(const float* ws, int B, int num_ws, int w_dim, const int64_t
 int ia_ray_sampler(const float* cam, int cam_stride, float* rays_o, float* rays_d, int B, int resolution, int normalize, void* stream);
 
 /*
+ * Activations as fp16 hi/lo pairs ("split format"), the input of ia_conv2d_mfma_sx:
+ *     xs[b][plane][c/8][y][x][c%8]   fp16, plane 0 = hi = fp16(v), plane 1 = lo = fp16((v - hi) * 2^11),  v = x[b,c,y,x] * styles[b,c]
+ * (v saturates at +-65504; |v| < 2^-14 rides entirely in the low plane: the MFMA flushes fp16 denormals).  4 bytes per element,
+ * the size of the fp32 tensor; hi + lo * 2^-11 carries 22 mantissa bits.  C % 8 == 0.  styles [B,C] or NULL (= 1).
+ * ia_act_split is the stand-alone producer; ia_fir_tail_split and ia_conv2d_mfma_sx emit the format from their epilogues.
+ */
+int ia_act_split(const float* x, const float* styles, void* xs, int B, int C, int H, int W, void* stream);
+
+/*
+ * ia_conv2d_mfma_s on split-format activations: same layer semantics, tiles, ksplit / scratch (ia_conv2d_plan with form = 2) and
+ * bit-identical results, but the operand split was done by the producer and both operands reach LDS by DMA
+ * (buffer_load ... lds) instead of through registers.  Replaces the same reference chain as ia_conv2d_mfma
+ * (training/networks_stylegan2.py:34-91, conv2d_resample.py:114-136) for the 3x3 layers of >= 32^2 (I % 8 == 0, O % 8 == 0).
+ *   xs          : input in split format, already multiplied by THIS layer's styles (there is no `styles` argument)
+ *   y           : [B,O,OH,OW] fp32 or NULL (stride-1 form only: a layer whose result is consumed only in split format)
+ *   ys          : the result in split format, multiplied by styles_next [B,O] (the styles of the consuming layer; NULL = 1), or
+ *                 NULL; stride-1 form only (the transposed form's (2H+1)^2 image goes through ia_fir_tail_split)
+ */
+int ia_conv2d_mfma_sx(const void* xs, const void* wk_split, int wk_exp, const float* demod, const float* noise,
+                      const float* noise_strength, const float* bias, const float* residual, float* y, void* ys,
+                      const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
+                      int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream);
+
+/*
  * Output side: float image batch -> uint8 picture grid, one pass.
  * Replaces layout_grid(img, grid_w, grid_h, float_to_uint8=True, chw_to_hwc) of the reference's scripts
  * (reenact_avatar_next3d.py:117-131): (img * 127.5 + 128).clamp(0, 255).to(uint8), frames tiled row-major into a

@@ -33,168 +33,9 @@
 // this parallel fix-up for every layer of the model.  This balances layers whose tile count is not a multiple of the
 // machine (e.g. the (H+1)x(W+1) point grids of the transposed form: 524 equal workgroups on 512 slots ran as two rounds)
 // and gives low-resolution layers, which have only a handful of tiles, a fine-grained K split.
-#include "ia_common.h"
-#include <type_traits>
+#include "conv_common.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int kPatchFloats = 1024;  // per-channel LDS patch capacity (floats)
-// The low parts of the activations' hi/lo fp16 split are scaled by 2^11 so that they are normal fp16 numbers (the MFMA
-// flushes fp16 denormals); the weight's high part is multiplied by 2^-11 where it meets one (see HM = 2 below).
-constexpr float kLoScale = 2048.f;
-// fp16 forms: one k-step of v_mfma_f32_32x32x16_f16 = 8 channels of TWO taps (lanes 0-31 carry the first tap of the pair,
-// lanes 32-63 the second).  The nine taps make five pairs; the odd tap out pairs with an all-zero tap (index 9).  In the
-// transposed form both taps of a pair must feed the same output phase: phase 0 owns taps {0,2,6,8}, phase 1 {1,7},
-// phase 2 {3,5}, phase 3 {4}.
-constexpr int kPairs = 5, kZeroTap = 9;
-__host__ __device__ constexpr int pair_t0(bool tr, int s) { return tr ? (s == 0 ? 0 : s == 1 ? 6 : s == 2 ? 1 : s == 3 ? 3 : 4) : 2 * s; }
-__host__ __device__ constexpr int pair_t1(bool tr, int s) { return tr ? (s == 0 ? 2 : s == 1 ? 8 : s == 2 ? 7 : s == 3 ? 5 : kZeroTap) : (s == 4 ? kZeroTap : 2 * s + 1); }
-__host__ __device__ constexpr int pair_phase(bool tr, int s) { return tr ? (s < 2 ? 0 : s - 1) : 0; }
-
-struct Geo {
-    int B, I, O, H, W;     // input
-    int GH, GW;            // point grid: conv H x W, transposed (H+1) x (W+1)
-    int OH, OW;            // output image
-    int G;                 // stream-K workers per batch element (0: none)
-    int C;                 // K chunks per tile
-    int TO, T;             // out-channel tiles, tiles in total (point tiles x out-channel tiles)
-    int T_dp;              // tiles [0, T_dp) run one per workgroup, tiles [T_dp, T) are stream-K
-    int patch_cap;         // floats per channel reserved for the patch in LDS
-    float acc_scale;       // fp16-pair form: 2^-wk_exp, takes the accumulators back from the scale of the packed weights
-};
-
-// unit range of worker w: [range_begin(w), range_begin(w+1)) over U = (T - T_dp)*C units
-__host__ __device__ inline int64_t range_begin(int w, int64_t U, int G) { return ((int64_t)w * U) / G; }
-
-struct Epi {
-    const float* demod;           // [B,O] or null
-    const float* noise;           // [OH*OW] or null
-    const float* noise_strength;  // device scalar (may be null => 1)
-    const float* bias;            // [O] or null
-    const float* residual;        // [B,O,OH,OW] or null, added after the clamp
-    int act;                      // IA_ACT_LINEAR or IA_ACT_LRELU
-    float alpha, gain, clamp;
-};
-
-// Input window of one tile (a contiguous range [p0, p_last] of the row-major point grid), as one or two row
-// segments that share a row stride PW.  Three shapes:
-//   single : the tile lies in one grid row            -> rows x (its columns + halo)
-//   split  : two grid rows of a WIDE image            -> segment 0 = tail of the first row, segment 1 = head of the second
-//   full   : anything else (narrow images, >= 3 rows) -> all needed rows x full width
-// Halo: stride-1 conv reads (r + ky - PAD, c + kx - PAD); the transposed form reads (r - ky/2, c - kx/2).
-struct Window {
-    int r0[2], nr[2], c0[2];   // first input row, row count, first input column of each segment
-    int PW, PSZ;               // shared row stride, floats per channel
-};
-
-__host__ __device__ inline Window tile_window(int p0, int p_last, int GW, int pad, bool tr) {
-    const int up = tr ? 1 : pad, dn = tr ? 0 : pad, lf = tr ? 1 : pad, rt = tr ? 0 : pad;
-    const int r_first = p0 / GW, r_last = p_last / GW;
-    const int c_first = p0 - r_first * GW, c_last = p_last - r_last * GW;
-    const int nrows = up + dn + 1;
-    Window w;
-    w.nr[1] = 0; w.r0[1] = 0; w.c0[1] = 0;
-    if (r_first == r_last) {
-        w.r0[0] = r_first - up; w.nr[0] = nrows; w.c0[0] = c_first - lf; w.PW = (c_last + rt) - w.c0[0] + 1;
-    } else {
-        const int w0 = (GW - 1 + rt) - (c_first - lf) + 1, w1 = (c_last + rt) - (0 - lf) + 1;
-        const int pw_split = w0 > w1 ? w0 : w1, pw_full = GW + lf + rt;
-        const int sz_split = 2 * nrows * pw_split, sz_full = (r_last - r_first + nrows) * pw_full;
-        if (r_last == r_first + 1 && sz_split < sz_full) {
-            w.r0[0] = r_first - up; w.nr[0] = nrows; w.c0[0] = c_first - lf;
-            w.r0[1] = r_last - up;  w.nr[1] = nrows; w.c0[1] = -lf;
-            w.PW = pw_split;
-        } else {
-            w.r0[0] = r_first - up; w.nr[0] = r_last - r_first + nrows; w.c0[0] = -lf; w.PW = pw_full;
-        }
-    }
-    w.PSZ = (w.nr[0] + w.nr[1]) * w.PW;
-    return w;
-}
-
-__device__ __forceinline__ float epilogue(float v, int b, int o, int64_t pix, int64_t ohw, const Geo& g, const Epi& e, float ns) {
-    if (e.demod) v *= e.demod[b * g.O + o];
-    if (e.noise) v = fmaf(e.noise[pix], ns, v);
-    if (e.bias) v += e.bias[o];
-    if (e.act == IA_ACT_LRELU) v = v > 0.f ? v : v * e.alpha;
-    v *= e.gain;
-    if (e.clamp >= 0.f) v = fminf(fmaxf(v, -e.clamp), e.clamp);
-    if (e.residual) v += e.residual[((int64_t)b * g.O + o) * ohw + pix];
-    return v;
-}
-
-// DB (two LDS stages) is used by the transposed 64ch x 64pt x 4-phase tile, which does a quarter of the MFMAs of the conv tile
-// per staged chunk, and by the 8-wave 128ch x 256pt tile, which is alone on its CU: one barrier per chunk, the next chunk is
-// committed to the other stage at the top of an iteration, and the loads of the chunk after that are spread over the MFMA
-// steps.  DB kernels require 16-byte aligned weight rows (O % 4 == 0); the host falls back to the single-stage form otherwise.
-__host__ __device__ constexpr bool db_family(bool tr, int fo, int fp, int wo, int wp) { return (tr && wo == 2) || wo * wp == 8; }
-
-// Accumulator tile -> global memory.  C/D map of the 32x32 MFMA: row(channel) = (r&3) + 8*(r>>2) + 4*half, col(point) = l31.
-template <bool TR, int FO, int FP, int WO, int WP>
-__device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][FP], float* __restrict__ y, const Geo& g, const Epi& e,
-                                           int b, int o0, int p0, int tid) {
-    constexpr int NPH = TR ? 4 : 1;
-    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int wo = wave / WP, wp = wave % WP;
-    const int npts = g.GH * g.GW;
-    const int64_t ohw = (int64_t)g.OH * g.OW;
-    const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
-    float* yb = y + ((int64_t)b * g.O) * ohw;
-#pragma unroll
-    for (int fp = 0; fp < FP; ++fp) {
-        const int p = p0 + (wp * FP + fp) * 32 + l31;
-        if (p >= npts) continue;
-        const int pr = p / g.GW, pc = p - pr * g.GW;
-        if constexpr (TR) {
-            // the two horizontal phases of a point are adjacent output pixels: one 8-byte store per (row phase, channel), so
-            // that a half-wave writes 64 consecutive floats instead of every other one twice
-            const int ox = 2 * pc;
-#pragma unroll
-            for (int py = 0; py < 2; ++py) {
-                const int oy = 2 * pr + py;
-                if (oy >= g.OH) continue;
-                const int64_t pix = (int64_t)oy * g.OW + ox;
-                const bool pair = ox + 1 < g.OW;
-#pragma unroll
-                for (int fo = 0; fo < FO; ++fo)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (o >= g.O) continue;
-                        float* dst = yb + (int64_t)o * ohw + pix;
-                        const float v0 = epilogue(acc[2 * py][fo][fp][r], b, o, pix, ohw, g, e, ns);
-                        if (pair) {
-                            const float v1 = epilogue(acc[2 * py + 1][fo][fp][r], b, o, pix + 1, ohw, g, e, ns);
-                            __builtin_memcpy(dst, &(const float2&)make_float2(v0, v1), 8);     // (rows of odd width: 4-byte aligned only)
-                        } else dst[0] = v0;
-                    }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int ph = 0; ph < NPH; ++ph) {
-            int64_t pix;
-            if (TR) {
-                const int oy = 2 * pr + (ph >> 1), ox = 2 * pc + (ph & 1);
-                if (oy >= g.OH || ox >= g.OW) continue;
-                pix = (int64_t)oy * g.OW + ox;
-            } else pix = p;
-#pragma unroll
-            for (int fo = 0; fo < FO; ++fo)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (o >= g.O) continue;
-                    yb[(int64_t)o * ohw + pix] = epilogue(acc[ph][fo][fp][r], b, o, pix, ohw, g, e, ns);
-                }
-        }
-    }
-}
 
 // FO x FP fragments (32 channels x 32 points each) per wave, WO x WP waves per workgroup, CC in-channels per K chunk,
 // NPOS patch positions staged per thread (>= ceil(worst PSZ / threads), chosen by the host).
@@ -541,87 +382,6 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_mfma_
   }   // segments of this worker
 }
 
-// Fix-up: stream-K tiles that were split between workers.  grid = (stream-K tile, batch, accumulator quad): a workgroup adds one
-// register quad (float4; a pair of them in the transposed form) of every thread position over the tile's slabs in worker order and stores it through the epilogue.
-// Loads of up to kFixBatch workers are in flight together (the adds keep the worker order).
-constexpr int kFixBatch = 8;
-template <bool TR, int FO, int FP, int WO, int WP>
-__global__ __launch_bounds__(WO * WP * 64) void conv_fixup_kernel(const float* __restrict__ slabs, float* __restrict__ y, Geo g, Epi e) {
-    constexpr int NPH = TR ? 4 : 1;
-    constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NTHREADS = WO * WP * 64;
-    constexpr int NACC = NPH * FO * FP * 16;
-    // (transposed form: blockIdx.z enumerates quads of ROW phases; the thread sums the quads of both horizontal phases and
-    // stores them as 8-byte pairs of adjacent output pixels, like store_tile)
-    constexpr int NQ = TR ? 2 : 1;
-    const int tile_l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int zq = blockIdx.z, rq = zq & 3, frp = zq >> 2, fp = frp % FP, fo = (frp / FP) % FO, pyh = frp / (FP * FO);
-    int q[NQ];
-#pragma unroll
-    for (int h = 0; h < NQ; ++h) q[h] = ((((TR ? 2 * pyh + h : 0) * FO + fo) * FP + fp) << 2) + rq;
-    const int64_t U = (int64_t)(g.T - g.T_dp) * g.C, t_begin = (int64_t)tile_l * g.C, t_end = t_begin + g.C;
-    int w_first = (int)((t_begin * g.G) / U);
-    while (w_first > 0 && range_begin(w_first, U, g.G) > t_begin) --w_first;
-    while (range_begin(w_first + 1, U, g.G) <= t_begin) ++w_first;
-    int w_last = w_first;
-    while (range_begin(w_last + 1, U, g.G) < t_end) ++w_last;
-    if (w_first == w_last) return;                       // the tile was finished by a single worker
-    const int64_t slab4 = (int64_t)NACC * NTHREADS / 4;
-    const float4* base = reinterpret_cast<const float4*>(slabs) + ((int64_t)b * g.G) * 2 * slab4 + tid;
-    // only the first worker can hold this tile in its trailing slot (1); every later worker starts inside the tile (slot 0)
-    const int slot_first = (tile_l == (int)(range_begin(w_first, U, g.G) / g.C)) ? 0 : 1;
-    constexpr int FB = kFixBatch / NQ;
-    float4 acc[NQ];
-#pragma unroll
-    for (int h = 0; h < NQ; ++h) acc[h] = base[((int64_t)w_first * 2 + slot_first) * slab4 + (int64_t)q[h] * NTHREADS];
-    for (int w = w_first + 1; w <= w_last; w += FB) {
-        float4 v[FB][NQ];
-#pragma unroll
-        for (int j = 0; j < FB; ++j)
-#pragma unroll
-            for (int h = 0; h < NQ; ++h) v[j][h] = base[((int64_t)min(w + j, w_last) * 2) * slab4 + (int64_t)q[h] * NTHREADS];
-#pragma unroll
-        for (int j = 0; j < FB; ++j)
-            if (w + j <= w_last) {
-#pragma unroll
-                for (int h = 0; h < NQ; ++h) { acc[h].x += v[j][h].x; acc[h].y += v[j][h].y; acc[h].z += v[j][h].z; acc[h].w += v[j][h].w; }
-            }
-    }
-    // decode (register index, thread) -> (channel, point) exactly as the MFMA kernel lays its accumulators out
-    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int wo = wave / WP, wp = wave % WP;
-    const int tile = g.T_dp + tile_l;
-    const int o0 = (tile % g.TO) * BO, p0 = (tile / g.TO) * BP;
-    const int npts = g.GH * g.GW;
-    const int64_t ohw = (int64_t)g.OH * g.OW;
-    const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
-    float* yb = y + ((int64_t)b * g.O) * ohw;
-    const int p = p0 + (wp * FP + fp) * 32 + l31;
-    if (p >= npts) return;
-    const int pr = p / g.GW, pc = p - pr * g.GW;
-    int64_t pix = p;
-    bool pair = false;
-    if (TR) {
-        const int oy = 2 * pr + pyh, ox = 2 * pc;
-        if (oy >= g.OH) return;
-        pix = (int64_t)oy * g.OW + ox;
-        pair = ox + 1 < g.OW;
-    }
-    const float v0[4] = {acc[0].x, acc[0].y, acc[0].z, acc[0].w};
-    const float v1[4] = {acc[NQ - 1].x, acc[NQ - 1].y, acc[NQ - 1].z, acc[NQ - 1].w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = rq * 4 + k;
-        const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o >= g.O) continue;
-        float* dst = yb + (int64_t)o * ohw + pix;
-        const float a0 = epilogue(v0[k], b, o, pix, ohw, g, e, ns);
-        if (TR && pair) {
-            const float a1 = epilogue(v1[k], b, o, pix + 1, ohw, g, e, ns);
-            __builtin_memcpy(dst, &(const float2&)make_float2(a0, a1), 8);
-        } else dst[0] = a0;
-    }
-}
-
 template <int KS, bool TR, int FO, int FP, int WO, int WP, int CC, int NPOS, bool DB, int HM = 0>
 int launch_npos(const float* x, const float* wk, const float* styles, float* y, float* scratch, const Geo& g_in, const Epi& e,
                 int worst, hipStream_t s) {
@@ -759,6 +519,14 @@ static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transpos
     return p;
 }
 
+// Tile plan of a layer for the sibling translation unit (conv_split.hip): same tiles, worker counts and slab sizes for both forms.
+int ia_conv2d_plan_tiles(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int* bo, int* bp, int* waves, int* T, int* TO,
+                         int* C, int* T_dp, int* slab_floats) {
+    const Plan p = make_plan(B, I, O, H, W, ksize, transposed, form);
+    *bo = p.bo; *bp = p.bp; *waves = p.waves; *T = p.T; *TO = p.TO; *C = p.C; *T_dp = p.T_dp; *slab_floats = p.slab_floats;
+    return IA_OK;
+}
+
 static size_t scratch_bytes_for(int B, int G, int slab_floats) { return (size_t)B * G * 2 * slab_floats * sizeof(float); }
 
 extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int* h_ksplit,
@@ -804,7 +572,7 @@ static int conv2d_entry(const float* x, const void* wk_any, const float* styles,
     }
     g.patch_cap = 0;
     g.acc_scale = ldexpf(1.f, -wk_exp);
-    Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp};
+    Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
     if (half_ops) {
         const bool wide = p.waves == 8;

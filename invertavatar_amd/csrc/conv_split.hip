@@ -1,0 +1,374 @@
+// ia_conv2d_mfma_sx / ia_act_split: the large 3x3 convolutions of the StyleGAN2 stack on activations that are ALREADY stored as
+// fp16 hi/lo pairs, with both operands DMA'd straight into LDS.
+//
+// Same arithmetic as ia_conv2d_mfma_s (conv_mfma.hip, HM = 2): every fp32 product a*b is taken as
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation, a = packed weights (hi, lo of w * 2^e),
+// b = style-scaled activation (hi, lo * 2^11); the results are bit-identical to that path.  What differs is where the split
+// happens and how the operands reach LDS:
+//
+//   * the PRODUCER of an activation (the FIR tail of an up-sampling layer, the epilogue of the previous convolution, or the
+//     stand-alone ia_act_split) multiplies it by the consumer's style and stores the pair as two planes of 8-channel, 16-byte
+//     units:  xs[b][plane][c/8][y][x][c%8]  (4 bytes per element, the size of the fp32 tensor it replaces).  The consumer's
+//     staging then needs no arithmetic at all;
+//   * both operands are fetched with buffer_load_dwordx4 ... lds (LDS-DMA): no staging registers, no VALU conversion, no
+//     ds_write -- in the register-staged kernel those cost as much time as the MFMAs (DESIGN.md 6.1 ablation).  Zero padding
+//     comes from the buffer bounds check (out-of-range lanes write zeros to LDS).  Two LDS stages: the DMA of chunk k+1 is in
+//     flight while chunk k is multiplied; one barrier per chunk.
+//
+// Tiles, the tile window, stream-K scheduling, slabs and the fix-up kernel are those of conv_mfma.hip (conv_common.h).
+// Replaces, like ia_conv2d_mfma, modulated_conv2d -> conv2d_resample -> conv2d / conv_transpose2d (+ bias_act) of the reference
+// (training/networks_stylegan2.py:34-91, torch_utils/ops/conv2d_resample.py:114-136).
+#include "conv_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+// fp32 NCHW (times an optional per-(batch, channel) style) -> split planes.  One thread = one pixel of one 8-channel group.
+__global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ x, const float* __restrict__ styles, h16x8* __restrict__ out,
+                                                       int B, int C, int64_t HW) {
+    const int C8 = C / 8;
+    const int64_t total = (int64_t)B * C8 * HW, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t pix = i % HW;
+        const int c8 = (int)((i / HW) % C8), b = (int)(i / (HW * C8));
+        h16x8 hi, lo;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int c = c8 * 8 + cc;
+            float v = x[((int64_t)b * C + c) * HW + pix];
+            if (styles) v *= styles[b * C + c];
+            _Float16 h, l;
+            ia::split_f16(v, h, l);
+            hi[cc] = h; lo[cc] = l;
+        }
+        out[((int64_t)(b * 2) * C8 + c8) * HW + pix] = hi;
+        out[((int64_t)(b * 2 + 1) * C8 + c8) * HW + pix] = lo;
+    }
+}
+
+// Accumulator tile -> fp32 NCHW (y, optional) and/or split planes (e.ys, optional); stride-1 form.
+template <int FO, int FP, int WO, int WP>
+__device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], float* __restrict__ y, const Geo& g, const Epi& e,
+                                                int b, int o0, int p0, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wo = wave / WP, wp = wave % WP;
+    const int npts = g.GH * g.GW;
+    const int64_t ohw = (int64_t)g.OH * g.OW;
+    const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
+    float* yb = y ? y + ((int64_t)b * g.O) * ohw : nullptr;
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp) {
+        const int p = p0 + (wp * FP + fp) * 32 + l31;
+        if (p >= npts) continue;
+#pragma unroll
+        for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                      // register quad q: channels 8q + 4*half + (0..3) of the fragment
+                const int o_first = o0 + (wo * FO + fo) * 32 + 8 * q + 4 * half;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int o = o_first + k;
+                    v[k] = o < g.O ? epilogue(acc[0][fo][fp][4 * q + k], b, o, p, ohw, g, e, ns) : 0.f;
+                    if (yb && o < g.O) yb[(int64_t)o * ohw + p] = v[k];
+                }
+                if (e.ys && o_first + 3 < g.O) split_store4(e.ys, e.styles_next, b, g.O, ohw, o_first, p, v);
+            }
+    }
+}
+
+// FO x FP fragments (32 channels x 32 points) per wave, WO x WP waves; 8 input channels per K chunk; JP = patch DMA
+// instructions per wave per chunk (host-chosen from the worst window of the launch); SK as in conv_mfma_kernel.
+template <bool TR, int FO, int FP, int WO, int WP, int JP, bool SK>
+__global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split_kernel(const h16x8* __restrict__ xs, const h16x8* __restrict__ wk,
+                                                                                      float* __restrict__ y, float* __restrict__ slabs, Geo g, Epi e) {
+    constexpr int KS = 3, NT = 9, NTP = NT + 1, CC = 8;
+    constexpr int NPH = TR ? 4 : 1;
+    constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NWAVES = WO * WP, NTHREADS = NWAVES * 64;
+    constexpr int PAD = TR ? 0 : KS / 2;
+    constexpr int NACC = NPH * FO * FP * 16;
+    constexpr int WSLOTS = 2 * NTP * BO;              // 16-byte slots of the weight region of a stage: [plane][tap (+ zero tap)][BO]
+    constexpr int WG = 2 * NT * BO / 64;              // weight DMA instructions per chunk (64 slots each), spread over the waves
+    constexpr int JW = (WG + NWAVES - 1) / NWAVES;
+    static_assert(BO % 64 == 0, "a DMA instruction fills 64 consecutive slots of one (plane, tap) row");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wo = wave / WP, wp = wave % WP;
+    const int b = blockIdx.y, worker = blockIdx.x;
+    const int npts = g.GH * g.GW;
+    const int cap = g.patch_cap;                       // patch positions reserved per plane (multiple of 64)
+    const int PG = 2 * cap / 64;                       // patch DMA instructions per chunk
+    const int stage_bytes = (WSLOTS + 2 * cap) * 16;
+    const int64_t U = (int64_t)(g.T - g.T_dp) * g.C;
+    const int64_t u_begin = SK ? range_begin(worker, U, g.G) : (int64_t)worker * g.C;
+    const int64_t u_end = SK ? range_begin(worker + 1, U, g.G) : u_begin + g.C;
+    const int first_tile = (int)(u_begin / g.C);
+    const int tile_base = SK ? g.T_dp : 0;
+    const int HW = g.H * g.W;
+    const int plane_bytes = (g.I / 8) * HW * 16;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16x8*>(xs) + (int64_t)b * 2 * (g.I / 8) * HW, 0, 2 * plane_bytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16x8*>(wk), 0, 2 * NT * (g.I / 8) * g.O * 16, 0x00020000);
+    lds_char* const lds_base = (lds_char*)lds;
+
+    // the all-zero tap of every plane, in both stages (the DMA never writes there)
+    for (int i = tid; i < 2 * 2 * BO; i += NTHREADS) {
+        const int stg = i / (2 * BO), r = i - stg * 2 * BO, pl = r / BO, o = r - pl * BO;
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + stg * stage_bytes + ((pl * NTP + NT) * BO + o) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+  for (int64_t u = u_begin; u < u_end;) {
+    // ---- one segment: tile `tile`, K chunks [c_lo, c_hi)
+    const int tile_l = (int)(u / g.C), c_lo = (int)(u - (int64_t)tile_l * g.C);
+    const int c_hi = (int)min((int64_t)g.C, (int64_t)c_lo + (u_end - u));
+    u += c_hi - c_lo;
+    const int tile = tile_base + tile_l;
+    const int o0 = (tile % g.TO) * BO;
+    const int p0 = (tile / g.TO) * BP;
+    const int p_last = min(p0 + BP, npts) - 1;
+    const Window win = tile_window(p0, p_last, g.GW, PAD, TR);
+    const int PW = win.PW, PSZ = win.PSZ, seg1_off = win.nr[0] * PW;
+    const int r_split = (win.nr[1] > 0) ? p_last / g.GW : (1 << 30);
+    const float inv_pw = 1.0f / (float)PW;
+
+    int bpos[FP];
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp) {
+        const int p = min(p0 + (wp * FP + fp) * 32 + l31, p_last);
+        const int r = p / g.GW, c = p - r * g.GW;
+        const int sg = (r == r_split) ? 1 : 0;
+        bpos[fp] = sg * seg1_off + (r - PAD - win.r0[sg]) * PW + (c - PAD - win.c0[sg]);
+    }
+    int toff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int ky = t / KS, kx = t % KS;
+        toff[t] = TR ? -((ky >> 1) * PW + (kx >> 1)) : ky * PW + kx;
+    }
+
+    f32x16 acc[NPH][FO][FP];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+            for (int fp = 0; fp < FP; ++fp)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] = 0.f;
+
+    // ---- DMA plan of this tile: per-lane source byte offsets (chunk 0), fixed for the whole K loop; a chunk adds an SGPR offset.
+    // Weight instruction j of this wave covers load slots [(j*NWAVES + wave)*64, +64) of the [plane][tap][BO] slab of a chunk.
+    constexpr int kOutside = 0x7ffffff0;
+    int w_voff[JW], p_voff[JP];
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+        const int e_ = min((j * NWAVES + wave) * 64 + lane, 2 * NT * BO - 1);
+        const int row = e_ / BO, o = e_ - row * BO;                         // row = plane*NT + tap
+        w_voff[j] = ((row * (g.I / 8)) * g.O + min(o0 + o, g.O - 1)) * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < JP; ++j) {
+        const int q = (j * NWAVES + wave) * 64 + lane;
+        const int pl = q >= cap ? 1 : 0, pp = q - pl * cap;
+        const int sg = (pp >= seg1_off && win.nr[1] > 0) ? 1 : 0;
+        const int qq = pp - sg * seg1_off;
+        const int pr = (int)(((float)qq + 0.5f) * inv_pw), pc = qq - pr * PW;
+        const int iy = win.r0[sg] + pr, ix = win.c0[sg] + pc;
+        const bool ok = pp < PSZ && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        p_voff[j] = ok ? pl * plane_bytes + (iy * g.W + ix) * 16 : kOutside;
+    }
+    auto issue = [&](int chunk, int stage) {            // every DMA of one chunk into one LDS stage
+        lds_char* st = lds_base + stage * stage_bytes;
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            const int gidx = j * NWAVES + wave;
+            if (gidx < WG) {
+                const int row = (gidx * 64) / BO, o = gidx * 64 - row * BO, pl = row / NT, tap = row - pl * NT;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, st + ((pl * NTP + tap) * BO + o) * 16, 16, w_voff[j], chunk * g.O * 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JP; ++j) {
+            const int gidx = j * NWAVES + wave;
+            if (gidx < PG)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, st + (WSLOTS + gidx * 64) * 16, 16, p_voff[j], chunk * HW * 16, 0, 0);
+        }
+    };
+
+    __syncthreads();                         // the previous segment's readers (and the zero-tap stores) are done
+    issue(c_lo, 0);
+    int cur = 0;
+    for (int ch = c_lo; ch < c_hi; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMAs of chunk `ch` have landed ...
+        __syncthreads();                                      // ... and everybody's; the other stage has no readers left
+        if (ch + 1 < c_hi) issue(ch + 1, cur ^ 1);
+        const h16x8* wh = reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(lds) + cur * stage_bytes);
+        const h16x8* ph = wh + WSLOTS;
+        // five k-steps: the 8 channels of a pair of taps (lanes 0-31 the first tap, lanes 32-63 the second).  Operand reads run one
+        // k-step ahead of the MFMAs that consume them.
+        h16x8 a_buf[2][2 * FO], b_buf[2][2 * FP];
+        auto load_ops = [&](int s, h16x8 (&a)[2 * FO], h16x8 (&bv)[2 * FP]) {
+            const int tap = half ? pair_t1(TR, s) : pair_t0(TR, s);
+            const int tof = pair_t1(TR, s) == kZeroTap ? (half ? 0 : toff[pair_t0(TR, s)]) : (half ? toff[pair_t1(TR, s)] : toff[pair_t0(TR, s)]);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo) a[pl * FO + fo] = wh[(pl * NTP + tap) * BO + (wo * FO + fo) * 32 + l31];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp) bv[pl * FP + fp] = ph[pl * cap + bpos[fp] + tof];
+        };
+        load_ops(0, a_buf[0], b_buf[0]);
+#pragma unroll
+        for (int s = 0; s < kPairs; ++s) {
+            const int c_ = s & 1;
+            if (s + 1 < kPairs) load_ops(s + 1, a_buf[(s + 1) & 1], b_buf[(s + 1) & 1]);
+            const int ph_ = pair_phase(TR, s);
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp) {   // lo*hi, (hi*2^-11)*(lo*2^11), hi*hi: all at the scale of the packed weights
+                    acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][FO + fo], b_buf[c_][fp], acc[ph_][fo][fp], 0, 0, 0);
+                    acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][fo] * (_Float16)(1.0f / kLoScale), b_buf[c_][FP + fp],
+                                                                              acc[ph_][fo][fp], 0, 0, 0);
+                    acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][fo], b_buf[c_][fp], acc[ph_][fo][fp], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (FO + FP), 0);      // next k-step's ds_reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * FO * FP, 0);        // ... then this k-step's MFMAs
+        }
+        cur ^= 1;
+    }
+
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+            for (int fp = 0; fp < FP; ++fp)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] *= g.acc_scale;   // back from the scale of the packed weights (exact)
+    if (!SK || (c_lo == 0 && c_hi == g.C)) {
+        if constexpr (TR) store_tile<TR, FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
+        else store_tile_dual<FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
+    } else if constexpr (SK) {
+        const int slot = (tile_l == first_tile) ? 0 : 1;
+        float4* slab = reinterpret_cast<float4*>(slabs + (((int64_t)b * g.G + worker) * 2 + slot) * ((int64_t)NACC * NTHREADS)) + tid;
+#pragma unroll
+        for (int q = 0; q < NACC / 4; ++q) {
+            const int fr = q >> 2, r0 = (q & 3) * 4;
+            const f32x16& a = acc[fr / (FP * FO)][(fr / FP) % FO][fr % FP];
+            slab[(int64_t)q * NTHREADS] = make_float4(a[r0], a[r0 + 1], a[r0 + 2], a[r0 + 3]);
+        }
+    }
+  }   // segments of this worker
+}
+
+template <bool TR, int FO, int FP, int WO, int WP, int JP>
+int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const Geo& g, const Epi& e, hipStream_t s) {
+    constexpr int BO = 32 * FO * WO;
+    const size_t lds = (size_t)2 * (2 * 10 * BO + 2 * g.patch_cap) * 16;
+    if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
+    int st = IA_OK;
+    if (g.T_dp > 0) {
+        auto k = conv_split_kernel<TR, FO, FP, WO, WP, JP, false>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
+        st = ia::check_launch("ia_conv2d_mfma_sx");
+    }
+    if (st == IA_OK && g.T > g.T_dp) {
+        auto k = conv_split_kernel<TR, FO, FP, WO, WP, JP, true>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
+        st = ia::check_launch("ia_conv2d_mfma_sx(stream-K)");
+        const int64_t U = (int64_t)(g.T - g.T_dp) * g.C;
+        const bool whole_tiles = U % g.G == 0 && (U / g.G) % g.C == 0;
+        if (st == IA_OK && !whole_tiles) {
+            constexpr int NACC = (TR ? 4 : 1) * FO * FP * 16;
+            hipLaunchKernelGGL((conv_fixup_kernel<TR, FO, FP, WO, WP>), dim3(g.T - g.T_dp, g.B, NACC / (TR ? 8 : 4)), dim3(WO * WP * 64), 0, s,
+                               scratch, y, g, e);
+            st = ia::check_launch("ia_conv2d_mfma_sx(fix-up)");
+        }
+    }
+    return st;
+}
+
+template <bool TR, int FO, int FP, int WO, int WP>
+int launch_sx(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const Geo& g_in, const Epi& e, hipStream_t s) {
+    constexpr int BP = 32 * FP * WP, NWAVES = WO * WP;
+    Geo g = g_in;
+    const int npts = g.GH * g.GW;
+    int worst = 0;
+    for (int q0 = 0; q0 < npts; q0 += BP) {
+        const int q1 = (q0 + BP < npts ? q0 + BP : npts) - 1;
+        const Window w = tile_window(q0, q1, g.GW, TR ? 0 : 1, TR);
+        if (w.PSZ > worst) worst = w.PSZ;
+    }
+    if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d positions exceeds the LDS budget", worst);
+    g.patch_cap = (worst + 63) & ~63;
+    const int per_wave = (2 * g.patch_cap / 64 + NWAVES - 1) / NWAVES;
+    if (per_wave <= 2) return launch_jp<TR, FO, FP, WO, WP, 2>(xs, wk, y, scratch, g, e, s);
+    if (per_wave <= 4) return launch_jp<TR, FO, FP, WO, WP, 4>(xs, wk, y, scratch, g, e, s);
+    return launch_jp<TR, FO, FP, WO, WP, 8>(xs, wk, y, scratch, g, e, s);
+}
+
+}  // namespace
+
+extern "C" int ia_act_split(const float* x, const float* styles, void* xs, int B, int C, int H, int W, void* stream) {
+    IA_REQUIRE(x && xs, "null pointer argument");
+    IA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "empty tensor");
+    IA_REQUIRE(C % 8 == 0, "the split format stores channels in groups of 8 (C = %d)", C);
+    IA_REQUIRE((int64_t)B * C * H * W <= INT32_MAX, "tensor is too large");
+    const int64_t work = (int64_t)B * (C / 8) * H * W;
+    hipLaunchKernelGGL(act_split_kernel, dim3(ia::streaming_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, styles,
+                       static_cast<h16x8*>(xs), B, C, (int64_t)H * W);
+    return ia::check_launch("ia_act_split");
+}
+
+// (make_plan / tile selection live in conv_mfma.hip: both forms of a layer share tiles, worker counts and slab sizes)
+int ia_conv2d_plan_tiles(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int* bo, int* bp, int* waves, int* T, int* TO,
+                         int* C, int* T_dp, int* slab_floats);
+
+extern "C" int ia_conv2d_mfma_sx(const void* xs, const void* wk_split, int wk_exp, const float* demod, const float* noise,
+                                 const float* noise_strength, const float* bias, const float* residual, float* y, void* ys,
+                                 const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
+                                 int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
+    IA_REQUIRE(xs && wk_split && (y || ys), "xs, wk and at least one of y / ys must be device pointers");
+    IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
+    IA_REQUIRE(I % 8 == 0 && O % 8 == 0, "the split form needs I %% 8 == 0 and O %% 8 == 0");
+    IA_REQUIRE(wk_exp >= -14 && wk_exp <= 30, "wk_exp is the power of two the weights were scaled by at pack time");
+    IA_REQUIRE(act == IA_ACT_LINEAR || act == IA_ACT_LRELU, "conv epilogue supports linear and lrelu");
+    IA_REQUIRE(ksplit >= 0, "worker count must be >= 0");
+    IA_REQUIRE(!transposed || (y && !ys && noise == nullptr && bias == nullptr && residual == nullptr && act == IA_ACT_LINEAR),
+               "the transposed form writes the fp32 (2H+1)x(2W+1) image only; FIR + bias_act (+ split) follow in ia_fir_tail_split");
+    Geo g;
+    g.B = B; g.I = I; g.O = O; g.H = H; g.W = W;
+    g.GH = transposed ? H + 1 : H; g.GW = transposed ? W + 1 : W;
+    g.OH = transposed ? 2 * H + 1 : H; g.OW = transposed ? 2 * W + 1 : W;
+    IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
+    int bo, bp, waves, slab_floats;
+    const int st_plan = ia_conv2d_plan_tiles(B, I, O, H, W, 3, transposed, 2, &bo, &bp, &waves, &g.T, &g.TO, &g.C, &g.T_dp, &slab_floats);
+    if (st_plan != IA_OK) return st_plan;
+    const bool wide = waves == 8;
+    IA_REQUIRE(wide || (transposed && bo == 64), "the split form covers 3x3 layers on the two-stage tiles (large stride-1 layers, stride-2 transposed)");
+    g.G = 0;
+    if (g.T_dp < g.T) {
+        IA_REQUIRE(ksplit >= 1, "this layer has stream-K tiles: pass the worker count from ia_conv2d_plan");
+        const int64_t Ur = (int64_t)(g.T - g.T_dp) * g.C;
+        g.G = (int)(ksplit > Ur ? Ur : ksplit);
+        const size_t need = (size_t)B * g.G * 2 * slab_floats * sizeof(float);
+        const bool whole_tiles = Ur % g.G == 0 && (Ur / g.G) % g.C == 0;
+        IA_REQUIRE(whole_tiles || (scratch && scratch_bytes >= need), "stream-K needs %zu bytes of scratch, got %zu", need, scratch_bytes);
+    }
+    g.patch_cap = 0;
+    g.acc_scale = ldexpf(1.f, -wk_exp);
+    Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp, ys, styles_next};
+    hipStream_t s = (hipStream_t)stream;
+    const h16x8* x8 = static_cast<const h16x8*>(xs);
+    const h16x8* w8 = static_cast<const h16x8*>(wk_split);
+    if (transposed && bp == 128) return launch_sx<true, 1, 2, 2, 2>(x8, w8, y, scratch, g, e, s);
+    if (transposed) return launch_sx<true, 1, 1, 2, 2>(x8, w8, y, scratch, g, e, s);
+    return launch_sx<false, 2, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
+}

@@ -54,6 +54,16 @@ template <> struct Num<double> {
     __device__ static void store(double* p, double v) { *p = v; }
 };
 
+// fp32 value -> fp16 pair for the "fp32 products from fp16 pairs" convolutions (conv_mfma.hip HM = 2, conv_split.hip):
+// hi = fp16(v), lo = fp16((v - hi) * 2^11).  v saturates at the fp16 range; a high part that would be a denormal (flushed by
+// the MFMA) is dropped so that the value rides entirely in the scaled low part.  hi + lo * 2^-11 carries 22 mantissa bits.
+constexpr float kSplitLoScale = 2048.f;
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.f : (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * kSplitLoScale);
+}
+
 }  // namespace ia
 
 #define IA_REQUIRE(cond, ...) \

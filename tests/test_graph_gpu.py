@@ -123,7 +123,7 @@ def test_config4_shard_of_eight_frames_full_width():
     g, ws, cams, uvs, jits, _ = _setup('full', nrr, frames)
     dist = frame_parallel.global_ray_dist(synthetic.camera_labels(list(range(64))).cuda())     # of a B = 64 batch
     with torch.no_grad():
-        call = lambda sl: g.synthesis(ws, cams[sl], {'uvcoords_image': uvs[sl]}, neural_rendering_resolution=nrr, noise_mode='const',   # noqa: E731
+        call = lambda sl: g.synthesis(ws.expand(cams[sl].shape[0], -1, -1), cams[sl], {'uvcoords_image': uvs[sl]}, neural_rendering_resolution=nrr, noise_mode='const',   # noqa: E731
                                       evaluation=True, jitter=jits[sl], ray_dist=dist)['image']
         batched = call(slice(0, 8)).clone()
         for i in range(8):
