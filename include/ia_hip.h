@@ -309,6 +309,23 @@ int ia_conv2d_mfma_sx(const void* xs, const void* wk_split, int wk_exp, const fl
                       int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream);
 
 /*
+ * ia_upfirdn2d_bias_act for the 4x4 filter at up = 1 (the FIR + noise + bias + activation tail of an up-sampling SynthesisLayer,
+ * training/networks_stylegan2.py:318-329 after conv2d_resample.py:114-131) with the result stored in SPLIT format for the next
+ * convolution: ys = split(tail(fir(x)) * styles_next[b, c]) (see ia_act_split; same FIR sums in the same order as
+ * ia_upfirdn2d_bias_act).  y (fp32 [n,c,out_h,out_w]) may be NULL when only the split result is consumed.  c % 8 == 0.
+ */
+int ia_fir_tail_split(const float* x, const float* f, const float* noise, const float* noise_strength, const float* bias,
+                      const float* styles_next, float* y, void* ys, int n, int c, int in_h, int in_w, int out_h, int out_w,
+                      int padx0, int pady0, int flip, float fir_gain, int act, float alpha, float act_gain, float clamp, void* stream);
+
+/*
+ * ia_cond_blend with the result in SPLIT format (ia_act_split) for the one layer that consumes it, multiplied by that layer's
+ * styles [B,C] (NULL = 1): ys = split((cond[:, :C] * a + x * (1 - a)) * styles_next), a = cond[:, C]
+ * (training_avatar_texture/networks_stylegan2_new.py:539-540 feeding the next block's conv0).  C % 8 == 0.
+ */
+int ia_cond_blend_split(const float* cond, const float* x, const float* styles_next, void* ys, int B, int C, int H, int W, void* stream);
+
+/*
  * Output side: float image batch -> uint8 picture grid, one pass.
  * Replaces layout_grid(img, grid_w, grid_h, float_to_uint8=True, chw_to_hwc) of the reference's scripts
  * (reenact_avatar_next3d.py:117-131): (img * 127.5 + 128).clamp(0, 255).to(uint8), frames tiled row-major into a

@@ -20,6 +20,15 @@
 // (training/networks_stylegan2.py:34-91, torch_utils/ops/conv2d_resample.py:114-136).
 #include "conv_common.h"
 
+// Compile-time ablations for tools/ablate_conv_split.sh (never set in the product build): 1 = no DMA after the first chunk of a
+// segment, 2 = no MFMAs (operand reads kept alive), 3 = no operand reads (MFMAs on stale registers), 4 = no output stores.
+#ifndef IA_ABLATE
+#define IA_ABLATE 0
+#endif
+#define IA_AB_NODMA (IA_ABLATE == 1 || IA_ABLATE >= 5)
+#define IA_AB_NOREAD (IA_ABLATE == 3 || IA_ABLATE >= 5)
+#define IA_AB_NOSTORE (IA_ABLATE == 4 || IA_ABLATE >= 5)
+
 namespace {
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -83,7 +92,7 @@ __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], 
 template <bool TR, int FO, int FP, int WO, int WP, int JP, bool SK>
 __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split_kernel(const h16x8* __restrict__ xs, const h16x8* __restrict__ wk,
                                                                                       float* __restrict__ y, float* __restrict__ slabs, Geo g, Epi e) {
-    constexpr int KS = 3, NT = 9, NTP = NT + 1, CC = 8;
+    constexpr int KS = 3, NT = 9, NTP = NT + 1;
     constexpr int NPH = TR ? 4 : 1;
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NWAVES = WO * WP, NTHREADS = NWAVES * 64;
     constexpr int PAD = TR ? 0 : KS / 2;
@@ -179,31 +188,35 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
         const bool ok = pp < PSZ && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
         p_voff[j] = ok ? pl * plane_bytes + (iy * g.W + ix) * 16 : kOutside;
     }
-    auto issue = [&](int chunk, int stage) {            // every DMA of one chunk into one LDS stage
-        lds_char* st = lds_base + stage * stage_bytes;
-#pragma unroll
-        for (int j = 0; j < JW; ++j) {
-            const int gidx = j * NWAVES + wave;
-            if (gidx < WG) {
-                const int row = (gidx * 64) / BO, o = gidx * 64 - row * BO, pl = row / NT, tap = row - pl * NT;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, st + ((pl * NTP + tap) * BO + o) * 16, 16, w_voff[j], chunk * g.O * 16, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < JP; ++j) {
-            const int gidx = j * NWAVES + wave;
-            if (gidx < PG)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, st + (WSLOTS + gidx * 64) * 16, 16, p_voff[j], chunk * HW * 16, 0, 0);
-        }
-    };
+    // every DMA of one chunk into one LDS stage.  (The voffset argument goes through a plain local: hipcc 7.2 silently drops the HOST
+    // stub of a kernel template that passes an element of a template-sized array straight to the raw_ptr_buffer_load_lds builtin
+    // -- the .so then fails to load with an undefined kernel symbol.)
+#define IA_ISSUE_DMA(chunk, stage)                                                                                                      \
+    do {                                                                                                                               \
+        lds_char* st_ = lds_base + (stage) * stage_bytes;                                                                              \
+        const int wso_ = (chunk) * g.O * 16, pso_ = (chunk) * HW * 16;                                                                 \
+        _Pragma("unroll") for (int j = 0; j < JW; ++j) {                                                                               \
+            const int gidx = j * NWAVES + wave;                                                                                        \
+            if (gidx < WG) {                                                                                                           \
+                const int row = (gidx * 64) / BO, o = gidx * 64 - row * BO, pl = row / NT, tap = row - pl * NT;                        \
+                const int vo_ = w_voff[j];                                                                                             \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, st_ + ((pl * NTP + tap) * BO + o) * 16, 16, vo_, wso_, 0, 0);           \
+            }                                                                                                                          \
+        }                                                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < JP; ++j) {                                                                               \
+            const int gidx = j * NWAVES + wave;                                                                                        \
+            const int vo_ = p_voff[j];                                                                                                 \
+            if (gidx < PG) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, st_ + (WSLOTS + gidx * 64) * 16, 16, vo_, pso_, 0, 0);       \
+        }                                                                                                                              \
+    } while (0)
 
     __syncthreads();                         // the previous segment's readers (and the zero-tap stores) are done
-    issue(c_lo, 0);
+    IA_ISSUE_DMA(c_lo, 0);
     int cur = 0;
     for (int ch = c_lo; ch < c_hi; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMAs of chunk `ch` have landed ...
-        __syncthreads();                                      // ... and everybody's; the other stage has no readers left
-        if (ch + 1 < c_hi) issue(ch + 1, cur ^ 1);
+        if (IA_ABLATE < 7 || ch == c_lo) __syncthreads();     // ... and everybody's; the other stage has no readers left
+        if (!IA_AB_NODMA && ch + 1 < c_hi) IA_ISSUE_DMA(ch + 1, cur ^ 1);
         const h16x8* wh = reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(lds) + cur * stage_bytes);
         const h16x8* ph = wh + WSLOTS;
         // five k-steps: the 8 channels of a pair of taps (lanes 0-31 the first tap, lanes 32-63 the second).  Operand reads run one
@@ -221,23 +234,42 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
 #pragma unroll
                 for (int fp = 0; fp < FP; ++fp) bv[pl * FP + fp] = ph[pl * cap + bpos[fp] + tof];
         };
-        load_ops(0, a_buf[0], b_buf[0]);
+        if (!IA_AB_NOREAD || ch == c_lo) load_ops(0, a_buf[0], b_buf[0]);
 #pragma unroll
         for (int s = 0; s < kPairs; ++s) {
             const int c_ = s & 1;
-            if (s + 1 < kPairs) load_ops(s + 1, a_buf[(s + 1) & 1], b_buf[(s + 1) & 1]);
+            // the NEXT k-step's operand reads are issued before this k-step's MFMAs and pinned there (sched_barrier): their LDS
+            // latency then hides under 12 x 32 MFMA cycles; left to itself the scheduler sinks them to just before their use
+            if ((!IA_AB_NOREAD || ch == c_lo) && s + 1 < kPairs) load_ops(s + 1, a_buf[(s + 1) & 1], b_buf[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#if IA_ABLATE == 2
+#pragma unroll
+            for (int q = 0; q < 2 * FO; ++q) asm volatile("" ::"v"(a_buf[c_][q]));
+#pragma unroll
+            for (int q = 0; q < 2 * FP; ++q) asm volatile("" ::"v"(b_buf[c_][q]));
+            continue;
+#endif
             const int ph_ = pair_phase(TR, s);
+            h16x8 a_sc[FO];                            // weight high parts at 2^-11: they meet the activation's low parts (scaled by 2^11)
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo) a_sc[fo] = IA_ABLATE >= 6 ? a_buf[c_][fo] : a_buf[c_][fo] * (_Float16)(1.0f / kLoScale);
+            // three products per fragment pair, product-major: consecutive MFMAs write different accumulators
 #pragma unroll
             for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
-                for (int fp = 0; fp < FP; ++fp) {   // lo*hi, (hi*2^-11)*(lo*2^11), hi*hi: all at the scale of the packed weights
+                for (int fp = 0; fp < FP; ++fp)      // lo * hi
                     acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][FO + fo], b_buf[c_][fp], acc[ph_][fo][fp], 0, 0, 0);
-                    acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][fo] * (_Float16)(1.0f / kLoScale), b_buf[c_][FP + fp],
-                                                                              acc[ph_][fo][fp], 0, 0, 0);
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp)      // (hi * 2^-11) * (lo * 2^11)
+                    acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[fo], b_buf[c_][FP + fp], acc[ph_][fo][fp], 0, 0, 0);
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp)      // hi * hi
                     acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][fo], b_buf[c_][fp], acc[ph_][fo][fp], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (FO + FP), 0);      // next k-step's ds_reads first ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * FO * FP, 0);        // ... then this k-step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
         }
         cur ^= 1;
     }
@@ -250,7 +282,18 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
             for (int fp = 0; fp < FP; ++fp)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] *= g.acc_scale;   // back from the scale of the packed weights (exact)
-    if (!SK || (c_lo == 0 && c_hi == g.C)) {
+    if (IA_AB_NOSTORE) {
+        float sink = 0.f;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sink += acc[ph][fo][fp][r];
+        if (sink == 123.456f) y[0] = sink;
+    } else if (!SK || (c_lo == 0 && c_hi == g.C)) {
         if constexpr (TR) store_tile<TR, FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
         else store_tile_dual<FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
     } else if constexpr (SK) {
@@ -264,6 +307,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
         }
     }
   }   // segments of this worker
+#undef IA_ISSUE_DMA
 }
 
 template <bool TR, int FO, int FP, int WO, int WP, int JP>

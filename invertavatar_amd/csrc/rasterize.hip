@@ -381,6 +381,45 @@ __global__ __launch_bounds__(256) void cond_blend_kernel(const float* __restrict
     reinterpret_cast<float4*>(y)[i] = o;
 }
 
+// The same blend for a feature map whose only consumer is the next block's first convolution (networks_stylegan2_new.py:539-540
+// then :448 of the next block): the result is written in SPLIT format (ia_act_split), multiplied by that layer's styles, and the
+// fp32 tensor is never materialised.  One thread = one pixel of one 8-channel group.
+typedef _Float16 h16x8_cb __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void cond_blend_split_kernel(const float* __restrict__ cond, const float* __restrict__ x,
+                                                               const float* __restrict__ styles_next, h16x8_cb* __restrict__ ys, int B, int C, int64_t hw) {
+    const int C8 = C / 8;
+    const int64_t total = (int64_t)B * C8 * hw, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t pix = i % hw;
+        const int c8 = (int)((i / hw) % C8), b = (int)(i / (hw * C8));
+        const float a = cond[((int64_t)b * (C + 1) + C) * hw + pix];
+        h16x8_cb hi, lo;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int c = c8 * 8 + cc;
+            const float cv = cond[((int64_t)b * (C + 1) + c) * hw + pix], xv = x[((int64_t)b * C + c) * hw + pix];
+            float v = cv * a + xv * (1.f - a);
+            if (styles_next) v *= styles_next[b * C + c];
+            _Float16 h, l;
+            ia::split_f16(v, h, l);
+            hi[cc] = h; lo[cc] = l;
+        }
+        ys[((int64_t)(b * 2) * C8 + c8) * hw + pix] = hi;
+        ys[((int64_t)(b * 2 + 1) * C8 + c8) * hw + pix] = lo;
+    }
+}
+
+extern "C" int ia_cond_blend_split(const float* cond, const float* x, const float* styles_next, void* ys, int B, int C, int H, int W, void* stream) {
+    IA_REQUIRE(cond && x && ys, "null pointer argument");
+    IA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "empty tensor");
+    IA_REQUIRE(C % 8 == 0, "the split format stores channels in groups of 8 (C = %d)", C);
+    IA_REQUIRE((int64_t)B * (C + 1) * H * W <= INT32_MAX, "tensor is too large");
+    const int64_t work = (int64_t)B * (C / 8) * H * W;
+    hipLaunchKernelGGL(cond_blend_split_kernel, dim3(ia::streaming_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, cond, x, styles_next,
+                       static_cast<h16x8_cb*>(ys), B, C, (int64_t)H * W);
+    return ia::check_launch("ia_cond_blend_split");
+}
+
 extern "C" int ia_cond_blend(const float* cond, const float* x, float* y, int B, int C, int H, int W, void* stream) {
     IA_REQUIRE(cond && x && y, "null pointer argument");
     IA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "empty tensor");

@@ -243,6 +243,101 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled_pipe(const T* __restrict_
     }
 }
 
+// FIR + tail of an up-sampling SynthesisLayer with the result stored in SPLIT format for the next convolution
+// (ia_conv2d_mfma_sx): the same sums, in the same order, as upfirdn2d_tiled_pipe<float, true>, then v * styles_next[b, c] split into
+// fp16 hi / lo * 2^11 (ia::split_f16) and written as 16-byte units of 8 channels.  The structure is that of the pipelined kernel
+// with the pipeline running over the EIGHT CHANNELS of a channel group instead of over tiles: a workgroup filters one 64 x 16
+// tile of channel k from one LDS image while the loads of channel k + 1 are in flight, keeps the 4 results per channel in
+// registers, and after the eighth channel every thread holds the 8 channels of its 4 pixels: 1 KB contiguous per wave, plane
+// and row.  Optionally the fp32 NCHW result is written as well (callers that still need it, e.g. the CS-SFT modulation).
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y,
+                                                            h16x8_t* __restrict__ ys, const float* __restrict__ styles_next, Geo g, int flip, Tail tail) {
+    constexpr int FS = 4;
+    constexpr int IH = TH + FS, IW = TW + FS, IWP = IW + 1, NLD = (IH * IW + 255) / 256;
+    __shared__ float k_lds[FS * FS];
+    __shared__ float in_lds[2][IH * IWP];
+    const int tiles_x = (g.out_w + TW - 1) / TW;
+    const int ox0 = (blockIdx.x % tiles_x) * TW, oy0 = (blockIdx.x / tiles_x) * TH;
+    const int C8 = g.c / 8, c8 = blockIdx.y % C8, b = blockIdx.y / C8;
+    const int iy0 = oy0 - g.pady0, ix0 = ox0 - g.padx0;
+    stage_filter(k_lds, f, FS, FS, FS, 1, flip, g.gain);
+    const int64_t in_plane = (int64_t)g.in_h * g.in_w, ohw = (int64_t)g.out_h * g.out_w;
+    const float* xb = x + ((int64_t)b * g.c + c8 * 8) * in_plane;
+    // per-thread slots of the input image (the same for all 8 channels): LDS offset and global offset inside a channel plane
+    int l_off[NLD], g_off[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = threadIdx.x + j * 256, r = i / IW, c = i - r * IW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        const bool ok = i < IH * IW && iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w;
+        l_off[j] = i < IH * IW ? r * IWP + c : -1;
+        g_off[j] = ok ? iy * g.in_w + ix : -1;
+    }
+    float v[NLD];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) v[j] = g_off[j] >= 0 ? xb[(int64_t)ch * in_plane + g_off[j]] : 0.f;
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (l_off[j] >= 0) in_lds[buf][l_off[j]] = v[j];
+    };
+    const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * RPT;
+    const int ox = ox0 + tx;
+    const float t_ns = tail.noise ? (tail.noise_strength ? *tail.noise_strength : 1.f) : 0.f;
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    float kf[FS * FS];
+#pragma unroll
+    for (int i = 0; i < FS * FS; ++i) kf[i] = k_lds[i];
+    float nz[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int oy = oy0 + ty + r;
+        nz[r] = (tail.noise && ox < g.out_w && oy < g.out_h) ? tail.noise[(int64_t)oy * g.out_w + ox] : 0.f;
+    }
+    h16x8_t hi[RPT], lo[RPT];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        const int buf = ch & 1, c = c8 * 8 + ch;
+        if (ch + 1 < 8) fetch(ch + 1);                            // in flight under the filter below
+        const float t_bias = tail.bias ? ((const float*)tail.bias)[c] : 0.f;
+        const float sn = styles_next ? styles_next[b * g.c + c] : 1.f;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < FS; ++a)
+#pragma unroll
+                for (int bb = 0; bb < FS; ++bb) acc = fmaf(in_lds[buf][(ty + r + a) * IWP + tx + bb], kf[a * FS + bb], acc);
+            if (tail.noise) acc = fmaf(nz[r], t_ns, acc);
+            acc += t_bias;
+            if (tail.act == IA_ACT_LRELU) acc = acc > 0.f ? acc : acc * tail.alpha;
+            acc *= tail.gain;
+            if (tail.clamp >= 0.f) acc = fminf(fmaxf(acc, -tail.clamp), tail.clamp);
+            const int oy = oy0 + ty + r;
+            if (y && ox < g.out_w && oy < g.out_h) y[((int64_t)b * g.c + c) * ohw + (int64_t)oy * g.out_w + ox] = acc;
+            _Float16 h, l;
+            ia::split_f16(styles_next ? acc * sn : acc, h, l);
+            hi[r][ch] = h; lo[r][ch] = l;
+        }
+        if (ch + 1 < 8) commit(buf ^ 1);                          // (its last readers passed the barrier of the previous channel)
+        __syncthreads();
+    }
+    if (ox >= g.out_w) return;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int oy = oy0 + ty + r;
+        if (oy >= g.out_h) break;
+        const int64_t pix = (int64_t)oy * g.out_w + ox;
+        ys[((int64_t)(b * 2) * C8 + c8) * ohw + pix] = hi[r];
+        ys[((int64_t)(b * 2 + 1) * C8 + c8) * ohw + pix] = lo[r];
+    }
+}
+
 template <class T>
 bool tiled_eligible(const Geo& g) {
     const bool nchw = g.xs[3] == 1 && g.xs[2] == g.in_w && g.xs[1] == (int64_t)g.in_h * g.in_w &&
@@ -324,4 +419,22 @@ extern "C" int ia_upfirdn2d_bias_act(const void* x, const float* f, const float*
     if (dtype == IA_F32 && tiled_eligible<float>(g)) return launch_tiled<float, true>(x, f, y, g, f_w, 1, flip, tail, s);
     if (dtype == IA_F16 && tiled_eligible<__half>(g)) return launch_tiled<__half, true>(x, f, y, g, f_w, 1, flip, tail, s);
     return ia::fail(IA_ERR_UNSUPPORTED, "ia_upfirdn2d_bias_act: needs contiguous NCHW f32/f16, up in {1,2}, 4x4 filter");
+}
+
+extern "C" int ia_fir_tail_split(const float* x, const float* f, const float* noise, const float* noise_strength, const float* bias,
+                                 const float* styles_next, float* y, void* ys, int n, int c, int in_h, int in_w, int out_h, int out_w,
+                                 int padx0, int pady0, int flip, float fir_gain, int act, float alpha, float act_gain, float clamp, void* stream) {
+    IA_REQUIRE(x && f && ys, "null pointer argument");
+    IA_REQUIRE(n > 0 && c > 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, "empty tensor");
+    IA_REQUIRE(c % 8 == 0, "the split format stores channels in groups of 8 (C = %d)", c);
+    IA_REQUIRE(act == IA_ACT_LINEAR || act == IA_ACT_LRELU, "fused tail supports linear and lrelu");
+    IA_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, "tensor is too large");
+    IA_REQUIRE((int64_t)n * (c / 8) <= 65535, "too many (batch, channel group) planes for one launch");
+    Geo g;
+    g.n = n; g.c = c; g.in_h = in_h; g.in_w = in_w; g.out_h = out_h; g.out_w = out_w;
+    g.f_h = g.f_w = 4; g.upx = g.upy = 1; g.downx = g.downy = 1; g.padx0 = padx0; g.pady0 = pady0; g.gain = fir_gain;
+    Tail tail{noise, noise_strength, bias, act, alpha, act_gain, clamp};
+    const dim3 grid(((out_w + TW - 1) / TW) * ((out_h + TH - 1) / TH), n * (c / 8));
+    hipLaunchKernelGGL(fir_tail_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, f, y, static_cast<h16x8_t*>(ys), styles_next, g, flip, tail);
+    return ia::check_launch("ia_fir_tail_split");
 }

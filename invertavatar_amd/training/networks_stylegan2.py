@@ -36,6 +36,11 @@ FP16_BLOCKS_COMPUTE_FP32 = True
 # (tests/test_conv_gpu.py) and twice as fast.  False keeps every layer on v_mfma_f32_32x32x2_f32.
 SPLIT_FP16_PRODUCTS = True
 
+# ... and where the INPUT can be had as fp16 hi/lo planes (hipops.SplitAct: written by the producing layer's epilogue, or by
+# ia_act_split), those layers run on ia_conv2d_mfma_sx: same arithmetic, same bits, operands DMA'd into LDS.  False keeps the
+# register-staged kernel (ia_conv2d_mfma_s) everywhere.
+USE_SPLIT_DMA = True
+
 
 @misc.profiled_function
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
@@ -335,8 +340,55 @@ class SynthesisLayer(torch.nn.Module):
         self._packed = _PackedWeights()
         self._pre = None   # (styles, demod) computed for this call by the owning network's StylePlan
 
-    def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp, demod=None, half_ops=False):
-        """conv + demod + noise + bias + lrelu + clamp on the MFMA path (one or two launches)."""
+    def _takes_split_input(self, in_res, noise_mode='const', half_ops=False):
+        """True when this layer, fed a [*, in_channels, in_res, in_res] activation, runs on ia_conv2d_mfma_sx."""
+        return (SPLIT_FP16_PRODUCTS and USE_SPLIT_DMA and not half_ops and self.weight.shape[2] == 3 and self.in_channels % 8 == 0
+                and self.out_channels % 8 == 0 and not (self.use_noise and noise_mode == 'random') and self.activation in hipops.ACT_ID
+                and hipops.conv_h_supported(self.in_channels, self.out_channels, in_res, in_res, 3, self.up == 2))
+
+    def _consumer_styles(self, split_for, out_res, noise_mode, half_ops=False):
+        """Styles of the layer that will consume this layer's result, if it can take it in split format (they were computed ahead
+        of the forward pass by the network's _StyleBatcher and are parked on the consumer as `_pre`)."""
+        if split_for is None or split_for._pre is None or split_for.in_channels != self.out_channels:
+            return None
+        return split_for._pre[0] if split_for._takes_split_input(out_res, noise_mode, half_ops) else None
+
+    def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp, demod=None, half_ops=False, split_for=None, keep_f32=True):
+        """conv + demod + noise + bias + lrelu + clamp on the MFMA path (one or two launches).
+
+        `x`: fp32 tensor (optionally carrying `_ia_split`, its split copy made for this layer) or a hipops.SplitAct.
+        `split_for`: the SynthesisLayer that consumes the result; when it can take split input the result is ALSO (keep_f32) or
+        ONLY (not keep_f32) produced as a SplitAct multiplied by that layer's styles."""
+        in_res = self.resolution // self.up
+        const_noise = self.use_noise and noise_mode == 'const'
+        res = self.resolution
+        if self._takes_split_input(in_res, noise_mode, half_ops):
+            wk = self._packed.get_split(self.weight)
+            if demod is None:
+                demod = hipops.modconv_demod(styles.float().contiguous(), self._packed.get(self.weight)[1])
+            carried = x if isinstance(x, hipops.SplitAct) else getattr(x, '_ia_split', None)
+            xs = carried if (carried is not None and carried.consumer is self) else \
+                hipops.act_split(x.float().contiguous(), styles.float().contiguous(), consumer=self)
+            nz = self.noise_const.reshape(-1) if const_noise else None
+            ns = self.noise_strength.detach().float().reshape(1) if const_noise else None
+            bias = self.bias.detach().float()
+            sn = self._consumer_styles(split_for, res, noise_mode, half_ops)
+            if self.up == 1:
+                out = hipops.conv2d_mfma_sx(xs, wk, demod, nz, ns, bias, act=self.activation, gain=act_gain, clamp=act_clamp,
+                                            want_f32=keep_f32 or sn is None, split_for=split_for if sn is not None else None, styles_next=sn)
+            else:
+                t = hipops.conv2d_mfma_sx(xs, wk, demod, transposed=True)
+                if sn is None:
+                    return hipops.upfirdn2d_bias_act(t, self.resample_filter, nz, ns, bias, up=1, pad0=(1, 1), out_hw=(res, res),
+                                                     fir_gain=4.0, act=self.activation, act_gain=act_gain, clamp=act_clamp)
+                out = hipops.fir_tail_split(t, self.resample_filter, nz, ns, bias, styles_next=sn, out_hw=(res, res), pad0=(1, 1), fir_gain=4.0,
+                                            act=self.activation, act_gain=act_gain, clamp=act_clamp, want_f32=keep_f32, split_for=split_for)
+            if isinstance(out, tuple):     # fp32 result with its split copy riding along for the consumer
+                out[0]._ia_split = out[1]
+                return out[0]
+            return out
+        if isinstance(x, hipops.SplitAct):
+            raise RuntimeError('a SplitAct reached a layer that cannot consume it (producer/consumer eligibility out of sync)')
         wk, wsq = self._packed.get(self.weight)
         if (half_ops or SPLIT_FP16_PRODUCTS) and hipops.conv_h_supported(self.in_channels, self.out_channels, x.shape[2], x.shape[3], 3,
                                                                         self.up == 2):
@@ -345,11 +397,9 @@ class SynthesisLayer(torch.nn.Module):
         if demod is None:
             demod = hipops.modconv_demod(styles, wsq)
         x = x.float().contiguous()
-        const_noise = self.use_noise and noise_mode == 'const'
         nz = self.noise_const.reshape(-1) if const_noise else None
         ns = self.noise_strength.detach().float().reshape(1) if const_noise else None
         bias = self.bias.detach().float()
-        res = self.resolution
         if self.use_noise and noise_mode == 'random':  # per-sample noise: keep it outside the fused tail
             rnd_noise = torch.randn([x.shape[0], 1, res, res], device=x.device) * self.noise_strength
             if self.up == 1:
@@ -362,20 +412,33 @@ class SynthesisLayer(torch.nn.Module):
             return hipops.conv2d_mfma(x, wk, styles, demod, nz, ns, bias, ksize=3, act=self.activation, gain=act_gain,
                                       clamp=act_clamp)
         t = hipops.conv2d_mfma(x, wk, styles, demod, ksize=3, transposed=True)
+        sn = None if half_ops else self._consumer_styles(split_for, res, noise_mode)
+        if sn is not None and self.out_channels % 8 == 0:      # (the consumer is on the split path although this layer is not)
+            out = hipops.fir_tail_split(t, self.resample_filter, nz, ns, bias, styles_next=sn, out_hw=(res, res), pad0=(1, 1), fir_gain=4.0,
+                                        act=self.activation, act_gain=act_gain, clamp=act_clamp, want_f32=keep_f32, split_for=split_for)
+            if isinstance(out, tuple):
+                out[0]._ia_split = out[1]
+                return out[0]
+            return out
         return hipops.upfirdn2d_bias_act(t, self.resample_filter, nz, ns, bias, up=1, pad0=(1, 1), out_hw=(res, res),
                                          fir_gain=4.0, act=self.activation, act_gain=act_gain, clamp=act_clamp)
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, half_ops=False):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, half_ops=False, split_for=None, keep_f32=True):
         assert noise_mode in ['random', 'const', 'none']
         in_res = self.resolution // self.up
-        misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
+        if isinstance(x, hipops.SplitAct):
+            assert tuple(x.shape[1:]) == (self.in_channels, in_res, in_res), (x.shape, self.in_channels, in_res)
+        else:
+            misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
         pre, self._pre = self._pre, None
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         if (_on_device(x) and self.activation in hipops.ACT_ID and self.weight.shape[2] == 3 and self.up in (1, 2)
                 and not _needs_autograd(x, w, self.weight, self.bias)):
             styles, demod = pre if pre is not None else (self.affine(w), None)
-            return self._fused_device_forward(x, styles, noise_mode, act_gain, act_clamp, demod, half_ops).to(x.dtype)
+            return self._fused_device_forward(x, styles, noise_mode, act_gain, act_clamp, demod, half_ops, split_for, keep_f32)
+        if isinstance(x, hipops.SplitAct):
+            raise RuntimeError('a SplitAct reached the torch route of a SynthesisLayer')
         styles = self.affine(w)
         noise = None
         if self.use_noise and noise_mode == 'random':
@@ -472,7 +535,9 @@ class SynthesisBlock(torch.nn.Module):
             self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2,
                                     resample_filter=resample_filter, channels_last=self.channels_last)
 
-    def forward(self, x, img, ws, condition=None, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
+    def forward(self, x, img, ws, condition=None, force_fp32=False, fused_modconv=None, update_emas=False, _next_conv=None, **layer_kwargs):
+        """`_next_conv`: the layer that consumes this block's x (the next block's conv0), given by the owning network on the device
+        inference path so that conv1 can emit its result in the format that layer reads (hipops.SplitAct)."""
         _ = update_emas
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
         w_iter = iter(ws.unbind(dim=1))
@@ -489,23 +554,26 @@ class SynthesisBlock(torch.nn.Module):
 
         if self.in_channels == 0:
             x = self.const.to(dtype=dtype, memory_format=fmt).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
-        else:
+        elif not isinstance(x, hipops.SplitAct):      # (a SplitAct was made for conv0 by its producer; conv0 checks its shape)
             misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
             x = x.to(dtype=dtype, memory_format=fmt)
 
         if self.in_channels == 0:
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, split_for=_next_conv, **layer_kwargs)
         elif self.architecture == 'resnet':
             y = self.skip(x, gain=np.sqrt(0.5))
             x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
             x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=np.sqrt(0.5), **layer_kwargs)
             x = y.add_(x)
         else:
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            # (conv0's result has one consumer, conv1: unless the CS-SFT condition edits it in between it is produced in conv1's
+            # input format only)
+            chain = dict(split_for=self.conv1, keep_f32=False) if condition is None else {}
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **chain, **layer_kwargs)
             if condition is not None:
                 half = int(x.size(1) // 2)
                 x = torch.cat([x[:, :half], x[:, half:] * condition[0] + condition[1]], dim=1)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, split_for=_next_conv, **layer_kwargs)
 
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
@@ -613,8 +681,13 @@ class SynthesisNetwork(torch.nn.Module):
         x = img = None
         self._prepare_styles(ws)
         for res, cur_ws in zip(self.block_resolutions, self._split_ws(ws)):
-            x, img = getattr(self, f'b{res}')(x, img, cur_ws, **block_kwargs)
+            x, img = getattr(self, f'b{res}')(x, img, cur_ws, _next_conv=self._next_conv(res), **block_kwargs)
         return img
+
+    def _next_conv(self, res):
+        """conv0 of the block after `res` (the consumer of this block's features), or None for the last block."""
+        nxt = getattr(self, f'b{res * 2}', None)
+        return getattr(nxt, 'conv0', None)
 
     def extra_repr(self):
         return (f'w_dim={self.w_dim:d}, num_ws={self.num_ws:d}, img_resolution={self.img_resolution:d}, '

@@ -19,10 +19,14 @@ from ..training.networks_stylegan2 import (normalize_2nd_moment, modulated_conv2
                                            MappingNetwork, SynthesisLayer, ToRGBLayer, SynthesisBlock)
 
 
-def _paste(cond, x, fused):
-    """cond[:, :-1] * a + x * (1 - a), a = cond[:, -1:] (reference :537-540)."""
+def _paste(cond, x, fused, consumer=None):
+    """cond[:, :-1] * a + x * (1 - a), a = cond[:, -1:] (reference :537-540).  `consumer`: the one layer that reads the result (the next
+    block's conv0); when it takes split input the blend is written in that format only (hipops.SplitAct)."""
     if fused and cond.dtype == torch.float32 and (x.shape[2] * x.shape[3]) % 4 == 0:
         from invertavatar_amd import hipops
+        if (consumer is not None and consumer._pre is not None and x.shape[1] % 8 == 0 and consumer.in_channels == x.shape[1]
+                and consumer._takes_split_input(x.shape[2])):
+            return hipops.cond_blend_split(cond.contiguous(), x.contiguous(), consumer._pre[0], consumer)
         return hipops.cond_blend(cond.contiguous(), x.contiguous())
     a = cond[:, -1:]
     return cond[:, :-1] * a + x * (1 - a)
@@ -39,7 +43,7 @@ class SynthesisNetwork(_base.SynthesisNetwork):
         for idx, (res, cur_ws) in enumerate(zip(self.block_resolutions, self._split_ws(ws))):
             if idx > first:
                 break
-            x, img = getattr(self, f'b{res}')(x, img, cur_ws, None, **block_kwargs)
+            x, img = getattr(self, f'b{res}')(x, img, cur_ws, None, _next_conv=self._next_conv(res), **block_kwargs)
         return x, img, first
 
     def forward(self, ws, cond_list, return_list, feat_conditions=None, return_imgs=False, out_res=(32, 256), _head=None, _tap=None,
@@ -58,13 +62,13 @@ class SynthesisNetwork(_base.SynthesisNetwork):
                     continue
                 x, img = _head[0], _head[1]                         # resume after the pre-computed head
             else:
-                x, img = getattr(self, f'b{res}')(x, img, cur_ws, cond, **block_kwargs)
+                x, img = getattr(self, f'b{res}')(x, img, cur_ws, cond, _next_conv=self._next_conv(res), **block_kwargs)
             if idx < first:
                 continue
             # On the device inference path nothing downstream writes x / img in place (every fused layer allocates its
             # output), so the taps are returned without the reference's defensive clones, and the condition paste
             # (four elementwise kernels in the reference, :537-540) is one launch.
-            fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()      # (x: this block's fp32 output)
             if return_list:
                 if idx == first:
                     feats.append(img if fused else img.clone())
@@ -75,7 +79,7 @@ class SynthesisNetwork(_base.SynthesisNetwork):
                 if idx == first:   # face region copied straight into the skip image
                     img = _paste(cond_list[0], img, fused)
                 if idx < last:     # ... and into the features of the next block's input
-                    x = _paste(cond_list[1 + idx - first], x, fused)
+                    x = _paste(cond_list[1 + idx - first], x, fused, self._next_conv(res))
         if return_list:
             feats.append(img)
             return feats

@@ -55,7 +55,8 @@ class _TwoBlockHead(torch.nn.Module):
             ws = _last_w(ws)
             self._prepare_styles(ws)
         x, rgb = _fit(x, rgb, self.input_resolution, self.sr_antialias)
-        x, rgb = self.block0(x, rgb, ws, **block_kwargs)
+        chain = dict(_next_conv=getattr(self.block1, 'conv0', None)) if isinstance(self.block0, SynthesisBlock) else {}
+        x, rgb = self.block0(x, rgb, ws, **chain, **block_kwargs)
         x, rgb = self.block1(x, rgb, ws, **block_kwargs)
         return rgb
 
@@ -177,7 +178,8 @@ class SuperresolutionHybrid4X(_TwoBlockHead):
         ws = _last_w(ws)
         if x.shape[-1] < self.input_resolution:   # this head only ever up-samples its input (:79)
             x, rgb = _fit(x, rgb, self.input_resolution, self.sr_antialias)
-        x, rgb = self.block0(x, rgb, ws, **block_kwargs)
+        chain = dict(_next_conv=getattr(self.block1, 'conv0', None)) if isinstance(self.block0, SynthesisBlock) else {}
+        x, rgb = self.block0(x, rgb, ws, **chain, **block_kwargs)
         x, rgb = self.block1(x, rgb, ws, **block_kwargs)
         return rgb
 

@@ -220,3 +220,94 @@ def test_split_fp16_form_large_transposed_tile():
     err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
     print(f'large transposed fp16-pair tile: relative max error vs fp64 {err:.2e}')
     assert err <= 1e-6
+
+
+# ---------------------------------------------------------------- split-format (LDS-DMA) convolution: ia_act_split + ia_conv2d_mfma_sx
+def _split_reference(x, s):
+    """The fp16 pair the kernels must store: hi = fp16(v) (0 below the normal range), lo = fp16((v - hi) * 2^11), v = x * s saturated."""
+    v = (x * s[:, :, None, None]).clamp(-65504.0, 65504.0)
+    hi = torch.where(v.abs() < 6.103515625e-5, torch.zeros_like(v), v).half()
+    lo = ((v - hi.float()) * 2048.0).half()
+    return hi, lo
+
+
+def test_act_split_format():
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(2, 24, 9, 13, device='cuda', generator=g) * torch.logspace(-7, 4, 24, device='cuda')[None, :, None, None]
+    x[0, 0, 0, 0], x[0, 1, 0, 0] = 1e6, -1e6                 # saturate
+    s = torch.rand(2, 24, device='cuda', generator=g) + 0.5
+    xs = hipops.act_split(x, s)
+    hi, lo = _split_reference(x, s)
+    got_hi = xs.data[:, 0].permute(0, 1, 4, 2, 3).reshape(2, 24, 9, 13)
+    got_lo = xs.data[:, 1].permute(0, 1, 4, 2, 3).reshape(2, 24, 9, 13)
+    assert torch.equal(got_hi, hi) and torch.equal(got_lo, lo)
+    v = (x * s[:, :, None, None]).clamp(-65504, 65504)
+    assert ((xs.float() - v).abs() <= v.abs() * 2.0 ** -21 + 2.0 ** -26).all()     # 22 mantissa bits
+
+
+@pytest.mark.parametrize('i,o,h,w,tr,batch', [(128, 128, 64, 64, False, 1), (64, 128, 40, 72, False, 2), (256, 256, 32, 32, False, 1),
+                                              (64, 64, 65, 65, True, 1), (32, 64, 128, 128, True, 1), (128, 64, 33, 47, True, 2),
+                                              (128, 128, 256, 256, False, 1), (128, 64, 256, 256, True, 1)])
+def test_split_dma_convolution_equals_the_register_staged_form(i, o, h, w, tr, batch):
+    """ia_conv2d_mfma_sx (pre-split activations, operands DMA'd into LDS) is the SAME arithmetic as ia_conv2d_mfma_s: every output
+    bit is equal, for whole-tile, stream-K and fix-up tiles, with the fused epilogue, and for the split second output."""
+    g = torch.Generator(device='cuda').manual_seed(11 + i + h)
+    x = torch.randn(batch, i, h, w, device='cuda', generator=g) * 2
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g)
+    s = torch.rand(batch, i, device='cuda', generator=g) + 0.5
+    sn = torch.rand(batch, o, device='cuda', generator=g) + 0.5
+    wk = hipops.pack_conv_weight_split(wt)
+    d = hipops.modconv_demod(s, hipops.weight_sq_sum(wt))
+    xs = hipops.act_split(x, s)
+    if tr:
+        want = hipops.conv2d_mfma(x, wk, styles=s, demod=d, ksize=3, transposed=True)
+        got = hipops.conv2d_mfma_sx(xs, wk, demod=d, transposed=True)
+        assert torch.equal(got, want)
+        return
+    bias = torch.randn(o, device='cuda', generator=g)
+    noise = torch.randn(h * w, device='cuda', generator=g)
+    ns = torch.full((1,), 0.3, device='cuda')
+    kw = dict(demod=d, noise=noise, noise_strength=ns, bias=bias, act='lrelu', gain=1.3, clamp=4.0)
+    want = hipops.conv2d_mfma(x, wk, styles=s, ksize=3, **kw)
+    got, got_s = hipops.conv2d_mfma_sx(xs, wk, styles_next=sn, **kw)
+    assert torch.equal(got, want)
+    hi, lo = _split_reference(want, sn)
+    assert torch.equal(got_s.data[:, 0].permute(0, 1, 4, 2, 3).reshape(want.shape), hi)
+    assert torch.equal(got_s.data[:, 1].permute(0, 1, 4, 2, 3).reshape(want.shape), lo)
+    only_s = hipops.conv2d_mfma_sx(xs, wk, styles_next=sn, want_f32=False, **kw)
+    assert torch.equal(only_s.data, got_s.data)
+
+
+@pytest.mark.parametrize('c,res,batch', [(16, 32, 2), (32, 64, 1), (8, 256, 1), (128, 128, 1)])
+def test_fir_tail_split_equals_fir_tail_then_split(c, res, batch):
+    """ia_fir_tail_split = ia_upfirdn2d_bias_act (same sums, bit for bit) followed by the split of (result * styles_next)."""
+    from invertavatar_amd.torch_utils.ops import upfirdn2d
+    g = torch.Generator(device='cuda').manual_seed(c + res)
+    t = torch.randn(batch, c, 2 * (res // 2) + 1, 2 * (res // 2) + 1, device='cuda', generator=g)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).cuda()
+    noise = torch.randn(res * res, device='cuda', generator=g)
+    ns = torch.full((1,), 0.25, device='cuda')
+    bias = torch.randn(c, device='cuda', generator=g)
+    sn = torch.rand(batch, c, device='cuda', generator=g) + 0.5
+    kw = dict(out_hw=(res, res), pad0=(1, 1), fir_gain=4.0, act='lrelu', act_gain=2 ** 0.5, clamp=3.0)
+    want = hipops.upfirdn2d_bias_act(t, f, noise, ns, bias, up=1, **kw)
+    y, ys = hipops.fir_tail_split(t, f, noise, ns, bias, styles_next=sn, want_f32=True, **kw)
+    assert torch.equal(y, want)
+    hi, lo = _split_reference(want, sn)
+    assert torch.equal(ys.data[:, 0].permute(0, 1, 4, 2, 3).reshape(want.shape), hi)
+    assert torch.equal(ys.data[:, 1].permute(0, 1, 4, 2, 3).reshape(want.shape), lo)
+    only = hipops.fir_tail_split(t, f, noise, ns, bias, styles_next=sn, **kw)
+    assert torch.equal(only.data, ys.data)
+
+
+def test_cond_blend_split_equals_cond_blend_then_split():
+    g = torch.Generator(device='cuda').manual_seed(8)
+    cond = torch.randn(2, 33, 64, 64, device='cuda', generator=g)
+    cond[:, -1] = torch.rand(2, 64, 64, device='cuda', generator=g)
+    x = torch.randn(2, 32, 64, 64, device='cuda', generator=g)
+    sn = torch.rand(2, 32, device='cuda', generator=g) + 0.5
+    want = hipops.cond_blend(cond, x)
+    got = hipops.cond_blend_split(cond, x, sn, None)
+    hi, lo = _split_reference(want, sn)
+    assert torch.equal(got.data[:, 0].permute(0, 1, 4, 2, 3).reshape(want.shape), hi)
+    assert torch.equal(got.data[:, 1].permute(0, 1, 4, 2, 3).reshape(want.shape), lo)
