@@ -326,6 +326,39 @@ int ia_fir_tail_split(const float* x, const float* f, const float* noise, const 
 int ia_cond_blend_split(const float* cond, const float* x, const float* styles_next, void* ys, int B, int C, int H, int W, void* stream);
 
 /*
+ * Fused filtered leaky ReLU: bias -> up-sample (zero insert, pad/crop, up-FIR x up^2) -> lrelu(slope) x gain -> clamp -> down-FIR ->
+ * decimate, the up-sampled intermediate kept in LDS.
+ * Replaces filtered_lrelu_plugin.filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp,
+ * flip_filter, writeSigns) -> (y, so, rc) (torch_utils/ops/filtered_lrelu.cpp:20-22,217; kernels filtered_lrelu.cu:144-1103) for
+ * the forward pass without sign tensors (si = None, writeSigns = false: what inference calls); semantics = the reference's own
+ * definition of the op, _filtered_lrelu_ref (filtered_lrelu.py:123-155).
+ *   x, y   : [n, c, in_h, in_w] / [n, c, out_h, out_w] contiguous NCHW of `dtype` (IA_F32 or IA_F16; f64 -> IA_ERR_UNSUPPORTED,
+ *            the caller composes bias_act + upfirdn2d, as the reference does when its plugin returns rc = -1, :225-231)
+ *   fu, fd : 2-D float32 filters [fu_h, fu_w] / [fd_h, fd_w], contiguous (separable filters are passed as their outer product),
+ *            or NULL with size 1x1 for identity
+ *   b      : [c] of `dtype` or NULL
+ *   out size must equal (in*up + pad0 + pad1 - (fu - 1) - (fd - 1) + (down - 1)) / down per axis (filtered_lrelu.py:142-143)
+ *   clamp < 0 : disabled
+ */
+int ia_filtered_lrelu(const void* x, const float* fu, const float* fd, const void* b, void* y, int dtype,
+                      int n, int c, int in_h, int in_w, int out_h, int out_w, int fu_h, int fu_w, int fd_h, int fd_w,
+                      int up, int down, int px0, int px1, int py0, int py1, float gain, float slope, float clamp,
+                      int flip_filter, void* stream);
+
+/*
+ * ConvGRU cell of the inversion encoder's recurrent up-path (encoder_inversion/models/unet_encoders.py:8-49): the element-wise
+ * work around its two convolutions, which stay library convolutions on the caller's side.
+ *   ia_convgru_gates : xrh = cat[x, sigmoid(gates_pre[:, :C]) * h]                  ([B,2C,H,W]; the input of conv_hh, :26-27)
+ *   ia_convgru_update: z = sigmoid(gates_pre[:, C:]); c = tanh(cand_pre) (PReLU with prelu_weight[C] when non-NULL, :19-20);
+ *                      h_out = (1 - z) * h + z * c (:28); with x_next / xh_next also xh_next = cat[x_next, h_out], the input of
+ *                      conv_ih of the next time step (:25)
+ * gates_pre = conv_ih(cat[x, h]) + bias [B,2C,H,W]; cand_pre = conv_hh(xrh) + bias [B,C,H,W]; all fp32 contiguous, H*W % 4 == 0.
+ */
+int ia_convgru_gates(const float* gates_pre, const float* x, const float* h, float* xrh, int B, int C, int H, int W, void* stream);
+int ia_convgru_update(const float* gates_pre, const float* cand_pre, const float* h, const float* prelu_weight, float* h_out,
+                      const float* x_next, float* xh_next, int B, int C, int H, int W, void* stream);
+
+/*
  * Output side: float image batch -> uint8 picture grid, one pass.
  * Replaces layout_grid(img, grid_w, grid_h, float_to_uint8=True, chw_to_hwc) of the reference's scripts
  * (reenact_avatar_next3d.py:117-131): (img * 127.5 + 128).clamp(0, 255).to(uint8), frames tiled row-major into a

@@ -44,6 +44,9 @@ _SIGNATURES = {
     'ia_conv2d_mfma_sx': [c_void_p] * 2 + [c_int] + [c_void_p] * 9 + [ctypes.c_size_t] + [c_int] * 7 + [c_float] * 3 + [c_int, c_void_p],
     'ia_fir_tail_split': [c_void_p] * 8 + [c_int] * 9 + [c_float, c_int, c_float, c_float, c_float, c_void_p],
     'ia_cond_blend_split': [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
+    'ia_filtered_lrelu': [c_void_p] * 5 + [c_int] * 17 + [c_float] * 3 + [c_int, c_void_p],
+    'ia_convgru_gates': [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
+    'ia_convgru_update': [c_void_p] * 7 + [c_int] * 4 + [c_void_p],
     'ia_layout_grid_u8': [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     'ia_ray_sampler': [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'ia_styles_demod': [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 from torch import nn
 from torch.nn import Module
+import torch.nn.functional as F
 
 from .helpers import irse50_trunk, run_trunk
 
@@ -24,7 +25,26 @@ class ConvGRU(torch.nn.Module):
         self.hh = torch.nn.Sequential(nn.Conv2d(channels * 2, channels, kernel_size, padding=padding),
                                       nn.PReLU(channels) if out_act_prelu else torch.nn.Tanh())
 
+    def _fused(self, x):
+        """Device inference path: the convolutions through the library, everything between them in two HIP launches per step."""
+        return (x.is_cuda and x.dtype == torch.float32 and (x.shape[-1] * x.shape[-2]) % 4 == 0
+                and not (torch.is_grad_enabled() and (x.requires_grad or self.ih[0].weight.requires_grad)))
+
+    def _step_fused(self, xh, x, h, x_next):
+        """xh = cat[x, h] (made by the previous step's update launch).  Returns (h', cat[x_next, h'] or None)."""
+        from ... import hipops
+        conv_ih, conv_hh, act = self.ih[0], self.hh[0], self.hh[1]
+        gates_pre = F.conv2d(xh, conv_ih.weight, conv_ih.bias, padding=conv_ih.padding)
+        xrh = hipops.convgru_gates(gates_pre, x, h)
+        cand_pre = F.conv2d(xrh, conv_hh.weight, conv_hh.bias, padding=conv_hh.padding)
+        prelu_w = act.weight.detach().float().contiguous() if isinstance(act, nn.PReLU) else None
+        return hipops.convgru_update(gates_pre, cand_pre, h, prelu_w, x_next)
+
     def forward_single_frame(self, x, h):
+        if self._fused(x):
+            x, h = x.contiguous(), h.contiguous()
+            h, _ = self._step_fused(torch.cat([x, h], dim=1), x, h, None)
+            return h, h
         r, z = self.ih(torch.cat([x, h], dim=1)).split(self.channels, dim=1)
         c = self.hh(torch.cat([x, r * h], dim=1))
         h = (1 - z) * h + z * c
@@ -32,6 +52,15 @@ class ConvGRU(torch.nn.Module):
 
     def forward_time_series(self, x, h, seq2seq):
         outs = []
+        if self._fused(x):
+            frames = [xt.contiguous() for xt in x.unbind(dim=1)]
+            h = h.contiguous()
+            xh = torch.cat([frames[0], h], dim=1)
+            for t, xt in enumerate(frames):
+                h, xh = self._step_fused(xh, xt, h, frames[t + 1] if t + 1 < len(frames) else None)
+                if seq2seq:
+                    outs.append(h)
+            return (torch.stack(outs, dim=1) if seq2seq else h), h
         for xt in x.unbind(dim=1):
             ot, h = self.forward_single_frame(xt, h)
             if seq2seq:

@@ -500,3 +500,27 @@ def ray_sampler(cam25, resolution, normalize=True):
                                         _lib.stream_ptr(cam25.device))
     _lib.check(st, 'ia_ray_sampler')
     return rays_o, rays_d
+
+
+def convgru_gates(gates_pre, x, h):
+    """cat[x, sigmoid(r_pre) * h] (see ia_convgru_gates)."""
+    b, c, hh, w = x.shape
+    xrh = torch.empty(b, 2 * c, hh, w, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        st = _lib.load().ia_convgru_gates(_p(_f32c(gates_pre, 'gates_pre')), _p(_f32c(x, 'x')), _p(_f32c(h, 'h')), _p(xrh), b, c, hh, w,
+                                          _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_convgru_gates')
+    return xrh
+
+
+def convgru_update(gates_pre, cand_pre, h, prelu_weight=None, x_next=None):
+    """h' = (1 - z) h + z tanh(c_pre) and, with x_next, cat[x_next, h'] for the next step (see ia_convgru_update)."""
+    b, c, hh, w = h.shape
+    h_out = torch.empty_like(h)
+    xh = torch.empty(b, 2 * c, hh, w, device=h.device, dtype=torch.float32) if x_next is not None else None
+    with torch.cuda.device(h.device):
+        st = _lib.load().ia_convgru_update(_p(_f32c(gates_pre, 'gates_pre')), _p(_f32c(cand_pre, 'cand_pre')), _p(_f32c(h, 'h')),
+                                           _p(None if prelu_weight is None else _f32c(prelu_weight, 'prelu_weight')), _p(h_out),
+                                           _p(None if x_next is None else _f32c(x_next, 'x_next')), _p(xh), b, c, hh, w, _lib.stream_ptr(h.device))
+    _lib.check(st, 'ia_convgru_update')
+    return h_out, xh

@@ -94,13 +94,58 @@ def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     return y
 
 
-def _filtered_lrelu_unavailable(*args, **kwargs):
-    raise NotImplementedError('filtered_lrelu has no HIP kernel yet (SURVEY.md 8f rank 2); use impl="ref"')
+def _as_2d_filter(f, device):
+    """None -> (NULL, 1, 1); [taps] -> outer product (the separable passes of upfirdn2d multiply out to it); [h, w] as is."""
+    if f is None:
+        return None, 1, 1
+    f = f.to(device=device, dtype=torch.float32)
+    if f.ndim == 1:
+        f = f[:, None] * f[None, :]
+    f = f.contiguous()
+    return f, int(f.shape[0]), int(f.shape[1])
+
+
+def filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filter, writeSigns):
+    """filtered_lrelu_plugin.filtered_lrelu (torch_utils/ops/filtered_lrelu.cpp:20-22) -> (y, so, return_code).
+    return_code -1 = "no kernel for this call" (sign tensors / float64 / oversized tile): the caller composes the op from
+    bias_act + upfirdn2d exactly as the reference's Python does (filtered_lrelu.py:225-231)."""
+    empty = torch.empty(0, device=x.device, dtype=torch.uint8)
+    if (si is not None and si.numel()) or writeSigns or x.dtype not in (torch.float32, torch.float16) or x.ndim != 4:
+        return None, empty, -1
+    x = x.contiguous()
+    fu2, fu_h, fu_w = _as_2d_filter(fu if (fu is None or fu.numel()) else None, x.device)
+    fd2, fd_h, fd_w = _as_2d_filter(fd if (fd is None or fd.numel()) else None, x.device)
+    n, c, ih, iw = x.shape
+    oh = (ih * up + py0 + py1 - (fu_h - 1) - (fd_h - 1) + (down - 1)) // down
+    ow = (iw * up + px0 + px1 - (fu_w - 1) - (fd_w - 1) + (down - 1)) // down
+    if oh < 1 or ow < 1:
+        raise RuntimeError('filtered_lrelu: output would be empty')
+    if b is not None and b.numel():
+        if b.dtype != x.dtype or b.numel() != c:
+            raise RuntimeError('b must be a 1-D tensor of the dtype of x with one entry per channel')
+        b = b.contiguous()
+    else:
+        b = None
+    y = torch.empty(n, c, oh, ow, device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        st = _lib.load().ia_filtered_lrelu(x.data_ptr(), None if fu2 is None else fu2.data_ptr(), None if fd2 is None else fd2.data_ptr(),
+                                           None if b is None else b.data_ptr(), y.data_ptr(), _lib.DTYPE_ID[x.dtype], n, c, ih, iw, oh, ow,
+                                           fu_h, fu_w, fd_h, fd_w, int(up), int(down), int(px0), int(px1), int(py0), int(py1), float(gain),
+                                           float(slope), float(clamp), 1 if flip_filter else 0, _lib.stream_ptr(x.device))
+    if st == -2:          # IA_ERR_UNSUPPORTED: no kernel for this configuration
+        return None, empty, -1
+    _lib.check(st, 'filtered_lrelu')
+    return y, empty, 0
+
+
+def filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, writeSigns):
+    """filtered_lrelu_plugin.filtered_lrelu_act_ (filtered_lrelu.cpp:217): the in-place activation with sign tensors that the
+    reference's BACKWARD pass uses.  Gradients are outside this backend's scope (inference needs grad = 0)."""
+    raise NotImplementedError('filtered_lrelu_act_ serves the gradient path only; differentiate through impl="ref"')
 
 
 TABLE = {
     'bias_act_plugin': {'bias_act': bias_act},
     'upfirdn2d_plugin': {'upfirdn2d': upfirdn2d},
-    'filtered_lrelu_plugin': {'filtered_lrelu': _filtered_lrelu_unavailable,
-                              'filtered_lrelu_act_': _filtered_lrelu_unavailable},
+    'filtered_lrelu_plugin': {'filtered_lrelu': filtered_lrelu, 'filtered_lrelu_act_': filtered_lrelu_act_},
 }

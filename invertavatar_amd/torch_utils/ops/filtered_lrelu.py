@@ -1,15 +1,15 @@
 """Filtered leaky ReLU: bias -> up-FIR -> lrelu*gain -> clamp -> down-FIR (reference API:
 torch_utils/ops/filtered_lrelu.py:58-118).
 
-Not reached by the Next3D++ generator (only by the StyleGAN3 backbone).  The op
-is expressed through ``bias_act`` and ``upfirdn2d``; on device tensors those are the HIP kernels,
-which is also what the reference does when its fused plugin reports "no kernel"
-(filtered_lrelu.py:225-231).  A single fused HIP kernel is a SURVEY.md 8f item."""
+Not reached by the Next3D++ generator (only by the StyleGAN3 backbone).  Device fp32 / fp16 tensors run the fused
+HIP kernel ``ia_filtered_lrelu`` (the up-sampled intermediate stays in LDS); everything else -- CPU tensors, float64, tensors
+that need gradients -- is expressed through ``bias_act`` and ``upfirdn2d``, which is what the reference does when its fused
+plugin reports "no kernel" (filtered_lrelu.py:225-231)."""
 import numpy as np
 import torch
 
 from .. import misc
-from . import bias_act, upfirdn2d
+from . import _plugins, bias_act, upfirdn2d
 from .upfirdn2d import _get_filter_size, _parse_padding
 
 
@@ -24,6 +24,13 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np
                    flip_filter=False, impl='cuda'):
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
+    if (impl == 'cuda' and x.device.type == 'cuda' and x.ndim == 4 and x.dtype in (torch.float32, torch.float16)
+            and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, fu, fd, b)))):
+        px0, px1, py0, py1 = _parse_padding(padding)
+        y, _, rc = _plugins.filtered_lrelu(x, fu, fd, b, None, int(up), int(down), px0, px1, py0, py1, 0, 0, float(gain), float(slope),
+                                           float(-1 if clamp is None else clamp), bool(flip_filter), False)
+        if rc == 0:
+            return y
     return _filtered_lrelu_ref(x, fu=fu, fd=fd, b=b, up=up, down=down, padding=padding, gain=gain, slope=slope,
                                clamp=clamp, flip_filter=flip_filter, impl=impl)
 

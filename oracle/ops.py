@@ -125,6 +125,17 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1.0):
     return acc[:, :, ::dny, ::dnx]
 
 
+def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=2 ** 0.5, slope=0.2, clamp=None, flip_filter=False):
+    """bias -> up-sample (up-FIR x up^2) -> lrelu(slope) x gain -> clamp -> down-FIR -> decimate.
+
+    Reference: the op's own definition torch_utils/ops/filtered_lrelu.py:123-155 (_filtered_lrelu_ref), which is also the
+    semantics of the fused CUDA kernel (filtered_lrelu.cu:144); composed here from the oracle's upfirdn2d / bias_act."""
+    t = bias_act(x, b)
+    t = upfirdn2d(t, fu, up=up, padding=padding, gain=float(up * up), flip_filter=flip_filter)
+    t = bias_act(t, act='lrelu', alpha=slope, gain=gain, clamp=clamp)
+    return upfirdn2d(t, fd, down=down, flip_filter=flip_filter)
+
+
 def upsample2d(x, f, up=2, gain=1.0):
     """Reference: torch_utils/ops/upfirdn2d.py:315-350."""
     fh, fw = (f.shape[0], f.shape[-1]) if f.ndim == 2 else (f.shape[0], f.shape[0])

@@ -261,6 +261,33 @@ def gen_generator_bench():
     npz('generator_full_nrr128.npz', **arrays)
 
 
+FLR_CASES = {   # name: (shape, fu taps (0 = None; negative = 2-D of that size), fd taps, up, down, padding, gain, slope, clamp, flip)
+    'sg3_up2_down2': ((2, 3, 20, 24), 12, 12, 2, 2, [10, 11, 9, 10], 2 ** 0.5, 0.2, 256.0, False),
+    'up4_down2_flip': ((1, 4, 9, 13), 8, 6, 4, 2, [5, 6, 7, 4], 1.7, 0.1, None, True),
+    'up2_only_2d': ((1, 2, 16, 16), -4, 0, 2, 1, [2, 1, 2, 1], 2 ** 0.5, 0.2, 0.8, False),
+    'down2_only': ((2, 2, 33, 31), 0, 5, 1, 2, 0, 1.0, 0.3, None, False),
+    'identity_filters': ((1, 3, 7, 9), 0, 0, 1, 1, [1, -1, 0, 2], 2 ** 0.5, 0.2, 1.0, False),
+    'crop_negative_pad': ((1, 2, 24, 24), 6, 6, 2, 2, [-3, 4, 2, -1], 2 ** 0.5, 0.2, None, False),
+}
+
+
+def gen_filtered_lrelu():
+    """Outputs of the reference's own definition of the op (_filtered_lrelu_ref = what filtered_lrelu() evaluates on CPU)."""
+    from torch_utils.ops import filtered_lrelu as flr
+    arrays = {}
+    for i, (name, (shape, nu, nd, up, down, pad, gain, slope, clamp, flip)) in enumerate(FLR_CASES.items()):
+        x = rnd(300 + i, *shape)
+        b = rnd(320 + i, shape[1]) * 0.5
+        mk = lambda seed, n: None if n == 0 else (rnd(seed, -n, -n).abs() / n ** 2 if n < 0 else rnd(seed, n).abs() / n)   # noqa: E731
+        fu, fd = mk(340 + i, nu), mk(360 + i, nd)
+        y = flr.filtered_lrelu(x, fu=fu, fd=fd, b=b, up=up, down=down, padding=pad, gain=gain, slope=slope, clamp=clamp, flip_filter=flip,
+                               impl='ref')
+        arrays[f'{name}/x'], arrays[f'{name}/b'], arrays[f'{name}/y'] = x, b, y
+        if fu is not None: arrays[f'{name}/fu'] = fu
+        if fd is not None: arrays[f'{name}/fd'] = fd
+    npz('filtered_lrelu.npz', **arrays)
+
+
 def import_reference_script(name):
     """Import one of the reference's top-level scripts (reenact_avatar_next3d.py, eval_seq.py) for its helpers.  Modules the
     scripts import at the top but the container lacks (imageio, torchvision.utils, the FaceVerse / pytorch3d renderer, the
@@ -412,7 +439,7 @@ def gen_names():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='ops,camera,renderer,small,full,bench,harness,names,encoder')
+    ap.add_argument('--only', default='ops,flr,camera,renderer,small,full,bench,harness,names,encoder')
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -420,6 +447,7 @@ def main():
     todo = args.only.split(',')
     with torch.no_grad():
         if 'ops' in todo: gen_ops()
+        if 'flr' in todo: gen_filtered_lrelu()
         if 'camera' in todo: gen_camera()
         if 'renderer' in todo: gen_renderer()
         if 'small' in todo: gen_generator('small')

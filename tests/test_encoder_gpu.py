@@ -13,3 +13,21 @@ def test_few_shot_inversion_matches_reference(golden):
     worst = compare_with_fixture(golden('encoder_fewshot.npz'), ws, res, r_list, image, tol=2e-3)
     print(f'few-shot inversion: worst relative deviation {worst:.2e}')
     assert image.shape == (1, 3, 512, 512)
+
+
+@pytest.mark.parametrize('prelu', [False, True])
+def test_convgru_cell_kernels_match_the_torch_cell(prelu):
+    """ia_convgru_gates / ia_convgru_update around the two library convolutions against the cell written with ATen ops
+    (unet_encoders.py:8-49), over a 4-frame series with a carried state; the CPU result of the same module is the reference."""
+    from invertavatar_amd.encoder_inversion.models.unet_encoders import ConvGRU
+    torch.manual_seed(3)
+    cell = ConvGRU(24, out_act_prelu=prelu).requires_grad_(False)
+    x = torch.randn(2, 4, 24, 16, 20)
+    h0 = torch.randn(2, 24, 16, 20)
+    want, want_h = cell(x, h0.clone(), seq2seq=True)
+    dev = cell.cuda()
+    got, got_h = dev(x.cuda(), h0.cuda(), seq2seq=True)
+    assert dev._fused(x.cuda())
+    assert (got.cpu() - want).abs().max().item() <= 2e-5 and (got_h.cpu() - want_h).abs().max().item() <= 2e-5
+    one, _ = dev(x[:, 0].cuda(), h0.cuda())
+    assert (one.cpu() - want[:, 0]).abs().max().item() <= 2e-5
