@@ -359,6 +359,22 @@ int ia_convgru_update(const float* gates_pre, const float* cand_pre, const float
                       const float* x_next, float* xh_next, int B, int C, int H, int W, void* stream);
 
 /*
+ * Driver-side UV rasteriser: projected FaceVerse mesh -> uvcoords_image, the mesh condition of TriPlaneGenerator.synthesis.
+ * Replaces Faceverse_manager.make_driven_rendering from the rasteriser call on (data_preprocess/FaceVerse/renderer.py:66-82:
+ * pytorch3d MeshRasterizer, ortho camera K = [-1,-1,0,0], T = [0,0,10], faces_per_pixel 1 -> render_after_rasterize
+ * (volumetric_rendering/renderer.py:556-571) -> x (vis * mask) -> crop -> HWC (u, v, mask >= 0.5)).
+ *   verts          : [B, V, 3] float32, the vertices handed to Meshes() (after batch_orth_proj and the z flip, :62-64)
+ *   tris           : [F, 3] int32
+ *   face_attrs     : [F, 3, 3] float32 = face_vertices(cat[uv * 2 - 1, mask], tris): (u, v, mask) of every corner (:33-34)
+ *   zbuf_scratch   : B * crop_w * crop_h * 8 bytes (caller-owned)
+ *   uvcoords_image : [B, crop_h, crop_w, 3] float32
+ *   raster_size 512, crop (128, 114, 256, 256), blur_radius 1e-6 in the reference (:13-14, :43)
+ */
+int ia_uv_rasterize(const float* verts, const int* tris, const float* face_attrs, void* zbuf_scratch, float* uvcoords_image,
+                    int B, int V, int F, int raster_size, int crop_left, int crop_top, int crop_w, int crop_h, float blur_radius,
+                    void* stream);
+
+/*
  * Output side: float image batch -> uint8 picture grid, one pass.
  * Replaces layout_grid(img, grid_w, grid_h, float_to_uint8=True, chw_to_hwc) of the reference's scripts
  * (reenact_avatar_next3d.py:117-131): (img * 127.5 + 128).clamp(0, 255).to(uint8), frames tiled row-major into a
