@@ -41,6 +41,9 @@ SPLIT_FP16_PRODUCTS = True
 # register-staged kernel (ia_conv2d_mfma_s) everywhere.
 USE_SPLIT_DMA = True
 
+# ToRGB + skip-image up-sampling + add as one streaming launch (ia_torgb); False: 1x1 MFMA convolution + separate FIR launch.
+FUSED_TORGB = True
+
 
 @misc.profiled_function
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
@@ -470,17 +473,25 @@ class ToRGBLayer(torch.nn.Module):
         self._packed = _PackedWeights()
         self._pre = None
 
-    def forward(self, x, w, fused_modconv=True, residual=None):
-        """`residual` (fp32, output-shaped) is added after the clamp: the skip-image add of
-        SynthesisBlock folded into this layer's epilogue on the device path."""
-        if _on_device(x) and self.weight.shape[2] == 1 and not _needs_autograd(x, w, self.weight, self.bias, residual):
+    def forward(self, x, w, fused_modconv=True, residual=None, skip=None, resample_filter=None):
+        """`residual` (fp32, output-shaped) is added after the clamp: the skip-image add of SynthesisBlock folded into this layer's
+        epilogue on the device path.  `skip` (+ `resample_filter`): the PREVIOUS block's image; its 2x up-sampling and the add run
+        inside the same launch (ia_torgb) -- the caller then passes no `residual`."""
+        if _on_device(x) and self.weight.shape[2] == 1 and not _needs_autograd(x, w, self.weight, self.bias, residual, skip):
             # weight_gain is folded into the packed weight instead of scaling the styles on every call
             wk, _ = self._packed.get(self.weight, scale=self.weight_gain)
-            res = None if residual is None else residual.float().contiguous()
             pre, self._pre = self._pre, None
             styles = pre[0] if pre is not None else self.affine(w).float().contiguous()
+            if FUSED_TORGB and residual is None and self.out_channels <= 96 and (skip is None or resample_filter is not None):
+                return hipops.torgb(x.float().contiguous(), wk, styles, self.bias.detach().float(),
+                                    None if skip is None else skip.float().contiguous(), resample_filter, clamp=self.conv_clamp)
+            if skip is not None:
+                residual = upfirdn2d.upsample2d(skip, resample_filter)
+            res = None if residual is None else residual.float().contiguous()
             return hipops.conv2d_mfma(x.float().contiguous(), wk, styles, None,
                                       bias=self.bias.detach().float(), residual=res, ksize=1, act='linear', clamp=self.conv_clamp)
+        if skip is not None:
+            residual = upfirdn2d.upsample2d(skip, resample_filter)
         styles = self.affine(w) * self.weight_gain
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         x = bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
@@ -577,10 +588,12 @@ class SynthesisBlock(torch.nn.Module):
 
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
-            img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
-            img = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, residual=img)
+            # img = upsample2d(img) + torgb(x): the up-sampling and the add happen inside the ToRGB launch
+            img = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, skip=img, resample_filter=self.resample_filter)
             img = img.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+        elif img is not None:
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
 
         assert x.dtype == dtype
         assert img is None or img.dtype == torch.float32
