@@ -382,7 +382,7 @@ int ia_uv_rasterize(const float* verts, const int* tris, const float* face_attrs
  *   x        : [B, I, H, W] fp32;  wk : [I, O] fp32 = weight[o, i] * weight_gain (pack_conv_weight layout for ksize 1)
  *   styles   : [B, I] (affine output, NOT multiplied by weight_gain: that is folded into wk)
  *   prev_img : [B, O, H/2, W/2] or NULL (first block);  f : the 4x4 resample filter (setup_filter([1,3,3,1])), needed with prev_img
- *   clamp < 0: disabled.  O <= 96.
+ *   clamp < 0: disabled.  O <= 96, H * W >= 64 (IA_ERR_UNSUPPORTED otherwise: callers use ia_conv2d_mfma with ksize 1).
  */
 int ia_torgb(const float* x, const float* wk, const float* styles, const float* bias, const float* prev_img, const float* f,
              float* y, int B, int I, int O, int H, int W, float clamp, void* stream);

@@ -40,12 +40,18 @@ __device__ __forceinline__ float upsample_tap_sum(const float* __restrict__ prev
     return acc;
 }
 
-// OPW = output channels per wave (O-split) or all output channels (K-split: KSPLIT = true)
+// OPW = output channels per wave (O-split) or all output channels (K-split: KSPLIT = true).
+// Weights and styles of a block of UN channels are fetched with VECTOR loads (lane l holds weight (channel l / OPW, output l % OPW)
+// of the block: consecutive lanes = consecutive outputs of a weight row) and handed to the FMAs with v_readlane: every load of a
+// block -- UN pixels rows, the weights, the styles -- is independent and in flight together, one wait per block.  (A first version
+// read the weights through the scalar cache: hipcc turned the per-output guards into branches around single s_load_dword's with a
+// wait each -- 200 us for a 4x4 image.)
 template <int OPW, bool KSPLIT>
 __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x, const float* __restrict__ wk, const float* __restrict__ styles,
                                                    const float* __restrict__ bias, const float* __restrict__ prev, const float* __restrict__ f,
                                                    float* __restrict__ y, RgbGeo g) {
     extern __shared__ float red[];                         // K-split only: [4][OPW][64]
+    constexpr int UN = 8, NV = UN * OPW, NL = (NV + 63) / 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     const int64_t hw = (int64_t)g.H * g.W;
@@ -57,25 +63,30 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x,
     float acc[OPW];
 #pragma unroll
     for (int j = 0; j < OPW; ++j) acc[j] = 0.f;
-    constexpr int UN = 8;
-    int i = i_lo;
-    for (; i + UN <= i_hi; i += UN) {
-        float xv[UN];
+    // per-lane weight slots of a block: value v = lane + 64 k  ->  (channel u = v / OPW, output j = v % OPW)
+    int w_u[NL], w_off[NL];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) xv[u] = xb[(int64_t)(i + u) * hw];
+    for (int k = 0; k < NL; ++k) {
+        const int v = lane + 64 * k, u = v / OPW, j = v - u * OPW;
+        w_u[k] = (v < NV && o0 + j < g.O) ? u : -1;
+        w_off[k] = u * g.O + o0 + j;
+    }
+    for (int i = i_lo; i < i_hi; i += UN) {
+        float xv[UN], wv[NL];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) xv[u] = xb[(int64_t)min(i + u, i_hi - 1) * hw];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) wv[k] = (w_u[k] >= 0 && i + w_u[k] < i_hi) ? wk[(int64_t)i * g.O + w_off[k]] : 0.f;     // channels past the range weigh 0
+        const float sv = sb[min(i + (lane & (UN - 1)), g.I - 1)];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const float xs = xv[u] * sb[i + u];
-            const float* wr = wk + (int64_t)(i + u) * g.O + o0;          // wave-uniform: scalar loads
+            const float xs = xv[u] * __builtin_amdgcn_readlane(sv, u);
 #pragma unroll
-            for (int j = 0; j < OPW; ++j) acc[j] = fmaf(xs, (o0 + j < g.O) ? wr[j] : 0.f, acc[j]);
+            for (int j = 0; j < OPW; ++j) {
+                const int v = u * OPW + j;
+                acc[j] = fmaf(xs, __builtin_amdgcn_readlane(wv[v / 64], v % 64), acc[j]);
+            }
         }
-    }
-    for (; i < i_hi; ++i) {
-        const float xs = xb[(int64_t)i * hw] * sb[i];
-        const float* wr = wk + (int64_t)i * g.O + o0;
-#pragma unroll
-        for (int j = 0; j < OPW; ++j) acc[j] = fmaf(xs, (o0 + j < g.O) ? wr[j] : 0.f, acc[j]);
     }
     const int oy = (int)(pc / g.W), ox = (int)(pc - (int64_t)oy * g.W);
     auto finish = [&](int o, float v) {
@@ -120,6 +131,7 @@ extern "C" int ia_torgb(const float* x, const float* wk, const float* styles, co
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
     IA_REQUIRE(prev_img == nullptr || (f != nullptr && H % 2 == 0 && W % 2 == 0), "the skip image is [B,O,H/2,W/2] and needs the 4x4 resample filter");
     IA_REQUIRE((int64_t)B * I * H * W <= INT32_MAX && (int64_t)B * O * H * W <= INT32_MAX, "tensor is too large");
+    if ((int64_t)H * W < 64) return ia::fail(IA_ERR_UNSUPPORTED, "ia_torgb: images below 8x8 run on ia_conv2d_mfma (ksize 1)");
     RgbGeo g{B, I, O, H, W, prev_img ? 1 : 0, clamp};
     hipStream_t s = (hipStream_t)stream;
     const bool small = (int64_t)H * W <= 1024 && I % 4 == 0;

@@ -42,7 +42,9 @@ SPLIT_FP16_PRODUCTS = True
 USE_SPLIT_DMA = True
 
 # ToRGB + skip-image up-sampling + add as one streaming launch (ia_torgb); False: 1x1 MFMA convolution + separate FIR launch.
-FUSED_TORGB = True
+# Measured r02 (MI355X, B = 1): the streaming kernel is load-latency bound -- 42-140 us where the MFMA form + FIR take 30-80 -- so
+# it is OFF; it stays as the C-ABI entry for callers that want the single launch (and as the starting point for a batched form).
+FUSED_TORGB = False
 
 
 @misc.profiled_function
@@ -482,7 +484,8 @@ class ToRGBLayer(torch.nn.Module):
             wk, _ = self._packed.get(self.weight, scale=self.weight_gain)
             pre, self._pre = self._pre, None
             styles = pre[0] if pre is not None else self.affine(w).float().contiguous()
-            if FUSED_TORGB and residual is None and self.out_channels <= 96 and (skip is None or resample_filter is not None):
+            if (FUSED_TORGB and residual is None and self.out_channels <= 96 and x.shape[2] * x.shape[3] >= 64
+                    and (skip is None or resample_filter is not None)):
                 return hipops.torgb(x.float().contiguous(), wk, styles, self.bias.detach().float(),
                                     None if skip is None else skip.float().contiguous(), resample_filter, clamp=self.conv_clamp)
             if skip is not None:

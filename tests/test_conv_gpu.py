@@ -313,7 +313,7 @@ def test_cond_blend_split_equals_cond_blend_then_split():
     assert torch.equal(got.data[:, 1].permute(0, 1, 4, 2, 3).reshape(want.shape), lo)
 
 
-@pytest.mark.parametrize('i,o,res,batch,prev', [(512, 32, 4, 1, False), (512, 32, 8, 2, True), (512, 96, 32, 1, True), (256, 32, 128, 1, True),
+@pytest.mark.parametrize('i,o,res,batch,prev', [(512, 32, 8, 1, False), (512, 32, 8, 2, True), (512, 96, 32, 1, True), (256, 32, 128, 1, True),
                                                 (128, 96, 256, 1, True), (128, 3, 512, 1, True), (256, 3, 256, 2, True), (64, 32, 64, 3, True)])
 def test_fused_torgb_matches_conv_plus_upsample(i, o, res, batch, prev):
     """ia_torgb = 1x1 modulated convolution (no demodulation) + bias + clamp + upsample2d(previous image) added: against the fp64
