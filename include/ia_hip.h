@@ -375,19 +375,6 @@ int ia_uv_rasterize(const float* verts, const int* tris, const float* face_attrs
                     void* stream);
 
 /*
- * ToRGBLayer + skip-image up-sampling + add of a 'skip' SynthesisBlock, one launch:
- *     y = clamp(sum_i wk[i, o] * (styles[b, i] * x[b, i, p]) + bias[o]) + upsample2d(prev_img)[b, o, p]
- * Replaces ToRGBLayer.forward (training/networks_stylegan2.py:340-357: 1x1 modulated conv without demodulation + bias_act) and
- * `img = upsample2d(img) + y` of SynthesisBlock.forward (:452-458; upfirdn2d up 2, pad [2,1,2,1], gain 4).
- *   x        : [B, I, H, W] fp32;  wk : [I, O] fp32 = weight[o, i] * weight_gain (pack_conv_weight layout for ksize 1)
- *   styles   : [B, I] (affine output, NOT multiplied by weight_gain: that is folded into wk)
- *   prev_img : [B, O, H/2, W/2] or NULL (first block);  f : the 4x4 resample filter (setup_filter([1,3,3,1])), needed with prev_img
- *   clamp < 0: disabled.  O <= 96, H * W >= 64 (IA_ERR_UNSUPPORTED otherwise: callers use ia_conv2d_mfma with ksize 1).
- */
-int ia_torgb(const float* x, const float* wk, const float* styles, const float* bias, const float* prev_img, const float* f,
-             float* y, int B, int I, int O, int H, int W, float clamp, void* stream);
-
-/*
  * Output side: float image batch -> uint8 picture grid, one pass.
  * Replaces layout_grid(img, grid_w, grid_h, float_to_uint8=True, chw_to_hwc) of the reference's scripts
  * (reenact_avatar_next3d.py:117-131): (img * 127.5 + 128).clamp(0, 255).to(uint8), frames tiled row-major into a

@@ -22,8 +22,10 @@
 //       second, 94%-empty MFMA tile.
 //   fp32 MFMA == fmaf chain bitwise (exact fp32); weights (pre-scaled by the FullyConnectedLayer gains) live in
 //   LDS in fragment order, staged once per persistent workgroup.
-//   The coarse pass evaluates the density only; coarse colours are recomputed in merged order in the final
-//   pass, which costs +25% decoder FLOPs and removes 12.7 KB/ray of colour storage.
+//   Every sample is decoded exactly ONCE: the coarse pass evaluates density AND colours of its 48 samples and parks them in LDS
+//   (33 floats per sample, 6.3 KB per ray), the fine pass does the same for the 48 importance samples, and the compositing pass
+//   walks the merged order reading both from LDS.  (The first version decoded the coarse samples twice -- density only, then
+//   everything again in merged order: a third of the tri-plane gathers and of layer 1, the two largest legs of the kernel.)
 //
 // Numerical contract: linspace bit rule of CPU torch; cumulative products / sums accumulate
 // in fp64 and round each prefix to fp32 like CPU torch.cumprod / cumsum; searchsorted(right=True) semantics and
@@ -36,7 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NS = 48;            // coarse samples == importance samples (depth_resolution[_importance])
 constexpr int NM = 2 * NS;        // merged
-constexpr int WAVES = 4;          // rays per workgroup pass
+constexpr int WAVES = 8;          // rays per workgroup pass: one workgroup per CU, two waves per SIMD, one LDS image of the weights
 constexpr int kEarlyPlanes = 1;   // planes whose texels are prefetched one sample group ahead (the third is loaded at use: registers)
 
 struct Params {
@@ -69,7 +71,10 @@ constexpr int WS_OFF = A2_OFF + 2 * 16 * 64;    // [16 ksteps][4 quarters]   den
 constexpr int B0_OFF = WS_OFF + 64;             // [64]
 constexpr int B1_OFF = B0_OFF + 64;             // [33] (+pad)
 constexpr int SCR_OFF = B1_OFF + 40;            // per-wave scratch
-constexpr int SCR = 10 * NS;                    // tc, sc, wc, av, pdf, cdf, bins, tf (8 x 48) + tm (96)
+constexpr int COL_OFF = 10 * NS;                // colours of the 96 samples, [sample][quarter][8] (coarse 0..47, fine 48..95)
+constexpr int SGF_OFF = COL_OFF + NM * 32;      // densities of the fine samples [48]
+constexpr int SRC_OFF = SGF_OFF + NS;           // merged slot -> sample index [96] (int)
+constexpr int SCR = SRC_OFF + NM;               // tc, sc, wc, av, pdf, cdf, bins, tf (8 x 48) + tm (96) + the above
 constexpr int LDS_FLOATS = SCR_OFF + WAVES * SCR;
 
 __device__ __forceinline__ void wave_sync() {
@@ -284,7 +289,7 @@ __device__ __forceinline__ void merge_sorted(float* scr, int lane, int& pos_c, i
     wave_sync();
 }
 
-__global__ __launch_bounds__(WAVES * 64, 2) void render_rays_kernel(Params p) {
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 15, q = lane >> 4;
@@ -349,6 +354,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void render_rays_kernel(Params p) {
             decoder_hidden(lds, lane, q, f, h);
             const float sg = decoder_sigma(lds, q, h);
             if (q == 0) sc[16 * g + s] = sg;
+            f32x4 col[2];
+            decoder_rgb(lds, lane, q, h, col);
+            float4* dst = reinterpret_cast<float4*>(scr + COL_OFF + (16 * g + s) * 32 + 8 * q);
+            dst[0] = make_float4(col[0][0], col[0][1], col[0][2], col[0][3]);
+            dst[1] = make_float4(col[1][0], col[1][1], col[1][2], col[1][3]);
         }
         wave_sync();
         // ---- coarse ray march: weights only (ray_marcher.py:26-42)
@@ -384,8 +394,40 @@ __global__ __launch_bounds__(WAVES * 64, 2) void render_rays_kernel(Params p) {
         }
         blk_min = fminf(blk_min, tm[0]);
         blk_max = fmaxf(blk_max, tm[NM - 1]);
+        int* src = reinterpret_cast<int*>(scr + SRC_OFF);
+        if (lane < NS) { src[pos_c] = lane; src[pos_f] = NS + lane; }
 
-        // ---- final pass over the 96 merged samples, 16 at a time; lane s composites the interval that ENDS at its sample
+        // ---- fine pass: the 48 importance samples, decoded once (density + colours) into LDS
+        {
+            const float* tf = scr + 7 * NS;
+            {
+                const float t = tf[s];
+                gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+            }
+#pragma unroll 1
+            for (int g = 0; g < NS / 16; ++g) {
+                const float t = tf[16 * g + s];
+                float f[8]; f32x4 h[4], col[2];
+                asm volatile("" ::: "memory");
+                gather_issue<kEarlyPlanes, 3>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                gather_reduce(raw, wgt, f);
+                if (g + 1 < NS / 16) {
+                    const float tn = tf[16 * (g + 1) + s];
+                    gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * p.box_scale, raw, wgt);
+                }
+                decoder_hidden(lds, lane, q, f, h);
+                const float sg = decoder_sigma(lds, q, h);
+                if (q == 0) scr[SGF_OFF + 16 * g + s] = sg;
+                decoder_rgb(lds, lane, q, h, col);
+                float4* dst = reinterpret_cast<float4*>(scr + COL_OFF + (NS + 16 * g + s) * 32 + 8 * q);
+                dst[0] = make_float4(col[0][0], col[0][1], col[0][2], col[0][3]);
+                dst[1] = make_float4(col[1][0], col[1][1], col[1][2], col[1][3]);
+            }
+        }
+        wave_sync();
+
+        // ---- compositing over the 96 merged samples, 16 at a time; lane s composites the interval that ENDS at its sample.
+        // Same arithmetic in the same order as when the colours came straight from the decoder: only their source changed.
         float acc_c[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc_c[c] = 0.f;
@@ -394,27 +436,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void render_rays_kernel(Params p) {
         float prev_t = 0.f, prev_sg = 0.f, prev_c[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) prev_c[c] = 0.f;
-        {
-            const float t = tm[s];
-            gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
-        }
 #pragma unroll 1
         for (int g = 0; g < NM / 16; ++g) {
             const float t = tm[16 * g + s];
-            float f[8]; f32x4 h[4], col[2];
-            asm volatile("" ::: "memory");
-            gather_issue<kEarlyPlanes, 3>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
-            gather_reduce(raw, wgt, f);
-            if (g + 1 < NM / 16) {
-                const float tn = tm[16 * (g + 1) + s];
-                gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * p.box_scale, raw, wgt);
-            }
-            decoder_hidden(lds, lane, q, f, h);
-            const float sg = decoder_sigma(lds, q, h);
-            decoder_rgb(lds, lane, q, h, col);
+            const int si = src[16 * g + s];
+            const float sg = si < NS ? sc[si] : scr[SGF_OFF + si - NS];
             float cur_c[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) cur_c[c] = col[c >> 2][c & 3];
+            {
+                const float4* cs = reinterpret_cast<const float4*>(scr + COL_OFF + si * 32 + 8 * q);
+                const float4 c0 = cs[0], c1 = cs[1];
+                cur_c[0] = c0.x; cur_c[1] = c0.y; cur_c[2] = c0.z; cur_c[3] = c0.w;
+                cur_c[4] = c1.x; cur_c[5] = c1.y; cur_c[6] = c1.z; cur_c[7] = c1.w;
+            }
             // neighbour (previous sample) values: lane s-1 of the same quarter, or the carry from the previous group
             float nb_t = __shfl_up(t, 1, 16), nb_sg = __shfl_up(sg, 1, 16), nb_c[8];
 #pragma unroll
@@ -439,11 +472,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void render_rays_kernel(Params p) {
             const double excl = (s == 0) ? 1.0 : up1;
             const float trans = (float)(carry_T * excl);
             carry_T *= __shfl(incl, 15, 16);
-            const float wgt = alpha * trans;
+            const float wgt_ = alpha * trans;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc_c[c] = fmaf(wgt, (nb_c[c] + cur_c[c]) * 0.5f, acc_c[c]);
-            acc_w += wgt;
-            acc_z = fmaf(wgt, (nb_t + t) * 0.5f, acc_z);
+            for (int c = 0; c < 8; ++c) acc_c[c] = fmaf(wgt_, (nb_c[c] + cur_c[c]) * 0.5f, acc_c[c]);
+            acc_w += wgt_;
+            acc_z = fmaf(wgt_, (nb_t + t) * 0.5f, acc_z);
             prev_t = __shfl(t, 15, 16); prev_sg = __shfl(sg, 15, 16);
 #pragma unroll
             for (int c = 0; c < 8; ++c) prev_c[c] = __shfl(cur_c[c], 15, 16);
@@ -526,7 +559,7 @@ __global__ __launch_bounds__(64) void importance_stage_kernel(const float* z_coa
 
 extern "C" int ia_render_rays_grid(int B, int R) {
     const int64_t quads = ((int64_t)B * R + WAVES - 1) / WAVES;
-    const int64_t cap = (int64_t)ia::kNumCU * 4;
+    const int64_t cap = (int64_t)ia::kNumCU;            // one resident workgroup per CU (146 KB of LDS)
     return (int)(quads < cap ? quads : cap);
 }
 
@@ -555,6 +588,8 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
     p.dbg_sigma_coarse = dbg_sigma_coarse;
     const int grid = ia_render_rays_grid(B, R);
     hipStream_t s = (hipStream_t)stream;
+    static_assert(LDS_FLOATS * sizeof(float) <= 160 * 1024, "one workgroup must fit a CU's LDS");
+    (void)hipFuncSetAttribute((const void*)render_rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_FLOATS * sizeof(float)));
     hipLaunchKernelGGL(render_rays_kernel, dim3(grid), dim3(WAVES * 64), LDS_FLOATS * sizeof(float), s, p);
     int st = ia::check_launch("ia_render_rays");
     if (st != IA_OK) return st;

@@ -525,22 +525,3 @@ def convgru_update(gates_pre, cand_pre, h, prelu_weight=None, x_next=None):
     _lib.check(st, 'ia_convgru_update')
     return h_out, xh
 
-
-def torgb(x, wk, styles, bias, prev_img=None, resample_filter=None, clamp=None):
-    """ToRGB + skip-image up-sampling + add in one launch (see ia_torgb).  wk = pack_conv_weight(weight * weight_gain) [1, I, O]."""
-    _f32c(x, 'x')
-    b, i, h, w = x.shape
-    o = wk.shape[-1]
-    if wk.dim() != 3 or wk.shape[0] != 1 or wk.shape[1] != i:
-        raise RuntimeError(f'packed 1x1 weight {tuple(wk.shape)} does not match in-channels {i}')
-    if prev_img is not None and tuple(prev_img.shape) != (b, o, h // 2, w // 2):
-        raise RuntimeError(f'skip image {tuple(prev_img.shape)} is not [B,O,H/2,W/2]')
-    y = torch.empty(b, o, h, w, device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device), _Timed('torgb', 2.0 * b * h * w * i * o, 4.0 * (x.numel() + y.numel() + (prev_img.numel() if prev_img is not None else 0)),
-                                             f'B{b} I{i} O{o} {h}x{w}'):
-        st = _lib.load().ia_torgb(_p(x), _p(_f32c(wk, 'wk')), _p(_f32c(styles, 'styles')), _p(_f32c(bias, 'bias')),
-                                  _p(None if prev_img is None else _f32c(prev_img, 'prev_img')),
-                                  _p(None if resample_filter is None else _f32c(resample_filter, 'resample_filter')), _p(y), b, i, o, h, w,
-                                  float(-1 if clamp is None else clamp), _lib.stream_ptr(x.device))
-    _lib.check(st, 'ia_torgb')
-    return y

@@ -41,11 +41,6 @@ SPLIT_FP16_PRODUCTS = True
 # register-staged kernel (ia_conv2d_mfma_s) everywhere.
 USE_SPLIT_DMA = True
 
-# ToRGB + skip-image up-sampling + add as one streaming launch (ia_torgb); False: 1x1 MFMA convolution + separate FIR launch.
-# Measured r02 (MI355X, B = 1): the streaming kernel is load-latency bound -- 42-140 us where the MFMA form + FIR take 30-80 -- so
-# it is OFF; it stays as the C-ABI entry for callers that want the single launch (and as the starting point for a batched form).
-FUSED_TORGB = False
-
 
 @misc.profiled_function
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
@@ -477,17 +472,14 @@ class ToRGBLayer(torch.nn.Module):
 
     def forward(self, x, w, fused_modconv=True, residual=None, skip=None, resample_filter=None):
         """`residual` (fp32, output-shaped) is added after the clamp: the skip-image add of SynthesisBlock folded into this layer's
-        epilogue on the device path.  `skip` (+ `resample_filter`): the PREVIOUS block's image; its 2x up-sampling and the add run
-        inside the same launch (ia_torgb) -- the caller then passes no `residual`."""
+        epilogue on the device path.  `skip` (+ `resample_filter`): the PREVIOUS block's image, up-sampled 2x here and added as the residual
+        (a single streaming launch for conv + up-sampling + add was measured in r02 and dropped: load-latency bound at B = 1, 42-140 us
+        where the MFMA form + FIR take 30-80)."""
         if _on_device(x) and self.weight.shape[2] == 1 and not _needs_autograd(x, w, self.weight, self.bias, residual, skip):
             # weight_gain is folded into the packed weight instead of scaling the styles on every call
             wk, _ = self._packed.get(self.weight, scale=self.weight_gain)
             pre, self._pre = self._pre, None
             styles = pre[0] if pre is not None else self.affine(w).float().contiguous()
-            if (FUSED_TORGB and residual is None and self.out_channels <= 96 and x.shape[2] * x.shape[3] >= 64
-                    and (skip is None or resample_filter is not None)):
-                return hipops.torgb(x.float().contiguous(), wk, styles, self.bias.detach().float(),
-                                    None if skip is None else skip.float().contiguous(), resample_filter, clamp=self.conv_clamp)
             if skip is not None:
                 residual = upfirdn2d.upsample2d(skip, resample_filter)
             res = None if residual is None else residual.float().contiguous()
@@ -592,7 +584,7 @@ class SynthesisBlock(torch.nn.Module):
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
         if self.is_last or self.architecture == 'skip':
-            # img = upsample2d(img) + torgb(x): the up-sampling and the add happen inside the ToRGB launch
+            # img = upsample2d(img) + torgb(x): the add happens in the ToRGB epilogue
             img = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, skip=img, resample_filter=self.resample_filter)
             img = img.to(dtype=torch.float32, memory_format=torch.contiguous_format)
         elif img is not None:

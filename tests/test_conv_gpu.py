@@ -312,28 +312,3 @@ def test_cond_blend_split_equals_cond_blend_then_split():
     assert torch.equal(got.data[:, 0].permute(0, 1, 4, 2, 3).reshape(want.shape), hi)
     assert torch.equal(got.data[:, 1].permute(0, 1, 4, 2, 3).reshape(want.shape), lo)
 
-
-@pytest.mark.parametrize('i,o,res,batch,prev', [(512, 32, 8, 1, False), (512, 32, 8, 2, True), (512, 96, 32, 1, True), (256, 32, 128, 1, True),
-                                                (128, 96, 256, 1, True), (128, 3, 512, 1, True), (256, 3, 256, 2, True), (64, 32, 64, 3, True)])
-def test_fused_torgb_matches_conv_plus_upsample(i, o, res, batch, prev):
-    """ia_torgb = 1x1 modulated convolution (no demodulation) + bias + clamp + upsample2d(previous image) added: against the fp64
-    evaluation of that definition and against the unfused launches it replaces."""
-    from invertavatar_amd.torch_utils.ops import upfirdn2d
-    g = torch.Generator(device='cuda').manual_seed(i + o + res)
-    x = torch.randn(batch, i, res, res, device='cuda', generator=g)
-    w = torch.randn(o, i, 1, 1, device='cuda', generator=g) / i ** 0.5
-    s = torch.rand(batch, i, device='cuda', generator=g) + 0.5
-    bias = torch.randn(o, device='cuda', generator=g)
-    img = torch.randn(batch, o, res // 2, res // 2, device='cuda', generator=g) if prev else None
-    f = upfirdn2d.setup_filter([1, 3, 3, 1]).cuda()
-    wk = hipops.pack_conv_weight(w)
-    got = hipops.torgb(x, wk, s, bias, img, f, clamp=2.0)
-    up = upfirdn2d.upsample2d(img, f) if prev else None
-    old = hipops.conv2d_mfma(x, wk, s, None, bias=bias, residual=up, ksize=1, act='linear', clamp=2.0)
-    ref = torch.einsum('bip,oi->bop', (x.double() * s.double()[:, :, None, None]).flatten(2), w.double()[:, :, 0, 0]).reshape(batch, o, res, res)
-    ref = (ref + bias.double()[None, :, None, None]).clamp(-2.0, 2.0)
-    if prev:
-        ref = ref + up.double()
-    scale = ref.abs().max().item()
-    assert (got.double() - ref).abs().max().item() <= 2e-6 * scale and (old.double() - ref).abs().max().item() <= 2e-6 * scale
-    assert (got - old).abs().max().item() <= 4e-6 * scale
