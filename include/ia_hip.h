@@ -294,8 +294,8 @@ int ia_ray_sampler(const float* cam, int cam_stride, float* rays_o, float* rays_
 int ia_act_split(const float* x, const float* styles, void* xs, int B, int C, int H, int W, void* stream);
 
 /*
- * ia_conv2d_mfma_s on split-format activations: same layer semantics, tiles, ksplit / scratch (ia_conv2d_plan with form = 2) and
- * bit-identical results, but the operand split was done by the producer and both operands reach LDS by DMA
+ * ia_conv2d_mfma_s on split-format activations: same layer semantics, tiles, ksplit / scratch (ia_conv2d_plan with form = 3) and
+ * results of the same arithmetic (bit-identical wherever both forms use the same tile), but the operand split was done by the producer and both operands reach LDS by DMA
  * (buffer_load ... lds) instead of through registers.  Replaces the same reference chain as ia_conv2d_mfma
  * (training/networks_stylegan2.py:34-91, conv2d_resample.py:114-136) for the 3x3 layers of >= 32^2 (I % 8 == 0, O % 8 == 0).
  *   xs          : input in split format, already multiplied by THIS layer's styles (there is no `styles` argument)

@@ -460,6 +460,7 @@ constexpr int kSmallPoints = 320;
 // workgroup per CU fetches the chunk's weight slab once instead of twice (the slab is 70 % of the staged bytes).
 constexpr int kWidePoints = 1024;
 constexpr int kWideTransposedPoints = 32768;   // (H+1)(W+1): the 256^2 -> 512^2 layers
+constexpr int kSplitWideTransposedPoints = 4096;   // split-DMA form: the 8-wave transposed tile for 64^2 inputs
 
 int worst_patch(int npts, int GW, int bp, int ksize, bool tr) {
     int worst = 0;
@@ -479,6 +480,11 @@ void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo
         // fp16-pair form on large images: two point fragments per wave (64ch x 128pt x 4 phases) -- one accumulator set leaves
         // the registers for it, and a k-step then reads 7 operand fragments for 6 MFMAs instead of 4 for 3
         *bo = 64; *bp = (form == 2 && O % 4 == 0 && npts >= kWideTransposedPoints) ? 128 : 64; *cc = kChunkTransposed;
+        // form 3 (ia_conv2d_mfma_sx, operands DMA'd into LDS): an 8-wave 64ch x 256pt x 4-phase tile, one workgroup per CU -- the
+        // weight slab of a chunk (the larger part of the DMA traffic) is fetched once for 240 MFMAs instead of once per 60 / 120
+        // (measured r02, B = 1: 72 -> 61 us on the 64^2 -> 128^2 layer; slower on the 32^2 / 128^2 / 256^2 inputs, whose tile counts
+        // balance better over 512 four-wave slots, so only that size takes it)
+        if (form == 3 && npts >= kSplitWideTransposedPoints && npts < 2 * kSplitWideTransposedPoints) { *bp = 256; *waves = 8; }
     }
     else if (O <= 32) { *bo = 32; *bp = 256; }
     else if (ksize == 3 && O >= 128 && O % 4 == 0 && npts >= kWidePoints && worst_patch(npts, W, 256, 3, false) <= kPatchFloats) {
@@ -533,7 +539,7 @@ extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int 
                               size_t* h_scratch_bytes) {
     IA_REQUIRE(h_ksplit && h_scratch_bytes, "null output pointer");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
-    IA_REQUIRE(form >= 0 && form <= 2, "form: 0 = ia_conv2d_mfma, 1 = ia_conv2d_mfma_h, 2 = ia_conv2d_mfma_s");
+    IA_REQUIRE(form >= 0 && form <= 3, "form: 0 = ia_conv2d_mfma, 1 = ia_conv2d_mfma_h, 2 = ia_conv2d_mfma_s, 3 = ia_conv2d_mfma_sx");
     const Plan p = make_plan(B, I, O, H, W, ksize, transposed, form);
     *h_ksplit = p.G;
     *h_scratch_bytes = scratch_bytes_for(B, p.G, p.slab_floats);

@@ -393,7 +393,7 @@ extern "C" int ia_conv2d_mfma_sx(const void* xs, const void* wk_split, int wk_ex
     g.OH = transposed ? 2 * H + 1 : H; g.OW = transposed ? 2 * W + 1 : W;
     IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
     int bo, bp, waves, slab_floats;
-    const int st_plan = ia_conv2d_plan_tiles(B, I, O, H, W, 3, transposed, 2, &bo, &bp, &waves, &g.T, &g.TO, &g.C, &g.T_dp, &slab_floats);
+    const int st_plan = ia_conv2d_plan_tiles(B, I, O, H, W, 3, transposed, 3, &bo, &bp, &waves, &g.T, &g.TO, &g.C, &g.T_dp, &slab_floats);
     if (st_plan != IA_OK) return st_plan;
     const bool wide = waves == 8;
     IA_REQUIRE(wide || (transposed && bo == 64), "the split form covers 3x3 layers on the two-stage tiles (large stride-1 layers, stride-2 transposed)");
@@ -412,6 +412,7 @@ extern "C" int ia_conv2d_mfma_sx(const void* xs, const void* wk_split, int wk_ex
     hipStream_t s = (hipStream_t)stream;
     const h16x8* x8 = static_cast<const h16x8*>(xs);
     const h16x8* w8 = static_cast<const h16x8*>(wk_split);
+    if (transposed && bp == 256) return launch_sx<true, 1, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
     if (transposed && bp == 128) return launch_sx<true, 1, 2, 2, 2>(x8, w8, y, scratch, g, e, s);
     if (transposed) return launch_sx<true, 1, 1, 2, 2>(x8, w8, y, scratch, g, e, s);
     return launch_sx<false, 2, 2, 2, 4>(x8, w8, y, scratch, g, e, s);

@@ -230,7 +230,7 @@ def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=Non
             _f32c(t, name)
     lib = _lib.load()
     plan_s, plan_bytes = ctypes.c_int(0), ctypes.c_size_t(0)
-    _lib.check(lib.ia_conv2d_plan(b, i, o, h, w, 3, int(transposed), 2, ctypes.byref(plan_s), ctypes.byref(plan_bytes)), 'ia_conv2d_plan')
+    _lib.check(lib.ia_conv2d_plan(b, i, o, h, w, 3, int(transposed), 3, ctypes.byref(plan_s), ctypes.byref(plan_bytes)), 'ia_conv2d_plan')
     nbytes = plan_bytes.value
     if ksplit is None:
         ksplit = plan_s.value

@@ -260,9 +260,13 @@ def test_split_dma_convolution_equals_the_register_staged_form(i, o, h, w, tr, b
     d = hipops.modconv_demod(s, hipops.weight_sq_sum(wt))
     xs = hipops.act_split(x, s)
     if tr:
+        # (the transposed DMA form runs on its own, larger tile: the K range of a tile is cut between stream-K workers at other
+        # places, so the fp32 sums agree to summation-order level instead of bit for bit)
         want = hipops.conv2d_mfma(x, wk, styles=s, demod=d, ksize=3, transposed=True)
         got = hipops.conv2d_mfma_sx(xs, wk, demod=d, transposed=True)
-        assert torch.equal(got, want)
+        assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+        ref = torch.nn.functional.conv_transpose2d((x * s[:, :, None, None]).double(), wt.double().transpose(0, 1), stride=2) * d.double()[:, :, None, None]
+        assert (got.double() - ref).abs().max().item() <= (want.double() - ref).abs().max().item() * 1.5 + 1e-7 * ref.abs().max().item()
         return
     bias = torch.randn(o, device='cuda', generator=g)
     noise = torch.randn(h * w, device='cuda', generator=g)

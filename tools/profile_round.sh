@@ -43,6 +43,18 @@ for s in ('fetch', 'write', 'sq'):
         e = summary.setdefault(k, {})
         e['dispatches'] = len(cnt[k])
         e.update({c: v for c, v in d.items()})
+# durations of the SAME dispatches (kernel trace of the sq pass): matrix-pipe utilisation = busy cycles / (SIMDs x kernel cycles)
+import glob
+dur = collections.defaultdict(float)
+for kt in glob.glob('/tmp/pmc_sq/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(kt)):
+        dur[fam(r['Kernel_Name'])] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+for k, e in summary.items():
+    if dur.get(k) and e.get('SQ_INSTS_MFMA'):
+        e['kernel_ns_in_sq_pass'] = dur[k]
+        # SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA = 32 (fp16 32x32x16) or 64 (fp32 32x32x2): per-SIMD pipe cycles of the whole chip;
+        # 1024 SIMDs, peak clock 2.4 GHz (the sustained clock under MFMA load is lower: this is utilisation against the PEAK)
+        e['mfma_pipe_util_vs_peak_clock'] = round(e['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * dur[k] * 2.4), 4)
 for k, e in summary.items():
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in e and e.get('SQ_BUSY_CYCLES'):
         # Ratios of counters of the SAME block are independent of how many XCDs / SEs the tool samples:
@@ -55,5 +67,5 @@ for k, e in summary.items():
 json.dump(summary, open(f'{out}/{tag}_pmc_summary.json', 'w'), indent=1, sort_keys=True)
 top = sorted(summary.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', kv[1].get('FETCH_SIZE', 0)))[:10]
 for k, e in top:
-    print(k, {c: e[c] for c in e if c in ('dispatches', 'FETCH_SIZE', 'WRITE_SIZE', 'mfma_busy_per_sq_busy', 'mfma_busy_cycles_per_mfma_inst', 'lds_bank_conflict_over_lds_active', 'SQ_INSTS_MFMA')})
+    print(k, {c: e[c] for c in e if c in ('dispatches', 'FETCH_SIZE', 'WRITE_SIZE', 'mfma_pipe_util_vs_peak_clock', 'mfma_busy_cycles_per_mfma_inst', 'lds_bank_conflict_over_lds_active', 'SQ_INSTS_MFMA')})
 PY
