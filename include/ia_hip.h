@@ -290,21 +290,25 @@ int ia_ray_sampler(const float* cam, int cam_stride, float* rays_o, float* rays_
  * (v saturates at +-65504; |v| < 2^-14 rides entirely in the low plane: the MFMA flushes fp16 denormals).  4 bytes per element,
  * the size of the fp32 tensor; hi + lo * 2^-11 carries 22 mantissa bits.  C % 8 == 0.  styles [B,C] or NULL (= 1).
  * ia_act_split is the stand-alone producer; ia_fir_tail_split and ia_conv2d_mfma_sx emit the format from their epilogues.
+ * planes = 2 is the format above; planes = 1 keeps plane 0 only, rounded once (hi = fp16(v), saturating): the operand format of the
+ * fp16 blocks (ia_conv2d_mfma_h arithmetic) and the fp16-STORAGE form of their activations, xs[b][c/8][y][x][c%8], 2 bytes / element.
  */
-int ia_act_split(const float* x, const float* styles, void* xs, int B, int C, int H, int W, void* stream);
+int ia_act_split(const float* x, const float* styles, void* xs, int planes, int B, int C, int H, int W, void* stream);
 
 /*
  * ia_conv2d_mfma_s on split-format activations: same layer semantics, tiles, ksplit / scratch (ia_conv2d_plan with form = 3) and
  * results of the same arithmetic (bit-identical wherever both forms use the same tile), but the operand split was done by the producer and both operands reach LDS by DMA
  * (buffer_load ... lds) instead of through registers.  Replaces the same reference chain as ia_conv2d_mfma
  * (training/networks_stylegan2.py:34-91, conv2d_resample.py:114-136) for the 3x3 layers of >= 32^2 (I % 8 == 0, O % 8 == 0).
- *   xs          : input in split format, already multiplied by THIS layer's styles (there is no `styles` argument)
+ *   xs, planes  : input in split format, already multiplied by THIS layer's styles (there is no `styles` argument); planes = 2 with
+ *                 wk_split from pack_conv_weight_split (three fp16 products per fp32 product: ia_conv2d_mfma_s arithmetic), planes = 1
+ *                 with the one-plane fp16 weights [tap][I/8][O][8] and wk_exp = 0 (fp16 operands: ia_conv2d_mfma_h arithmetic)
  *   y           : [B,O,OH,OW] fp32 or NULL (stride-1 form only: a layer whose result is consumed only in split format)
- *   ys          : the result in split format, multiplied by styles_next [B,O] (the styles of the consuming layer; NULL = 1), or
+ *   ys, ys_planes : the result in split format (ys_planes planes), multiplied by styles_next [B,O] (the styles of the consuming layer; NULL = 1), or
  *                 NULL; stride-1 form only (the transposed form's (2H+1)^2 image goes through ia_fir_tail_split)
  */
-int ia_conv2d_mfma_sx(const void* xs, const void* wk_split, int wk_exp, const float* demod, const float* noise,
-                      const float* noise_strength, const float* bias, const float* residual, float* y, void* ys,
+int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
+                      const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                       const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
                       int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream);
 
@@ -315,7 +319,7 @@ int ia_conv2d_mfma_sx(const void* xs, const void* wk_split, int wk_exp, const fl
  * ia_upfirdn2d_bias_act).  y (fp32 [n,c,out_h,out_w]) may be NULL when only the split result is consumed.  c % 8 == 0.
  */
 int ia_fir_tail_split(const float* x, const float* f, const float* noise, const float* noise_strength, const float* bias,
-                      const float* styles_next, float* y, void* ys, int n, int c, int in_h, int in_w, int out_h, int out_w,
+                      const float* styles_next, float* y, void* ys, int ys_planes, int n, int c, int in_h, int in_w, int out_h, int out_w,
                       int padx0, int pady0, int flip, float fir_gain, int act, float alpha, float act_gain, float clamp, void* stream);
 
 /*

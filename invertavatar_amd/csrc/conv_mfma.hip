@@ -578,7 +578,7 @@ static int conv2d_entry(const float* x, const void* wk_any, const float* styles,
     }
     g.patch_cap = 0;
     g.acc_scale = ldexpf(1.f, -wk_exp);
-    Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp, nullptr, nullptr};
+    Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp, nullptr, nullptr, 2};
     hipStream_t s = (hipStream_t)stream;
     if (half_ops) {
         const bool wide = p.waves == 8;

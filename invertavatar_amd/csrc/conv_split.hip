@@ -35,7 +35,7 @@ typedef __attribute__((address_space(3))) char lds_char;
 
 // fp32 NCHW (times an optional per-(batch, channel) style) -> split planes.  One thread = one pixel of one 8-channel group.
 __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ x, const float* __restrict__ styles, h16x8* __restrict__ out,
-                                                       int B, int C, int64_t HW) {
+                                                       int B, int C, int64_t HW, int planes) {
     const int C8 = C / 8;
     const int64_t total = (int64_t)B * C8 * HW, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -47,12 +47,11 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
             const int c = c8 * 8 + cc;
             float v = x[((int64_t)b * C + c) * HW + pix];
             if (styles) v *= styles[b * C + c];
-            _Float16 h, l;
-            ia::split_f16(v, h, l);
-            hi[cc] = h; lo[cc] = l;
+            if (planes == 2) { _Float16 h, l; ia::split_f16(v, h, l); hi[cc] = h; lo[cc] = l; }
+            else hi[cc] = ia::round_f16(v);
         }
-        out[((int64_t)(b * 2) * C8 + c8) * HW + pix] = hi;
-        out[((int64_t)(b * 2 + 1) * C8 + c8) * HW + pix] = lo;
+        out[((int64_t)(b * planes) * C8 + c8) * HW + pix] = hi;
+        if (planes == 2) out[((int64_t)(b * 2 + 1) * C8 + c8) * HW + pix] = lo;
     }
 }
 
@@ -82,14 +81,17 @@ __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], 
                     v[k] = o < g.O ? epilogue(acc[0][fo][fp][4 * q + k], b, o, p, ohw, g, e, ns) : 0.f;
                     if (yb && o < g.O) yb[(int64_t)o * ohw + p] = v[k];
                 }
-                if (e.ys && o_first + 3 < g.O) split_store4(e.ys, e.styles_next, b, g.O, ohw, o_first, p, v);
+                if (e.ys && o_first + 3 < g.O) split_store4(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, p, v);
             }
     }
 }
 
 // FO x FP fragments (32 channels x 32 points) per wave, WO x WP waves; 8 input channels per K chunk; JP = patch DMA
 // instructions per wave per chunk (host-chosen from the worst window of the launch); SK as in conv_mfma_kernel.
-template <bool TR, int FO, int FP, int WO, int WP, int JP, bool SK>
+// NP = operand planes: 2 = hi / lo pairs, three products per k-step (fp32-equivalent, the arithmetic of ia_conv2d_mfma_s);
+// 1 = one fp16 plane, one product (fp16 operands / fp32 accumulation, the arithmetic of ia_conv2d_mfma_h: the reference's fp16
+// blocks) -- the fp16-STORAGE form of the SR head: activations travel between its convolutions as 2 bytes per element.
+template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP, bool SK>
 __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split_kernel(const h16x8* __restrict__ xs, const h16x8* __restrict__ wk,
                                                                                       float* __restrict__ y, float* __restrict__ slabs, Geo g, Epi e) {
     constexpr int KS = 3, NT = 9, NTP = NT + 1;
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NWAVES = WO * WP, NTHREADS = NWAVES * 64;
     constexpr int PAD = TR ? 0 : KS / 2;
     constexpr int NACC = NPH * FO * FP * 16;
-    constexpr int WSLOTS = 2 * NTP * BO;              // 16-byte slots of the weight region of a stage: [plane][tap (+ zero tap)][BO]
-    constexpr int WG = 2 * NT * BO / 64;              // weight DMA instructions per chunk (64 slots each), spread over the waves
+    constexpr int WSLOTS = NP * NTP * BO;             // 16-byte slots of the weight region of a stage: [plane][tap (+ zero tap)][BO]
+    constexpr int WG = NP * NT * BO / 64;              // weight DMA instructions per chunk (64 slots each), spread over the waves
     constexpr int JW = (WG + NWAVES - 1) / NWAVES;
     static_assert(BO % 64 == 0, "a DMA instruction fills 64 consecutive slots of one (plane, tap) row");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
     const int b = blockIdx.y, worker = blockIdx.x;
     const int npts = g.GH * g.GW;
     const int cap = g.patch_cap;                       // patch positions reserved per plane (multiple of 64)
-    const int PG = 2 * cap / 64;                       // patch DMA instructions per chunk
-    const int stage_bytes = (WSLOTS + 2 * cap) * 16;
+    const int PG = NP * cap / 64;                      // patch DMA instructions per chunk
+    const int stage_bytes = (WSLOTS + NP * cap) * 16;
     const int64_t U = (int64_t)(g.T - g.T_dp) * g.C;
     const int64_t u_begin = SK ? range_begin(worker, U, g.G) : (int64_t)worker * g.C;
     const int64_t u_end = SK ? range_begin(worker + 1, U, g.G) : u_begin + g.C;
@@ -118,13 +120,13 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
     const int tile_base = SK ? g.T_dp : 0;
     const int HW = g.H * g.W;
     const int plane_bytes = (g.I / 8) * HW * 16;
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16x8*>(xs) + (int64_t)b * 2 * (g.I / 8) * HW, 0, 2 * plane_bytes, 0x00020000);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16x8*>(wk), 0, 2 * NT * (g.I / 8) * g.O * 16, 0x00020000);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16x8*>(xs) + (int64_t)b * NP * (g.I / 8) * HW, 0, NP * plane_bytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16x8*>(wk), 0, NP * NT * (g.I / 8) * g.O * 16, 0x00020000);
     lds_char* const lds_base = (lds_char*)lds;
 
     // the all-zero tap of every plane, in both stages (the DMA never writes there)
-    for (int i = tid; i < 2 * 2 * BO; i += NTHREADS) {
-        const int stg = i / (2 * BO), r = i - stg * 2 * BO, pl = r / BO, o = r - pl * BO;
+    for (int i = tid; i < 2 * NP * BO; i += NTHREADS) {
+        const int stg = i / (NP * BO), r = i - stg * NP * BO, pl = r / BO, o = r - pl * BO;
         *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + stg * stage_bytes + ((pl * NTP + NT) * BO + o) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
     int w_voff[JW], p_voff[JP];
 #pragma unroll
     for (int j = 0; j < JW; ++j) {
-        const int e_ = min((j * NWAVES + wave) * 64 + lane, 2 * NT * BO - 1);
+        const int e_ = min((j * NWAVES + wave) * 64 + lane, NP * NT * BO - 1);
         const int row = e_ / BO, o = e_ - row * BO;                         // row = plane*NT + tap
         w_voff[j] = ((row * (g.I / 8)) * g.O + min(o0 + o, g.O - 1)) * 16;
     }
@@ -221,16 +223,16 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
         const h16x8* ph = wh + WSLOTS;
         // five k-steps: the 8 channels of a pair of taps (lanes 0-31 the first tap, lanes 32-63 the second).  Operand reads run one
         // k-step ahead of the MFMAs that consume them.
-        h16x8 a_buf[2][2 * FO], b_buf[2][2 * FP];
-        auto load_ops = [&](int s, h16x8 (&a)[2 * FO], h16x8 (&bv)[2 * FP]) {
+        h16x8 a_buf[2][NP * FO], b_buf[2][NP * FP];
+        auto load_ops = [&](int s, h16x8 (&a)[NP * FO], h16x8 (&bv)[NP * FP]) {
             const int tap = half ? pair_t1(TR, s) : pair_t0(TR, s);
             const int tof = pair_t1(TR, s) == kZeroTap ? (half ? 0 : toff[pair_t0(TR, s)]) : (half ? toff[pair_t1(TR, s)] : toff[pair_t0(TR, s)]);
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int fo = 0; fo < FO; ++fo) a[pl * FO + fo] = wh[(pl * NTP + tap) * BO + (wo * FO + fo) * 32 + l31];
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int fp = 0; fp < FP; ++fp) bv[pl * FP + fp] = ph[pl * cap + bpos[fp] + tof];
         };
@@ -244,30 +246,32 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
             __builtin_amdgcn_sched_barrier(0);
 #if IA_ABLATE == 2
 #pragma unroll
-            for (int q = 0; q < 2 * FO; ++q) asm volatile("" ::"v"(a_buf[c_][q]));
+            for (int q = 0; q < NP * FO; ++q) asm volatile("" ::"v"(a_buf[c_][q]));
 #pragma unroll
-            for (int q = 0; q < 2 * FP; ++q) asm volatile("" ::"v"(b_buf[c_][q]));
+            for (int q = 0; q < NP * FP; ++q) asm volatile("" ::"v"(b_buf[c_][q]));
             continue;
 #endif
             const int ph_ = pair_phase(TR, s);
-            h16x8 a_sc[FO];                            // weight high parts at 2^-11: they meet the activation's low parts (scaled by 2^11)
+            if constexpr (NP == 2) {
+                h16x8 a_sc[FO];                        // weight high parts at 2^-11: they meet the activation's low parts (scaled by 2^11)
 #pragma unroll
-            for (int fo = 0; fo < FO; ++fo) a_sc[fo] = IA_ABLATE >= 6 ? a_buf[c_][fo] : a_buf[c_][fo] * (_Float16)(1.0f / kLoScale);
-            // three products per fragment pair, product-major: consecutive MFMAs write different accumulators
+                for (int fo = 0; fo < FO; ++fo) a_sc[fo] = IA_ABLATE >= 6 ? a_buf[c_][fo] : a_buf[c_][fo] * (_Float16)(1.0f / kLoScale);
+                // three products per fragment pair, product-major: consecutive MFMAs write different accumulators
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp)      // lo * hi
+                        acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][(NP - 1) * FO + fo], b_buf[c_][fp], acc[ph_][fo][fp], 0, 0, 0);
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp)      // (hi * 2^-11) * (lo * 2^11)
+                        acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[fo], b_buf[c_][(NP - 1) * FP + fp], acc[ph_][fo][fp], 0, 0, 0);
+            }
 #pragma unroll
             for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
-                for (int fp = 0; fp < FP; ++fp)      // lo * hi
-                    acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][FO + fo], b_buf[c_][fp], acc[ph_][fo][fp], 0, 0, 0);
-#pragma unroll
-            for (int fo = 0; fo < FO; ++fo)
-#pragma unroll
-                for (int fp = 0; fp < FP; ++fp)      // (hi * 2^-11) * (lo * 2^11)
-                    acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[fo], b_buf[c_][FP + fp], acc[ph_][fo][fp], 0, 0, 0);
-#pragma unroll
-            for (int fo = 0; fo < FO; ++fo)
-#pragma unroll
-                for (int fp = 0; fp < FP; ++fp)      // hi * hi
+                for (int fp = 0; fp < FP; ++fp)          // hi * hi
                     acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][fo], b_buf[c_][fp], acc[ph_][fo][fp], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
 #pragma unroll
             for (int fp = 0; fp < FP; ++fp)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] *= g.acc_scale;   // back from the scale of the packed weights (exact)
+                for (int r = 0; r < 16; ++r) acc[ph][fo][fp][r] *= g.acc_scale;   // back from the scale of the packed weights (exact; 1 for NP = 1)
     if (IA_AB_NOSTORE) {
         float sink = 0.f;
 #pragma unroll
@@ -310,20 +314,20 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split
 #undef IA_ISSUE_DMA
 }
 
-template <bool TR, int FO, int FP, int WO, int WP, int JP>
+template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP>
 int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const Geo& g, const Epi& e, hipStream_t s) {
     constexpr int BO = 32 * FO * WO;
-    const size_t lds = (size_t)2 * (2 * 10 * BO + 2 * g.patch_cap) * 16;
+    const size_t lds = (size_t)2 * (NP * 10 * BO + NP * g.patch_cap) * 16;
     if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
     int st = IA_OK;
     if (g.T_dp > 0) {
-        auto k = conv_split_kernel<TR, FO, FP, WO, WP, JP, false>;
+        auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, false>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma_sx");
     }
     if (st == IA_OK && g.T > g.T_dp) {
-        auto k = conv_split_kernel<TR, FO, FP, WO, WP, JP, true>;
+        auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, true>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma_sx(stream-K)");
@@ -339,7 +343,7 @@ int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     return st;
 }
 
-template <bool TR, int FO, int FP, int WO, int WP>
+template <int NP, bool TR, int FO, int FP, int WO, int WP>
 int launch_sx(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const Geo& g_in, const Epi& e, hipStream_t s) {
     constexpr int BP = 32 * FP * WP, NWAVES = WO * WP;
     Geo g = g_in;
@@ -352,22 +356,23 @@ int launch_sx(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     }
     if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d positions exceeds the LDS budget", worst);
     g.patch_cap = (worst + 63) & ~63;
-    const int per_wave = (2 * g.patch_cap / 64 + NWAVES - 1) / NWAVES;
-    if (per_wave <= 2) return launch_jp<TR, FO, FP, WO, WP, 2>(xs, wk, y, scratch, g, e, s);
-    if (per_wave <= 4) return launch_jp<TR, FO, FP, WO, WP, 4>(xs, wk, y, scratch, g, e, s);
-    return launch_jp<TR, FO, FP, WO, WP, 8>(xs, wk, y, scratch, g, e, s);
+    const int per_wave = (NP * g.patch_cap / 64 + NWAVES - 1) / NWAVES;
+    if (per_wave <= 2) return launch_jp<NP, TR, FO, FP, WO, WP, 2>(xs, wk, y, scratch, g, e, s);
+    if (per_wave <= 4) return launch_jp<NP, TR, FO, FP, WO, WP, 4>(xs, wk, y, scratch, g, e, s);
+    return launch_jp<NP, TR, FO, FP, WO, WP, 8>(xs, wk, y, scratch, g, e, s);
 }
 
 }  // namespace
 
-extern "C" int ia_act_split(const float* x, const float* styles, void* xs, int B, int C, int H, int W, void* stream) {
+extern "C" int ia_act_split(const float* x, const float* styles, void* xs, int planes, int B, int C, int H, int W, void* stream) {
+    IA_REQUIRE(planes == 1 || planes == 2, "planes: 2 = hi / lo pair, 1 = one fp16 plane");
     IA_REQUIRE(x && xs, "null pointer argument");
     IA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "empty tensor");
     IA_REQUIRE(C % 8 == 0, "the split format stores channels in groups of 8 (C = %d)", C);
     IA_REQUIRE((int64_t)B * C * H * W <= INT32_MAX, "tensor is too large");
     const int64_t work = (int64_t)B * (C / 8) * H * W;
     hipLaunchKernelGGL(act_split_kernel, dim3(ia::streaming_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, styles,
-                       static_cast<h16x8*>(xs), B, C, (int64_t)H * W);
+                       static_cast<h16x8*>(xs), B, C, (int64_t)H * W, planes);
     return ia::check_launch("ia_act_split");
 }
 
@@ -375,14 +380,16 @@ extern "C" int ia_act_split(const float* x, const float* styles, void* xs, int B
 int ia_conv2d_plan_tiles(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int* bo, int* bp, int* waves, int* T, int* TO,
                          int* C, int* T_dp, int* slab_floats);
 
-extern "C" int ia_conv2d_mfma_sx(const void* xs, const void* wk_split, int wk_exp, const float* demod, const float* noise,
-                                 const float* noise_strength, const float* bias, const float* residual, float* y, void* ys,
+extern "C" int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
+                                 const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                                  const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
                                  int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
     IA_REQUIRE(xs && wk_split && (y || ys), "xs, wk and at least one of y / ys must be device pointers");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
     IA_REQUIRE(I % 8 == 0 && O % 8 == 0, "the split form needs I %% 8 == 0 and O %% 8 == 0");
     IA_REQUIRE(wk_exp >= -14 && wk_exp <= 30, "wk_exp is the power of two the weights were scaled by at pack time");
+    IA_REQUIRE((planes == 1 && wk_exp == 0) || planes == 2, "planes: 2 = hi / lo pairs (weights from pack_conv_weight_split), 1 = fp16 operands (wk_exp 0)");
+    IA_REQUIRE(!ys || ys_planes == 1 || ys_planes == 2, "ys_planes must be 1 or 2");
     IA_REQUIRE(act == IA_ACT_LINEAR || act == IA_ACT_LRELU, "conv epilogue supports linear and lrelu");
     IA_REQUIRE(ksplit >= 0, "worker count must be >= 0");
     IA_REQUIRE(!transposed || (y && !ys && noise == nullptr && bias == nullptr && residual == nullptr && act == IA_ACT_LINEAR),
@@ -408,12 +415,18 @@ extern "C" int ia_conv2d_mfma_sx(const void* xs, const void* wk_split, int wk_ex
     }
     g.patch_cap = 0;
     g.acc_scale = ldexpf(1.f, -wk_exp);
-    Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp, ys, styles_next};
+    Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp, ys, styles_next, ys_planes};
     hipStream_t s = (hipStream_t)stream;
     const h16x8* x8 = static_cast<const h16x8*>(xs);
     const h16x8* w8 = static_cast<const h16x8*>(wk_split);
-    if (transposed && bp == 256) return launch_sx<true, 1, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
-    if (transposed && bp == 128) return launch_sx<true, 1, 2, 2, 2>(x8, w8, y, scratch, g, e, s);
-    if (transposed) return launch_sx<true, 1, 1, 2, 2>(x8, w8, y, scratch, g, e, s);
-    return launch_sx<false, 2, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
+    if (planes == 1) {
+        if (transposed && bp == 256) return launch_sx<1, true, 1, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
+        if (transposed && bp == 128) return launch_sx<1, true, 1, 2, 2, 2>(x8, w8, y, scratch, g, e, s);
+        if (transposed) return launch_sx<1, true, 1, 1, 2, 2>(x8, w8, y, scratch, g, e, s);
+        return launch_sx<1, false, 2, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
+    }
+    if (transposed && bp == 256) return launch_sx<2, true, 1, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
+    if (transposed && bp == 128) return launch_sx<2, true, 1, 2, 2, 2>(x8, w8, y, scratch, g, e, s);
+    if (transposed) return launch_sx<2, true, 1, 1, 2, 2>(x8, w8, y, scratch, g, e, s);
+    return launch_sx<2, false, 2, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
 }

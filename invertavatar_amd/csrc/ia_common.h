@@ -64,6 +64,9 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((v - (float)hi) * kSplitLoScale);
 }
 
+// One-plane form of the same format (fp16 operands, the arithmetic of the reference's fp16 blocks): the saturated value rounded once.
+__device__ __forceinline__ _Float16 round_f16(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
+
 }  // namespace ia
 
 #define IA_REQUIRE(cond, ...) \

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled_pipe(const T* __restrict_
 // and row.  Optionally the fp32 NCHW result is written as well (callers that still need it, e.g. the CS-SFT modulation).
 typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y,
-                                                            h16x8_t* __restrict__ ys, const float* __restrict__ styles_next, Geo g, int flip, Tail tail) {
+                                                            h16x8_t* __restrict__ ys, const float* __restrict__ styles_next, Geo g, int flip, Tail tail, int planes) {
     constexpr int FS = 4;
     constexpr int IH = TH + FS, IW = TW + FS, IWP = IW + 1, NLD = (IH * IW + 255) / 256;
     __shared__ float k_lds[FS * FS];
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __rest
             if (tail.clamp >= 0.f) acc = fminf(fmaxf(acc, -tail.clamp), tail.clamp);
             const int oy = oy0 + ty + r;
             if (y && ox < g.out_w && oy < g.out_h) y[((int64_t)b * g.c + c) * ohw + (int64_t)oy * g.out_w + ox] = acc;
-            _Float16 h, l;
-            ia::split_f16(styles_next ? acc * sn : acc, h, l);
-            hi[r][ch] = h; lo[r][ch] = l;
+            const float t = styles_next ? acc * sn : acc;
+            if (planes == 2) { _Float16 h, l; ia::split_f16(t, h, l); hi[r][ch] = h; lo[r][ch] = l; }
+            else hi[r][ch] = ia::round_f16(t);
         }
         if (ch + 1 < 8) commit(buf ^ 1);                          // (its last readers passed the barrier of the previous channel)
         __syncthreads();
@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __rest
         const int oy = oy0 + ty + r;
         if (oy >= g.out_h) break;
         const int64_t pix = (int64_t)oy * g.out_w + ox;
-        ys[((int64_t)(b * 2) * C8 + c8) * ohw + pix] = hi[r];
-        ys[((int64_t)(b * 2 + 1) * C8 + c8) * ohw + pix] = lo[r];
+        ys[((int64_t)(b * planes) * C8 + c8) * ohw + pix] = hi[r];
+        if (planes == 2) ys[((int64_t)(b * 2 + 1) * C8 + c8) * ohw + pix] = lo[r];
     }
 }
 
@@ -422,11 +422,12 @@ extern "C" int ia_upfirdn2d_bias_act(const void* x, const float* f, const float*
 }
 
 extern "C" int ia_fir_tail_split(const float* x, const float* f, const float* noise, const float* noise_strength, const float* bias,
-                                 const float* styles_next, float* y, void* ys, int n, int c, int in_h, int in_w, int out_h, int out_w,
+                                 const float* styles_next, float* y, void* ys, int ys_planes, int n, int c, int in_h, int in_w, int out_h, int out_w,
                                  int padx0, int pady0, int flip, float fir_gain, int act, float alpha, float act_gain, float clamp, void* stream) {
     IA_REQUIRE(x && f && ys, "null pointer argument");
     IA_REQUIRE(n > 0 && c > 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, "empty tensor");
     IA_REQUIRE(c % 8 == 0, "the split format stores channels in groups of 8 (C = %d)", c);
+    IA_REQUIRE(ys_planes == 1 || ys_planes == 2, "ys_planes must be 1 or 2");
     IA_REQUIRE(act == IA_ACT_LINEAR || act == IA_ACT_LRELU, "fused tail supports linear and lrelu");
     IA_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, "tensor is too large");
     IA_REQUIRE((int64_t)n * (c / 8) <= 65535, "too many (batch, channel group) planes for one launch");
@@ -435,6 +436,6 @@ extern "C" int ia_fir_tail_split(const float* x, const float* f, const float* no
     g.f_h = g.f_w = 4; g.upx = g.upy = 1; g.downx = g.downy = 1; g.padx0 = padx0; g.pady0 = pady0; g.gain = fir_gain;
     Tail tail{noise, noise_strength, bias, act, alpha, act_gain, clamp};
     const dim3 grid(((out_w + TW - 1) / TW) * ((out_h + TH - 1) / TH), n * (c / 8));
-    hipLaunchKernelGGL(fir_tail_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, f, y, static_cast<h16x8_t*>(ys), styles_next, g, flip, tail);
+    hipLaunchKernelGGL(fir_tail_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, f, y, static_cast<h16x8_t*>(ys), styles_next, g, flip, tail, ys_planes);
     return ia::check_launch("ia_fir_tail_split");
 }

@@ -181,43 +181,49 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
 
 
 class SplitAct:
-    """An activation stored as fp16 hi/lo planes [B, 2, C/8, H, W, 8] (the input format of ia_conv2d_mfma_sx, see
-    include/ia_hip.h), already multiplied by the styles of the layer `consumer` (any object; None = unscaled)."""
+    """An activation stored as fp16 planes [B, planes, C/8, H, W, 8] (the input format of ia_conv2d_mfma_sx, see include/ia_hip.h):
+    planes = 2 hi / lo pairs (fp32-equivalent consumers), planes = 1 one rounded fp16 plane (fp16-operand consumers: the
+    fp16-storage form); already multiplied by the styles of the layer `consumer` (any object; None = unscaled)."""
 
     def __init__(self, data, channels, consumer=None):
         self.data, self.channels, self.consumer = data, channels, consumer
-        b, _, c8, h, w, _ = data.shape
+        b, self.planes, c8, h, w, _ = data.shape
         self.shape = (b, channels, h, w)
         self.device, self.dtype = data.device, torch.float32      # stands in for an fp32 activation
 
     def float(self):     # inverse of the split (tests / fallbacks): hi + lo * 2^-11, channel groups unfolded
-        hi, lo = self.data[:, 0].float(), self.data[:, 1].float()
-        v = hi + lo * (1.0 / 2048.0)
+        v = self.data[:, 0].float()
+        if self.planes == 2:
+            v = v + self.data[:, 1].float() * (1.0 / 2048.0)
         b, c8, h, w, _ = v.shape
         return v.permute(0, 1, 4, 2, 3).reshape(b, c8 * 8, h, w)
 
 
-def act_split(x, styles=None, consumer=None):
+def act_split(x, styles=None, consumer=None, planes=2):
     """fp32 NCHW (x styles [B,C]) -> SplitAct (see ia_act_split)."""
     _f32c(x, 'x')
     b, c, h, w = x.shape
     if c % 8:
         raise RuntimeError('the split format needs channels % 8 == 0')
-    out = torch.empty(b, 2, c // 8, h, w, 8, device=x.device, dtype=torch.float16)
-    with torch.cuda.device(x.device), _Timed('act_split', 0.0, 8.0 * x.numel()):
-        st = _lib.load().ia_act_split(_p(x), _p(None if styles is None else _f32c(styles, 'styles')), _p(out), b, c, h, w, _lib.stream_ptr(x.device))
+    out = torch.empty(b, planes, c // 8, h, w, 8, device=x.device, dtype=torch.float16)
+    with torch.cuda.device(x.device), _Timed('act_split', 0.0, (4.0 + 2.0 * planes) * x.numel()):
+        st = _lib.load().ia_act_split(_p(x), _p(None if styles is None else _f32c(styles, 'styles')), _p(out), int(planes), b, c, h, w,
+                                      _lib.stream_ptr(x.device))
     _lib.check(st, 'ia_act_split')
     return SplitAct(out, c, consumer)
 
 
 def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=None, residual=None, transposed=False, act='linear',
-                   alpha=0.2, gain=1.0, clamp=None, want_f32=True, split_for=None, styles_next=None, ksplit=None):
+                   alpha=0.2, gain=1.0, clamp=None, want_f32=True, split_for=None, styles_next=None, ksplit=None, split_planes=2):
     """ia_conv2d_mfma_sx: 3x3 convolution of a SplitAct (already multiplied by this layer's styles).  Returns the fp32 result,
-    a SplitAct for `split_for` (multiplied by styles_next), or the pair (y, ys) when both are asked for."""
+    a SplitAct for `split_for` (multiplied by styles_next, `split_planes` planes), or the pair (y, ys) when both are asked for.
+    A two-plane input takes weights from pack_conv_weight_split, a one-plane input those of pack_conv_weight_h."""
     if not isinstance(xs, SplitAct):
         raise RuntimeError('xs must be a SplitAct (hipops.act_split or a producing layer)')
-    if not (wk.dtype == torch.float16 and wk.dim() == 5 and wk.shape[0] == 2 and hasattr(wk, 'wk_exp')):
+    if xs.planes == 2 and not (wk.dtype == torch.float16 and wk.dim() == 5 and wk.shape[0] == 2 and hasattr(wk, 'wk_exp')):
         raise RuntimeError('wk must come from pack_conv_weight_split')
+    if xs.planes == 1 and not (wk.dtype == torch.float16 and wk.dim() == 4):
+        raise RuntimeError('a one-plane input takes the weights of pack_conv_weight_h')
     b, i, h, w = xs.shape
     o = wk.shape[-2]
     if wk.shape[-4] != 9 or wk.shape[-3] * 8 != i:
@@ -239,15 +245,15 @@ def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=Non
     oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (h, w)
     dev = xs.data.device
     y = torch.empty(b, o, oh, ow, device=dev, dtype=torch.float32) if want_f32 else None
-    ys = torch.empty(b, 2, o // 8, oh, ow, 8, device=dev, dtype=torch.float16) if want_split else None
+    ys = torch.empty(b, split_planes, o // 8, oh, ow, 8, device=dev, dtype=torch.float16) if want_split else None
     scratch = _scratch_buffer(dev, nbytes) if nbytes else None
     flops = 2.0 * b * h * w * i * o * 9
-    traffic = 4.0 * (xs.data.numel() // 2 * 2 // 2 + wk.numel() // 2 + (y.numel() if want_f32 else 0) + (o * b * oh * ow if want_split else 0)
-                     + (residual.numel() if residual is not None else 0))
+    traffic = (2.0 * (xs.data.numel() + wk.numel()) + 4.0 * (y.numel() if want_f32 else 0) + 2.0 * (ys.numel() if want_split else 0)
+               + 4.0 * (residual.numel() if residual is not None else 0))
     with torch.cuda.device(dev), _Timed('conv2d_mfma_t' if transposed else 'conv2d_mfma_k3', flops, traffic,
-                                        f'B{b} I{i} O{o} {h}x{w} G{ksplit} f16x3 dma'):
-        st = lib.ia_conv2d_mfma_sx(_p(xs.data), _p(wk), int(wk.wk_exp), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(residual),
-                                   _p(y), _p(ys), _p(styles_next), _p(scratch), nbytes, b, i, o, h, w, int(transposed), ACT_ID[act],
+                                        f'B{b} I{i} O{o} {h}x{w} G{ksplit} ' + ('f16x3 dma' if xs.planes == 2 else 'f16 dma')):
+        st = lib.ia_conv2d_mfma_sx(_p(xs.data), int(xs.planes), _p(wk), int(getattr(wk, 'wk_exp', 0)), _p(demod), _p(noise), _p(noise_strength),
+                                   _p(bias), _p(residual), _p(y), _p(ys), int(split_planes), _p(styles_next), _p(scratch), nbytes, b, i, o, h, w, int(transposed), ACT_ID[act],
                                    float(alpha), float(gain), float(-1 if clamp is None else clamp), int(ksplit), _lib.stream_ptr(dev))
     _lib.check(st, 'ia_conv2d_mfma_sx')
     out_s = SplitAct(ys, o, split_for) if want_split else None
@@ -276,7 +282,7 @@ def upfirdn2d_bias_act(x, f, noise=None, noise_strength=None, bias=None, up=1, p
 
 
 def fir_tail_split(x, f, noise=None, noise_strength=None, bias=None, styles_next=None, out_hw=None, pad0=(1, 1), fir_gain=1.0, act='linear',
-                   alpha=0.2, act_gain=1.0, clamp=None, flip=False, want_f32=False, split_for=None):
+                   alpha=0.2, act_gain=1.0, clamp=None, flip=False, want_f32=False, split_for=None, planes=2):
     """upfirdn2d_bias_act (4x4 filter, up 1) whose result goes out in split format for `split_for` (see ia_fir_tail_split).
     Returns the SplitAct, or (y, SplitAct) with want_f32."""
     _f32c(x, 'x')
@@ -284,12 +290,12 @@ def fir_tail_split(x, f, noise=None, noise_strength=None, bias=None, styles_next
     if tuple(f.shape) != (4, 4) or c % 8:
         raise RuntimeError('fir_tail_split needs the 4x4 filter and channels % 8 == 0')
     oh, ow = out_hw
-    ys = torch.empty(n, 2, c // 8, oh, ow, 8, device=x.device, dtype=torch.float16)
+    ys = torch.empty(n, planes, c // 8, oh, ow, 8, device=x.device, dtype=torch.float16)
     y = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.float32) if want_f32 else None
     with torch.cuda.device(x.device), _Timed('upfirdn2d_bias_act', 2.0 * n * c * oh * ow * 16, 4.0 * (x.numel() + n * c * oh * ow * (2 if want_f32 else 1)),
                                              'split'):
         st = _lib.load().ia_fir_tail_split(_p(x), _p(_f32c(f, 'f')), _p(noise), _p(noise_strength), _p(bias), _p(styles_next), _p(y), _p(ys),
-                                           n, c, ih, iw, oh, ow, int(pad0[0]), int(pad0[1]), 1 if flip else 0, float(fir_gain), ACT_ID[act],
+                                           int(planes), n, c, ih, iw, oh, ow, int(pad0[0]), int(pad0[1]), 1 if flip else 0, float(fir_gain), ACT_ID[act],
                                            float(alpha), float(act_gain), float(-1 if clamp is None else clamp), _lib.stream_ptr(x.device))
     _lib.check(st, 'ia_fir_tail_split')
     out = SplitAct(ys, c, split_for)

@@ -342,7 +342,7 @@ class SynthesisLayer(torch.nn.Module):
 
     def _takes_split_input(self, in_res, noise_mode='const', half_ops=False):
         """True when this layer, fed a [*, in_channels, in_res, in_res] activation, runs on ia_conv2d_mfma_sx."""
-        return (SPLIT_FP16_PRODUCTS and USE_SPLIT_DMA and not half_ops and self.weight.shape[2] == 3 and self.in_channels % 8 == 0
+        return ((SPLIT_FP16_PRODUCTS or half_ops) and USE_SPLIT_DMA and self.weight.shape[2] == 3 and self.in_channels % 8 == 0
                 and self.out_channels % 8 == 0 and not (self.use_noise and noise_mode == 'random') and self.activation in hipops.ACT_ID
                 and hipops.conv_h_supported(self.in_channels, self.out_channels, in_res, in_res, 3, self.up == 2))
 
@@ -353,7 +353,8 @@ class SynthesisLayer(torch.nn.Module):
             return None
         return split_for._pre[0] if split_for._takes_split_input(out_res, noise_mode, half_ops) else None
 
-    def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp, demod=None, half_ops=False, split_for=None, keep_f32=True):
+    def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp, demod=None, half_ops=False, split_for=None, keep_f32=True,
+                              next_half_ops=None):
         """conv + demod + noise + bias + lrelu + clamp on the MFMA path (one or two launches).
 
         `x`: fp32 tensor (optionally carrying `_ia_split`, its split copy made for this layer) or a hipops.SplitAct.
@@ -363,26 +364,33 @@ class SynthesisLayer(torch.nn.Module):
         const_noise = self.use_noise and noise_mode == 'const'
         res = self.resolution
         if self._takes_split_input(in_res, noise_mode, half_ops):
-            wk = self._packed.get_split(self.weight)
+            # half_ops (a block in the reference's fp16 precision): ONE fp16 plane in and out -- fp16 operands, fp32 accumulation,
+            # and the activation between the convolutions stored as 2 bytes per element
+            planes = 1 if half_ops else 2
+            wk = self._packed.get_half(self.weight) if half_ops else self._packed.get_split(self.weight)
             if demod is None:
                 demod = hipops.modconv_demod(styles.float().contiguous(), self._packed.get(self.weight)[1])
             carried = x if isinstance(x, hipops.SplitAct) else getattr(x, '_ia_split', None)
-            xs = carried if (carried is not None and carried.consumer is self) else \
-                hipops.act_split(x.float().contiguous(), styles.float().contiguous(), consumer=self)
+            xs = carried if (carried is not None and carried.consumer is self and carried.planes == planes) else \
+                hipops.act_split(x.float().contiguous(), styles.float().contiguous(), consumer=self, planes=planes)
             nz = self.noise_const.reshape(-1) if const_noise else None
             ns = self.noise_strength.detach().float().reshape(1) if const_noise else None
             bias = self.bias.detach().float()
-            sn = self._consumer_styles(split_for, res, noise_mode, half_ops)
+            next_half = half_ops if next_half_ops is None else next_half_ops
+            sn = self._consumer_styles(split_for, res, noise_mode, next_half)
+            out_planes = 1 if next_half else 2
             if self.up == 1:
                 out = hipops.conv2d_mfma_sx(xs, wk, demod, nz, ns, bias, act=self.activation, gain=act_gain, clamp=act_clamp,
-                                            want_f32=keep_f32 or sn is None, split_for=split_for if sn is not None else None, styles_next=sn)
+                                            want_f32=keep_f32 or sn is None, split_for=split_for if sn is not None else None, styles_next=sn,
+                                            split_planes=out_planes)
             else:
                 t = hipops.conv2d_mfma_sx(xs, wk, demod, transposed=True)
                 if sn is None:
                     return hipops.upfirdn2d_bias_act(t, self.resample_filter, nz, ns, bias, up=1, pad0=(1, 1), out_hw=(res, res),
                                                      fir_gain=4.0, act=self.activation, act_gain=act_gain, clamp=act_clamp)
                 out = hipops.fir_tail_split(t, self.resample_filter, nz, ns, bias, styles_next=sn, out_hw=(res, res), pad0=(1, 1), fir_gain=4.0,
-                                            act=self.activation, act_gain=act_gain, clamp=act_clamp, want_f32=keep_f32, split_for=split_for)
+                                            act=self.activation, act_gain=act_gain, clamp=act_clamp, want_f32=keep_f32, split_for=split_for,
+                                            planes=out_planes)
             if isinstance(out, tuple):     # fp32 result with its split copy riding along for the consumer
                 out[0]._ia_split = out[1]
                 return out[0]
@@ -412,10 +420,12 @@ class SynthesisLayer(torch.nn.Module):
             return hipops.conv2d_mfma(x, wk, styles, demod, nz, ns, bias, ksize=3, act=self.activation, gain=act_gain,
                                       clamp=act_clamp)
         t = hipops.conv2d_mfma(x, wk, styles, demod, ksize=3, transposed=True)
-        sn = None if half_ops else self._consumer_styles(split_for, res, noise_mode)
+        next_half = half_ops if next_half_ops is None else next_half_ops
+        sn = self._consumer_styles(split_for, res, noise_mode, next_half)
         if sn is not None and self.out_channels % 8 == 0:      # (the consumer is on the split path although this layer is not)
             out = hipops.fir_tail_split(t, self.resample_filter, nz, ns, bias, styles_next=sn, out_hw=(res, res), pad0=(1, 1), fir_gain=4.0,
-                                        act=self.activation, act_gain=act_gain, clamp=act_clamp, want_f32=keep_f32, split_for=split_for)
+                                        act=self.activation, act_gain=act_gain, clamp=act_clamp, want_f32=keep_f32, split_for=split_for,
+                                        planes=1 if next_half else 2)
             if isinstance(out, tuple):
                 out[0]._ia_split = out[1]
                 return out[0]
@@ -423,7 +433,7 @@ class SynthesisLayer(torch.nn.Module):
         return hipops.upfirdn2d_bias_act(t, self.resample_filter, nz, ns, bias, up=1, pad0=(1, 1), out_hw=(res, res),
                                          fir_gain=4.0, act=self.activation, act_gain=act_gain, clamp=act_clamp)
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, half_ops=False, split_for=None, keep_f32=True):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, half_ops=False, split_for=None, keep_f32=True, next_half_ops=None):
         assert noise_mode in ['random', 'const', 'none']
         in_res = self.resolution // self.up
         if isinstance(x, hipops.SplitAct):
@@ -436,7 +446,7 @@ class SynthesisLayer(torch.nn.Module):
         if (_on_device(x) and self.activation in hipops.ACT_ID and self.weight.shape[2] == 3 and self.up in (1, 2)
                 and not _needs_autograd(x, w, self.weight, self.bias)):
             styles, demod = pre if pre is not None else (self.affine(w), None)
-            return self._fused_device_forward(x, styles, noise_mode, act_gain, act_clamp, demod, half_ops, split_for, keep_f32)
+            return self._fused_device_forward(x, styles, noise_mode, act_gain, act_clamp, demod, half_ops, split_for, keep_f32, next_half_ops)
         if isinstance(x, hipops.SplitAct):
             raise RuntimeError('a SplitAct reached the torch route of a SynthesisLayer')
         styles = self.affine(w)
@@ -541,7 +551,8 @@ class SynthesisBlock(torch.nn.Module):
             self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2,
                                     resample_filter=resample_filter, channels_last=self.channels_last)
 
-    def forward(self, x, img, ws, condition=None, force_fp32=False, fused_modconv=None, update_emas=False, _next_conv=None, **layer_kwargs):
+    def forward(self, x, img, ws, condition=None, force_fp32=False, fused_modconv=None, update_emas=False, _next_conv=None, _next_half=None,
+                **layer_kwargs):
         """`_next_conv`: the layer that consumes this block's x (the next block's conv0), given by the owning network on the device
         inference path so that conv1 can emit its result in the format that layer reads (hipops.SplitAct)."""
         _ = update_emas
@@ -579,7 +590,7 @@ class SynthesisBlock(torch.nn.Module):
             if condition is not None:
                 half = int(x.size(1) // 2)
                 x = torch.cat([x[:, :half], x[:, half:] * condition[0] + condition[1]], dim=1)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, split_for=_next_conv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, split_for=_next_conv, next_half_ops=_next_half, **layer_kwargs)
 
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])

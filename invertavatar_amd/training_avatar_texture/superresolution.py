@@ -55,7 +55,11 @@ class _TwoBlockHead(torch.nn.Module):
             ws = _last_w(ws)
             self._prepare_styles(ws)
         x, rgb = _fit(x, rgb, self.input_resolution, self.sr_antialias)
-        chain = dict(_next_conv=getattr(self.block1, 'conv0', None)) if isinstance(self.block0, SynthesisBlock) else {}
+        chain = {}
+        if isinstance(self.block0, SynthesisBlock):     # block0.conv1 writes block1.conv0's operand format (fp16 plane(s), see hipops.SplitAct)
+            from ..training import networks_stylegan2 as sg2
+            next_half = bool(getattr(self.block1, 'use_fp16', False)) and ws.is_cuda and not sg2.FP16_BLOCKS_COMPUTE_FP32
+            chain = dict(_next_conv=getattr(self.block1, 'conv0', None), _next_half=next_half)
         x, rgb = self.block0(x, rgb, ws, **chain, **block_kwargs)
         x, rgb = self.block1(x, rgb, ws, **block_kwargs)
         return rgb
@@ -178,7 +182,11 @@ class SuperresolutionHybrid4X(_TwoBlockHead):
         ws = _last_w(ws)
         if x.shape[-1] < self.input_resolution:   # this head only ever up-samples its input (:79)
             x, rgb = _fit(x, rgb, self.input_resolution, self.sr_antialias)
-        chain = dict(_next_conv=getattr(self.block1, 'conv0', None)) if isinstance(self.block0, SynthesisBlock) else {}
+        chain = {}
+        if isinstance(self.block0, SynthesisBlock):     # block0.conv1 writes block1.conv0's operand format (fp16 plane(s), see hipops.SplitAct)
+            from ..training import networks_stylegan2 as sg2
+            next_half = bool(getattr(self.block1, 'use_fp16', False)) and ws.is_cuda and not sg2.FP16_BLOCKS_COMPUTE_FP32
+            chain = dict(_next_conv=getattr(self.block1, 'conv0', None), _next_half=next_half)
         x, rgb = self.block0(x, rgb, ws, **chain, **block_kwargs)
         x, rgb = self.block1(x, rgb, ws, **block_kwargs)
         return rgb

@@ -316,3 +316,29 @@ def test_cond_blend_split_equals_cond_blend_then_split():
     assert torch.equal(got.data[:, 0].permute(0, 1, 4, 2, 3).reshape(want.shape), hi)
     assert torch.equal(got.data[:, 1].permute(0, 1, 4, 2, 3).reshape(want.shape), lo)
 
+
+
+@pytest.mark.parametrize('i,o,h,w,tr', [(128, 128, 64, 64, False), (256, 128, 48, 80, False), (64, 64, 65, 65, True), (32, 256, 128, 128, True)])
+def test_one_plane_dma_convolution_equals_the_fp16_operand_form(i, o, h, w, tr):
+    """The fp16-storage form (one fp16 plane in, one product per k-step) is the arithmetic of ia_conv2d_mfma_h: same bits, with the
+    activation stored as 2 bytes per element; its split second output is the rounded fp16 plane of (result * styles_next)."""
+    g = torch.Generator(device='cuda').manual_seed(5 + i + h)
+    x = torch.randn(2, i, h, w, device='cuda', generator=g) * 2
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g)
+    s = torch.rand(2, i, device='cuda', generator=g) + 0.5
+    sn = torch.rand(2, o, device='cuda', generator=g) + 0.5
+    wk = hipops.pack_conv_weight_h(wt)
+    d = hipops.modconv_demod(s, hipops.weight_sq_sum(wt))
+    xs = hipops.act_split(x, s, planes=1)
+    assert xs.data.shape[1] == 1 and torch.equal(xs.data[:, 0].permute(0, 1, 4, 2, 3).reshape(x.shape), (x * s[:, :, None, None]).half())
+    if tr:
+        want = hipops.conv2d_mfma(x, wk, styles=s, demod=d, ksize=3, transposed=True)
+        got = hipops.conv2d_mfma_sx(xs, wk, demod=d, transposed=True)
+        assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+        return
+    bias = torch.randn(o, device='cuda', generator=g)
+    kw = dict(demod=d, bias=bias, act='lrelu', gain=1.3, clamp=256.0)
+    want = hipops.conv2d_mfma(x, wk, styles=s, ksize=3, **kw)
+    got, got_s = hipops.conv2d_mfma_sx(xs, wk, styles_next=sn, split_planes=1, **kw)
+    assert torch.equal(got, want)
+    assert got_s.planes == 1 and torch.equal(got_s.data[:, 0].permute(0, 1, 4, 2, 3).reshape(want.shape), (want * sn[:, :, None, None]).half())
