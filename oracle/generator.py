@@ -154,6 +154,67 @@ def superresolution_8xdc(sd, rgb, x, ws, noise_mode='none', fused=True, conv_cla
     return rgb
 
 
+def _h(t):
+    """One fp16 storage rounding (the tensor lives in fp16 in the reference's fp16 blocks)."""
+    return t.to(torch.float16).to(torch.float32)
+
+
+def _modconv_fp16(x, weight, styles, up, resample_filter, demodulate):
+    """modulated_conv2d with x.dtype == float16, fused branch (training/networks_stylegan2.py:52-57,60-66,81-91): weight and styles
+    are pre-normalised by their max-norms when demodulating (:54-56), the per-sample weight w * s * d is formed in fp32 and ROUNDED
+    to fp16 (`w.to(x.dtype)`, :87), the convolution runs on fp16 operands (fp32 accumulation in the library) and every tensor it
+    writes is fp16: the conv output, and for up = 2 the stride-2 transposed conv output AND the FIR output
+    (conv2d_resample.py:114-131).  PARITY UNPINNED: the CPU reference forces fp32 (networks_stylegan2.py:437), so no fixture of
+    this path can be generated here; this follows the cited lines."""
+    o, i, kh, kw = weight.shape
+    if demodulate:
+        weight = weight * (1 / math.sqrt(i * kh * kw) / weight.abs().amax(dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.abs().amax(dim=1, keepdim=True)
+    outs = []
+    for b in range(x.shape[0]):
+        wb = weight * styles[b].reshape(1, i, 1, 1)
+        if demodulate:
+            wb = wb * (wb.square().sum(dim=[1, 2, 3], keepdim=True) + 1e-8).rsqrt()
+        wb = _h(wb)
+        if up == 1:
+            yb = _h(F.conv2d(x[b:b + 1], wb, padding=kh // 2))
+        else:
+            yb = _h(F.conv_transpose2d(x[b:b + 1], wb.transpose(0, 1), stride=2))
+            yb = _h(ops.upfirdn2d(yb, resample_filter, padding=(1, 1, 1, 1), gain=4.0))
+        outs.append(yb)
+    return torch.cat(outs, 0)
+
+
+def synthesis_block_fp16(sd, x, img, ws, conv_clamp=256):
+    """SynthesisBlock.forward with use_fp16 on a CUDA device, noise_mode 'none' (training/networks_stylegan2.py:417-460): x is cast
+    to fp16 at the top (:436-437); each SynthesisLayer = fp16 modulated conv -> bias_act computed in fp32, stored fp16, clamp 256
+    (:327-329); ToRGB likewise (no demodulation: no pre-normalisation) and its result goes to fp32 before the skip add (:456-458)."""
+    x = _h(x)
+    wi = 0
+    for name, up in (('conv0', 2), ('conv1', 1)):
+        lsd = sub(sd, name)
+        styles = ops.fully_connected(ws[:, wi], lsd['affine.weight'], lsd['affine.bias']); wi += 1
+        y = _modconv_fp16(x, lsd['weight'], styles, up, lsd['resample_filter'], True)
+        x = _h(ops.bias_act(y, _h(lsd['bias']), act='lrelu', gain=ops.SQRT2, clamp=conv_clamp))
+    img = ops.upsample2d(img, sd['resample_filter'])
+    tsd = sub(sd, 'torgb')
+    styles = ops.fully_connected(ws[:, wi], tsd['affine.weight'], tsd['affine.bias']) * (1 / math.sqrt(tsd['weight'].shape[1]))
+    y = _modconv_fp16(x, tsd['weight'], styles, 1, None, False)
+    y = _h(ops.bias_act(y, _h(tsd['bias']), clamp=conv_clamp))
+    return x, img + y
+
+
+def superresolution_8xdc_fp16(sd, rgb, x, ws):
+    """SuperresolutionHybrid8XDC with sr_num_fp16_res > 0 as deployed (superresolution.py:263-289, use_fp16 + conv_clamp 256)."""
+    ws3 = ws[:, -1:, :].repeat(1, 3, 1)
+    if x.shape[-1] != 128:
+        x = ops.resize_bilinear_aa(x, (128, 128))
+        rgb = ops.resize_bilinear_aa(rgb, (128, 128))
+    x, rgb = synthesis_block_fp16(sub(sd, 'block0'), x, rgb, ws3)
+    x, rgb = synthesis_block_fp16(sub(sd, 'block1'), x, rgb, ws3)
+    return rgb
+
+
 def split_static(static_feats):
     """triplane_v20.py:109-112: keep plane 0 of the two 96-channel entries."""
     b = static_feats[0].shape[0]

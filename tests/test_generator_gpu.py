@@ -124,7 +124,13 @@ def test_bench_configuration_batched_vs_reference(golden, full):
     _check_bench_frame(out, gld, 'b2')
 
 
-TOL_RGB_FP16_SR = 2e-2   # fp16 operands (11-bit mantissa) in the 6 SR convolutions; the reference's own fp16 path also stores fp16
+# SR head in the reference's deployed precision (sr_num_fp16_res = 4).  Two statements of "fp16": this backend rounds x * style and w
+# (fp16 operands, fp32 accumulate, demodulation in the fp32 epilogue, activations stored as one fp16 plane between the convolutions);
+# the reference rounds x, w * s * d and every stored tensor (oracle/generator.py:superresolution_8xdc_fp16, a restatement -- the CPU
+# reference forces fp32, so that leg is "parity unpinned").  Measured r02 (full width, nrr 64): this backend 1.66e-3 from the fp32
+# fixture, the restated reference path 3.42e-3 from it, the two 4.68e-3 from each other (bounded by the sum of the former two).
+TOL_RGB_FP16_SR = 4e-3            # vs the reference's fp32 output (r01: 2e-2)
+TOL_RGB_FP16_SR_VS_RESTATEMENT = 7e-3
 
 
 def test_full_width_generator_with_fp16_sr_head(golden):
@@ -149,6 +155,16 @@ def test_full_width_generator_with_fp16_sr_head(golden):
     print(f'full generator, fp16 SR head: max|dRGB| = {err:.2e}')
     assert err <= TOL_RGB_FP16_SR
     assert abs(out['image'].abs().mean().item() - gld['image_mean_abs']) <= 2e-3
+    # against the restatement of the reference's fp16 rounding points, fed the SAME rendered features
+    from oracle import generator as OG
+    sd = {k[len('superresolution.'):]: v.detach().cpu() for k, v in g.state_dict().items() if k.startswith('superresolution.')}
+    feat = out['feature_image'].cpu()
+    with torch.no_grad():
+        ref16 = OG.superresolution_8xdc_fp16(sd, feat[:, :3].contiguous(), feat, ws.cpu())
+    err16 = max_abs(out['image'].cpu(), ref16)
+    err16_vs_f32 = max_abs(ref16[..., ::4, ::4], gld['image_sub4'])
+    print(f'fp16 SR head: max|dRGB| vs restated reference fp16 path = {err16:.2e} (that path vs the fp32 fixture: {err16_vs_f32:.2e})')
+    assert err16 <= TOL_RGB_FP16_SR_VS_RESTATEMENT
 
 
 def test_fill_mouth_known_answers_on_device(golden):
