@@ -92,7 +92,7 @@ __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], 
 // 1 = one fp16 plane, one product (fp16 operands / fp32 accumulation, the arithmetic of ia_conv2d_mfma_h: the reference's fp16
 // blocks) -- the fp16-STORAGE form of the SR head: activations travel between its convolutions as 2 bytes per element.
 template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP, bool SK>
-__global__ __launch_bounds__(WO * WP * 64, WO * WP == 8 ? 1 : 2) void conv_split_kernel(const h16x8* __restrict__ xs, const h16x8* __restrict__ wk,
+__global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void conv_split_kernel(const h16x8* __restrict__ xs, const h16x8* __restrict__ wk,
                                                                                       float* __restrict__ y, float* __restrict__ slabs, Geo g, Epi e) {
     constexpr int KS = 3, NT = 9, NTP = NT + 1;
     constexpr int NPH = TR ? 4 : 1;
@@ -428,5 +428,7 @@ extern "C" int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_spli
     if (transposed && bp == 256) return launch_sx<2, true, 1, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
     if (transposed && bp == 128) return launch_sx<2, true, 1, 2, 2, 2>(x8, w8, y, scratch, g, e, s);
     if (transposed) return launch_sx<2, true, 1, 1, 2, 2>(x8, w8, y, scratch, g, e, s);
+    // (16 waves of 32ch x 64pt on the same 128 x 256 tile -- four waves per SIMD to overlap DMA issue, operand reads and MFMAs of
+    // different waves -- measured 240 vs 245 us on 256->256 @256^2 and slower on the smaller layers: not kept)
     return launch_sx<2, false, 2, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
 }
