@@ -167,6 +167,8 @@ def fill_encoder_parameters(net, skip_prefix='generator.', salt=0):
                     if pname == 'weight': t.copy_(draw(full, shape, 0.1, 1.0))
                     elif pname == 'running_var': t.copy_(draw(full, shape, 0.1, 1.0, absolute=True))
                     else: t.copy_(draw(full, shape, 0.1))
+                elif kind == 'LayerNorm':
+                    t.copy_(draw(full, shape, 0.1, 1.0) if pname == 'weight' else draw(full, shape, 0.1))
                 elif kind == 'PReLU':
                     t.copy_(draw(full, shape, 0.05, 0.25))
                 elif pname == 'weight' and t.ndim >= 2:

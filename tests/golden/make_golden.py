@@ -427,6 +427,72 @@ def gen_encoder():
     print(f'encoder_state_names.txt: {len(lines)} tensors')
 
 
+def install_timm_stub():
+    """mix_transformer.py imports three helpers from timm (absent here): identity DropPath at rate 0, to_2tuple, trunc_normal_."""
+    class DropPath(torch.nn.Module):
+        def __init__(self, drop_prob=0.):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            assert self.drop_prob == 0. or not self.training
+            return x
+    layers = types.ModuleType('timm.models.layers')
+    layers.DropPath, layers.to_2tuple, layers.trunc_normal_ = DropPath, (lambda v: v if isinstance(v, tuple) else (v, v)), torch.nn.init.trunc_normal_
+    reg = types.ModuleType('timm.models.registry'); reg.register_model = lambda f: f
+    vit = types.ModuleType('timm.models.vision_transformer'); vit._cfg = lambda **k: {}
+    for name, mod in (('timm', types.ModuleType('timm')), ('timm.models', types.ModuleType('timm.models')), ('timm.models.layers', layers),
+                      ('timm.models.registry', reg), ('timm.models.vision_transformer', vit)):
+        sys.modules.setdefault(name, mod)
+
+
+def one_shot_inputs(nrr=32):
+    src, drive = [12], [40]
+    return dict(image=synthetic.source_frames(9, 1), uv=synthetic.source_uv(19, src), c=synthetic.camera_labels(src),
+                uvcoords=synthetic.uv_conditions(src), jitter=synthetic.jitter(src, nrr * nrr),
+                drive_c=synthetic.camera_labels(drive), drive_uvcoords=synthetic.uv_conditions(drive), drive_jitter=synthetic.jitter(drive, nrr * nrr))
+
+
+def gen_encoder_new():
+    """eval_updated_os.py flow (:94-95,171-179,198) with the reference's uvnet_new.inversionNet: eval() mode, one source frame,
+    one-shot forward, one drive frame."""
+    install_timm_stub()
+    from encoder_inversion.models.uvnet_new import inversionNet
+    g = build_reference_generator('full')
+    net = inversionNet(generator=g, encoding_triplane=True, encoding_texture=True).eval().requires_grad_(False)
+    synthetic.fill_encoder_parameters(net)
+    nrr = 32
+    g.neural_rendering_resolution = nrr
+    inp = one_shot_inputs(nrr)
+    ws = net.encode(inp['image'])
+    tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
+    sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
+    with fixed_randomness(inp['jitter']):
+        out = net({'image': inp['image'], 'uv': inp['uv']}, inp['c'], {'uvcoords_image': inp['uvcoords']},
+                  e4e_results={'w': ws, 'texture': tex, 'static': sta}, return_feats=True)
+    static = sta[:-1] + out['static'][-1:]
+    with fixed_randomness(inp['drive_jitter']):
+        img = g.synthesis_withTexture(ws, out['texture'], inp['drive_c'], {'uvcoords_image': inp['drive_uvcoords']}, noise_mode='const',
+                                      static_feats=static, evaluation=True)['image']
+    arrays = dict(ws=ws)
+
+    def thin(name, t):
+        stride = 1
+        while t[..., ::stride, ::stride].numel() > 50000:
+            stride *= 2
+        arrays[f'{name}_s{stride}'] = t[..., ::stride, ::stride]
+    thin('drive_image', img)
+    for i, t in enumerate(out['texture']):
+        thin(f'texture{i}', t)
+    thin('static5', static[-1])
+    npz('encoder_oneshot.npz', **arrays)
+    lines = [f'{n}\t{tuple(t.shape)}\t{str(t.dtype).replace("torch.", "")}' for n, t in sorted(net.state_dict().items())
+             if n.startswith('unet_encoder.')]
+    with open(os.path.join(HERE, 'encoder_new_state_names.txt'), 'w') as fh:
+        fh.write('\n'.join(lines) + '\n')
+    print(f'encoder_new_state_names.txt: {len(lines)} tensors')
+
+
 def gen_names():
     """(name, shape, dtype) of every parameter/buffer: the checkpoint-compatibility contract."""
     for width, fname in (('full', 'generator_state_names.txt'), ('small', 'generator_state_names_small.txt')):
@@ -439,7 +505,7 @@ def gen_names():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='ops,flr,camera,renderer,small,full,bench,harness,names,encoder')
+    ap.add_argument('--only', default='ops,flr,camera,renderer,small,full,bench,harness,names,encoder,encoder_new')
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -456,6 +522,7 @@ def main():
         if 'harness' in todo: gen_harness()
         if 'names' in todo: gen_names()
         if 'encoder' in todo: gen_encoder()
+        if 'encoder_new' in todo: gen_encoder_new()
 
 
 if __name__ == '__main__':
