@@ -7,10 +7,12 @@
 //     s    = AA_resize( static_k[:, :, bbox], bbox -> res )                 (2x up-sampling of the face crop)
 //     out[:, :C] = rend * a + s * (1 - a);   out[:, C] = AA_resize( upper_mouth_alpha, 256 -> res )
 // The reference materialises the 256^2 x C grid_sample result (134 MB at C = 512) and three resized tensors per
-// level.  Here a workgroup owns 4 horizontally adjacent output pixels: it builds, once, the list of source pixels
-// of their anti-aliasing footprint with the four bilinear (texel, weight) pairs of each (LDS), then every thread
-// (= one channel of the CHANNELS-LAST texture, so each gather is a coalesced 256-byte line per wave) walks that
-// list.  Weights follow aten's _upsample_bilinear2d_aa and grid_sampler_2d (C4) in fp32.
+// level.  Here a workgroup owns 4 horizontally adjacent output pixels: it stages the source pixels of their anti-aliasing
+// footprint once (bilinear cell, fractions, AA weights; LDS), MERGES their weights per texel (a level's texture has the
+// resolution of its output, so the 40 .. 640 source pixels land on about 18 texels; see "Merge windows" below) and then
+// every thread (= four channels of the CHANNELS-LAST texture, so each gather is a coalesced line per wave) walks the
+// merged list.  Weights follow aten's _upsample_bilinear2d_aa and grid_sampler_2d (C4) in fp32; the merge
+// changes the summation order only (per-texel weight sums first), results stay within 2e-5 of aten's (tests).
 //
 // ia_blend_planes -- the plane blend of triplane_v20.py:119-128 fused with the layout change the renderer wants:
 // AA-resize the face stitch + alpha to 128^2, paste into the bbox of plane 0, blend over the static planes and
@@ -22,7 +24,6 @@ namespace {
 constexpr int kSrc = 256;                  // UV / alpha maps are 256 x 256 (triplane_v20.py:114,322)
 constexpr int PXB = 4;                     // output pixels per workgroup (one float4 store per channel)
 constexpr int kMaxScale = 8;
-constexpr int kMaxRows = 2 * kMaxScale, kMaxCols = (PXB + 1) * kMaxScale;
 
 // aten's anti-aliased triangle filter along one axis: taps [lo, hi) and their normalised weights for output o.
 __device__ __forceinline__ void aa_taps(int o, int n_in, int n_out, int& lo, int& hi, float& center, float& inv, float& total) {
@@ -50,15 +51,34 @@ struct RastParams {
     int by0, by1, bx0, bx1;   // crop of the static level that is resized to res
 };
 
-__global__ __launch_bounds__(512) void rasterize_level_kernel(RastParams p) {
-    __shared__ int4 s_idx[kMaxRows * kMaxCols];     // 4 texel indices (pre-multiplied by C) per source pixel
-    __shared__ float4 s_w[kMaxRows * kMaxCols];     // 4 bilinear weights * row AA weight (0 for padding)
+// Merge windows: the texels under the anti-aliasing footprint of a workgroup's 4 output pixels.  A texture level has the
+// resolution of its output, so the 16 x 40 .. 4 x 10 source pixels of a footprint land on a handful of texels (about 3 x 6
+// for a UV map at the scale of the image); their (AA weight x bilinear weight) products are summed PER TEXEL first (64-bit
+// fixed-point LDS atomics: integer adds commute, so the sums do not depend on the order the threads arrive in) and the
+// channel walk then gathers each texel once.  Two windows, because the footprints along the silhouette of the face see two
+// clusters: the face's texels and the one texel the constant background UV points at.  Window A is anchored at the corner of
+// the bounding box of all bilinear cells, window B at the corner of the bounding box of the cells A does not hold; when
+// cells are left over after that (a seam inside a strongly stretched region) the workgroup takes the direct form.
+constexpr int kWinW = 16, kWinH = 8, kWinN = kWinW * kWinH;
+constexpr int kChunk = 128, kList = 4 * kChunk;      // direct form: 128 source pixels (x 4 bilinear taps) a pass
+constexpr float kFix = 1099511627776.f;              // 2^40
+static_assert(kList >= 2 * kWinN, "the merged list must fit the list buffers");
+
+// S = 256 / res (8, 4, 2): sizes the footprint staging buffers
+template <int S>
+__global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
+    constexpr int kMaxRows = 2 * S, kMaxCols = (PXB + 1) * S;
+    __shared__ float4 s_px[kMaxRows * kMaxCols];    // per source pixel: (fx, fy, row AA weight, packed clamped (x0, y0))
     __shared__ float4 s_wx[kMaxCols];               // column AA weight of each source column for the 4 output pixels
     __shared__ float s_alpha[kMaxRows * kMaxCols], s_upper[kMaxRows * kMaxCols];
+    __shared__ unsigned long long s_acc[2 * kWinN * PXB];
+    __shared__ int s_lidx[kList];                   // walk list: texel offset (pre-multiplied by C) ...
+    __shared__ float4 s_lw[kList];                  // ... and its weight for each of the 4 output pixels
+    __shared__ int s_bb[8], s_n[1];
     __shared__ float s_a[PXB], s_u[PXB];
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // partial sums of the split walk
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int res = p.res;
     // Workgroup -> output tile, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, so id % 8 picks the
     // XCD and id / 8 the position inside that XCD's share; each XCD then owns a contiguous band of output rows and its
@@ -78,17 +98,22 @@ __global__ __launch_bounds__(512) void rasterize_level_kernel(RastParams p) {
     for (int k = 0; k < PXB; ++k) aa_taps(min(xt + k, res - 1), kSrc, res, xlo[k], xhi[k], xc[k], xinv[k], xtot[k]);
     const int c0 = xlo[0], ncols = xhi[PXB - 1] - c0, nrows = yhi - ylo, nsrc = nrows * ncols;
 
-    for (int i = tid; i < ncols; i += blockDim.x) {
+    if (tid == 0) { s_bb[0] = s_bb[1] = s_bb[4] = s_bb[5] = INT_MAX; s_bb[2] = s_bb[3] = s_bb[6] = s_bb[7] = INT_MIN; }
+    for (int i = tid; i < 2 * kWinN * PXB; i += nthr) s_acc[i] = 0ull;
+    for (int i = tid; i < ncols; i += nthr) {
         const int X = c0 + i;
         float w[PXB];
 #pragma unroll
         for (int k = 0; k < PXB; ++k) w[k] = (X >= xlo[k] && X < xhi[k] && xt + k < res) ? aa_weight(X, xc[k], xinv[k], xtot[k]) : 0.f;
         s_wx[i] = make_float4(w[0], w[1], w[2], w[3]);
     }
+    __syncthreads();
     const float* uvb = p.uv + (int64_t)b * kSrc * kSrc * 3;
     const float* upb = p.upper + (int64_t)b * kSrc * kSrc;
     const int Rt = p.Rt;
-    for (int i = tid; i < nsrc; i += blockDim.x) {
+    // ---- stage the footprint: bilinear cell + fractions of every source pixel, and the bounding box of the texels they touch
+    int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+    for (int i = tid; i < nsrc; i += nthr) {
         const int r = i / ncols, cidx = i - r * ncols;
         const int Y = ylo + r, X = c0 + cidx;
         const float wy = aa_weight(Y, yc, yinv, ytot);
@@ -99,19 +124,13 @@ __global__ __launch_bounds__(512) void rasterize_level_kernel(RastParams p) {
         const float x0f = floorf(ix), y0f = floorf(iy);
         const float fx = ix - x0f, fy = iy - y0f;
         const int x0 = (int)fminf(fmaxf(x0f, -2.f), (float)Rt + 1.f), y0 = (int)fminf(fmaxf(y0f, -2.f), (float)Rt + 1.f);
-        int id[4]; float w[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
-            const bool ok = xi >= 0 && xi < Rt && yi >= 0 && yi < Rt;
-            id[t] = ok ? (yi * Rt + xi) * p.C : 0;
-            w[t] = ok ? ((t & 1) ? fx : 1.f - fx) * ((t >> 1) ? fy : 1.f - fy) * wy : 0.f;
-        }
-        s_idx[i] = make_int4(id[0], id[1], id[2], id[3]);
-        s_w[i] = make_float4(w[0], w[1], w[2], w[3]);
+        s_px[i] = make_float4(fx, fy, wy, __int_as_float(((y0 + 2) << 16) | (x0 + 2)));
         s_alpha[i] = px[2] * wy;
         s_upper[i] = upb[(int64_t)Y * kSrc + X] * wy;
+        const int ax = max(x0, 0), bx = min(x0 + 1, Rt - 1), ay = max(y0, 0), by = min(y0 + 1, Rt - 1);
+        if (ax <= bx && ay <= by) { mnx = min(mnx, ax); mxx = max(mxx, bx); mny = min(mny, ay); mxy = max(mxy, by); }
     }
+    if (mnx <= mxx) { atomicMin(&s_bb[0], mnx); atomicMin(&s_bb[1], mny); atomicMax(&s_bb[2], mxx); atomicMax(&s_bb[3], mxy); }
     __syncthreads();
     // ---- resized alpha / upper-mouth alpha of the 4 output pixels (wave 0)
     if (tid < 64) {
@@ -131,7 +150,75 @@ __global__ __launch_bounds__(512) void rasterize_level_kernel(RastParams p) {
             for (int k = 0; k < PXB; ++k) { s_a[k] = a[k]; s_u[k] = u[k]; }
         }
     }
-    __syncthreads();
+    // ---- merged form: per-texel weight sums over the windows, then an ordered compaction into the walk list
+    const int ax0 = s_bb[0], ay0 = s_bb[1];
+    const bool none = s_bb[2] < s_bb[0];                                   // every bilinear cell lies in the zero padding
+    const bool one = none || (s_bb[2] - ax0 < kWinW && s_bb[3] - ay0 < kWinH);
+    // clamped extent of a staged pixel's bilinear cell, and whether window A holds all of it
+    auto cell = [&](float packed, int& x0, int& y0) { const int pk = __float_as_int(packed); x0 = (pk & 0xffff) - 2; y0 = (pk >> 16) - 2; };
+    auto in_a = [&](int x0, int y0) {
+        const int lx = max(x0, 0), hx = min(x0 + 1, Rt - 1), ly = max(y0, 0), hy = min(y0 + 1, Rt - 1);
+        return lx > hx || ly > hy || (hx - ax0 < kWinW && hy - ay0 < kWinH);
+    };
+    if (!one) {                                                            // (uniform) second window: bounding box of what A leaves
+        int bnx = INT_MAX, bny = INT_MAX, bxx = INT_MIN, bxy = INT_MIN;
+        for (int i = tid; i < nsrc; i += nthr) {
+            int x0, y0;
+            cell(s_px[i].w, x0, y0);
+            if (!in_a(x0, y0)) { bnx = min(bnx, max(x0, 0)); bxx = max(bxx, min(x0 + 1, Rt - 1)); bny = min(bny, max(y0, 0)); bxy = max(bxy, min(y0 + 1, Rt - 1)); }
+        }
+        if (bnx <= bxx) { atomicMin(&s_bb[4], bnx); atomicMin(&s_bb[5], bny); atomicMax(&s_bb[6], bxx); atomicMax(&s_bb[7], bxy); }
+        __syncthreads();
+    }
+    const int bx0 = s_bb[4], by0 = s_bb[5];
+    const bool merged = one || (s_bb[6] - bx0 < kWinW && s_bb[7] - by0 < kWinH);
+    int nlist = 0;
+    if (merged) {
+        if (!none) {
+            for (int i = tid; i < nsrc; i += nthr) {
+                const float4 q = s_px[i];
+                const float4 wxv = s_wx[i % ncols];
+                const float wx[PXB] = {wxv.x, wxv.y, wxv.z, wxv.w};
+                int x0, y0;
+                cell(q.w, x0, y0);
+                const bool a = one || in_a(x0, y0);
+                unsigned long long* win = s_acc + (a ? 0 : kWinN * PXB);
+                const int ox = a ? ax0 : bx0, oy = a ? ay0 : by0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+                    if (xi < 0 || xi >= Rt || yi < 0 || yi >= Rt) continue;
+                    const float w = ((t & 1) ? q.x : 1.f - q.x) * ((t >> 1) ? q.y : 1.f - q.y) * q.z;
+                    unsigned long long* slot = win + ((yi - oy) * kWinW + (xi - ox)) * PXB;
+#pragma unroll
+                    for (int k = 0; k < PXB; ++k) {
+                        const unsigned long long v = (unsigned long long)(w * wx[k] * kFix);
+                        if (v) atomicAdd(slot + k, v);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {                                                    // wave 0: ordered compaction, 64 window slots a step
+            int cnt = 0;
+            for (int base = 0; base < (one ? kWinN : 2 * kWinN); base += 64) {
+                const int e = base + tid;
+                const unsigned long long a0 = s_acc[e * PXB], a1 = s_acc[e * PXB + 1], a2 = s_acc[e * PXB + 2], a3 = s_acc[e * PXB + 3];
+                const bool nz = (a0 | a1 | a2 | a3) != 0ull;
+                const unsigned long long m = __ballot(nz);
+                if (nz) {
+                    const int pos = cnt + __popcll(m & ((1ull << tid) - 1ull));
+                    const int slot = e % kWinN, ox = e < kWinN ? ax0 : bx0, oy = e < kWinN ? ay0 : by0;
+                    s_lidx[pos] = ((oy + slot / kWinW) * Rt + ox + slot % kWinW) * p.C;
+                    s_lw[pos] = make_float4((float)a0 * (1.f / kFix), (float)a1 * (1.f / kFix), (float)a2 * (1.f / kFix), (float)a3 * (1.f / kFix));
+                }
+                cnt += __popcll(m);
+            }
+            if (tid == 0) s_n[0] = cnt;
+        }
+        __syncthreads();
+        nlist = s_n[0];
+    }
 
     // ---- static crop: 2-tap (per axis) AA up-sampling weights, identical for every channel
     const int crop_h = p.by1 - p.by0, crop_w = p.bx1 - p.bx0;
@@ -145,48 +232,33 @@ __global__ __launch_bounds__(512) void rasterize_level_kernel(RastParams p) {
     const int64_t rr = (int64_t)res * res;
     float* outb = p.out + (int64_t)b * (p.C + 1) * rr + (int64_t)y * res + xt;
     const bool vec_ok = (xt + PXB <= res) && (res % 4 == 0);
-    // each thread owns 4 consecutive channels (one 16-byte gather per texel) when C % 4 == 0, else one channel;
-    // when the level has fewer channel groups than the workgroup has threads, the threads split the footprint's source
-    // pixels nsplit ways (every nsplit-th pixel) and the partial sums are added through LDS in split order: the walk
-    // over the footprint is a chain of dependent-latency gathers, so more walkers per output pixel is what makes it fast.
+    // each thread owns 4 consecutive channels (one 16-byte gather per texel) when C % 4 == 0, else one channel; when the
+    // level has fewer channel groups than the workgroup has threads, the threads split the walk list nsplit ways (every
+    // nsplit-th entry) and the partial sums are added through LDS in split order.
     const int CV = (p.C % 4 == 0) ? 4 : 1;
     const int ncq = (p.C + CV - 1) / CV;
-    const int nsplit = (CV == 4 && ncq <= (int)blockDim.x) ? (int)blockDim.x / ncq : 1;
-    float* s_red = reinterpret_cast<float*>(s_dyn);                 // [nsplit][ncq][16]
+    const int lanes = min(ncq, nthr);                                      // channel groups walked concurrently
+    const int nsplit = min(8, nthr / lanes);
+    float* s_red = reinterpret_cast<float*>(s_dyn);                        // [nsplit][lanes][16]
 
-    // walk source pixels first, first + step, ... of the footprint for channels c .. c+CV-1
-    auto walk = [&](int c, int first, int step, float (&acc)[4][PXB]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int k = 0; k < PXB; ++k) acc[j][k] = 0.f;
+    // add entries first, first + step, ... (< n) of the walk list for channels c .. c+CV-1
+    auto walk = [&](int c, int first, int step, int n, float (&acc)[4][PXB]) {
         const float* tc = texb + c;
         if (CV == 4) {
-#pragma unroll 2
-            for (int i = first; i < nsrc; i += step) {
-                const int4 id = s_idx[i];
-                const float4 w = s_w[i];
-                const float4 wx = s_wx[i % ncols];
-                const float4 t0 = *(const float4*)(tc + id.x), t1 = *(const float4*)(tc + id.y);
-                const float4 t2 = *(const float4*)(tc + id.z), t3 = *(const float4*)(tc + id.w);
-                const float v[4] = {fmaf(t3.x, w.w, fmaf(t2.x, w.z, fmaf(t1.x, w.y, t0.x * w.x))),
-                                    fmaf(t3.y, w.w, fmaf(t2.y, w.z, fmaf(t1.y, w.y, t0.y * w.x))),
-                                    fmaf(t3.z, w.w, fmaf(t2.z, w.z, fmaf(t1.z, w.y, t0.z * w.x))),
-                                    fmaf(t3.w, w.w, fmaf(t2.w, w.z, fmaf(t1.w, w.y, t0.w * w.x)))};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[j][0] = fmaf(v[j], wx.x, acc[j][0]); acc[j][1] = fmaf(v[j], wx.y, acc[j][1]);
-                    acc[j][2] = fmaf(v[j], wx.z, acc[j][2]); acc[j][3] = fmaf(v[j], wx.w, acc[j][3]);
-                }
+#pragma unroll 8
+            for (int e = first; e < n; e += step) {
+                const float4 t = *(const float4*)(tc + s_lidx[e]);
+                const float4 w = s_lw[e];
+                acc[0][0] = fmaf(t.x, w.x, acc[0][0]); acc[0][1] = fmaf(t.x, w.y, acc[0][1]); acc[0][2] = fmaf(t.x, w.z, acc[0][2]); acc[0][3] = fmaf(t.x, w.w, acc[0][3]);
+                acc[1][0] = fmaf(t.y, w.x, acc[1][0]); acc[1][1] = fmaf(t.y, w.y, acc[1][1]); acc[1][2] = fmaf(t.y, w.z, acc[1][2]); acc[1][3] = fmaf(t.y, w.w, acc[1][3]);
+                acc[2][0] = fmaf(t.z, w.x, acc[2][0]); acc[2][1] = fmaf(t.z, w.y, acc[2][1]); acc[2][2] = fmaf(t.z, w.z, acc[2][2]); acc[2][3] = fmaf(t.z, w.w, acc[2][3]);
+                acc[3][0] = fmaf(t.w, w.x, acc[3][0]); acc[3][1] = fmaf(t.w, w.y, acc[3][1]); acc[3][2] = fmaf(t.w, w.z, acc[3][2]); acc[3][3] = fmaf(t.w, w.w, acc[3][3]);
             }
         } else {
-            for (int i = first; i < nsrc; i += step) {
-                const int4 id = s_idx[i];
-                const float4 w = s_w[i];
-                const float4 wx = s_wx[i % ncols];
-                const float v = fmaf(tc[id.w], w.w, fmaf(tc[id.z], w.z, fmaf(tc[id.y], w.y, tc[id.x] * w.x)));
-                acc[0][0] = fmaf(v, wx.x, acc[0][0]); acc[0][1] = fmaf(v, wx.y, acc[0][1]);
-                acc[0][2] = fmaf(v, wx.z, acc[0][2]); acc[0][3] = fmaf(v, wx.w, acc[0][3]);
+            for (int e = first; e < n; e += step) {
+                const float t = tc[s_lidx[e]];
+                const float4 w = s_lw[e];
+                acc[0][0] = fmaf(t, w.x, acc[0][0]); acc[0][1] = fmaf(t, w.y, acc[0][1]); acc[0][2] = fmaf(t, w.z, acc[0][2]); acc[0][3] = fmaf(t, w.w, acc[0][3]);
             }
         }
     };
@@ -250,40 +322,67 @@ __global__ __launch_bounds__(512) void rasterize_level_kernel(RastParams p) {
         }
     };
 
-    float acc[4][PXB];
-    if (nsplit > 1) {
-        // The walk over the footprint is a chain of dependent-latency gathers, and a level has fewer channel groups than
-        // the workgroup has threads: the threads split the source pixels nsplit ways (every nsplit-th pixel) and the
-        // partial sums are added through LDS in split order.
-        const int sp = tid / ncq, cq = tid - sp * ncq;
-        const bool active = sp < nsplit;
-        if (active) {
-            walk(cq * CV, sp, nsplit, acc);
-            float* mine = s_red + ((int64_t)sp * ncq + cq) * 16;
+    const int sp = tid / lanes, cq = tid - sp * lanes;
+    const bool walker = sp < nsplit;
+    for (int cbase = 0; cbase < ncq; cbase += lanes) {                     // one pass unless C > 4 * workgroup size
+        const int mycq = cbase + cq;
+        const bool active = walker && mycq < ncq;
+        float acc[4][PXB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int k = 0; k < PXB; ++k) mine[j * PXB + k] = acc[j][k];
+            for (int k = 0; k < PXB; ++k) acc[j][k] = 0.f;
+        if (merged) {
+            if (active) walk(mycq * CV, sp, nsplit, nlist, acc);
+        } else {
+            // direct form: the footprint touches more texels than the window holds (a seam or the silhouette of the UV map):
+            // every (source pixel, bilinear tap) becomes its own list entry, 128 source pixels a pass
+            for (int base = 0; base < nsrc; base += kChunk) {
+                const int cnt = min(kChunk, nsrc - base);
+                __syncthreads();
+                for (int i = tid; i < cnt; i += nthr) {
+                    const float4 q = s_px[base + i];
+                    const float4 wxv = s_wx[(base + i) % ncols];
+                    const int pk = __float_as_int(q.w), x0 = (pk & 0xffff) - 2, y0 = (pk >> 16) - 2;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+                        const bool ok = xi >= 0 && xi < Rt && yi >= 0 && yi < Rt;
+                        const float w = ok ? ((t & 1) ? q.x : 1.f - q.x) * ((t >> 1) ? q.y : 1.f - q.y) * q.z : 0.f;
+                        s_lidx[4 * i + t] = ok ? (yi * Rt + xi) * p.C : 0;
+                        s_lw[4 * i + t] = make_float4(w * wxv.x, w * wxv.y, w * wxv.z, w * wxv.w);
+                    }
+                }
+                __syncthreads();
+                if (active) walk(mycq * CV, sp, nsplit, 4 * cnt, acc);
+            }
         }
-        __syncthreads();
-        if (sp == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int k = 0; k < PXB; ++k) acc[j][k] = 0.f;
-            for (int q = 0; q < nsplit; ++q) {
-                const float* part = s_red + ((int64_t)q * ncq + cq) * 16;
+        if (nsplit > 1) {
+            __syncthreads();                                               // s_red of the previous pass has been read
+            if (active) {
+                float* mine = s_red + ((int64_t)sp * lanes + cq) * 16;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int k = 0; k < PXB; ++k) acc[j][k] += part[j * PXB + k];
+                    for (int k = 0; k < PXB; ++k) mine[j * PXB + k] = acc[j][k];
             }
-            finish(cq * CV, acc);
-        }
-    } else {
-        for (int c = tid * CV; c < p.C; c += blockDim.x * CV) {
-            walk(c, 0, 1, acc);
-            finish(c, acc);
+            __syncthreads();
+            if (active && sp == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < PXB; ++k) acc[j][k] = 0.f;
+                for (int q = 0; q < nsplit; ++q) {
+                    const float* part = s_red + ((int64_t)q * lanes + cq) * 16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int k = 0; k < PXB; ++k) acc[j][k] += part[j * PXB + k];
+                }
+                finish(mycq * CV, acc);
+            }
+        } else if (active) {
+            finish(mycq * CV, acc);
         }
     }
     if (tid < PXB && xt + tid < res) outb[(int64_t)p.C * rr + tid] = s_u[tid];
@@ -353,15 +452,18 @@ extern "C" int ia_rasterize_level(const float* tex_cl, const float* uv, const fl
     RastParams p{tex_cl, uv, upper_alpha, sta, out, sta_batch_stride, B, C, tex_res, sta_res, res, by0, by1, bx0, bx1};
     const int nblk = ((res + PXB - 1) / PXB) * res * B;
     dim3 grid(((nblk + 7) / 8) * 8);
-    // 4 channels per thread; the footprint walk is split over the remaining threads of a 256-thread workgroup (512 threads
-    // for the coarse levels, whose footprint is 640 source pixels per workgroup)
-    int threads = 256;
-    if (C % 4 == 0 && res <= 32 && C / 4 <= 512) threads = 512;
-    if (res > 32) threads = (C % 4 == 0) ? (C >= 512 ? 128 : 64) : 256;   // finer levels: enough workgroups, no split
+    // one thread per group of 4 channels (64 .. 256 threads); spare threads split the walk list up to 8 ways
     const int ncq = C % 4 == 0 ? C / 4 : C;
-    const int nsplit = (C % 4 == 0 && ncq <= threads) ? threads / ncq : 1;
-    const size_t red_bytes = nsplit > 1 ? (size_t)nsplit * ncq * 16 * sizeof(float) : 0;
-    hipLaunchKernelGGL(rasterize_level_kernel, grid, dim3(threads), red_bytes, (hipStream_t)stream, p);
+    const int threads = ncq <= 64 ? 64 : ncq <= 128 ? 128 : 256;
+    const int lanes = ncq < threads ? ncq : threads;
+    const int nsplit = threads / lanes < 8 ? threads / lanes : 8;
+    const size_t red_bytes = nsplit > 1 ? (size_t)nsplit * lanes * 16 * sizeof(float) : 0;
+    const hipStream_t s = (hipStream_t)stream;
+    switch (kSrc / res) {
+        case 8: hipLaunchKernelGGL(rasterize_level_kernel<8>, grid, dim3(threads), red_bytes, s, p); break;
+        case 4: hipLaunchKernelGGL(rasterize_level_kernel<4>, grid, dim3(threads), red_bytes, s, p); break;
+        default: hipLaunchKernelGGL(rasterize_level_kernel<2>, grid, dim3(threads), red_bytes, s, p); break;
+    }
     return ia::check_launch("ia_rasterize_level");
 }
 

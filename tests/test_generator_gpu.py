@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from invertavatar_amd import synthetic
+from invertavatar_amd import hipops, synthetic
 from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
 from conftest import max_abs
 
@@ -238,3 +238,28 @@ def test_drive_loop_equals_full_synthesis(small):
     torch.cuda.synchronize()
     assert torch.equal(full['image'], drive['image'])
     assert torch.equal(full['image_depth'], drive['image_depth'])
+
+
+@pytest.mark.parametrize('chans,res', [(6, 32), (40, 64), (24, 128), (1032, 32)])
+def test_rasterize_level_seams_and_channel_counts(chans, res):
+    """ia_rasterize_level on a UV map with a silhouette (constant background UV), a seam (u jumps across the texture) and a
+    strongly stretched region -- footprints that do not fit the kernel's texel-merge window take its direct form -- and on
+    channel counts that are not a multiple of 4 / exceed one pass, against aten's grid_sample + anti-aliased resize on the CPU."""
+    import torch.nn.functional as F
+    from conftest import rnd
+    uv = synthetic.uv_conditions([5, 60]).clone()
+    u, v, m = uv[..., 0], uv[..., 1], uv[..., 2]
+    u[m < 0.5] = -1.0; v[m < 0.5] = -1.0                       # background: one constant texel, far from the face's texels
+    seam = (u > 0.3) & (m > 0.5)
+    u[seam] = u[seam] - 1.2                                    # seam: neighbouring pixels half a texture apart
+    v[:, 40:70, :] = v[:, 40:70, :] * 6.0                      # stretch: one source row spans several texels (and leaves the texture)
+    tex, sta = rnd(90, 2, chans, res, res), rnd(91, 2, chans + 3, res, res)
+    upper = (m * 0.5 + 0.25).contiguous()
+    y0, y1, x0, x1 = [round(t * res / 256) for t in (57, 185, 64, 192)]
+    aa = lambda t: F.interpolate(t, size=(res, res), mode='bilinear', align_corners=False, antialias=True)  # noqa: E731
+    rend, a = aa(F.grid_sample(tex, uv[..., :2], align_corners=False)), aa(m[:, None])
+    ref = torch.cat([rend * a + aa(sta[:, :chans, y0:y1, x0:x1]) * (1 - a), aa(upper[:, None])], 1)
+    got = hipops.rasterize_level(tex.cuda(), uv.cuda(), upper.cuda(), sta.cuda()[:, :chans], (y0, y1, x0, x1), res)
+    assert got.shape == ref.shape and max_abs(got.cpu(), ref) <= 2e-5, max_abs(got.cpu(), ref)
+    again = hipops.rasterize_level(tex.cuda(), uv.cuda(), upper.cuda(), sta.cuda()[:, :chans], (y0, y1, x0, x1), res)
+    assert torch.equal(got, again)                             # the per-texel sums are integer atomics: order-independent

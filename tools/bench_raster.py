@@ -7,9 +7,12 @@ import torch
 
 from invertavatar_amd import hipops, synthetic
 
-uv = synthetic.uv_conditions([3]).cuda().contiguous()
-upper = uv[..., 2].clamp(0, 1).contiguous()
-for c, r in [(32, 32), (512, 32), (512, 64), (256, 128)]:
+uv_smooth = synthetic.uv_conditions([3]).cuda().contiguous()
+uv_sil = uv_smooth.clone()                 # UV = 0 outside the face, as ia_uv_rasterize writes it: silhouette footprints see two texel clusters
+uv_sil[..., 0][uv_sil[..., 2] < 0.5] = 0.0
+uv_sil[..., 1][uv_sil[..., 2] < 0.5] = 0.0
+for (name, uv), (c, r) in [(u, l) for u in (('smooth', uv_smooth), ('silhouette', uv_sil)) for l in [(32, 32), (512, 32), (512, 64), (256, 128)]]:
+    upper = uv[..., 2].clamp(0, 1).contiguous()
     tex = torch.randn(1, c, r, r, device='cuda')
     sta = torch.randn(1, c, r, r, device='cuda')
     bbox = [round(v * r / 256) for v in (57, 185, 64, 192)]
@@ -24,4 +27,4 @@ for c, r in [(32, 32), (512, 32), (512, 64), (256, 128)]:
         fn()
     e1.record()
     torch.cuda.synchronize()
-    print(f'C={c:4d} res={r:4d}: {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us', flush=True)
+    print(f'{name:10s} C={c:4d} res={r:4d}: {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us', flush=True)
