@@ -497,7 +497,7 @@ void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo
 
 // Shared by the planner and the entry point: tile counts and the split between whole rounds and stream-K.
 struct Plan { int bo, bp, cc, waves, T, TO, C, T_dp, G, slab_floats; };
-constexpr int kSmallLayerWorkers = ia::kNumCU / 2;
+constexpr int kSmallLayerWorkers = ia::kNumCU / 2, kSmallLayerPoints = 65 * 65;
 static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int form) {
     Plan p;
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
@@ -520,9 +520,10 @@ static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transpos
         if (G > Gb) G = Gb;
         // ... but a layer smaller than the machine takes at most half of the CUs (one worker per tile if it has more tiles than
         // that): a frame runs the low-resolution layers of three networks on parallel streams, and a 512-workgroup launch of
-        // 250-VGPR waves leaves no room for the other streams' kernels to be resident (measured +4 % frames/s at batch 1;
-        // at batch >= 4 the per-element share Gb is below the cap anyway).
-        if (rounds == 0) {
+        // 250-VGPR waves leaves no room for the other streams' kernels to be resident.  Up to 64^2 (65^2 points transposed) only:
+        // measured 272 -> 280-284 frames/s at batch 1 for 0.241 -> 0.222 single-stream MFMA utilisation of the fp16-pair family;
+        // capping the 128^2 layers too gives 283-285 and 0.213.  At batch >= 4 the per-element share Gb is below the cap anyway.
+        if (rounds == 0 && npts <= kSmallLayerPoints) {
             const int64_t lim = p.T > kSmallLayerWorkers ? p.T : kSmallLayerWorkers;
             if (G > lim) G = lim;
         }
