@@ -323,6 +323,17 @@ int ia_fir_tail_split(const float* x, const float* f, const float* noise, const 
                       int padx0, int pady0, int flip, float fir_gain, int act, float alpha, float act_gain, float clamp, void* stream);
 
 /*
+ * ToRGB layer as a streaming kernel: y = clamp((w * styles) (*) x + bias) + residual for a 1x1 modulated convolution without
+ * demodulation.  Replaces ToRGBLayer.forward (training/networks_stylegan2.py:353-362: modulated_conv2d(demodulate=False) :34-91 +
+ * bias_act(clamp) ) and the skip-image add of SynthesisBlock.forward (:457).  x [B,I,H,W], wk [I,O] (ia_conv2d_mfma's packing
+ * for ksize 1, weight_gain folded in), styles [B,I] or NULL, bias [O] or NULL, residual [B,O,H,W] or NULL (added after the
+ * clamp), y [B,O,H,W]; clamp < 0 = none.  O <= 96, I % 32 == 0, H*W % 4 == 0, else IA_ERR_UNSUPPORTED (callers use
+ * ia_conv2d_mfma).  One launch, no scratch.
+ */
+int ia_conv1x1(const float* x, const float* wk, const float* styles, const float* bias, const float* residual, float* y,
+               int B, int I, int O, int H, int W, float clamp, void* stream);
+
+/*
  * ia_cond_blend with the result in SPLIT format (ia_act_split) for the one layer that consumes it, multiplied by that layer's
  * styles [B,C] (NULL = 1): ys = split((cond[:, :C] * a + x * (1 - a)) * styles_next), a = cond[:, C]
  * (training_avatar_texture/networks_stylegan2_new.py:539-540 feeding the next block's conv0).  C % 8 == 0.

@@ -1,0 +1,187 @@
+// ia_conv1x1: the ToRGB layer -- a modulated 1x1 convolution without demodulation, + bias, clamp, + skip image
+// (training/networks_stylegan2.py:340-362 ToRGBLayer.forward; the skip add of SynthesisBlock.forward :457) -- as a
+// STREAMING kernel.  A ToRGB layer reads C_in x H x W floats once and writes 3 .. 96 channels: 33 MB at 256^2 x 128
+// channels for 0.4 - 1.6 GFLOP, so HBM (or, for 96 output channels, the fp32 MFMA) bounds it, not the tile machinery of the
+// 3x3 kernels: no LDS staging, no stream-K slabs, no fix-up launch.
+//
+// One wave owns 32*V consecutive pixels (V = 4 or 2) and one block of 32 output channels (blockIdx.z; layers with 33 .. 96
+// output channels read their activations up to three times, from L2 after the first -- one wave holding all 96 channels
+// runs at one wave per SIMD and measured 75 us at 256^2 x 128 -> 96 where three independent blocks take a third).  v_mfma_f32_32x32x2_f32
+// with A = weights [32 channels out x 2 channels in], B = activations [2 channels in x 32 pixels]: lane l loads V
+// consecutive pixels of input channel k + l/32 as one 16- or 8-byte load (a wave reads two 128*V-byte runs) and feeds
+// component j to MFMA j, so MFMA j computes pixels {V*n + j}; in the accumulators a lane then holds V CONSECUTIVE pixels
+// of an output channel and stores them as one vector.  Weights come from the packed [C_in][C_out] array (coalesced 128-byte
+// runs, L2-resident) and are multiplied by the styles in registers, (w * s) * x like the reference's fused_modconv path.
+// KS waves of a workgroup split the input channels (small images have too few pixel tiles to fill the machine) and add
+// their accumulators through LDS in wave order.
+#include "ia_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct C1Params {
+    const float* x;          // [B][I][P]
+    const float* wk;         // [I][O]
+    const float* styles;     // [B][I] or null
+    const float* bias;       // [O] or null
+    const float* residual;   // [B][O][P] or null (added after the clamp)
+    float* y;                // [B][O][P]
+    int I, O;
+    int64_t P;
+    float clamp;             // < 0: none
+};
+
+template <int V> struct PixVec;
+template <> struct PixVec<4> { using type = float4; };
+template <> struct PixVec<2> { using type = float2; };
+
+template <int V> __device__ __forceinline__ float comp(const typename PixVec<V>::type& v, int j);
+template <> __device__ __forceinline__ float comp<4>(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+template <> __device__ __forceinline__ float comp<2>(const float2& v, int j) { return j == 0 ? v.x : v.y; }
+
+template <int V, int KS>
+__global__ __launch_bounds__(64 * KS) void conv1x1_kernel(C1Params p) {
+    using vec = typename PixVec<V>::type;
+    constexpr int NB = 1;
+    constexpr int U = 8;                                       // k-steps (channel pairs) in flight per wave
+    __shared__ float s_red[KS > 1 ? NB * V * 16 * 64 : 1];
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.y, o0 = blockIdx.z * 32;
+    const int64_t pix = (int64_t)blockIdx.x * (32 * V) + V * l31;
+    const bool pvalid = pix < p.P;
+    const int kw = p.I / KS, k_begin = ks * kw, k_end = k_begin + kw;     // this wave's input channels
+    const float* xp = p.x + ((int64_t)b * p.I + half) * p.P + (pvalid ? pix : 0);
+    const float* sp = p.styles ? p.styles + (int64_t)b * p.I + half : nullptr;
+    const float* wp = p.wk + (int64_t)half * p.O + o0 + l31;
+    bool ovalid[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) ovalid[blk] = o0 + blk * 32 + l31 < p.O;
+
+    f32x16 acc[NB][V];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[blk][j][r] = 0.f;
+
+    vec xn[U];
+    float wn[U][NB], sn[U];
+    auto load_block = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 2 * u;
+            xn[u] = pvalid ? *reinterpret_cast<const vec*>(xp + (int64_t)k * p.P) : vec{};
+            sn[u] = sp ? sp[k] : 1.f;
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) wn[u][blk] = ovalid[blk] ? wp[(int64_t)k * p.O + blk * 32] : 0.f;
+        }
+    };
+    load_block(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += 2 * U) {
+        vec xc[U];
+        float wc[U][NB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xc[u] = xn[u];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) wc[u][blk] = wn[u][blk] * sn[u];
+        }
+        if (k0 + 2 * U < k_end) load_block(k0 + 2 * U);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    acc[blk][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[u][blk], comp<V>(xc[u], j), acc[blk][j], 0, 0, 0);
+    }
+
+    if constexpr (KS > 1) {       // waves 1 .. KS-1 hand their sums to wave 0, one after the other (fixed order)
+        for (int w = 1; w < KS; ++w) {
+            if (ks == w) {
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                    for (int j = 0; j < V; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s_red[((blk * V + j) * 16 + r) * 64 + lane] = acc[blk][j][r];
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                    for (int j = 0; j < V; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[blk][j][r] += s_red[((blk * V + j) * 16 + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (ks != 0) return;
+    }
+    if (!pvalid) return;
+    // C/D map of the 32x32 MFMA: row (output channel) = (r&3) + 8*(r>>2) + 4*half, column (pixel group) = l31
+    float* yb = p.y + (int64_t)b * p.O * p.P + pix;
+    const float* rb = p.residual ? p.residual + (int64_t)b * p.O * p.P + pix : nullptr;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (o >= p.O) continue;
+            const float bo = p.bias ? p.bias[o] : 0.f;
+            float v[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                v[j] = acc[blk][j][r] + bo;
+                if (p.clamp >= 0.f) v[j] = fminf(fmaxf(v[j], -p.clamp), p.clamp);
+            }
+            if (rb) {
+                const vec rv = *reinterpret_cast<const vec*>(rb + (int64_t)o * p.P);
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[j] += comp<V>(rv, j);
+            }
+            vec out;
+            if constexpr (V == 4) out = make_float4(v[0], v[1], v[2], v[3]);
+            else out = make_float2(v[0], v[1]);
+            *reinterpret_cast<vec*>(yb + (int64_t)o * p.P) = out;
+        }
+}
+
+template <int V>
+void launch_ks(int ksplit, dim3 grid, hipStream_t s, const C1Params& p) {
+    switch (ksplit) {
+        case 4: hipLaunchKernelGGL((conv1x1_kernel<V, 4>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv1x1_kernel<V, 2>), grid, dim3(128), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv1x1_kernel<V, 1>), grid, dim3(64), 0, s, p); break;
+    }
+}
+
+}  // namespace
+
+extern "C" int ia_conv1x1(const float* x, const float* wk, const float* styles, const float* bias, const float* residual, float* y,
+                          int B, int I, int O, int H, int W, float clamp, void* stream) {
+    IA_REQUIRE(x && wk && y, "x, wk and y must be device pointers");
+    IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
+    const int64_t P = (int64_t)H * W;
+    if (O > 96 || I % 32 != 0 || P % 4 != 0)
+        return ia::fail(IA_ERR_UNSUPPORTED, "ia_conv1x1 covers C_out <= 96, C_in %% 32 == 0 and H*W %% 4 == 0 (got C_in %d, C_out %d, %d x %d)", I, O, H, W);
+    IA_REQUIRE(B <= 65535, "batch too large for one launch");
+    // pixels per wave: 128, or 64 when that leaves the machine short of waves; then split the input channels over up to 4 waves
+    // of a workgroup until there are about two waves per SIMD (each wave keeps >= 16 input channels)
+    const int64_t want = 2 * 4 * (int64_t)ia::kNumCU;
+    const int oblocks = (O + 31) / 32;
+    int v = 4;
+    if (((P + 127) / 128) * B * oblocks * 4 < want) v = 2;
+    const int64_t tiles = (P + 32 * v - 1) / (32 * v);
+    int ksplit = 1;
+    while (ksplit < 4 && tiles * B * oblocks * ksplit < want && (I / (ksplit * 2)) % 16 == 0) ksplit *= 2;
+    C1Params p{x, wk, styles, bias, residual, y, I, O, P, clamp};
+    const dim3 grid((unsigned)tiles, (unsigned)B, (unsigned)oblocks);
+    const hipStream_t s = (hipStream_t)stream;
+    if (v == 4) launch_ks<4>(ksplit, grid, s, p);
+    else launch_ks<2>(ksplit, grid, s, p);
+    return ia::check_launch("ia_conv1x1");
+}

@@ -180,6 +180,33 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     return y
 
 
+def conv1x1_supported(i, o, h, w):
+    """Shapes ia_conv1x1 covers (see include/ia_hip.h)."""
+    return o <= 96 and i % 32 == 0 and (h * w) % 4 == 0
+
+
+def conv1x1(x, wk, styles=None, bias=None, residual=None, clamp=None):
+    """ToRGB layer in one streaming launch (see ia_conv1x1): clamp((wk * styles) (*) x + bias) + residual.  wk [1, I, O] or [I, O]
+    (pack_conv_weight of a 1x1 weight)."""
+    _f32c(x, 'x')
+    _f32c(wk, 'wk')
+    b, i, h, w = x.shape
+    o = wk.shape[-1]
+    if wk.numel() != i * o:
+        raise RuntimeError(f'wk has {wk.numel()} elements, expected {i} x {o}')
+    for t, name, n in ((styles, 'styles', b * i), (bias, 'bias', o), (residual, 'residual', b * o * h * w)):
+        if t is not None and (_f32c(t, name).numel() != n):
+            raise RuntimeError(f'{name} has {t.numel()} elements, expected {n}')
+    y = torch.empty(b, o, h, w, device=x.device, dtype=torch.float32)
+    flops = 2.0 * b * h * w * i * o
+    traffic = 4.0 * (x.numel() + wk.numel() + y.numel() + (residual.numel() if residual is not None else 0))
+    with torch.cuda.device(x.device), _Timed('conv1x1', flops, traffic, f'B{b} I{i} O{o} {h}x{w}'):
+        st = _lib.load().ia_conv1x1(_p(x), _p(wk), _p(styles), _p(bias), _p(residual), _p(y), b, i, o, h, w,
+                                    float(-1 if clamp is None else clamp), _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_conv1x1')
+    return y
+
+
 class SplitAct:
     """An activation stored as fp16 planes [B, planes, C/8, H, W, 8] (the input format of ia_conv2d_mfma_sx, see include/ia_hip.h):
     planes = 2 hi / lo pairs (fp32-equivalent consumers), planes = 1 one rounded fp16 plane (fp16-operand consumers: the

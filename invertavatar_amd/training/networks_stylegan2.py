@@ -34,6 +34,7 @@ FP16_BLOCKS_COMPUTE_FP32 = True
 # fp32 layers: where the shape allows (hipops.conv_h_supported), the 3x3 convolutions form their fp32 products from hi/lo
 # fp16 pairs on the fp16 MFMA (ia_conv2d_mfma_s): as accurate against an fp64 convolution as the fp32 MFMA form
 # (tests/test_conv_gpu.py) and twice as fast.  False keeps every layer on v_mfma_f32_32x32x2_f32.
+STREAMING_TORGB = True           # ToRGB layers through ia_conv1x1 (one streaming launch) instead of the tiled ia_conv2d_mfma form
 SPLIT_FP16_PRODUCTS = True
 
 # ... and where the INPUT can be had as fp16 hi/lo planes (hipops.SplitAct: written by the producing layer's epilogue, or by
@@ -493,7 +494,10 @@ class ToRGBLayer(torch.nn.Module):
             if skip is not None:
                 residual = upfirdn2d.upsample2d(skip, resample_filter)
             res = None if residual is None else residual.float().contiguous()
-            return hipops.conv2d_mfma(x.float().contiguous(), wk, styles, None,
+            x = x.float().contiguous()
+            if STREAMING_TORGB and hipops.conv1x1_supported(x.shape[1], wk.shape[-1], x.shape[2], x.shape[3]):
+                return hipops.conv1x1(x, wk, styles, bias=self.bias.detach().float(), residual=res, clamp=self.conv_clamp)
+            return hipops.conv2d_mfma(x, wk, styles, None,
                                       bias=self.bias.detach().float(), residual=res, ksize=1, act='linear', clamp=self.conv_clamp)
         if skip is not None:
             residual = upfirdn2d.upsample2d(skip, resample_filter)

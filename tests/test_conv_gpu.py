@@ -342,3 +342,30 @@ def test_one_plane_dma_convolution_equals_the_fp16_operand_form(i, o, h, w, tr):
     got, got_s = hipops.conv2d_mfma_sx(xs, wk, styles_next=sn, split_planes=1, **kw)
     assert torch.equal(got, want)
     assert got_s.planes == 1 and torch.equal(got_s.data[:, 0].permute(0, 1, 4, 2, 3).reshape(want.shape), (want * sn[:, :, None, None]).half())
+
+
+@pytest.mark.parametrize('b,i,o,h,w', [(1, 512, 32, 64, 64), (1, 256, 96, 128, 128), (2, 128, 3, 256, 256), (1, 128, 96, 256, 256),
+                                       (1, 64, 40, 36, 36), (3, 32, 32, 6, 6), (1, 128, 3, 512, 512)])
+def test_conv1x1_streaming_matches_torch(b, i, o, h, w):
+    """ia_conv1x1 (ToRGB: modulated 1x1 convolution, bias, clamp, skip add) against the reference's op order in torch fp64
+    and against the tiled ia_conv2d_mfma form it replaces (same products, different summation order)."""
+    from conftest import rnd
+    x, wgt = rnd(1, b, i, h, w).cuda(), (rnd(2, o, i, 1, 1) / i ** 0.5).cuda()
+    styles, bias, res = (rnd(3, b, i) * 0.3 + 1).cuda(), rnd(4, o).cuda(), rnd(5, b, o, h, w).cuda()
+    wk = hipops.pack_conv_weight(wgt)
+    clamp = 1.5
+    ref = torch.einsum('bihw,boi->bohw', x.double(), wgt.double()[None, :, :, 0, 0] * styles.double()[:, None, :])
+    ref = (ref + bias.double()[None, :, None, None]).clamp(-clamp, clamp) + res.double()
+    got = hipops.conv1x1(x, wk, styles, bias=bias, residual=res, clamp=clamp)
+    assert got.shape == ref.shape and max_abs(got.double(), ref) <= 2e-5, max_abs(got.double(), ref)
+    tiled = hipops.conv2d_mfma(x, wk, styles, None, bias=bias, residual=res, ksize=1, act='linear', clamp=clamp)
+    assert max_abs(got, tiled) <= 2e-5
+    plain = hipops.conv1x1(x, wk)                                   # no styles / bias / residual / clamp
+    assert max_abs(plain.double(), torch.einsum('bihw,oi->bohw', x.double(), wgt.double()[:, :, 0, 0])) <= 2e-5
+
+
+def test_conv1x1_rejects_unsupported_shapes():
+    x = torch.zeros(1, 48, 8, 8, device='cuda')
+    with pytest.raises(RuntimeError, match='ia_conv1x1 covers'):
+        hipops.conv1x1(x, torch.zeros(1, 48, 8, device='cuda'))
+    assert not hipops.conv1x1_supported(48, 8, 8, 8) and not hipops.conv1x1_supported(64, 128, 8, 8) and hipops.conv1x1_supported(64, 96, 8, 8)

@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
 
 from invertavatar_amd import hipops, synthetic
+from invertavatar_amd.training_avatar_texture import triplane_v20
 from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+
+triplane_v20.SINGLE_STREAM = '--single' in sys.argv      # program order on one stream: clean per-launch durations
 
 gen = TriPlaneGenerator(**synthetic.generator_kwargs('full')).eval().requires_grad_(False)
 synthetic.fill_parameters(gen)
