@@ -34,7 +34,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from invertavatar_amd import frame_parallel, hipops, synthetic  # noqa: E402
+from invertavatar_amd.torch_utils import custom_ops  # noqa: E402
 from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator  # noqa: E402
+
+custom_ops.verbosity = 'none'      # the reference's "Setting up PyTorch plugin ..." lines would share stdout with the JSON line
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense fp16 MFMA
