@@ -323,6 +323,22 @@ int ia_fir_tail_split(const float* x, const float* f, const float* noise, const 
                       int padx0, int pady0, int flip, float fir_gain, int act, float alpha, float act_gain, float clamp, void* stream);
 
 /*
+ * ia_conv2d_mfma_sx (stride 1) with the ToRGB layer that consumes its result evaluated in the epilogue: the last block of the SR head
+ * (SynthesisBlock.forward, training/networks_stylegan2.py:448-457: conv1, then torgb(x) added to the up-sampled image) reads its
+ * 128 x 512^2 activation only through ToRGB, so neither that tensor nor its re-read has to exist.
+ *   rgb_out[b,c] = clamp( sum_o (rgb_wk[o,c] * rgb_styles[b,o]) * v[b,o] + rgb_bias[c], rgb_clamp ) + rgb_residual[b,c]
+ * with v the layer's own result (after noise / bias / activation / clamp).  rgb_wk [O, rgb_channels] is ia_conv2d_mfma's ksize-1
+ * packing of the ToRGB weight (weight_gain folded in), rgb_channels <= 4.  y and ys may both be NULL.  The layer must run in whole
+ * rounds of tiles that hold every output channel (O <= 128 at the sizes the planner gives the 128 x 256 tile), else
+ * IA_ERR_UNSUPPORTED (callers use ia_conv2d_mfma_sx + ia_conv1x1).  Other arguments as ia_conv2d_mfma_sx.
+ */
+int ia_conv2d_mfma_sx_rgb(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
+                          const float* noise_strength, const float* bias, float* y, void* ys, int ys_planes, const float* styles_next,
+                          const float* rgb_wk, const float* rgb_styles, const float* rgb_bias, const float* rgb_residual, float* rgb_out,
+                          int rgb_channels, float rgb_clamp, int B, int I, int O, int H, int W, int act, float alpha, float gain, float clamp,
+                          void* stream);
+
+/*
  * ToRGB layer as a streaming kernel: y = clamp((w * styles) (*) x + bias) + residual for a 1x1 modulated convolution without
  * demodulation.  Replaces ToRGBLayer.forward (training/networks_stylegan2.py:353-362: modulated_conv2d(demodulate=False) :34-91 +
  * bias_act(clamp) ) and the skip-image add of SynthesisBlock.forward (:457).  x [B,I,H,W], wk [I,O] (ia_conv2d_mfma's packing

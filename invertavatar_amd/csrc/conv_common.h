@@ -54,7 +54,17 @@ struct Epi {
     void* ys;
     const float* styles_next;
     int ys_planes;                // 2: hi / lo planes (fp32-equivalent consumers), 1: one fp16 plane (fp16-operand consumers)
+    // optional third output (conv_split.hip, stride-1 tiles that hold every output channel): the ToRGB layer that consumes this
+    // result, evaluated in the epilogue:  rgb_out[b][c][pix] = clamp(sum_o (rgb_w[o][c] * rgb_styles[b][o]) * v[o] + rgb_bias[c]) + rgb_res
+    const float* rgb_w = nullptr;       // [O][rgb_n] (ia_conv2d_mfma's ksize-1 packing)
+    const float* rgb_styles = nullptr;  // [B][O] or null
+    const float* rgb_bias = nullptr;    // [rgb_n] or null
+    const float* rgb_res = nullptr;     // [B][rgb_n][OH*OW] or null, added after the clamp
+    float* rgb_out = nullptr;           // [B][rgb_n][OH*OW]
+    float rgb_clamp = -1.f;
+    int rgb_n = 0;
 };
+constexpr int kMaxRgb = 4;
 
 typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
 

@@ -86,12 +86,96 @@ __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], 
     }
 }
 
+// store_tile_dual + the ToRGB layer that consumes the tile (Epi::rgb_*): the tile holds every output channel of its pixels, so the
+// 1x1 convolution over them is a reduction inside the workgroup -- per lane over its 16*FO channels, across the two half-waves
+// by a shuffle, across the WO channel waves through LDS (fixed order).  `lds_f`: the K loop's stage memory, free by now.
+template <int FO, int FP, int WO, int WP>
+__device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], float* __restrict__ y, const Geo& g, const Epi& e,
+                                               int b, int o0, int p0, int tid, float* lds_f) {
+    constexpr int BO = 32 * FO * WO, NTHREADS = WO * WP * 64;
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wo = wave / WP, wp = wave % WP;
+    const int npts = g.GH * g.GW;
+    const int64_t ohw = (int64_t)g.OH * g.OW;
+    const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
+    float* yb = y ? y + ((int64_t)b * g.O) * ohw : nullptr;
+    float* ws = lds_f;                              // [kMaxRgb][BO]: ToRGB weight x style of the tile's channels
+    float* red = lds_f + kMaxRgb * BO;              // [WO][WP][FP][kMaxRgb][32]
+    __syncthreads();                                // the K loop's last operand reads are done
+    for (int i = tid; i < kMaxRgb * BO; i += NTHREADS) {
+        const int c = i / BO, o = o0 + i - c * BO;
+        ws[i] = (c < e.rgb_n && o < g.O) ? e.rgb_w[o * e.rgb_n + c] * (e.rgb_styles ? e.rgb_styles[b * g.O + o] : 1.f) : 0.f;
+    }
+    __syncthreads();
+    int pp[FP];
+    bool valid[FP];
+    float part[FP][kMaxRgb];
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp) {
+        const int pr = p0 + (wp * FP + fp) * 32 + l31;
+        valid[fp] = pr < npts;
+        pp[fp] = valid[fp] ? pr : npts - 1;
+#pragma unroll
+        for (int c = 0; c < kMaxRgb; ++c) part[fp][c] = 0.f;
+    }
+    // channel-major: the ToRGB weights of a channel are read once and meet that channel's value at every pixel of the lane
+#pragma unroll
+    for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ol = (wo * FO + fo) * 32 + 8 * q + 4 * half, o_first = o0 + ol;
+            float v[FP][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int o = o_first + k;
+                float wc[kMaxRgb];
+#pragma unroll
+                for (int c = 0; c < kMaxRgb; ++c) wc[c] = ws[c * BO + ol + k];
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp) {
+                    v[fp][k] = o < g.O ? epilogue(acc[0][fo][fp][4 * q + k], b, o, pp[fp], ohw, g, e, ns) : 0.f;
+                    if (yb && valid[fp] && o < g.O) yb[(int64_t)o * ohw + pp[fp]] = v[fp][k];
+#pragma unroll
+                    for (int c = 0; c < kMaxRgb; ++c) part[fp][c] = fmaf(v[fp][k], wc[c], part[fp][c]);
+                }
+            }
+#pragma unroll
+            for (int fp = 0; fp < FP; ++fp)
+                if (e.ys && valid[fp] && o_first + 3 < g.O) split_store4(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, pp[fp], v[fp]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the next quad's weight / noise / bias loads from being hoisted over this one
+        }
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp)
+#pragma unroll
+        for (int c = 0; c < kMaxRgb; ++c) {
+            part[fp][c] += __shfl_xor(part[fp][c], 32);
+            if (half == 0) red[((((wo * WP + wp) * FP + fp) * kMaxRgb) + c) * 32 + l31] = part[fp][c];
+        }
+    __syncthreads();
+    if (wo != 0 || half != 0) return;
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp) {
+        const int p = p0 + (wp * FP + fp) * 32 + l31;
+        if (p >= npts) continue;
+        for (int c = 0; c < e.rgb_n; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WO; ++w) s += red[((((w * WP + wp) * FP + fp) * kMaxRgb) + c) * 32 + l31];
+            if (e.rgb_bias) s += e.rgb_bias[c];
+            if (e.rgb_clamp >= 0.f) s = fminf(fmaxf(s, -e.rgb_clamp), e.rgb_clamp);
+            const int64_t at = ((int64_t)b * e.rgb_n + c) * ohw + p;
+            if (e.rgb_res) s += e.rgb_res[at];
+            e.rgb_out[at] = s;
+        }
+    }
+}
+
 // FO x FP fragments (32 channels x 32 points) per wave, WO x WP waves; 8 input channels per K chunk; JP = patch DMA
 // instructions per wave per chunk (host-chosen from the worst window of the launch); SK as in conv_mfma_kernel.
 // NP = operand planes: 2 = hi / lo pairs, three products per k-step (fp32-equivalent, the arithmetic of ia_conv2d_mfma_s);
 // 1 = one fp16 plane, one product (fp16 operands / fp32 accumulation, the arithmetic of ia_conv2d_mfma_h: the reference's fp16
 // blocks) -- the fp16-STORAGE form of the SR head: activations travel between its convolutions as 2 bytes per element.
-template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP, bool SK>
+template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP, bool SK, bool RGB = false>
 __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void conv_split_kernel(const h16x8* __restrict__ xs, const h16x8* __restrict__ wk,
                                                                                       float* __restrict__ y, float* __restrict__ slabs, Geo g, Epi e) {
     constexpr int KS = 3, NT = 9, NTP = NT + 1;
@@ -299,6 +383,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
         if (sink == 123.456f) y[0] = sink;
     } else if (!SK || (c_lo == 0 && c_hi == g.C)) {
         if constexpr (TR) store_tile<TR, FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
+        else if constexpr (RGB) store_tile_rgb<FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid, lds);
         else store_tile_dual<FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
     } else if constexpr (SK) {
         const int slot = (tile_l == first_tile) ? 0 : 1;
@@ -321,6 +406,14 @@ int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
     int st = IA_OK;
     if (g.T_dp > 0) {
+        if constexpr (!TR) {
+            if (e.rgb_out) {      // (the fused ToRGB epilogue is its own instantiation: it costs the plain kernel registers otherwise)
+                auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, false, true>;
+                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
+                return ia::check_launch("ia_conv2d_mfma_sx_rgb");
+            }
+        }
         auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, false>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
@@ -380,11 +473,13 @@ extern "C" int ia_act_split(const float* x, const float* styles, void* xs, int p
 int ia_conv2d_plan_tiles(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int* bo, int* bp, int* waves, int* T, int* TO,
                          int* C, int* T_dp, int* slab_floats);
 
-extern "C" int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
-                                 const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
-                                 const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
-                                 int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
-    IA_REQUIRE(xs && wk_split && (y || ys), "xs, wk and at least one of y / ys must be device pointers");
+struct RgbArgs { const float* w; const float* styles; const float* bias; const float* res; float* out; int n; float clamp; };
+
+static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
+                        const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
+                        const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
+                        int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream, const RgbArgs& rgb) {
+    IA_REQUIRE(xs && wk_split && (y || ys || rgb.out), "xs, wk and at least one output must be device pointers");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
     IA_REQUIRE(I % 8 == 0 && O % 8 == 0, "the split form needs I %% 8 == 0 and O %% 8 == 0");
     IA_REQUIRE(wk_exp >= -14 && wk_exp <= 30, "wk_exp is the power of two the weights were scaled by at pack time");
@@ -404,6 +499,9 @@ extern "C" int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_spli
     if (st_plan != IA_OK) return st_plan;
     const bool wide = waves == 8;
     IA_REQUIRE(wide || (transposed && bo == 64), "the split form covers 3x3 layers on the two-stage tiles (large stride-1 layers, stride-2 transposed)");
+    if (rgb.out && (transposed || g.TO != 1 || g.T_dp != g.T))
+        return ia::fail(IA_ERR_UNSUPPORTED, "the fused ToRGB needs a stride-1 layer whose tiles hold every output channel and run in whole rounds "
+                        "(O %d, %d channel tiles, %d of %d tiles in whole rounds)", O, g.TO, g.T_dp, g.T);
     g.G = 0;
     if (g.T_dp < g.T) {
         IA_REQUIRE(ksplit >= 1, "this layer has stream-K tiles: pass the worker count from ia_conv2d_plan");
@@ -416,6 +514,10 @@ extern "C" int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_spli
     g.patch_cap = 0;
     g.acc_scale = ldexpf(1.f, -wk_exp);
     Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp, ys, styles_next, ys_planes};
+    if (rgb.out) {
+        IA_REQUIRE(rgb.w && rgb.n >= 1 && rgb.n <= kMaxRgb, "the fused ToRGB takes 1 .. %d output channels and its packed weight", kMaxRgb);
+        e.rgb_w = rgb.w; e.rgb_styles = rgb.styles; e.rgb_bias = rgb.bias; e.rgb_res = rgb.res; e.rgb_out = rgb.out; e.rgb_n = rgb.n; e.rgb_clamp = rgb.clamp;
+    }
     hipStream_t s = (hipStream_t)stream;
     const h16x8* x8 = static_cast<const h16x8*>(xs);
     const h16x8* w8 = static_cast<const h16x8*>(wk_split);
@@ -431,4 +533,22 @@ extern "C" int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_spli
     // (16 waves of 32ch x 64pt on the same 128 x 256 tile -- four waves per SIMD to overlap DMA issue, operand reads and MFMAs of
     // different waves -- measured 240 vs 245 us on 256->256 @256^2 and slower on the smaller layers: not kept)
     return launch_sx<2, false, 2, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
+}
+
+extern "C" int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
+                                 const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
+                                 const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
+                                 int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
+    return conv_sx_impl(xs, planes, wk_split, wk_exp, demod, noise, noise_strength, bias, residual, y, ys, ys_planes, styles_next, scratch, scratch_bytes,
+                        B, I, O, H, W, transposed, act, alpha, gain, clamp, ksplit, stream, RgbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1.f});
+}
+
+extern "C" int ia_conv2d_mfma_sx_rgb(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
+                                     const float* noise_strength, const float* bias, float* y, void* ys, int ys_planes, const float* styles_next,
+                                     const float* rgb_wk, const float* rgb_styles, const float* rgb_bias, const float* rgb_residual, float* rgb_out,
+                                     int rgb_channels, float rgb_clamp, int B, int I, int O, int H, int W, int act, float alpha, float gain, float clamp,
+                                     void* stream) {
+    IA_REQUIRE(rgb_out && rgb_wk, "rgb_out and rgb_wk must be device pointers");
+    return conv_sx_impl(xs, planes, wk_split, wk_exp, demod, noise, noise_strength, bias, nullptr, y, ys, ys_planes, styles_next, nullptr, 0,
+                        B, I, O, H, W, 0, act, alpha, gain, clamp, 0, stream, RgbArgs{rgb_wk, rgb_styles, rgb_bias, rgb_residual, rgb_out, rgb_channels, rgb_clamp});
 }

@@ -289,6 +289,52 @@ def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=Non
     return y if want_f32 else out_s
 
 
+def conv_sx_rgb_supported(b, i, o, h, w):
+    """Layers ia_conv2d_mfma_sx_rgb covers: stride-1 layers that run in whole rounds of tiles holding every output channel."""
+    if o > 128 or i % 8 or o % 8:
+        return False
+    plan_s, plan_bytes = ctypes.c_int(0), ctypes.c_size_t(0)
+    st = _lib.load().ia_conv2d_plan(b, i, o, h, w, 3, 0, 3, ctypes.byref(plan_s), ctypes.byref(plan_bytes))
+    return st == 0 and plan_s.value == 0 and h * w >= 8192
+
+
+def conv2d_mfma_sx_rgb(xs, wk, rgb_wk, rgb_styles=None, rgb_bias=None, rgb_residual=None, rgb_clamp=None, demod=None, noise=None,
+                       noise_strength=None, bias=None, act='linear', alpha=0.2, gain=1.0, clamp=None, want_f32=False, split_for=None,
+                       styles_next=None, split_planes=2):
+    """ia_conv2d_mfma_sx_rgb: the stride-1 3x3 convolution of a SplitAct AND the ToRGB layer that reads its result, in one launch.
+    rgb_wk = pack_conv_weight of the 1x1 ToRGB weight ([1, O, RC] or [O, RC]).  Returns (y or None, SplitAct or None, rgb)."""
+    if not isinstance(xs, SplitAct):
+        raise RuntimeError('xs must be a SplitAct (hipops.act_split or a producing layer)')
+    b, i, h, w = xs.shape
+    o = wk.shape[-2]
+    if wk.shape[-4] != 9 or wk.shape[-3] * 8 != i:
+        raise RuntimeError(f'packed weight {tuple(wk.shape)} does not match 3x3, in-channels {i}')
+    _f32c(rgb_wk, 'rgb_wk')
+    rc = rgb_wk.shape[-1]
+    if rgb_wk.numel() != o * rc:
+        raise RuntimeError(f'rgb_wk has {rgb_wk.numel()} elements, expected {o} x {rc}')
+    for name, t, n in (('demod', demod, b * o), ('noise', noise, h * w), ('bias', bias, o), ('styles_next', styles_next, b * o),
+                       ('rgb_styles', rgb_styles, b * o), ('rgb_bias', rgb_bias, rc), ('rgb_residual', rgb_residual, b * rc * h * w)):
+        if t is not None and _f32c(t, name).numel() != n:
+            raise RuntimeError(f'{name} has {t.numel()} elements, expected {n}')
+    want_split = split_for is not None or styles_next is not None
+    dev = xs.data.device
+    y = torch.empty(b, o, h, w, device=dev, dtype=torch.float32) if want_f32 else None
+    ys = torch.empty(b, split_planes, o // 8, h, w, 8, device=dev, dtype=torch.float16) if want_split else None
+    rgb = torch.empty(b, rc, h, w, device=dev, dtype=torch.float32)
+    flops = 2.0 * b * h * w * i * o * 9
+    traffic = (2.0 * (xs.data.numel() + wk.numel()) + 4.0 * (y.numel() if want_f32 else 0) + 2.0 * (ys.numel() if want_split else 0)
+               + 4.0 * rgb.numel() * (2 if rgb_residual is not None else 1))
+    with torch.cuda.device(dev), _Timed('conv2d_mfma_k3', flops, traffic, f'B{b} I{i} O{o} {h}x{w} G0 ' + ('f16x3 dma' if xs.planes == 2 else 'f16 dma') + ' +rgb'):
+        st = _lib.load().ia_conv2d_mfma_sx_rgb(_p(xs.data), int(xs.planes), _p(wk), int(getattr(wk, 'wk_exp', 0)), _p(demod), _p(noise),
+                                               _p(noise_strength), _p(bias), _p(y), _p(ys), int(split_planes), _p(styles_next), _p(rgb_wk),
+                                               _p(rgb_styles), _p(rgb_bias), _p(rgb_residual), _p(rgb), int(rc),
+                                               float(-1 if rgb_clamp is None else rgb_clamp), b, i, o, h, w, ACT_ID[act], float(alpha), float(gain),
+                                               float(-1 if clamp is None else clamp), _lib.stream_ptr(dev))
+    _lib.check(st, 'ia_conv2d_mfma_sx_rgb')
+    return y, (SplitAct(ys, o, split_for) if want_split else None), rgb
+
+
 def upfirdn2d_bias_act(x, f, noise=None, noise_strength=None, bias=None, up=1, pad0=(1, 1), out_hw=None, fir_gain=1.0,
                        act='linear', alpha=0.2, act_gain=1.0, clamp=None, flip=False):
     """FIR + noise + bias + activation in one pass (see ia_upfirdn2d_bias_act)."""

@@ -34,6 +34,7 @@ FP16_BLOCKS_COMPUTE_FP32 = True
 # fp32 layers: where the shape allows (hipops.conv_h_supported), the 3x3 convolutions form their fp32 products from hi/lo
 # fp16 pairs on the fp16 MFMA (ia_conv2d_mfma_s): as accurate against an fp64 convolution as the fp32 MFMA form
 # (tests/test_conv_gpu.py) and twice as fast.  False keeps every layer on v_mfma_f32_32x32x2_f32.
+FUSED_TORGB = True               # a block whose x nobody reads (last SR block): ToRGB evaluated in conv1's epilogue (ia_conv2d_mfma_sx_rgb)
 STREAMING_TORGB = True           # ToRGB layers through ia_conv1x1 (one streaming launch) instead of the tiled ia_conv2d_mfma form
 SPLIT_FP16_PRODUCTS = True
 
@@ -434,6 +435,37 @@ class SynthesisLayer(torch.nn.Module):
         return hipops.upfirdn2d_bias_act(t, self.resample_filter, nz, ns, bias, up=1, pad0=(1, 1), out_hw=(res, res),
                                          fir_gain=4.0, act=self.activation, act_gain=act_gain, clamp=act_clamp)
 
+    def forward_with_torgb(self, x, w, torgb, w_rgb, skip, resample_filter, noise_mode='random', gain=1, half_ops=False, **_unused):
+        """This layer AND the ToRGB layer that is the only reader of its result, in one launch (ia_conv2d_mfma_sx_rgb): returns the
+        image `upsample2d(skip) + torgb(conv(x))`, or None when the pair is not eligible (the caller then runs the two layers)."""
+        res = self.resolution
+        if not (FUSED_TORGB and self.up == 1 and _on_device(x) and self.activation in hipops.ACT_ID and self.weight.shape[2] == 3
+                and torgb.weight.shape[2] == 1 and torgb.out_channels <= 4 and torgb.in_channels == self.out_channels
+                and noise_mode != 'random' and not _needs_autograd(x, w, w_rgb, self.weight, self.bias, torgb.weight, torgb.bias, skip)
+                and self._takes_split_input(res, noise_mode, half_ops)
+                and hipops.conv_sx_rgb_supported(x.shape[0], self.in_channels, self.out_channels, res, res)):
+            return None
+        pre, self._pre = self._pre, None
+        styles, demod = pre if pre is not None else (self.affine(w), None)
+        pre_rgb, torgb._pre = torgb._pre, None
+        rgb_styles = pre_rgb[0] if pre_rgb is not None else torgb.affine(w_rgb).float().contiguous()
+        planes = 1 if half_ops else 2
+        wk = self._packed.get_half(self.weight) if half_ops else self._packed.get_split(self.weight)
+        if demod is None:
+            demod = hipops.modconv_demod(styles.float().contiguous(), self._packed.get(self.weight)[1])
+        carried = x if isinstance(x, hipops.SplitAct) else getattr(x, '_ia_split', None)
+        xs = carried if (carried is not None and carried.consumer is self and carried.planes == planes) else \
+            hipops.act_split(x.float().contiguous(), styles.float().contiguous(), consumer=self, planes=planes)
+        const_noise = self.use_noise and noise_mode == 'const'
+        nz = self.noise_const.reshape(-1) if const_noise else None
+        ns = self.noise_strength.detach().float().reshape(1) if const_noise else None
+        rgb_wk, _ = torgb._packed.get(torgb.weight, scale=torgb.weight_gain)
+        residual = None if skip is None else upfirdn2d.upsample2d(skip, resample_filter).float().contiguous()
+        _, _, img = hipops.conv2d_mfma_sx_rgb(xs, wk, rgb_wk, rgb_styles, torgb.bias.detach().float(), residual, torgb.conv_clamp, demod, nz, ns,
+                                              self.bias.detach().float(), act=self.activation, gain=self.act_gain * gain,
+                                              clamp=self.conv_clamp * gain if self.conv_clamp is not None else None)
+        return img
+
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, half_ops=False, split_for=None, keep_f32=True, next_half_ops=None):
         assert noise_mode in ['random', 'const', 'none']
         in_res = self.resolution // self.up
@@ -556,9 +588,11 @@ class SynthesisBlock(torch.nn.Module):
                                     resample_filter=resample_filter, channels_last=self.channels_last)
 
     def forward(self, x, img, ws, condition=None, force_fp32=False, fused_modconv=None, update_emas=False, _next_conv=None, _next_half=None,
-                **layer_kwargs):
+                _x_unused=False, **layer_kwargs):
         """`_next_conv`: the layer that consumes this block's x (the next block's conv0), given by the owning network on the device
-        inference path so that conv1 can emit its result in the format that layer reads (hipops.SplitAct)."""
+        inference path so that conv1 can emit its result in the format that layer reads (hipops.SplitAct).
+        `_x_unused`: the caller drops the returned x (last block of a head): conv1 may then evaluate ToRGB in its epilogue and x comes
+        back as None."""
         _ = update_emas
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
         w_iter = iter(ws.unbind(dim=1))
@@ -594,6 +628,13 @@ class SynthesisBlock(torch.nn.Module):
             if condition is not None:
                 half = int(x.size(1) // 2)
                 x = torch.cat([x[:, :half], x[:, half:] * condition[0] + condition[1]], dim=1)
+            fused_img = None
+            if _x_unused and condition is None and (self.is_last or self.architecture == 'skip'):
+                w_conv1, w_rgb = next(w_iter), next(w_iter)
+                fused_img = self.conv1.forward_with_torgb(x, w_conv1, self.torgb, w_rgb, img, self.resample_filter, **layer_kwargs)
+                if fused_img is not None:
+                    return None, fused_img.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+                w_iter = iter((w_conv1, w_rgb))
             x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, split_for=_next_conv, next_half_ops=_next_half, **layer_kwargs)
 
         if img is not None:

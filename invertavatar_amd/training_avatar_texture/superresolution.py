@@ -61,7 +61,8 @@ class _TwoBlockHead(torch.nn.Module):
             next_half = bool(getattr(self.block1, 'use_fp16', False)) and ws.is_cuda and not sg2.FP16_BLOCKS_COMPUTE_FP32
             chain = dict(_next_conv=getattr(self.block1, 'conv0', None), _next_half=next_half)
         x, rgb = self.block0(x, rgb, ws, **chain, **block_kwargs)
-        x, rgb = self.block1(x, rgb, ws, **block_kwargs)
+        last = dict(_x_unused=True) if isinstance(self.block1, SynthesisBlock) else {}      # block1's x has no reader: ToRGB in conv1's epilogue
+        x, rgb = self.block1(x, rgb, ws, **last, **block_kwargs)
         return rgb
 
 
@@ -188,7 +189,8 @@ class SuperresolutionHybrid4X(_TwoBlockHead):
             next_half = bool(getattr(self.block1, 'use_fp16', False)) and ws.is_cuda and not sg2.FP16_BLOCKS_COMPUTE_FP32
             chain = dict(_next_conv=getattr(self.block1, 'conv0', None), _next_half=next_half)
         x, rgb = self.block0(x, rgb, ws, **chain, **block_kwargs)
-        x, rgb = self.block1(x, rgb, ws, **block_kwargs)
+        last = dict(_x_unused=True) if isinstance(self.block1, SynthesisBlock) else {}      # block1's x has no reader: ToRGB in conv1's epilogue
+        x, rgb = self.block1(x, rgb, ws, **last, **block_kwargs)
         return rgb
 
 

@@ -369,3 +369,30 @@ def test_conv1x1_rejects_unsupported_shapes():
     with pytest.raises(RuntimeError, match='ia_conv1x1 covers'):
         hipops.conv1x1(x, torch.zeros(1, 48, 8, device='cuda'))
     assert not hipops.conv1x1_supported(48, 8, 8, 8) and not hipops.conv1x1_supported(64, 128, 8, 8) and hipops.conv1x1_supported(64, 96, 8, 8)
+
+
+@pytest.mark.parametrize('res,planes', [(256, 2), (512, 2), (256, 1)])
+def test_conv_sx_with_fused_torgb(res, planes):
+    """ia_conv2d_mfma_sx_rgb = ia_conv2d_mfma_sx followed by ia_conv1x1 on its result (the last SR block: conv1, ToRGB, skip add)."""
+    b, c, rc = 1, 128, 3
+    x, styles = rnd(11, b, c, res, res).cuda(), (rnd(12, b, c) * 0.3 + 1).cuda()
+    w3 = (rnd(13, c, c, 3, 3) / (9 * c) ** 0.5).cuda()
+    wk = hipops.pack_conv_weight_split(w3) if planes == 2 else hipops.pack_conv_weight_h(w3)
+    demod = (rnd(14, b, c).abs() + 0.5).cuda()
+    noise, ns, bias = rnd(15, res * res).cuda(), torch.tensor([0.3], device='cuda'), rnd(16, c).cuda()
+    rgb_w = hipops.pack_conv_weight((rnd(17, rc, c, 1, 1) / c ** 0.5).cuda())
+    rgb_styles, rgb_bias, skip = (rnd(18, b, c) * 0.3 + 1).cuda(), rnd(19, rc).cuda(), rnd(20, b, rc, res, res).cuda()
+    assert hipops.conv_sx_rgb_supported(b, c, c, res, res)
+    xs = hipops.act_split(x, styles, planes=planes)
+    kw = dict(act='lrelu', gain=2 ** 0.5, clamp=256)
+    y = hipops.conv2d_mfma_sx(xs, wk, demod, noise, ns, bias, **kw)
+    ref = hipops.conv1x1(y, rgb_w, rgb_styles, bias=rgb_bias, residual=skip, clamp=1.5)
+    y2, ys2, got = hipops.conv2d_mfma_sx_rgb(xs, wk, rgb_w, rgb_styles, rgb_bias, skip, 1.5, demod, noise, ns, bias, **kw)
+    assert y2 is None and ys2 is None and got.shape == ref.shape
+    assert max_abs(got, ref) <= 2e-5, max_abs(got, ref)
+    y3, _, got3 = hipops.conv2d_mfma_sx_rgb(xs, wk, rgb_w, rgb_styles, rgb_bias, skip, 1.5, demod, noise, ns, bias, want_f32=True, **kw)
+    assert torch.equal(y3, y) and torch.equal(got3, got)         # the layer's own output is unchanged by the extra epilogue
+    assert not hipops.conv_sx_rgb_supported(1, 128, 128, 128, 128) and not hipops.conv_sx_rgb_supported(1, 256, 256, 256, 256)
+    with pytest.raises(RuntimeError, match='fused ToRGB'):
+        small = hipops.act_split(x[:, :, :128, :128].contiguous(), styles, planes=planes)
+        hipops.conv2d_mfma_sx_rgb(small, wk, rgb_w, rgb_styles, rgb_bias, None, 1.5, demod)

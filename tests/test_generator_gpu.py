@@ -263,3 +263,27 @@ def test_rasterize_level_seams_and_channel_counts(chans, res):
     assert got.shape == ref.shape and max_abs(got.cpu(), ref) <= 2e-5, max_abs(got.cpu(), ref)
     again = hipops.rasterize_level(tex.cuda(), uv.cuda(), upper.cuda(), sta.cuda()[:, :chans], (y0, y1, x0, x1), res)
     assert torch.equal(got, again)                             # the per-texel sums are integer atomics: order-independent
+
+
+def test_sr_head_fused_torgb_equals_two_launches(golden, full):
+    """The last SR block with ToRGB evaluated in conv1's epilogue (ia_conv2d_mfma_sx_rgb) against the two-launch form
+    (ia_conv2d_mfma_sx, ia_conv1x1): same image within fp32 summation order, and the fused launch is the one that runs."""
+    from invertavatar_amd.training import networks_stylegan2 as sg2
+    gld = golden('generator_full_nrr128.npz')
+    nrr, ws, k = gld['nrr'], gld['ws'].cuda(), gld['frames'].tolist()[0]
+    args = (ws, synthetic.camera_labels([k]).cuda(), {'uvcoords_image': synthetic.uv_conditions([k]).cuda()})
+    kw = dict(neural_rendering_resolution=nrr, noise_mode='const', evaluation=True, jitter=synthetic.jitter([k], nrr * nrr).cuda())
+    imgs = {}
+    saved = sg2.FUSED_TORGB
+    try:
+        for flag in (True, False):
+            sg2.FUSED_TORGB = flag
+            hipops.PROFILE = []
+            with torch.no_grad():
+                imgs[flag] = full.synthesis(*args, **kw)['image']
+            torch.cuda.synchronize()
+            recs, hipops.PROFILE = hipops.PROFILE, None
+            assert any(r[5].endswith('+rgb') for r in recs) == flag
+    finally:
+        sg2.FUSED_TORGB, hipops.PROFILE = saved, None
+    assert max_abs(imgs[True], imgs[False]) <= 1e-5, max_abs(imgs[True], imgs[False])
