@@ -38,3 +38,39 @@ def test_device_tensor_ops_never_fall_back(monkeypatch):
     with pytest.raises(RuntimeError):
         from invertavatar_amd.torch_utils.ops import _plugins
         _plugins.bias_act(x, torch.randn(3), None, None, None, 0, 1, 3, 0.2, 1.0, -1.0)  # CPU tensor at the plugin level
+
+
+def _plan(b, i, o, h, w, ksize=3, transposed=0, form=0):
+    lib = _lib.load()
+    workers, nbytes = ctypes.c_int(-1), ctypes.c_size_t(0)
+    st = lib.ia_conv2d_plan(b, i, o, h, w, ksize, transposed, form, ctypes.byref(workers), ctypes.byref(nbytes))
+    assert st == 0, _lib.last_error()
+    return workers.value, nbytes.value
+
+
+def test_conv_planner_host_logic():
+    """ia_conv2d_plan is host-only arithmetic: worker counts of the stream-K split (include/ia_hip.h).  Layers smaller than the machine
+    up to 64^2 are capped at half of the 256 CUs (one worker per tile if they have more tiles); layers that fill whole rounds of
+    tiles have no stream-K part; the per-element share shrinks with the batch."""
+    for res in (4, 8, 16):
+        workers, nbytes = _plan(1, 512, 512, res, res)
+        assert workers == 128 and nbytes > 0, (res, workers)
+    assert _plan(1, 512, 512, 64, 64, form=3)[0] == 128
+    assert _plan(1, 256, 256, 128, 128, form=3)[0] == 256           # 128^2 keeps the whole machine
+    for shape in ((1, 128, 128, 512, 512), (1, 256, 256, 256, 256), (1, 128, 128, 256, 256)):
+        assert _plan(*shape, form=3) == (0, 0), shape               # whole rounds of whole tiles: no workers, no scratch
+    assert _plan(8, 512, 512, 16, 16)[0] <= 64                      # 512 slots shared by 8 batch elements
+    lib = _lib.load()
+    assert lib.ia_conv2d_plan(1, 512, 512, 16, 16, 3, 0, 7, ctypes.byref(ctypes.c_int()), ctypes.byref(ctypes.c_size_t())) == -1
+    assert 'form' in _lib.last_error()
+
+
+def test_streaming_torgb_shape_rules():
+    from invertavatar_amd import hipops
+    assert hipops.conv1x1_supported(512, 96, 4, 4) and hipops.conv1x1_supported(128, 3, 512, 512)
+    assert not hipops.conv1x1_supported(48, 8, 8, 8)                # C_in % 32
+    assert not hipops.conv1x1_supported(64, 128, 8, 8)              # C_out > 96
+    assert not hipops.conv1x1_supported(64, 32, 3, 3)               # H*W % 4
+    assert hipops.conv_sx_rgb_supported(1, 128, 128, 512, 512) and hipops.conv_sx_rgb_supported(1, 128, 128, 256, 256)
+    assert not hipops.conv_sx_rgb_supported(1, 256, 256, 256, 256)  # two channel tiles
+    assert not hipops.conv_sx_rgb_supported(1, 128, 128, 128, 128)  # stream-K layer
