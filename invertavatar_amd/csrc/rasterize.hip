@@ -397,46 +397,50 @@ struct BlendParams {
     int B, y0, y1, x0, x1;   // bbox of the 128^2 paste (triplane_v20.py:114)
 };
 
-// One thread per (b, plane, y, x): 32 channels.  Plane 0 inside the bbox: AA 256->128 resize of stitch and alpha.
+// One thread per (b, plane, channel group of 8, y, x).  Plane 0 inside the bbox: AA 256->128 resize of stitch and alpha (16 taps per
+// channel); four channel groups per pixel so that the 128^2 bbox pixels -- 16x the work of the others -- are spread over four times
+// as many workgroups (with 32 channels per thread the bbox workgroups alone set the kernel's duration: 40 us for 58 MB).
+constexpr int kBlendCh = 8;
 __global__ __launch_bounds__(256) void blend_planes_kernel(BlendParams p) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int plane = blockIdx.z % 3, b = blockIdx.z / 3;
-    const float* st = p.sta + (int64_t)b * p.sta_bs + (int64_t)plane * 32 * 65536 + (int64_t)y * 256 + x;
-    float v[32];
+    const int cg = blockIdx.z % 4, plane = (blockIdx.z / 4) % 3, b = blockIdx.z / 12;
+    const int c0 = cg * kBlendCh;
+    const float* st = p.sta + (int64_t)b * p.sta_bs + ((int64_t)plane * 32 + c0) * 65536 + (int64_t)y * 256 + x;
+    float v[kBlendCh];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) v[c] = st[(int64_t)c * 65536];
+    for (int c = 0; c < kBlendCh; ++c) v[c] = st[(int64_t)c * 65536];
     if (plane == 0 && y >= p.y0 && y < p.y1 && x >= p.x0 && x < p.x1) {
         const int oy = y - p.y0, ox = x - p.x0, n_out = p.y1 - p.y0;       // 128
         int ylo, yhi, xlo, xhi; float yc, yinv, ytot, xc, xinv, xtot;
         aa_taps(oy, 256, n_out, ylo, yhi, yc, yinv, ytot);
         aa_taps(ox, 256, n_out, xlo, xhi, xc, xinv, xtot);
-        float a = 0.f, s[32];
+        float a = 0.f, s[kBlendCh];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) s[c] = 0.f;
-        const float* sb = p.stitch + (int64_t)b * 32 * 65536;
+        for (int c = 0; c < kBlendCh; ++c) s[c] = 0.f;
+        const float* sb = p.stitch + ((int64_t)b * 32 + c0) * 65536;
         const float* ab = p.alpha + (int64_t)b * 65536;
         // aten resizes separably (rows of the horizontal pass feed the vertical pass); the two-pass order is kept
         for (int j = ylo; j < yhi; ++j) {
             const float wy = aa_weight(j, yc, yinv, ytot);
-            float ra = 0.f, rs[32];
+            float ra = 0.f, rs[kBlendCh];
 #pragma unroll
-            for (int c = 0; c < 32; ++c) rs[c] = 0.f;
+            for (int c = 0; c < kBlendCh; ++c) rs[c] = 0.f;
             for (int i = xlo; i < xhi; ++i) {
                 const float wx = aa_weight(i, xc, xinv, xtot);
                 ra = fmaf(ab[j * 256 + i], wx, ra);
 #pragma unroll
-                for (int c = 0; c < 32; ++c) rs[c] = fmaf(sb[(int64_t)c * 65536 + j * 256 + i], wx, rs[c]);
+                for (int c = 0; c < kBlendCh; ++c) rs[c] = fmaf(sb[(int64_t)c * 65536 + j * 256 + i], wx, rs[c]);
             }
             a = fmaf(ra, wy, a);
 #pragma unroll
-            for (int c = 0; c < 32; ++c) s[c] = fmaf(rs[c], wy, s[c]);
+            for (int c = 0; c < kBlendCh; ++c) s[c] = fmaf(rs[c], wy, s[c]);
         }
 #pragma unroll
-        for (int c = 0; c < 32; ++c) v[c] = s[c] * a + v[c] * (1.f - a);
+        for (int c = 0; c < kBlendCh; ++c) v[c] = s[c] * a + v[c] * (1.f - a);
     }
-    float4* dst = (float4*)(p.planes_cl + ((((int64_t)b * 3 + plane) * 256 + y) * 256 + x) * 32);
+    float4* dst = (float4*)(p.planes_cl + ((((int64_t)b * 3 + plane) * 256 + y) * 256 + x) * 32 + c0);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) dst[c] = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    for (int c = 0; c < kBlendCh / 4; ++c) dst[c] = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
 }
 
 }  // namespace
@@ -537,6 +541,6 @@ extern "C" int ia_blend_planes(const float* stitch, const float* full_alpha, con
     IA_REQUIRE(B > 0, "empty tensor");
     IA_REQUIRE(y0 >= 0 && y1 <= 256 && x0 >= 0 && x1 <= 256 && y1 - y0 == x1 - x0 && y1 > y0, "bbox must be a square inside 256^2");
     BlendParams p{stitch, full_alpha, static_planes, planes_cl, sta_batch_stride, B, y0, y1, x0, x1};
-    hipLaunchKernelGGL(blend_planes_kernel, dim3(4, 64, 3 * B), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(blend_planes_kernel, dim3(4, 64, 12 * B), dim3(256), 0, (hipStream_t)stream, p);
     return ia::check_launch("ia_blend_planes");
 }
