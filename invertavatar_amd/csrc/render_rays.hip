@@ -14,8 +14,9 @@
 // Work decomposition (wave64, one ray per wave, 16 samples x 4 lane-quarters per step):
 //   lane = s + 16*q : s = sample within the group of 16, q = quarter.  The decoder runs on
 //   v_mfma_f32_16x16x4_f32 as D[unit, sample] = W[unit, k] * X[k, sample]; with that orientation
-//     - the tri-plane gather feeds the B operand directly: quarter q fetches channels 8q..8q+7 (32 bytes) of
-//       each of the 12 texels of its sample from channels-last planes,
+//     - the tri-plane gather runs in its own lane role (lane = 4 * sample + chunk: four consecutive lanes read 64 contiguous
+//       bytes of a texel, 32-bit texel offsets on a scalar plane base) and hands the blended features to the decoder role
+//       through the sample's 128-byte colour slot in LDS: decoder lane (s, q) reads channels 8q..8q+7 -- that IS the B operand,
 //     - layer-1 results land as 16 hidden units per lane which ARE the B operand of layer 2 (k permuted
 //       identically on the weight side), so no cross-lane shuffle sits between gather, layer 1 and layer 2,
 //     - the density row (1 of 33 outputs) is a 16-term VALU dot product + 2 butterfly adds instead of a
@@ -82,7 +83,17 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float softplus_fast(float x) { return x > 20.f ? x : __logf(1.f + __expf(x)); }
+// softplus = log(1 + exp(x)) with the bits of __logf(1.f + __expf(x)).  __expf is v_exp_f32(x * log2e); __logf is v_log_f32 followed
+// by an extended-precision multiplication by ln 2 (hi / lo split with two fmas) plus a range fix-up for denormal and infinite
+// arguments -- the argument here is 1 + exp(x) in [1, 1 + e^20], so the fix-up (5 of the 11 instructions) is dropped.
+__device__ __forceinline__ float exp_raw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float log_of_normal(float x) {
+    const float y = __builtin_amdgcn_logf(x);
+    const float ln2_hi = __uint_as_float(0x3f317217u), ln2_lo = __uint_as_float(0x3377d1cfu);
+    const float r = y * ln2_hi;
+    return r + __fmaf_rn(y, ln2_lo, __fmaf_rn(y, ln2_hi, -r));
+}
+__device__ __forceinline__ float softplus_fast(float x) { return x > 20.f ? x : log_of_normal(1.f + exp_raw(x)); }
 
 // CPU torch.linspace bit rule.
 __device__ __forceinline__ float linspace_at(float s, float e, float step, int k, int n) {
@@ -130,8 +141,10 @@ __device__ __forceinline__ void gather_features(const float* __restrict__ planes
 // a clamped, valid texel with weight 0: fmaf(v, 0, acc) == acc, so the sum is the bits of gather_features), gather_reduce
 // is the accumulation in the same order.
 template <int P0, int P1>
-__device__ __forceinline__ void gather_issue(const float* __restrict__ planes_b, int PH, int PW, int q, float x, float y, float z,
+__device__ __forceinline__ void gather_issue(const float* __restrict__ planes_b, int PH, int PW, int c, float x, float y, float z,
                                              float4 (&raw)[24], float (&wgt)[12]) {
+    // planes_b is wave-uniform (scalar base); the texel offsets are 32-bit byte offsets (the host checks 3*PH*PW*128 < 2^32)
+    const char* base = reinterpret_cast<const char*>(planes_b);
 #pragma unroll
     for (int p = P0; p < P1; ++p) {
         const float gx = (p == 2) ? z : x;
@@ -141,16 +154,19 @@ __device__ __forceinline__ void gather_issue(const float* __restrict__ planes_b,
         const float x0f = floorf(ix), y0f = floorf(iy);
         const float fx = ix - x0f, fy = iy - y0f;
         const int x0 = (int)fminf(fmaxf(x0f, -2.f), (float)PW + 1.f), y0 = (int)fminf(fmaxf(y0f, -2.f), (float)PH + 1.f);
-        const float* pl = planes_b + (int64_t)p * PH * PW * 32 + 8 * q;
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        // per-axis weights, zero outside the plane: the products are the four bilinear weights (0 for a tap outside)
+        const float wx0 = (unsigned)x0 < (unsigned)PW ? 1.f - fx : 0.f, wx1 = (unsigned)x1 < (unsigned)PW ? fx : 0.f;
+        const float wy0 = (unsigned)y0 < (unsigned)PH ? 1.f - fy : 0.f, wy1 = (unsigned)y1 < (unsigned)PH ? fy : 0.f;
+        wgt[p * 4 + 0] = wx0 * wy0; wgt[p * 4 + 1] = wx1 * wy0; wgt[p * 4 + 2] = wx0 * wy1; wgt[p * 4 + 3] = wx1 * wy1;
+        const unsigned xc0 = (unsigned)min(max(x0, 0), PW - 1), xc1 = (unsigned)min(max(x1, 0), PW - 1);
+        const unsigned r0 = __umul24((unsigned)min(max(y0, 0), PH - 1), (unsigned)PW), r1 = __umul24((unsigned)min(max(y1, 0), PH - 1), (unsigned)PW);
+        const unsigned po = (unsigned)p * (unsigned)(PH * PW) * 128u + 16u * (unsigned)c;     // plane + this lane's 16-byte chunk
+        const unsigned off[4] = {((r0 + xc0) << 7) + po, ((r0 + xc1) << 7) + po, ((r1 + xc0) << 7) + po, ((r1 + xc1) << 7) + po};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
-            const bool ok = xi >= 0 && xi < PW && yi >= 0 && yi < PH;
-            wgt[p * 4 + t] = ok ? ((t & 1) ? fx : 1.f - fx) * ((t >> 1) ? fy : 1.f - fy) : 0.f;
-            const int xc = min(max(xi, 0), PW - 1), yc = min(max(yi, 0), PH - 1);
-            const float4* src = (const float4*)(pl + ((int64_t)yc * PW + xc) * 32);
-            raw[(p * 4 + t) * 2] = src[0];
-            raw[(p * 4 + t) * 2 + 1] = src[1];
+            raw[(p * 4 + t) * 2] = *reinterpret_cast<const float4*>(base + off[t]);             // channels 4c .. 4c+3 (chunk c of the 128-byte texel)
+            raw[(p * 4 + t) * 2 + 1] = *reinterpret_cast<const float4*>(base + off[t] + 64u);   // channels 16+4c .. 16+4c+3 (chunk 4 + c)
         }
     }
 }
@@ -173,6 +189,19 @@ __device__ __forceinline__ void gather_reduce(const float4 (&raw)[24], const flo
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) f[c] = (acc[0][c] + acc[1][c] + acc[2][c]) * (1.f / 3.f);
+}
+
+// Gather layout -> MFMA operand layout, through the sample's colour slot in LDS (the colours overwrite it afterwards).
+// In : f = channels {4c..4c+3, 16+4c..16+4c+3} of sample gj (what gather_reduce leaves in lane 4*gj + c).
+// Out: f = channels 8q..8q+7 of sample s (lane s + 16q): the B operand of layer 1, k-slot q, k-step t <-> channel 8q + t.
+__device__ __forceinline__ void features_to_operand(float* group_slots, int gj, int gc, int s, int q, float (&f)[8]) {
+    float4* w = reinterpret_cast<float4*>(group_slots + gj * 32 + 4 * gc);
+    w[0] = make_float4(f[0], f[1], f[2], f[3]);
+    w[4] = make_float4(f[4], f[5], f[6], f[7]);
+    wave_sync();
+    const float4* r = reinterpret_cast<const float4*>(group_slots + s * 32 + 8 * q);
+    const float4 a = r[0], b = r[1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
 // Layer 1 (32 -> 64, softplus) on MFMA.  In: f[8] = channels 8q..8q+7 of this lane's sample.
@@ -219,7 +248,7 @@ __device__ __forceinline__ void decoder_rgb(const float* __restrict__ lds, int l
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v = c[U][r] + lds[B1_OFF + 1 + 16 * U + 4 * q + r];
-            c[U][r] = __builtin_amdgcn_rcpf(1.f + __expf(-v)) * 1.002f - 0.001f;   // sigmoid * (1 + 2e-3) - 1e-3 (v_rcp_f32: 1 ulp)
+            c[U][r] = __builtin_amdgcn_rcpf(1.f + exp_raw(-v)) * 1.002f - 0.001f;   // sigmoid * (1 + 2e-3) - 1e-3 (v_rcp_f32: 1 ulp)
         }
 }
 
@@ -292,7 +321,8 @@ __device__ __forceinline__ void merge_sorted(float* scr, int lane, int& pos_c, i
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = lane & 15, q = lane >> 4;
+    const int s = lane & 15, q = lane >> 4;       // decoder (MFMA operand) role of the lane: sample s of the group, k-slot q
+    const int gj = lane >> 2, gc = lane & 3;      // gather role: sample gj of the group, 16-byte chunks gc and 4 + gc of its texels
 
     // ---- stage decoder weights in MFMA-fragment order
     for (int e = tid; e < 4 * 8 * 64; e += WAVES * 64) {
@@ -323,8 +353,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
 
     const int nrays = p.B * p.R;
     for (int ray0 = blockIdx.x * WAVES; ray0 < nrays; ray0 += gridDim.x * WAVES) {
-        const int ray = ray0 + wave;
-        if (ray >= nrays) continue;                      // wave-uniform
+        const int ray = __builtin_amdgcn_readfirstlane(ray0 + wave);      // wave-uniform: ray constants and the plane base are scalars
+        if (ray >= nrays) continue;
         const int b = ray / p.R;
         const float* planes_b = p.planes + (int64_t)b * 3 * p.PH * p.PW * 32;
         const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
@@ -335,21 +365,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         wave_sync();
         float4 raw[24]; float wgt[12];
         {
-            const float t = tc[s];
-            gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+            const float t = tc[gj];
+            gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
         }
 #pragma unroll 1
         for (int g = 0; g < NS / 16; ++g) {
             float f[8]; f32x4 h[4];
             asm volatile("" ::: "memory");   // decoder weights are re-read from LDS every group: their registers hold the prefetched texels
             {
-                const float t = tc[16 * g + s];
-                gather_issue<kEarlyPlanes, 3>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                const float t = tc[16 * g + gj];
+                gather_issue<kEarlyPlanes, 3>(planes_b, p.PH, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
             }
             gather_reduce(raw, wgt, f);
+            features_to_operand(scr + COL_OFF + (16 * g) * 32, gj, gc, s, q, f);
             if (g + 1 < NS / 16) {      // next group's loads fly under this group's decoder
-                const float t = tc[16 * (g + 1) + s];
-                gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                const float t = tc[16 * (g + 1) + gj];
+                gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
             }
             decoder_hidden(lds, lane, q, f, h);
             const float sg = decoder_sigma(lds, q, h);
@@ -401,19 +432,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         {
             const float* tf = scr + 7 * NS;
             {
-                const float t = tf[s];
-                gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                const float t = tf[gj];
+                gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
             }
 #pragma unroll 1
             for (int g = 0; g < NS / 16; ++g) {
-                const float t = tf[16 * g + s];
+                const float t = tf[16 * g + gj];
                 float f[8]; f32x4 h[4], col[2];
                 asm volatile("" ::: "memory");
-                gather_issue<kEarlyPlanes, 3>(planes_b, p.PH, p.PW, q, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                gather_issue<kEarlyPlanes, 3>(planes_b, p.PH, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
                 gather_reduce(raw, wgt, f);
+                features_to_operand(scr + COL_OFF + (NS + 16 * g) * 32, gj, gc, s, q, f);
                 if (g + 1 < NS / 16) {
-                    const float tn = tf[16 * (g + 1) + s];
-                    gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, q, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * p.box_scale, raw, wgt);
+                    const float tn = tf[16 * (g + 1) + gj];
+                    gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, gc, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * p.box_scale, raw, wgt);
                 }
                 decoder_hidden(lds, lane, q, f, h);
                 const float sg = decoder_sigma(lds, q, h);
@@ -577,6 +609,8 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
         return ia::fail(IA_ERR_UNSUPPORTED, "depth_resolution=%d / depth_resolution_importance=%d: this build is specialised for 48/48",
                         n_coarse, n_importance);
     IA_REQUIRE(box_warp > 0.f, "box_warp must be positive");
+    IA_REQUIRE(plane_h < (1 << 23) && plane_w < (1 << 23) && (int64_t)3 * plane_h * plane_w * 128 < ((int64_t)1 << 32),
+               "planes of one batch element must stay below 4 GiB (32-bit texel offsets)");
     Params p;
     p.planes = planes_cl; p.rays_o = rays_o; p.rays_d = rays_d; p.jitter = jitter; p.dist = dist;
     p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;

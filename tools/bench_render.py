@@ -1,9 +1,13 @@
-"""Micro-benchmark of ia_render_rays at the BASELINE shape (B=1, 128^2 rays, 256^2 planes)."""
+"""Micro-benchmark of ia_render_rays at the BASELINE shape (B=1, 128^2 rays, 256^2 planes).  Prints a digest of every output
+(image features, depth, weight sum, fine depths, index / order buffers) so that two builds of the kernel (IA_HIP_LIB=...) can be
+compared bit for bit."""
+import hashlib
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
 from invertavatar_amd import hipops, synthetic
 from oracle import renderer as OR
+torch.manual_seed(0)
 B, nrr = int(sys.argv[1]) if len(sys.argv) > 1 else 1, 128
 frames = list(range(B))
 planes = hipops.planes_channels_last(torch.randn(B, 3, 32, 256, 256, device='cuda') * 0.5)
@@ -23,3 +27,11 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 fl = B * nrr * nrr * 96 * 2.0 * (32 * 64 + 64 * 33)       # 13.09 GFLOP per frame
 print(f'B={B}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s algorithmic ({fl/ms/1e9/157.3*100:.1f}% of fp32 peak)')
+rgb, depth, wsum, aux = hipops.render_rays(planes, ro, rd, jit, dist, w0, b0, w1, b1, debug=True)
+h = hashlib.sha256()
+for t in (rgb, depth, wsum, aux['z_fine'], aux['inds'], aux['order'], aux['w_coarse'], aux['sigma_coarse']):
+    h.update(t.cpu().numpy().tobytes())
+print('output digest', h.hexdigest()[:16], ' rgb sum %.9g' % rgb.double().sum().item())
+print('  per output:', ' '.join(n + '=' + hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:8] for n, t in
+                              (('rgb', rgb), ('depth', depth), ('wsum', wsum), ('z_fine', aux['z_fine']), ('inds', aux['inds']),
+                               ('order', aux['order']), ('w_coarse', aux['w_coarse']), ('sigma_coarse', aux['sigma_coarse']))))
