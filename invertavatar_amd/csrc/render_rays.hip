@@ -93,7 +93,13 @@ __device__ __forceinline__ float log_of_normal(float x) {
     const float r = y * ln2_hi;
     return r + __fmaf_rn(y, ln2_lo, __fmaf_rn(y, ln2_hi, -r));
 }
-__device__ __forceinline__ float softplus_fast(float x) { return x > 20.f ? x : log_of_normal(1.f + exp_raw(x)); }
+// Branch-free on purpose (a bit select, not ?:): the 16 softplus of a lane must stay ONE basic block so that their exp / log
+// chains interleave; as 16 conditional blocks each one exposes its own transcendental and LDS latencies.
+__device__ __forceinline__ float softplus_fast(float x) {
+    const float l = log_of_normal(1.f + exp_raw(x));
+    const unsigned big = x > 20.f ? 0xffffffffu : 0u;
+    return __uint_as_float((__float_as_uint(x) & big) | (__float_as_uint(l) & ~big));
+}
 
 // CPU torch.linspace bit rule.
 __device__ __forceinline__ float linspace_at(float s, float e, float step, int k, int n) {
