@@ -274,21 +274,25 @@ __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __rest
         l_off[j] = i < IH * IW ? r * IWP + c : -1;
         g_off[j] = ok ? iy * g.in_w + ix : -1;
     }
-    float v[NLD];
-    auto fetch = [&](int ch) {
+    // two channels in flight per workgroup (register sets v[0], v[1]): with one, a workgroup waits out a full memory round trip per
+    // channel and eight workgroups per CU do not keep enough bytes in flight for the HBM stream
+    float v[2][NLD];
+    auto fetch = [&](int ch, int set) {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) v[j] = g_off[j] >= 0 ? xb[(int64_t)ch * in_plane + g_off[j]] : 0.f;
+        for (int j = 0; j < NLD; ++j) v[set][j] = g_off[j] >= 0 ? xb[(int64_t)ch * in_plane + g_off[j]] : 0.f;
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int set) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j)
-            if (l_off[j] >= 0) in_lds[buf][l_off[j]] = v[j];
+            if (l_off[j] >= 0) in_lds[buf][l_off[j]] = v[set][j];
     };
     const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * RPT;
     const int ox = ox0 + tx;
     const float t_ns = tail.noise ? (tail.noise_strength ? *tail.noise_strength : 1.f) : 0.f;
-    fetch(0);
-    commit(0);
+    fetch(0, 0);
+    fetch(1, 1);
+    commit(0, 0);
+    fetch(2, 0);
     __syncthreads();
     float kf[FS * FS];
 #pragma unroll
@@ -303,7 +307,6 @@ __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __rest
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
         const int buf = ch & 1, c = c8 * 8 + ch;
-        if (ch + 1 < 8) fetch(ch + 1);                            // in flight under the filter below
         const float t_bias = tail.bias ? ((const float*)tail.bias)[c] : 0.f;
         const float sn = styles_next ? styles_next[b * g.c + c] : 1.f;
 #pragma unroll
@@ -324,7 +327,8 @@ __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __rest
             if (planes == 2) { _Float16 h, l; ia::split_f16(t, h, l); hi[r][ch] = h; lo[r][ch] = l; }
             else hi[r][ch] = ia::round_f16(t);
         }
-        if (ch + 1 < 8) commit(buf ^ 1);                          // (its last readers passed the barrier of the previous channel)
+        if (ch + 1 < 8) commit(buf ^ 1, (ch + 1) & 1);            // (its last readers passed the barrier of the previous channel)
+        if (ch + 3 < 8) fetch(ch + 3, (ch + 1) & 1);              // channels ch + 2 and ch + 3 stay in flight under the next filter
         __syncthreads();
     }
     if (ox >= g.out_w) return;
