@@ -254,6 +254,27 @@ __device__ __forceinline__ void decoder_rgb(const float* __restrict__ lds, int l
         }
 }
 
+// Data-parallel-primitive moves inside a row of 16 lanes (the 16 samples of a group live in one DPP row per quarter): register
+// moves on the VALU instead of ds_bpermute round trips through the LDS crossbar.
+//   row_ror<N>: lane s receives lane (s - N) mod 16 of its row (row_ror1: lane 0 receives lane 15);
+//   row_shr<N>: lane s >= N receives lane s - N, lanes below N keep their own value.
+template <int N>
+__device__ __forceinline__ float row_ror(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_ror1(float x) { return row_ror<1>(x); }
+template <int N>
+__device__ __forceinline__ double row_shr(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x110 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x110 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double lane_value(double x, int l) {      // wave-uniform copy of lane l's value (v_readlane, no LDS)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
 // Smoothed inverse-CDF importance resampling of one ray, all in per-wave LDS scratch.
 //   in : tc[48] coarse depths, wc[47] coarse weights        out: tf[48] fine depths, returns ind for lane < 48
 __device__ __forceinline__ int importance_resample(float* scr, int lane) {
@@ -284,18 +305,36 @@ __device__ __forceinline__ int importance_resample(float* scr, int lane) {
     wave_sync();
     if (lane < NS - 3) pdf[lane] = (av[lane + 1] + 1e-5f) / total;
     wave_sync();
-    // cdf[0] = 0, cdf[j] = fl32(sum_{i<j} pdf[i]) accumulated sequentially in fp64 (CPU torch.cumsum, C10)
-    if (lane < NS - 2) {
-        double run = 0.0;
-        for (int i = 0; i < lane; ++i) run += (double)pdf[i];
-        cdf[lane] = (float)run;
+    // cdf[0] = 0, cdf[j] = fl32(sum_{i<j} pdf[i]) accumulated in fp64 (CPU torch.cumsum, C10).  The pdf entries are fp32 numbers
+    // in [1e-4, 1] (every smoothed weight is >= 0.01 of a total <= 46 * 1.02) with a sum of 1, so every partial sum needs at most
+    // 24 + 14 significant bits: the fp64 additions are EXACT and a parallel scan gives the bits of the sequential loop.
+    {
+        const double mine = lane < NS - 3 ? (double)pdf[lane] : 0.0;
+        double incl = mine;
+        { const double u = row_shr<1>(incl); if ((lane & 15) >= 1) incl += u; }
+        { const double u = row_shr<2>(incl); if ((lane & 15) >= 2) incl += u; }
+        { const double u = row_shr<4>(incl); if ((lane & 15) >= 4) incl += u; }
+        { const double u = row_shr<8>(incl); if ((lane & 15) >= 8) incl += u; }
+        const double r0 = lane_value(incl, 15), r1 = lane_value(incl, 31);  // totals of rows 0 and 1 (lanes >= 48 hold no cdf entry)
+        const int row = lane >> 4;
+        const double before = row == 0 ? 0.0 : (row == 1 ? r0 : r0 + r1);
+        if (lane < NS - 2) cdf[lane] = (float)(before + incl - mine);
     }
     wave_sync();
     int ind = 0;
     if (lane < NS) {
         const float ustep = 1.0f / (float)(NS - 1);
         const float u = linspace_at(0.f, 1.f, ustep, lane, NS);
-        for (int j = 0; j < NS - 2; ++j) ind += (cdf[j] <= u) ? 1 : 0;          // searchsorted(right=True)
+        // searchsorted(right=True) on the non-decreasing cdf[0..45]: number of entries <= u, by bisection
+        int lo = 0, hi = NS - 2;                      // the count lies in [lo, hi]
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {              // 2^6 > 47 candidates
+            const int mid = (lo + hi) >> 1;
+            const bool active = lo < hi, le = cdf[mid] <= u;     // (mid <= 46 < NS: always a readable slot)
+            lo = (active && le) ? mid + 1 : lo;
+            hi = (active && !le) ? mid : hi;
+        }
+        ind = lo;
         const int below = max(ind - 1, 0), above = min(ind, NS - 3);
         const float c0 = cdf[below], c1 = cdf[above], b0 = bins[below], b1 = bins[above];
         float denom = c1 - c0;
@@ -312,9 +351,17 @@ __device__ __forceinline__ void merge_sorted(float* scr, int lane, int& pos_c, i
     pos_c = pos_f = 0;
     if (lane < NS) {
         const float a = tc[lane], b = tf[lane];
-        int nc = 0, nf = 0;
-        for (int j = 0; j < NS; ++j) { nc += (tf[j] < a) ? 1 : 0; nf += (tc[j] <= b) ? 1 : 0; }
-        pos_c = lane + nc; pos_f = lane + nf;
+        // both lists ascend: nc = #{tf < a} (lower bound), nf = #{tc <= b} (upper bound), by bisection over 49 candidates each
+        int lc = 0, hc = NS, lf = 0, hf = NS;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int mc = (lc + hc) >> 1, mf = (lf + hf) >> 1;
+            const bool ac = lc < hc, af = lf < hf;
+            const bool c_lt = tf[min(mc, NS - 1)] < a, f_le = tc[min(mf, NS - 1)] <= b;
+            lc = (ac && c_lt) ? mc + 1 : lc; hc = (ac && !c_lt) ? mc : hc;
+            lf = (af && f_le) ? mf + 1 : lf; hf = (af && !f_le) ? mf : hf;
+        }
+        pos_c = lane + lc; pos_f = lane + lf;
         tm[pos_c] = a; tm[pos_f] = b;
     }
     wave_sync();
@@ -482,15 +529,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
                 cur_c[0] = c0.x; cur_c[1] = c0.y; cur_c[2] = c0.z; cur_c[3] = c0.w;
                 cur_c[4] = c1.x; cur_c[5] = c1.y; cur_c[6] = c1.z; cur_c[7] = c1.w;
             }
-            // neighbour (previous sample) values: lane s-1 of the same quarter, or the carry from the previous group
-            float nb_t = __shfl_up(t, 1, 16), nb_sg = __shfl_up(sg, 1, 16), nb_c[8];
+            // neighbour (previous sample) values: lane s-1 of the same quarter; lane 0 takes what the rotation delivered to it in
+            // the previous group (= that group's lane 15)
+            const float rot_t = row_ror1(t), rot_sg = row_ror1(sg);
+            float rot_c[8], nb_c[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) nb_c[c] = __shfl_up(cur_c[c], 1, 16);
-            if (s == 0) {
-                nb_t = prev_t; nb_sg = prev_sg;
+            for (int c = 0; c < 8; ++c) rot_c[c] = row_ror1(cur_c[c]);
+            const float nb_t = (s == 0) ? prev_t : rot_t, nb_sg = (s == 0) ? prev_sg : rot_sg;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) nb_c[c] = prev_c[c];
-            }
+            for (int c = 0; c < 8; ++c) nb_c[c] = (s == 0) ? prev_c[c] : rot_c[c];
             const bool has_interval = (g > 0) || (s > 0);
             float alpha = 0.f;
             double fac = 1.0;
@@ -500,9 +547,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
                 fac = (double)(1.f - alpha + 1e-10f);
             }
             double incl = fac;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) { const double u = __shfl_up(incl, off, 16); if (s >= off) incl *= u; }
-            const double up1 = __shfl_up(incl, 1, 16);
+            { const double u = row_shr<1>(incl); if (s >= 1) incl *= u; }
+            { const double u = row_shr<2>(incl); if (s >= 2) incl *= u; }
+            { const double u = row_shr<4>(incl); if (s >= 4) incl *= u; }
+            { const double u = row_shr<8>(incl); if (s >= 8) incl *= u; }
+            const double up1 = row_shr<1>(incl);
             const double excl = (s == 0) ? 1.0 : up1;
             const float trans = (float)(carry_T * excl);
             carry_T *= __shfl(incl, 15, 16);
@@ -511,18 +560,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             for (int c = 0; c < 8; ++c) acc_c[c] = fmaf(wgt_, (nb_c[c] + cur_c[c]) * 0.5f, acc_c[c]);
             acc_w += wgt_;
             acc_z = fmaf(wgt_, (nb_t + t) * 0.5f, acc_z);
-            prev_t = __shfl(t, 15, 16); prev_sg = __shfl(sg, 15, 16);
+            prev_t = rot_t; prev_sg = rot_sg;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) prev_c[c] = __shfl(cur_c[c], 15, 16);
+            for (int c = 0; c < 8; ++c) prev_c[c] = rot_c[c];
         }
-        // reduce the 16 lanes of each quarter
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc_c[c] += __shfl_xor(acc_c[c], off, 16);
-            acc_w += __shfl_xor(acc_w, off, 16);
-            acc_z += __shfl_xor(acc_z, off, 16);
+        // reduce the 16 lanes of each quarter: rotations by 8, 4, 2, 1 add the same pairs as the xor butterfly (after the step of
+        // distance d the partial sums are periodic with period d), so every lane ends with the butterfly's bits
+#define IA_ROW_SUM_STEP(N)                                                            \
+        {                                                                             \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c) acc_c[c] += row_ror<N>(acc_c[c]); \
+            acc_w += row_ror<N>(acc_w);                                               \
+            acc_z += row_ror<N>(acc_z);                                               \
         }
+        IA_ROW_SUM_STEP(8) IA_ROW_SUM_STEP(4) IA_ROW_SUM_STEP(2) IA_ROW_SUM_STEP(1)
+#undef IA_ROW_SUM_STEP
         if (s == 0) {
             float* out = p.rgb + (int64_t)ray * 32;
 #pragma unroll
