@@ -367,6 +367,9 @@ __device__ __forceinline__ void merge_sorted(float* scr, int lane, int& pos_c, i
     wave_sync();
 }
 
+// SQ: square planes (every tri-plane generator's case).  The gather then sees PH == PW at compile time and the per-axis work of a
+// coordinate that two planes share (x: planes 0, 1 as column and plane 2 as row; z: plane 1 as row, plane 2 as column) is done once.
+template <bool SQ>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
     float blk_min = INFINITY, blk_max = 0.f;
 
     const int nrays = p.B * p.R;
+    const int PHs = SQ ? p.PW : p.PH;
     for (int ray0 = blockIdx.x * WAVES; ray0 < nrays; ray0 += gridDim.x * WAVES) {
         const int ray = __builtin_amdgcn_readfirstlane(ray0 + wave);      // wave-uniform: ray constants and the plane base are scalars
         if (ray >= nrays) continue;
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         float4 raw[24]; float wgt[12];
         {
             const float t = tc[gj];
-            gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+            gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
         }
 #pragma unroll 1
         for (int g = 0; g < NS / 16; ++g) {
@@ -423,13 +427,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             asm volatile("" ::: "memory");   // decoder weights are re-read from LDS every group: their registers hold the prefetched texels
             {
                 const float t = tc[16 * g + gj];
-                gather_issue<kEarlyPlanes, 3>(planes_b, p.PH, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                gather_issue<kEarlyPlanes, 3>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
             }
             gather_reduce(raw, wgt, f);
             features_to_operand(scr + COL_OFF + (16 * g) * 32, gj, gc, s, q, f);
             if (g + 1 < NS / 16) {      // next group's loads fly under this group's decoder
                 const float t = tc[16 * (g + 1) + gj];
-                gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
             }
             decoder_hidden(lds, lane, q, f, h);
             const float sg = decoder_sigma(lds, q, h);
@@ -482,19 +486,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             const float* tf = scr + 7 * NS;
             {
                 const float t = tf[gj];
-                gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
             }
 #pragma unroll 1
             for (int g = 0; g < NS / 16; ++g) {
                 const float t = tf[16 * g + gj];
                 float f[8]; f32x4 h[4], col[2];
                 asm volatile("" ::: "memory");
-                gather_issue<kEarlyPlanes, 3>(planes_b, p.PH, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                gather_issue<kEarlyPlanes, 3>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
                 gather_reduce(raw, wgt, f);
                 features_to_operand(scr + COL_OFF + (NS + 16 * g) * 32, gj, gc, s, q, f);
                 if (g + 1 < NS / 16) {
                     const float tn = tf[16 * (g + 1) + gj];
-                    gather_issue<0, kEarlyPlanes>(planes_b, p.PH, p.PW, gc, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * p.box_scale, raw, wgt);
+                    gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * p.box_scale, raw, wgt);
                 }
                 decoder_hidden(lds, lane, q, f, h);
                 const float sg = decoder_sigma(lds, q, h);
@@ -676,8 +680,9 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
     const int grid = ia_render_rays_grid(B, R);
     hipStream_t s = (hipStream_t)stream;
     static_assert(LDS_FLOATS * sizeof(float) <= 160 * 1024, "one workgroup must fit a CU's LDS");
-    (void)hipFuncSetAttribute((const void*)render_rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_FLOATS * sizeof(float)));
-    hipLaunchKernelGGL(render_rays_kernel, dim3(grid), dim3(WAVES * 64), LDS_FLOATS * sizeof(float), s, p);
+    const auto kernel = plane_h == plane_w ? render_rays_kernel<true> : render_rays_kernel<false>;
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_FLOATS * sizeof(float)));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), LDS_FLOATS * sizeof(float), s, p);
     int st = ia::check_launch("ia_render_rays");
     if (st != IA_OK) return st;
     hipLaunchKernelGGL(render_finalize_kernel, dim3(ia::streaming_grid((int64_t)B * R, 256)), dim3(256), 0, s, depth, minmax_scratch, grid, B * R);

@@ -55,10 +55,12 @@ def test_fused_renderer_vs_reference_fixture(golden):
     assert max_abs(wsum.cpu(), g['wsum']) <= 1e-4
 
 
-@pytest.mark.parametrize('res,nrr,batch', [(256, 32, 1), (64, 16, 3), (8, 8, 1)])
+@pytest.mark.parametrize('res,nrr,batch', [(256, 32, 1), (64, 16, 3), (8, 8, 1), ((48, 80), 16, 2)])
 def test_fused_renderer_vs_oracle(res, nrr, batch):
+    """Square planes take the kernel's shared-axis instantiation, the (48, 80) case the general one."""
     frames = list(range(7, 7 + batch))
-    planes = rnd(30 + res, batch, 3, 32, res, res)
+    ph, pw = res if isinstance(res, tuple) else (res, res)
+    planes = rnd(30 + ph, batch, 3, 32, ph, pw)
     cams = synthetic.camera_labels(frames)
     ro, rd = OR.ray_sampler_zxc(cams[:, :16].view(-1, 4, 4), cams[:, 16:25].view(-1, 3, 3), nrr)
     jit = synthetic.jitter(frames, nrr * nrr)
