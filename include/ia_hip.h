@@ -417,6 +417,15 @@ int ia_uv_rasterize(const float* verts, const int* tris, const float* face_attrs
  */
 int ia_layout_grid_u8(const float* img, uint8_t* out, int B, int C, int H, int W, int grid_w, int grid_h, int chw_to_hwc, void* stream);
 
+/*
+ * Input side of a captured frame: n <= 8 device-to-device segment copies in ONE launch (src[k] -> dst[k], nbytes[k] bytes).
+ * The frame loop of the reference hands synthesis() fresh tensors every frame (reenact_avatar_next3d.py:196-214: ws, camera,
+ * uvcoords_image); a replayed hipGraph reads fixed buffers, so the per-frame inputs are copied into them first -- with this entry
+ * point as one kernel instead of one copy launch per tensor (4 x ~12 us on the frame's critical path).
+ *   src, dst, nbytes : HOST arrays of n device pointers / byte counts (any alignment; 16-byte aligned segments move as uint4)
+ */
+int ia_stage_inputs(const void* const* src, void* const* dst, const int64_t* nbytes, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,12 +56,12 @@ class GraphedSynthesis:
     def __call__(self, ws, c, uvcoords_image, jitter, ray_dist=None):
         if (ray_dist is None) != (self.ray_dist is None):
             raise ValueError('ray_dist must be passed exactly when the graph was built with with_ray_dist=True')
+        from . import hipops
+        pairs = [(ws if ws.shape == self.ws.shape else ws.expand_as(self.ws), self.ws), (c[:, -25:], self.c),
+                 (uvcoords_image, self.uv), (jitter.reshape(self.jitter.shape), self.jitter)]
         if ray_dist is not None:
-            self.ray_dist.copy_(ray_dist.reshape(1))
-        self.ws.copy_(ws.expand_as(self.ws))
-        self.c.copy_(c[:, -25:])
-        self.uv.copy_(uvcoords_image)
-        self.jitter.copy_(jitter.reshape(self.jitter.shape))
+            pairs.append((ray_dist.reshape(1), self.ray_dist))
+        hipops.stage_inputs(pairs)          # one launch for the frame's inputs (strided / broadcast sources: Tensor.copy_)
         if self.graph is None:
             self.capture()
         self.graph.replay()
@@ -98,10 +98,9 @@ class FramePipeline:
         done_prev = self.pending[i]
         stream.wait_stream(main)                       # inputs produced on the caller's stream are ready
         with torch.cuda.stream(stream):
-            slot.ws.copy_(ws.expand_as(slot.ws), non_blocking=True)
-            slot.c.copy_(c[:, -25:], non_blocking=True)
-            slot.uv.copy_(uvcoords_image, non_blocking=True)
-            slot.jitter.copy_(jitter.reshape(slot.jitter.shape), non_blocking=True)
+            from . import hipops
+            hipops.stage_inputs([(ws if ws.shape == slot.ws.shape else ws.expand_as(slot.ws), slot.ws), (c[:, -25:], slot.c),
+                                 (uvcoords_image, slot.uv), (jitter.reshape(slot.jitter.shape), slot.jitter)])
             slot.graph.replay()
             ev = torch.cuda.Event()
             ev.record(stream)

@@ -604,3 +604,27 @@ def convgru_update(gates_pre, cand_pre, h, prelu_weight=None, x_next=None):
     _lib.check(st, 'ia_convgru_update')
     return h_out, xh
 
+
+
+def stage_inputs(pairs):
+    """Copy each (src, dst) pair of same-shaped contiguous device tensors in ONE launch (ia_stage_inputs): the per-frame inputs
+    of a captured frame into the graph's static buffers.  Pairs the kernel cannot take (broadcast / strided / other dtype sources)
+    fall through to Tensor.copy_."""
+    import ctypes
+    segs = []
+    for src, dst in pairs:
+        if (src.is_cuda and src.device == dst.device and src.dtype == dst.dtype and src.shape == dst.shape
+                and src.is_contiguous() and dst.is_contiguous() and src.numel() > 0):
+            segs.append((src, dst))
+        else:
+            dst.copy_(src)
+    for i in range(0, len(segs), 8):
+        part = segs[i:i + 8]
+        n = len(part)
+        srcs = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_, _ in part])
+        dsts = (ctypes.c_void_p * n)(*[d_.data_ptr() for _, d_ in part])
+        nbytes = (ctypes.c_int64 * n)(*[s_.numel() * s_.element_size() for s_, _ in part])
+        dev = part[0][1].device
+        with torch.cuda.device(dev):
+            st = _lib.load().ia_stage_inputs(srcs, dsts, nbytes, n, _lib.stream_ptr(dev))
+        _lib.check(st, 'ia_stage_inputs')

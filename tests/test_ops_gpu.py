@@ -119,3 +119,17 @@ def test_cond_blend_is_the_reference_expression_bit_for_bit():
     a = cond[:, -1:]
     ref = cond[:, :-1] * a + x * (1 - a)
     assert torch.equal(hipops.cond_blend(cond, x), ref)
+
+
+def test_stage_inputs_copies_segments_in_one_launch():
+    from invertavatar_amd import hipops
+    """ia_stage_inputs: aligned and unaligned segments, odd byte counts, a strided source (falls through to copy_)."""
+    torch.manual_seed(3)
+    big = torch.randn(128 * 128 * 48 + 3, device='cuda')
+    srcs = [torch.randn(1, 14, 512, device='cuda'), torch.randn(1, 25, device='cuda'), big[1:],        # big[1:]: 4-byte aligned only
+            torch.randint(0, 255, (4099,), device='cuda', dtype=torch.uint8), torch.randn(6, 10, device='cuda')[:, ::2]]
+    dsts = [torch.zeros_like(s, memory_format=torch.contiguous_format) for s in srcs]
+    hipops.stage_inputs(list(zip(srcs, dsts)))
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(s, d)
