@@ -179,6 +179,9 @@ int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed,
  */
 int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B, int I, int O, void* stream);
 
+#define IA_RENDER_WHITE_BACK 1
+#define IA_RENDER_RGB_CHANNEL_MAJOR 2
+
 /*
  * The fused importance renderer: one launch replaces ImportanceRenderer_bsMotion.forward(evaluation=True)
  * (training_avatar_texture/volumetric_rendering/renderer.py:309-351) together with sample_from_planes (:85-97),
@@ -192,8 +195,11 @@ int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B,
  *   w0,b0,w1,b1 : OSGDecoder parameters net.0.weight [64,32], net.0.bias [64], net.2.weight [33,64], net.2.bias [33]
  *               (un-scaled; lr_multiplier = decoder_lr_mul is applied as FullyConnectedLayer does)
  *   n_coarse / n_importance : must both be 48 (train_avatar_texture.py:341-342); others -> IA_ERR_UNSUPPORTED
- *   rgb  : [B, R, 32] composited features scaled to (-1, 1);  depth : [B, R] clamped to the batch-global sample
- *          range;  wsum : [B, R] sum of compositing weights
+ *   flags : bit 0 (IA_RENDER_WHITE_BACK) = rendering_kwargs['white_back']; bit 1 (IA_RENDER_RGB_CHANNEL_MAJOR) = store rgb as
+ *          [B, 32, R] -- the feature image [B, 32, nrr, nrr] the super-resolution head reads (triplane_v20.py:313) -- instead of
+ *          the renderer's [B, R, 32], which saves the permute + copy between the renderer and the head
+ *   rgb  : [B, R, 32] (or [B, 32, R], see flags) composited features scaled to (-1, 1);  depth : [B, R] clamped to the
+ *          batch-global sample range;  wsum : [B, R] sum of compositing weights
  *   minmax_scratch : 2 * ia_render_rays_grid(B, R) floats of caller scratch
  *   dbg_* : optional stage outputs for parity tests (NULL in production): fine depths [B,R,48], searchsorted
  *          indices [B,R,48] (int32), merge order [B,R,96] (int32, < 48 = coarse sample, >= 48 = fine sample),
@@ -201,7 +207,7 @@ int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B,
  */
 int ia_render_rays(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
                    const float* dist, const float* w0, const float* b0, const float* w1, const float* b1,
-                   float lr_multiplier, float box_warp, int white_back,
+                   float lr_multiplier, float box_warp, int flags,
                    int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
                    float* rgb, float* depth, float* wsum, float* minmax_scratch,
                    float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,

@@ -52,8 +52,8 @@ struct Params {
     float w0_gain, w1_gain, b_gain;
     float box_scale;              // 2 / box_warp
     int B, R, PH, PW;
-    int white_back;
-    float* rgb;                   // [B][R][32]
+    int white_back, channel_major;
+    float* rgb;                   // [B][R][32], or [B][32][R] when channel_major
     float* depth;                 // [B][R]   un-clamped (may be +inf), see ia_render_finalize
     float* wsum;                  // [B][R]
     float* minmax;                // [gridDim.x][2] per-workgroup min / max of all sample depths
@@ -579,12 +579,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         IA_ROW_SUM_STEP(8) IA_ROW_SUM_STEP(4) IA_ROW_SUM_STEP(2) IA_ROW_SUM_STEP(1)
 #undef IA_ROW_SUM_STEP
         if (s == 0) {
-            float* out = p.rgb + (int64_t)ray * 32;
+            const int64_t ch_stride = p.channel_major ? p.R : 1;
+            float* out = p.channel_major ? p.rgb + (int64_t)b * 32 * p.R + (ray - b * p.R) : p.rgb + (int64_t)ray * 32;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 float v = acc_c[c];
                 if (p.white_back) v = v + 1.f - acc_w;
-                out[16 * (c >> 2) + 4 * q + (c & 3)] = v * 2.f - 1.f;
+                out[(16 * (c >> 2) + 4 * q + (c & 3)) * ch_stride] = v * 2.f - 1.f;
             }
             if (q == 0) {
                 float dpt = acc_z / acc_w;
@@ -654,7 +655,7 @@ extern "C" int ia_render_rays_grid(int B, int R) {
 
 extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
                               const float* dist, const float* w0, const float* b0, const float* w1, const float* b1,
-                              float lr_multiplier, float box_warp, int white_back,
+                              float lr_multiplier, float box_warp, int flags,
                               int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
                               float* rgb, float* depth, float* wsum, float* minmax_scratch,
                               float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
@@ -673,7 +674,8 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
     p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
     p.w0_gain = lr_multiplier / sqrtf(32.f); p.w1_gain = lr_multiplier / sqrtf(64.f); p.b_gain = lr_multiplier;
     p.box_scale = 2.f / box_warp;
-    p.B = B; p.R = R; p.PH = plane_h; p.PW = plane_w; p.white_back = white_back;
+    p.B = B; p.R = R; p.PH = plane_h; p.PW = plane_w;
+    p.white_back = (flags & IA_RENDER_WHITE_BACK) != 0; p.channel_major = (flags & IA_RENDER_RGB_CHANNEL_MAJOR) != 0;
     p.rgb = rgb; p.depth = depth; p.wsum = wsum; p.minmax = minmax_scratch;
     p.dbg_z_fine = dbg_z_fine; p.dbg_inds = dbg_inds; p.dbg_order = dbg_order; p.dbg_w_coarse = dbg_w_coarse;
     p.dbg_sigma_coarse = dbg_sigma_coarse;

@@ -608,7 +608,9 @@ class SynthesisBlock(torch.nn.Module):
             fused_modconv = (not self.training)
 
         if self.in_channels == 0:
-            x = self.const.to(dtype=dtype, memory_format=fmt).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+            x = self.const.to(dtype=dtype, memory_format=fmt).unsqueeze(0)
+            if ws.shape[0] != 1:      # (one frame: conv1 reads the parameter in place -- no copy launch at the head of the network)
+                x = x.repeat([ws.shape[0], 1, 1, 1])
         elif not isinstance(x, hipops.SplitAct):      # (a SplitAct was made for conv0 by its producer; conv0 checks its shape)
             misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
             x = x.to(dtype=dtype, memory_format=fmt)

@@ -206,7 +206,8 @@ class ImportanceRenderer_bsMotion(_RendererBase):
             return hipops.render_rays(planes_cl, ray_origins.contiguous(), ray_directions.contiguous(),
                                       jitter, dist, decoder.net[0].weight.detach(), decoder.net[0].bias.detach(),
                                       decoder.net[2].weight.detach(), decoder.net[2].bias.detach(), lr_multiplier=lr_mul,
-                                      box_warp=rendering_options['box_warp'], white_back=rendering_options.get('white_back', False))
+                                      box_warp=rendering_options['box_warp'], white_back=rendering_options.get('white_back', False),
+                                      channel_major=True)     # [B,R,32] view of a [B,32,R] image: the caller's permute is free
         # torch definition (CPU tensors, training, non-standard options)
         self.plane_axes = self.plane_axes.to(ray_origins.device)
         dist = torch.norm(ray_origins, dim=-1).mean().item() if dist is None else float(dist.reshape(-1)[0].item())

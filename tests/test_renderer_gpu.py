@@ -72,6 +72,24 @@ def test_fused_renderer_vs_oracle(res, nrr, batch):
     assert max_abs(wsum.cpu(), ref_w) <= 1e-4
 
 
+def test_channel_major_output_is_the_same_image():
+    """ia_render_rays with IA_RENDER_RGB_CHANNEL_MAJOR: the [B,R,32] view equals the default output bit for bit, and its
+    permutation to [B,32,nrr,nrr] (what TriPlaneGenerator._render builds) is contiguous without a copy."""
+    nrr, frames = 16, [3, 4]
+    planes = hipops.planes_channels_last(rnd(77, 2, 3, 32, 64, 64).cuda())
+    cams = synthetic.camera_labels(frames)
+    ro, rd = OR.ray_sampler_zxc(cams[:, :16].view(-1, 4, 4), cams[:, 16:25].view(-1, 3, 3), nrr)
+    ro, rd = ro.cuda().contiguous(), rd.cuda().contiguous()
+    jit = synthetic.jitter(frames, nrr * nrr).squeeze(-1).cuda().contiguous()
+    dist = torch.norm(ro, dim=-1).mean().reshape(1)
+    dec = {k: v.cuda() for k, v in _decoder().items()}
+    args = (planes, ro, rd, jit, dist, dec['net.0.weight'], dec['net.0.bias'], dec['net.2.weight'], dec['net.2.bias'])
+    a = hipops.render_rays(*args)
+    b = hipops.render_rays(*args, channel_major=True)
+    assert b[0].shape == a[0].shape and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert b[0].permute(0, 2, 1).reshape(2, 32, nrr, nrr).is_contiguous() and not a[0].permute(0, 2, 1).is_contiguous()
+
+
 def test_empty_space_depth_clamp_and_properties():
     """Strongly negative densities: weights vanish, depth is NaN -> +inf -> clamped to the global max sample depth."""
     nrr = 16
