@@ -588,7 +588,7 @@ class SynthesisBlock(torch.nn.Module):
                                     resample_filter=resample_filter, channels_last=self.channels_last)
 
     def forward(self, x, img, ws, condition=None, force_fp32=False, fused_modconv=None, update_emas=False, _next_conv=None, _next_half=None,
-                _x_unused=False, **layer_kwargs):
+                _x_unused=False, _img_stream=None, _img_wait=None, **layer_kwargs):
         """`_next_conv`: the layer that consumes this block's x (the next block's conv0), given by the owning network on the device
         inference path so that conv1 can emit its result in the format that layer reads (hipops.SplitAct).
         `_x_unused`: the caller drops the returned x (last block of a head): conv1 may then evaluate ToRGB in its epilogue and x comes
@@ -631,6 +631,8 @@ class SynthesisBlock(torch.nn.Module):
                 half = int(x.size(1) // 2)
                 x = torch.cat([x[:, :half], x[:, half:] * condition[0] + condition[1]], dim=1)
             fused_img = None
+            if _img_wait is not None:      # the incoming skip image was made on a side stream (see _img_stream below): join it here
+                torch.cuda.current_stream(x.device if torch.is_tensor(x) else ws.device).wait_stream(_img_wait)
             if _x_unused and condition is None and (self.is_last or self.architecture == 'skip'):
                 w_conv1, w_rgb = next(w_iter), next(w_iter)
                 fused_img = self.conv1.forward_with_torgb(x, w_conv1, self.torgb, w_rgb, img, self.resample_filter, **layer_kwargs)
@@ -643,8 +645,17 @@ class SynthesisBlock(torch.nn.Module):
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
         if self.is_last or self.architecture == 'skip':
             # img = upsample2d(img) + torgb(x): the add happens in the ToRGB epilogue
-            img = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, skip=img, resample_filter=self.resample_filter)
-            img = img.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            if _img_stream is not None and torch.is_tensor(x) and x.is_cuda:
+                # The skip image is not an input of the next block's convolutions: a caller whose machine is otherwise idle (the
+                # SR head) lets it run beside them.  The caller keeps x alive until it has joined the stream (_img_wait).
+                cur = torch.cuda.current_stream(x.device)
+                _img_stream.wait_stream(cur)
+                with torch.cuda.stream(_img_stream):
+                    img = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, skip=img, resample_filter=self.resample_filter)
+                    img = img.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            else:
+                img = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, skip=img, resample_filter=self.resample_filter)
+                img = img.to(dtype=torch.float32, memory_format=torch.contiguous_format)
         elif img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
 

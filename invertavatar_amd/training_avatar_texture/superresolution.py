@@ -24,6 +24,10 @@ def _fit(x, rgb, size, antialias):
     return x, rgb
 
 
+import os as _os
+SKIP_IMAGE_STREAM = _os.environ.get('IA_SKIP_IMAGE_STREAM', '1') != '0'     # block0's skip image on a side stream (see _TwoBlockHead.forward)
+
+
 class _TwoBlockHead(torch.nn.Module):
     """block0 then block1, both fed the last w three times."""
 
@@ -60,9 +64,22 @@ class _TwoBlockHead(torch.nn.Module):
             from ..training import networks_stylegan2 as sg2
             next_half = bool(getattr(self.block1, 'use_fp16', False)) and ws.is_cuda and not sg2.FP16_BLOCKS_COMPUTE_FP32
             chain = dict(_next_conv=getattr(self.block1, 'conv0', None), _next_half=next_half)
-        x, rgb = self.block0(x, rgb, ws, **chain, **block_kwargs)
+        side = None
+        if SKIP_IMAGE_STREAM and x.is_cuda and isinstance(self.block0, SynthesisBlock) and isinstance(self.block1, SynthesisBlock) \
+                and not torch.is_grad_enabled():
+            # block0's ToRGB (+ the up-sampling of the incoming image) feeds only the final image: on a side stream it runs beside
+            # block1.conv0 instead of between the two largest convolutions of the frame (nothing else occupies the GPU here)
+            side = getattr(rt, 'img_stream', None)
+            if side is None or side.device != x.device:
+                side = rt.img_stream = torch.cuda.Stream(device=x.device)
+            chain['_img_stream'] = side
+        rgb_in = rgb                     # read on the side stream: must outlive the join as well
+        x0, rgb = self.block0(x, rgb, ws, **chain, **block_kwargs)
         last = dict(_x_unused=True) if isinstance(self.block1, SynthesisBlock) else {}      # block1's x has no reader: ToRGB in conv1's epilogue
-        x, rgb = self.block1(x, rgb, ws, **last, **block_kwargs)
+        if side is not None:
+            last['_img_wait'] = side
+        x, rgb = self.block1(x0, rgb, ws, **last, **block_kwargs)
+        del x0, rgb_in                   # (block0's features and input image stayed alive until block1 had joined the side stream)
         return rgb
 
 
