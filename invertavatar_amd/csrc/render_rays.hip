@@ -73,7 +73,8 @@ constexpr int B0_OFF = WS_OFF + 64;             // [64]
 constexpr int B1_OFF = B0_OFF + 64;             // [33] (+pad)
 constexpr int SCR_OFF = B1_OFF + 40;            // per-wave scratch
 constexpr int COL_OFF = 10 * NS;                // colours of the 96 samples, [sample][quarter][8] (coarse 0..47, fine 48..95)
-constexpr int SGF_OFF = COL_OFF + NM * 32;      // densities of the fine samples [48]
+constexpr int CS = 36;                          // floats per colour slot: 32 + 4 of padding (slots 128 bytes apart put the 16 samples of a group on two banks)
+constexpr int SGF_OFF = COL_OFF + NM * CS;      // densities of the fine samples [48]
 constexpr int SRC_OFF = SGF_OFF + NS;           // merged slot -> sample index [96] (int)
 constexpr int SCR = SRC_OFF + NM;               // tc, sc, wc, av, pdf, cdf, bins, tf (8 x 48) + tm (96) + the above
 constexpr int LDS_FLOATS = SCR_OFF + WAVES * SCR;
@@ -197,11 +198,11 @@ __device__ __forceinline__ void gather_reduce(const float4 (&raw)[24], const flo
 // In : f = channels {4c..4c+3, 16+4c..16+4c+3} of sample gj (what gather_reduce leaves in lane 4*gj + c).
 // Out: f = channels 8q..8q+7 of sample s (lane s + 16q): the B operand of layer 1, k-slot q, k-step t <-> channel 8q + t.
 __device__ __forceinline__ void features_to_operand(float* group_slots, int gj, int gc, int s, int q, float (&f)[8]) {
-    float4* w = reinterpret_cast<float4*>(group_slots + gj * 32 + 4 * gc);
+    float4* w = reinterpret_cast<float4*>(group_slots + gj * CS + 4 * gc);
     w[0] = make_float4(f[0], f[1], f[2], f[3]);
     w[4] = make_float4(f[4], f[5], f[6], f[7]);
     wave_sync();
-    const float4* r = reinterpret_cast<const float4*>(group_slots + s * 32 + 8 * q);
+    const float4* r = reinterpret_cast<const float4*>(group_slots + s * CS + 8 * q);
     const float4 a = r[0], b = r[1];
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
                 gather_issue<kEarlyPlanes, 3>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
             }
             gather_reduce(raw, wgt, f);
-            features_to_operand(scr + COL_OFF + (16 * g) * 32, gj, gc, s, q, f);
+            features_to_operand(scr + COL_OFF + (16 * g) * CS, gj, gc, s, q, f);
             if (g + 1 < NS / 16) {      // next group's loads fly under this group's decoder
                 const float t = tc[16 * (g + 1) + gj];
                 gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             if (q == 0) sc[16 * g + s] = sg;
             f32x4 col[2];
             decoder_rgb(lds, lane, q, h, col);
-            float4* dst = reinterpret_cast<float4*>(scr + COL_OFF + (16 * g + s) * 32 + 8 * q);
+            float4* dst = reinterpret_cast<float4*>(scr + COL_OFF + (16 * g + s) * CS + 8 * q);
             dst[0] = make_float4(col[0][0], col[0][1], col[0][2], col[0][3]);
             dst[1] = make_float4(col[1][0], col[1][1], col[1][2], col[1][3]);
         }
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
                 asm volatile("" ::: "memory");
                 gather_issue<kEarlyPlanes, 3>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
                 gather_reduce(raw, wgt, f);
-                features_to_operand(scr + COL_OFF + (NS + 16 * g) * 32, gj, gc, s, q, f);
+                features_to_operand(scr + COL_OFF + (NS + 16 * g) * CS, gj, gc, s, q, f);
                 if (g + 1 < NS / 16) {
                     const float tn = tf[16 * (g + 1) + gj];
                     gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * p.box_scale, raw, wgt);
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
                 const float sg = decoder_sigma(lds, q, h);
                 if (q == 0) scr[SGF_OFF + 16 * g + s] = sg;
                 decoder_rgb(lds, lane, q, h, col);
-                float4* dst = reinterpret_cast<float4*>(scr + COL_OFF + (NS + 16 * g + s) * 32 + 8 * q);
+                float4* dst = reinterpret_cast<float4*>(scr + COL_OFF + (NS + 16 * g + s) * CS + 8 * q);
                 dst[0] = make_float4(col[0][0], col[0][1], col[0][2], col[0][3]);
                 dst[1] = make_float4(col[1][0], col[1][1], col[1][2], col[1][3]);
             }
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             const float sg = si < NS ? sc[si] : scr[SGF_OFF + si - NS];
             float cur_c[8];
             {
-                const float4* cs = reinterpret_cast<const float4*>(scr + COL_OFF + si * 32 + 8 * q);
+                const float4* cs = reinterpret_cast<const float4*>(scr + COL_OFF + si * CS + 8 * q);
                 const float4 c0 = cs[0], c1 = cs[1];
                 cur_c[0] = c0.x; cur_c[1] = c0.y; cur_c[2] = c0.z; cur_c[3] = c0.w;
                 cur_c[4] = c1.x; cur_c[5] = c1.y; cur_c[6] = c1.z; cur_c[7] = c1.w;
