@@ -74,3 +74,14 @@ def test_streaming_torgb_shape_rules():
     assert hipops.conv_sx_rgb_supported(1, 128, 128, 512, 512) and hipops.conv_sx_rgb_supported(1, 128, 128, 256, 256)
     assert not hipops.conv_sx_rgb_supported(1, 256, 256, 256, 256)  # two channel tiles
     assert not hipops.conv_sx_rgb_supported(1, 128, 128, 128, 128)  # stream-K layer
+
+
+def test_stage_inputs_host_tensors_take_the_copy_route():
+    """hipops.stage_inputs: pairs the one-launch kernel cannot take (host tensors here; strided / broadcast sources on the device)
+    are copied by Tensor.copy_ -- the captured-frame wrapper works unchanged for a CPU generator."""
+    import torch
+    from invertavatar_amd import hipops
+    src = [torch.arange(12.).reshape(3, 4), torch.arange(6.).reshape(2, 3)[:, ::2]]
+    dst = [torch.zeros(3, 4), torch.zeros(2, 2)]
+    hipops.stage_inputs(list(zip(src, dst)))
+    assert all(torch.equal(s, d) for s, d in zip(src, dst))
