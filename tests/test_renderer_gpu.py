@@ -90,6 +90,24 @@ def test_channel_major_output_is_the_same_image():
     assert b[0].permute(0, 2, 1).reshape(2, 32, nrr, nrr).is_contiguous() and not a[0].permute(0, 2, 1).is_contiguous()
 
 
+def test_render_rays_is_run_to_run_deterministic():
+    """Three launches on the same inputs give the same bits in every output and stage buffer (an experimental decoder variant of
+    r02 that mixed fp16 and fp32 MFMAs did not: DESIGN 4.2)."""
+    nrr, frames = 32, [5]
+    planes = hipops.planes_channels_last(rnd(91, 1, 3, 32, 128, 128).cuda())
+    cams = synthetic.camera_labels(frames)
+    ro, rd = OR.ray_sampler_zxc(cams[:, :16].view(-1, 4, 4), cams[:, 16:25].view(-1, 3, 3), nrr)
+    ro, rd = ro.cuda().contiguous(), rd.cuda().contiguous()
+    jit = synthetic.jitter(frames, nrr * nrr).squeeze(-1).cuda().contiguous()
+    dist = torch.norm(ro, dim=-1).mean().reshape(1)
+    dec = {k: v.cuda() for k, v in _decoder().items()}
+    args = (planes, ro, rd, jit, dist, dec['net.0.weight'], dec['net.0.bias'], dec['net.2.weight'], dec['net.2.bias'])
+    runs = [hipops.render_rays(*args, debug=True) for _ in range(3)]
+    for other in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0][:3], other[:3]))
+        assert all(torch.equal(runs[0][3][k], other[3][k]) for k in runs[0][3])
+
+
 def test_empty_space_depth_clamp_and_properties():
     """Strongly negative densities: weights vanish, depth is NaN -> +inf -> clamped to the global max sample depth."""
     nrr = 16
