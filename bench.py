@@ -12,8 +12,13 @@ per GPU, RCCL over xGMI).  A step = one pass of the generator hot path over one 
          rate of the same per-rank work (8 frames per call) is printed at N = 1 as `batch8`.
 
 Inputs are resident in HBM before the timed region; EXACTLY K steps are timed between barrier + synchronize pairs, MAX
-over ranks; rank 0 prints ONE JSON line.  Other workloads: --workload drive (BASELINE configs[4]: cached identity features,
-256 drive frames sharded over the ranks, SR head in its deployed fp16 precision).
+over ranks; rank 0 prints ONE JSON line.  Other workloads: --workload drive (BASELINE configs[4]: few-shot ConvGRU inversion of
+8 source frames -> identity features, then 256 drive frames sharded over the ranks in calls of 8, SR head in its deployed fp16
+precision; the per-rank call is a captured hipGraph).
+
+Plumbing switches for the test-suite / one-GPU rehearsals of the N > 1 path (never used by the driver): --dist-backend gloo
+(collectives over gloo instead of RCCL: several ranks can then share ONE GPU), --device cpu (the product's CPU formulation, eager),
+--nrr (neural rendering resolution, 128 = BASELINE).
 
 Extra legs on rank 0 at N == 1 (all outside the timed region):
   sustained    -- the same step repeated until the GPU has been busy for >= 2 s (an external sampler can see it)
@@ -44,7 +49,13 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense fp16 MFMA
 PEAK_HBM_GBS = 8000.0
 NRR = 128
 FRAMES_PER_RANK_SHARDED = 8     # configs[3]: B = 64 over 8 GPUs
-PMC_FILE = os.path.join(REPO, 'profiles', 'r02_pmc_frame_hbm_traffic.json')
+PMC_FILE = os.path.join(REPO, 'profiles', 'r03_pmc_frame_hbm_traffic.json')
+DEV = torch.device('cuda')      # set by setup_distributed
+
+
+def sync():
+    if DEV.type == 'cuda':
+        torch.cuda.synchronize()
 
 
 def parse():
@@ -61,21 +72,41 @@ def parse():
     ap.add_argument('--no-extra', action='store_true', help='skip the variant legs (f32_mfma_only, sr_fp16, drive_loop, batch8, encoder)')
     ap.add_argument('--cpu-frames', type=int, default=3)
     ap.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL over xGMI (the product); gloo: rehearsal plumbing')
+    ap.add_argument('--device', default='cuda', choices=['cuda', 'cpu'], help='cpu: CPU formulation of the API mirror (test-suite plumbing)')
+    ap.add_argument('--nrr', type=int, default=128, help='neural rendering resolution (BASELINE: 128)')
+    ap.add_argument('--features', default='encoder', choices=['encoder', 'backbone'],
+                    help='--workload drive: identity features from the few-shot inversion (configs[4]) or straight from the backbones')
+    ap.add_argument('--drive-frames', type=int, default=256, help='--workload drive: length of the drive sequence (BASELINE: 256)')
     return ap.parse_args()
 
 
-def setup_distributed(n):
+def setup_distributed(args):
+    global DEV, NRR
+    NRR = args.nrr
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    if n > 1 or world > 1:
+    if args.device == 'cuda':
+        idx = local % torch.cuda.device_count()        # (gloo rehearsal: more ranks than GPUs share them)
+        torch.cuda.set_device(idx)
+        DEV = torch.device('cuda', idx)
+    else:
+        DEV = torch.device('cpu')
+    if args.gpus > 1 or world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        torch.cuda.set_device(local)
-        torch.distributed.init_process_group('nccl', rank=rank, world_size=world)   # nccl == RCCL on ROCm
-    else:
-        torch.cuda.set_device(0)
+        torch.distributed.init_process_group(args.dist_backend, rank=rank, world_size=world)   # nccl == RCCL on ROCm
     return rank, world, local
+
+
+def all_gather_frames(gathered, part):
+    """ONE collective per step: every rank's [per, ...] block into the [world * per, ...] batch."""
+    if torch.distributed.get_backend() == 'gloo':      # (gloo has no _allgather_base for every dtype / device: list form, same bytes)
+        torch.distributed.all_gather(list(gathered.chunk(torch.distributed.get_world_size())), part)
+    else:
+        torch.distributed.all_gather_into_tensor(gathered, part)
+    return gathered
 
 
 class Workload:
@@ -85,17 +116,18 @@ class Workload:
     def __init__(self, gen, per_rank, rank, world, n_sets):
         self.per_rank, self.rank, self.world, self.n_sets = per_rank, rank, world, n_sets
         batch = per_rank * world
-        self.ws = gen.mapping(synthetic.latent(0, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14)
-        self.cams, self.uvs, self.jits, self.dists, self.frames = [], [], [], [], []
+        self.ws = gen.mapping(synthetic.latent(0, 1).to(DEV), synthetic.conditioning_camera().to(DEV), truncation_psi=0.7, truncation_cutoff=14)
+        self.cams, self.uvs, self.jits, self.dists, self.frames, self.frame_dists = [], [], [], [], [], []
         for s in range(n_sets):
             frames_all = [(s * batch + j) % 240 for j in range(batch)]
             mine = frames_all[rank * per_rank:(rank + 1) * per_rank]
-            cams_all = synthetic.camera_labels(frames_all).cuda()
+            cams_all = synthetic.camera_labels(frames_all).to(DEV)
             self.frames.append(mine)
             self.cams.append(cams_all[rank * per_rank:(rank + 1) * per_rank].contiguous())
-            self.uvs.append(synthetic.uv_conditions(mine).cuda())
-            self.jits.append(synthetic.jitter(mine, NRR * NRR).squeeze(-1).cuda())
+            self.uvs.append(synthetic.uv_conditions(mine).to(DEV))
+            self.jits.append(synthetic.jitter(mine, NRR * NRR).squeeze(-1).to(DEV))
             self.dists.append(frame_parallel.global_ray_dist(cams_all))          # batch-global, from the FULL camera batch
+            self.frame_dists.append(frame_parallel.per_frame_ray_dist(self.cams[-1]))   # (drive workload: one value per frame)
 
     def eager(self, gen, s):
         return gen.synthesis(self.ws.expand(self.per_rank, -1, -1), self.cams[s], {'uvcoords_image': self.uvs[s]}, neural_rendering_resolution=NRR, noise_mode='const',
@@ -111,7 +143,7 @@ def make_step(gen, wl, graphed, gather_dtype):
     world, per = wl.world, wl.per_rank
     if world > 1:
         shape = (world * per, 512, 512, 3) if gather_dtype == 'u8' else (world * per, 3, 512, 512)
-        gathered = torch.empty(shape, device='cuda', dtype=torch.uint8 if gather_dtype == 'u8' else torch.float32)
+        gathered = torch.empty(shape, device=DEV, dtype=torch.uint8 if gather_dtype == 'u8' else torch.float32)
 
     def step(k):
         s = k % wl.n_sets
@@ -119,8 +151,7 @@ def make_step(gen, wl, graphed, gather_dtype):
         img = out['image']
         if world > 1:
             part = to_uint8_hwc(img) if gather_dtype == 'u8' else img.contiguous()
-            torch.distributed.all_gather_into_tensor(gathered, part)
-            return gathered
+            return all_gather_frames(gathered, part)
         return img
     return step
 
@@ -130,16 +161,16 @@ def timed(step, steps, warmup, world):
         step(k)
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for k in range(steps):
         step(k)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        t = torch.tensor([dt], device=DEV, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     return dt
@@ -296,33 +327,13 @@ def variant_leg(gen, wl, args, batch=1, **flags):
 def drive_loop_leg(gen, wl, args):
     """The drive loop of eval_seq.py:212 / BASELINE configs[2]: the texture and static features of the identity are computed
     once (inversion result) and every drive frame is `synthesis_withTexture` = rasterize + face backbone + renderer + SR."""
+    from invertavatar_amd.graphed import GraphedDrive
     ws = wl.ws
     tex = gen.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
     sta = gen.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
-    c_s, uv_s, jit_s = wl.cams[0].clone(), wl.uvs[0].clone(), wl.jits[0].clone()
-
-    def call():
-        return gen.synthesis_withTexture(ws, tex, c_s, {'uvcoords_image': uv_s}, static_feats=sta, neural_rendering_resolution=NRR,
-                                         noise_mode='const', evaluation=True, jitter=jit_s)['image']
-    ref = wl.eager(gen, 0)['image']
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            img = call()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    err = (img - ref).abs().max().item()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        out = call()
-
-    def step(k):
-        s = k % wl.n_sets
-        c_s.copy_(wl.cams[s]); uv_s.copy_(wl.uvs[s]); jit_s.copy_(wl.jits[s])
-        graph.replay()
-        return out
-    dt = timed(step, args.steps, args.warmup, 1)
+    graphed = GraphedDrive(gen, ws, tex, sta, batch=1, neural_rendering_resolution=NRR)
+    err = (graphed(wl.cams[0], wl.uvs[0], wl.jits[0])['image'] - wl.eager(gen, 0)['image']).abs().max().item()
+    dt = timed(lambda k: graphed(wl.cams[k % wl.n_sets], wl.uvs[k % wl.n_sets], wl.jits[k % wl.n_sets])['image'], args.steps, args.warmup, 1)
     return dict(value=round(args.steps / dt, 3), unit='frames/s', ms_per_step=round(dt / args.steps * 1e3, 3),
                 workload='synthesis_withTexture per drive frame, texture + static backbone features cached (eval_seq.py:212)',
                 max_abs_rgb_vs_full_synthesis=float(f'{err:.3e}'))
@@ -345,8 +356,11 @@ def extra_legs(result, gen, wl, args):
     def sr_fp16():
         gen16 = sr_fp16_generator(gen, args.width)
         r, img = variant_leg(gen16, wl, args, FP16_BLOCKS_COMPUTE_FP32=False)
-        r.update(dtype='f32 backbones + renderer, SR head: fp16 operands / f32 accumulate',
-                 max_abs_rgb_vs_f32_run=float(f'{(img - headline_img).abs().max().item():.3e}'))
+        r.update(dtype='f32 backbones + renderer, SR head: fp16 operands and fp16 activation storage / f32 accumulate',
+                 max_abs_rgb_vs_f32_run=float(f'{(img - headline_img).abs().max().item():.3e}'),
+                 note='the reference\'s own fp16 SR path (fp16 storage + conv_clamp 256, networks_stylegan2.py:417-437), restated in oracle/'
+                      ' (the reference forces fp32 on CPU, so it is unpinned), is 3.4e-3 from its fp32 output: the 1e-3 RGB bound of'
+                      ' BASELINE is a statement about the fp32 head (the headline), not about this mode')
         return r
 
     def batch8():
@@ -368,48 +382,106 @@ def extra_legs(result, gen, wl, args):
 def sr_fp16_generator(gen, width):
     gen16 = TriPlaneGenerator(**synthetic.generator_kwargs(width, sr_num_fp16_res=4)).eval().requires_grad_(False)
     gen16.load_state_dict(gen.state_dict())
-    return gen16.cuda()
+    return gen16.to(DEV)
+
+
+def inversion_features(gen, n_sources=8, repeats=2):
+    """BASELINE configs[4], first half: few-shot ConvGRU inversion of 8 source frames through the script's own flow
+    (invertavatar_amd.eval_seq.few_shot_inversion: encode + 2 interleaved AR_eval_forward groups, module modes of eval_seq.py:91-97).
+    Every rank runs it (replicated: the identity is shared by all drive frames).  Returns (ws, results, milliseconds of the last run)."""
+    from invertavatar_amd import eval_seq
+    from invertavatar_amd.encoder_inversion.models.uvnet import inversionNet
+    net = inversionNet(generator=gen, encoding_triplane=True, encoding_texture=True).requires_grad_(False)
+    synthetic.fill_encoder_parameters(net)
+    net = net.to(DEV)
+    eval_seq.set_eval_seq_modes(net)
+    gen.neural_rendering_resolution = NRR
+    src_frames = [int(round(k * 32 / n_sources)) for k in range(n_sources)]
+    images = torch.cat([synthetic.source_frames(7 + k // 4, 4)[k % 4:k % 4 + 1] for k in range(n_sources)]).to(DEV)
+    uvs = synthetic.source_uv(17, src_frames).to(DEV)
+    cams, uvc = synthetic.camera_labels(src_frames).to(DEV), synthetic.uv_conditions(src_frames).to(DEV)
+    for _ in range(repeats):      # (the first run pays allocations and the library's kernel selection)
+        sync()
+        t0 = time.perf_counter()
+        ws, res, _ = eval_seq.few_shot_inversion(net, images, uvs, cams, uvc)
+        sync()
+        ms = (time.perf_counter() - t0) * 1e3
+    return ws, res, ms
 
 
 def drive_main(args, rank, world):
-    """BASELINE configs[4] (the generator side; the ConvGRU inversion that produces the features is timed by the `encoder` leg at
-    N = 1): 256 drive frames, sharded 256/N per rank in calls of 8 frames, identity features cached, SR head in fp16, frames
-    collected with one all-gather per call.  A step = one call on every rank (8 N frames)."""
+    """BASELINE configs[4]: few-shot ConvGRU incremental inversion of 8 source frames -> `--drive-frames` (256) drive frames, SR head
+    in fp16.  The inversion runs once per identity on every rank (reported as `inversion_ms`, outside the timed steps); the drive
+    sequence is sharded over the ranks in calls of `per` = 8 frames: a step = one call on every rank (8 N frames) + ONE all-gather.
+    Every drive frame keeps the depth range of the script's one-frame call (per-frame `ray_dist`, eval_seq.py:206-212), so sharding
+    and batching do not change the frames.  The per-rank call is a captured hipGraph (validated against the eager call)."""
+    from invertavatar_amd.graphed import GraphedDrive
     from invertavatar_amd.training import networks_stylegan2 as sg2
     gen = TriPlaneGenerator(**synthetic.generator_kwargs(args.width, sr_num_fp16_res=4)).eval().requires_grad_(False)
     synthetic.fill_parameters(gen)
-    gen = gen.cuda()
+    gen = gen.to(DEV)
     sg2.FP16_BLOCKS_COMPUTE_FP32 = False
     per = args.frames_per_rank or FRAMES_PER_RANK_SHARDED
+    features = args.features if args.width == 'full' else 'backbone'      # (the UNet heads are sized for the full-width pyramid)
     with torch.no_grad():
-        wl = Workload(gen, per, rank, world, n_sets=max(1, 256 // (per * world)))
-        tex = gen.texture_backbone.synthesis(wl.ws, cond_list=None, return_list=True, noise_mode='const')
-        sta = gen.backbone.synthesis(wl.ws, cond_list=None, return_list=True, noise_mode='const')
-        ws8 = wl.ws.expand(per, -1, -1).contiguous()
-        tex = [t.expand(per, -1, -1, -1).contiguous() for t in tex]
-        sta = [t.expand(per, -1, -1, -1).contiguous() for t in sta]
-        gathered = torch.empty(world * per, 3, 512, 512, device='cuda') if world > 1 else None
+        wl = Workload(gen, per, rank, world, n_sets=max(1, args.drive_frames // (per * world)))
+        inversion_ms = None
+        if features == 'encoder':
+            ws, res, inversion_ms = inversion_features(gen)
+            tex, sta = res['texture'], res['static']
+        else:
+            ws = wl.ws
+            tex = gen.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+            sta = gen.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
+        ws8 = ws.expand(per, -1, -1).contiguous()
+        tex8 = [t.expand(per, -1, -1, -1).contiguous() for t in tex]
+        sta8 = [t.expand(per, -1, -1, -1).contiguous() for t in sta]
+        gathered = torch.empty(world * per, 3, 512, 512, device=DEV) if world > 1 else None
+
+        def eager(s):
+            return gen.synthesis_withTexture(ws8, tex8, wl.cams[s], {'uvcoords_image': wl.uvs[s]}, static_feats=sta8, neural_rendering_resolution=NRR,
+                                             noise_mode='const', evaluation=True, jitter=wl.jits[s],
+                                             ray_dist=wl.frame_dists[s] if per > 1 else None)['image']
+        graphed, launch = None, 'eager'
+        if DEV.type == 'cuda' and not args.eager:
+            try:
+                graphed = GraphedDrive(gen, ws, tex, sta, batch=per, neural_rendering_resolution=NRR, ray_dist_elems=per if per > 1 else 0)
+                img_g = graphed(wl.cams[0], wl.uvs[0], wl.jits[0], wl.frame_dists[0] if per > 1 else None)['image'].clone()
+                err = (img_g - eager(0)).abs().max().item()
+                if not err <= 1e-5:
+                    raise RuntimeError(f'graph replay differs from eager by {err}')
+                launch = 'hipGraph replay (validated against eager: max |d| = %.1e)' % err
+            except Exception as exc:   # noqa: BLE001
+                graphed, launch = None, f'eager (graph capture unavailable: {exc})'
 
         def step(k):
             s = k % wl.n_sets
-            img = gen.synthesis_withTexture(ws8, tex, wl.cams[s], {'uvcoords_image': wl.uvs[s]}, static_feats=sta,
-                                            neural_rendering_resolution=NRR, noise_mode='const', evaluation=True, jitter=wl.jits[s])['image']
+            img = graphed(wl.cams[s], wl.uvs[s], wl.jits[s], wl.frame_dists[s] if per > 1 else None)['image'] if graphed is not None else eager(s)
             if world > 1:
-                torch.distributed.all_gather_into_tensor(gathered, img.contiguous())
+                return all_gather_frames(gathered, img.contiguous())
             return img
         dt = timed(step, args.steps, args.warmup, world)
-    return {'metric': 'frames/sec (512^2 out, 128^2 neural render)', 'value': round(world * per * args.steps / dt, 3), 'unit': 'frames/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 backbones + renderer; SR head fp16 operands / f32 accumulate', 'data': 'synthetic',
-            'config': {'workload': 'drive loop of the few-shot inversion (BASELINE configs[4], generator side): synthesis_withTexture, '
-                                   f'{per} frames per rank per call, identity features cached, SR head fp16, eager launches',
-                       'width': args.width, 'frames_per_rank_per_step': per, 'parallelism': f'frame-sharded dp{world}'}}
+    fps = world * per * args.steps / dt
+    out = {'metric': 'frames/sec (512^2 out, 128^2 neural render)', 'value': round(fps, 3), 'unit': 'frames/s',
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32 backbones + renderer; SR head fp16 operands and fp16 activation storage / f32 accumulate', 'data': 'synthetic',
+           'config': {'workload': 'BASELINE configs[4]: few-shot ConvGRU inversion (8 sources, eval_seq.py flow) -> drive loop '
+                                  f'synthesis_withTexture, {per} frames per rank per call, SR head fp16',
+                      'width': args.width, 'nrr': NRR, 'frames_per_rank_per_step': per, 'global_batch': per * world,
+                      'identity_features': features, 'parallelism': f'frame-sharded dp{world}', 'launch': launch,
+                      'collective': f'one all_gather of the step\'s [{per * world},3,512,512] f32 frames' if world > 1 else 'none'}}
+    if inversion_ms is not None:
+        n = args.drive_frames
+        out['inversion_ms'] = round(inversion_ms, 2)
+        out['clip'] = dict(frames=n, seconds=round(inversion_ms * 1e-3 + n / fps, 4), frames_per_s=round(n / (inversion_ms * 1e-3 + n / fps), 2),
+                           note='inversion (replicated on every rank) + the whole drive sequence at the measured rate')
+    return out
 
 
 def main():
     args = parse()
-    rank, world, _ = setup_distributed(args.gpus)
+    rank, world, _ = setup_distributed(args)
     torch.backends.cudnn.benchmark = False
     if args.workload == 'drive':
         result = drive_main(args, rank, world)
@@ -420,12 +492,12 @@ def main():
         return
     gen = TriPlaneGenerator(**synthetic.generator_kwargs(args.width)).eval().requires_grad_(False)
     synthetic.fill_parameters(gen)
-    gen = gen.cuda()
+    gen = gen.to(DEV)
     per = args.frames_per_rank or (1 if world == 1 else FRAMES_PER_RANK_SHARDED)
     with torch.no_grad():
         wl = Workload(gen, per, rank, world, n_sets=16 if per == 1 else 4)
         graphed, launch_mode = None, 'eager'
-        if not args.eager:
+        if not args.eager and DEV.type == 'cuda':
             try:
                 graphed, launch_mode = capture(gen, wl, per)
             except Exception as exc:   # noqa: BLE001  fall back to eager launches, and say so in the JSON line
@@ -440,14 +512,16 @@ def main():
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (3x3 convolutions >= 32^2 form their f32 products from fp16 hi/lo pairs on the f16 MFMA, f32 accumulate; '
                      'all other arithmetic f32)', 'data': 'synthetic',
-            'config': {'workload': f'TriPlaneGenerator.synthesis, BASELINE {cfg}: 512^2 out, neural_rendering_resolution=128, all three '
+            'config': {'workload': f'TriPlaneGenerator.synthesis, BASELINE {cfg}: 512^2 out, neural_rendering_resolution={NRR}, all three '
                                    'backbones + rasterize + fused renderer + SR 8XDC recomputed every frame',
                        'width': args.width, 'frames_per_rank_per_step': per, 'global_batch': per * world,
                        'parallelism': f'frame-sharded dp{world}',
                        'collective': f'one all_gather of the step\'s [{per * world},3,512,512] frames as {args.gather}' if world > 1 else 'none',
                        'launch': launch_mode},
         }
-        if rank == 0 and world == 1 and per == 1:
+        if args.dist_backend != 'nccl' or args.device != 'cuda':
+            result['config']['rehearsal'] = f'backend {args.dist_backend}, device {args.device}: plumbing run, not a measurement'
+        if rank == 0 and world == 1 and per == 1 and DEV.type == 'cuda':
             # keep the GPU busy for >= 2 s with the same step (the timed K steps alone can be shorter than a sampler's period)
             n, t_s = 0, time.perf_counter()
             while time.perf_counter() - t_s < 2.0:

@@ -181,6 +181,7 @@ int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B,
 
 #define IA_RENDER_WHITE_BACK 1
 #define IA_RENDER_RGB_CHANNEL_MAJOR 2
+#define IA_RENDER_DIST_PER_FRAME 4
 
 /*
  * The fused importance renderer: one launch replaces ImportanceRenderer_bsMotion.forward(evaluation=True)
@@ -197,7 +198,9 @@ int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B,
  *   n_coarse / n_importance : must both be 48 (train_avatar_texture.py:341-342); others -> IA_ERR_UNSUPPORTED
  *   flags : bit 0 (IA_RENDER_WHITE_BACK) = rendering_kwargs['white_back']; bit 1 (IA_RENDER_RGB_CHANNEL_MAJOR) = store rgb as
  *          [B, 32, R] -- the feature image [B, 32, nrr, nrr] the super-resolution head reads (triplane_v20.py:313) -- instead of
- *          the renderer's [B, R, 32], which saves the permute + copy between the renderer and the head
+ *          the renderer's [B, R, 32], which saves the permute + copy between the renderer and the head; bit 2
+ *          (IA_RENDER_DIST_PER_FRAME) = `dist` holds B values, frame b uses dist[b]: a batch of frames that the script renders one
+ *          call each (eval_seq.py:206-212, where `dist` is every frame's own |ray origin|) keeps those results when batched
  *   rgb  : [B, R, 32] (or [B, 32, R], see flags) composited features scaled to (-1, 1);  depth : [B, R] clamped to the
  *          batch-global sample range;  wsum : [B, R] sum of compositing weights
  *   minmax_scratch : 2 * ia_render_rays_grid(B, R) floats of caller scratch
@@ -405,11 +408,13 @@ int ia_convgru_update(const float* gates_pre, const float* cand_pre, const float
  *   face_attrs     : [F, 3, 3] float32 = face_vertices(cat[uv * 2 - 1, mask], tris): (u, v, mask) of every corner (:33-34)
  *   zbuf_scratch   : B * crop_w * crop_h * 8 bytes (caller-owned)
  *   uvcoords_image : [B, crop_h, crop_w, 3] float32
+ *   binarize_mask  : 1 = channel 2 is (mask >= 0.5) as the script returns it at the native size (:82); 0 = the continuous
+ *                    mask * vis * mask product, for a caller that interpolates to another `res` first and thresholds afterwards (:78-82)
  *   raster_size 512, crop (128, 114, 256, 256), blur_radius 1e-6 in the reference (:13-14, :43)
  */
 int ia_uv_rasterize(const float* verts, const int* tris, const float* face_attrs, void* zbuf_scratch, float* uvcoords_image,
                     int B, int V, int F, int raster_size, int crop_left, int crop_top, int crop_w, int crop_h, float blur_radius,
-                    void* stream);
+                    int binarize_mask, void* stream);
 
 /*
  * Output side: float image batch -> uint8 picture grid, one pass.

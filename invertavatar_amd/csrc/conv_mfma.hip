@@ -395,13 +395,13 @@ int launch_npos(const float* x, const float* wk, const float* styles, float* y, 
     int st = IA_OK;
     if (g.T_dp > 0) {   // whole rounds: one tile per workgroup
         auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, false, DB, HM>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (const int rs = ia::reserve_lds((const void*)k, (size_t)(lds), "conv_mfma")) return rs;
         hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma");
     }
     if (st == IA_OK && g.T > g.T_dp) {   // the rest: stream-K, then the fix-up of the tiles that were shared
         auto k = conv_mfma_kernel<KS, TR, FO, FP, WO, WP, CC, NPOS, true, DB, HM>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (const int rs = ia::reserve_lds((const void*)k, (size_t)(lds), "conv_mfma")) return rs;
         hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, x, wk, styles, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma(stream-K)");
         const int64_t U = (int64_t)(g.T - g.T_dp) * g.C;

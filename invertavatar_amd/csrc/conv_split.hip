@@ -409,19 +409,19 @@ int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
         if constexpr (!TR) {
             if (e.rgb_out) {      // (the fused ToRGB epilogue is its own instantiation: it costs the plain kernel registers otherwise)
                 auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, false, true>;
-                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (const int rs = ia::reserve_lds((const void*)k, (size_t)(lds), "conv_split")) return rs;
                 hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
                 return ia::check_launch("ia_conv2d_mfma_sx_rgb");
             }
         }
         auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, false>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (const int rs = ia::reserve_lds((const void*)k, (size_t)(lds), "conv_split")) return rs;
         hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma_sx");
     }
     if (st == IA_OK && g.T > g.T_dp) {
         auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, true>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (const int rs = ia::reserve_lds((const void*)k, (size_t)(lds), "conv_split")) return rs;
         hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma_sx(stream-K)");
         const int64_t U = (int64_t)(g.T - g.T_dp) * g.C;

@@ -164,7 +164,7 @@ extern "C" int ia_fill_mouth(const float* alpha, float* mouth, int B, int H, int
     }
     const size_t lds = (size_t)H * (W + 4);
     if (lds > 150 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "mask %dx%d does not fit the LDS label image", H, W);
-    (void)hipFuncSetAttribute((const void*)fill_mouth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (const int rs = ia::reserve_lds((const void*)fill_mouth_kernel, (size_t)(lds), "fill_mouth")) return rs;
     hipLaunchKernelGGL(fill_mouth_kernel, dim3(B), dim3(kThreads), lds, (hipStream_t)stream, alpha, mouth, H, W);
     return ia::check_launch("ia_fill_mouth");
 }

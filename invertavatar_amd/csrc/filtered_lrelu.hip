@@ -106,7 +106,7 @@ int launch_flr(const void* x, const float* fu, const float* fd, const void* b, v
     const size_t lds = sizeof(float) * ((size_t)g.fuh * g.fuw + (size_t)g.fdh * g.fdw + (size_t)g.tih * g.tiw + (size_t)g.tmh * g.tmw);
     if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "ia_filtered_lrelu: tile needs %zu bytes of LDS", lds);
     auto k = filtered_lrelu_kernel<T>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (const int rs = ia::reserve_lds((const void*)k, (size_t)(lds), "filtered_lrelu")) return rs;
     const dim3 grid(((g.ow + TOX - 1) / TOX) * ((g.oh + TOY - 1) / TOY), g.n * g.c);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)x, fu, fd, (const T*)b, (T*)y, g);
     return ia::check_launch("ia_filtered_lrelu");

@@ -23,6 +23,17 @@ inline int check_launch(const char* what) {
     return IA_OK;
 }
 
+// Opt a kernel in to `bytes` of dynamic LDS.  The attribute call is the capacity check: a device whose workgroups cannot hold the
+// tile (a 64 KB-LDS part, where gfx950 has 160 KB) refuses it, and the entry point reports IA_ERR_UNSUPPORTED instead of a
+// generic launch failure, so callers with an unfused composition can take it.
+inline int reserve_lds(const void* kernel, size_t bytes, const char* what) {
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) return IA_OK;
+    (void)hipGetLastError();
+    return fail(IA_ERR_UNSUPPORTED, "%s: %zu bytes of LDS per workgroup are not available on this device (%s)", what, bytes,
+                hipGetErrorString(e));
+}
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr int kWave = 64;        // CDNA wavefront

@@ -47,12 +47,12 @@ struct Params {
     const float* rays_o;          // [B][R][3]
     const float* rays_d;          // [B][R][3]
     const float* jitter;          // [B][R][48]
-    const float* dist;            // device scalar: batch mean of |ray origin| (renderer.py:311)
+    const float* dist;            // device scalar: batch mean of |ray origin| (renderer.py:311); [B] with dist_per_frame
     const float* w0; const float* b0; const float* w1; const float* b1;   // decoder parameters, reference layout
     float w0_gain, w1_gain, b_gain;
     float box_scale;              // 2 / box_warp
     int B, R, PH, PW;
-    int white_back, channel_major;
+    int white_back, channel_major, dist_per_frame;
     float* rgb;                   // [B][R][32], or [B][32][R] when channel_major
     float* depth;                 // [B][R]   un-clamped (may be +inf), see ia_render_finalize
     float* wsum;                  // [B][R]
@@ -397,11 +397,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
     float* scr = lds + SCR_OFF + wave * SCR;
     float* tc = scr; float* sc = scr + NS; float* wc = scr + 2 * NS; float* tm = scr + 8 * NS;
 
-    // depth range: renderer.py:311-313,404-406 (python doubles, fp32 tensors)
-    const double dist = (double)(*p.dist);
-    const float t_start = (float)(dist - 0.45), t_end = (float)(dist + 0.6);
-    const float t_step = (t_end - t_start) / (float)(NS - 1);
-    const float t_delta = (float)(((dist + 0.6) - (dist - 0.45)) / (double)(NS - 1));
     float blk_min = INFINITY, blk_max = 0.f;
 
     const int nrays = p.B * p.R;
@@ -410,6 +405,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         const int ray = __builtin_amdgcn_readfirstlane(ray0 + wave);      // wave-uniform: ray constants and the plane base are scalars
         if (ray >= nrays) continue;
         const int b = ray / p.R;
+        // depth range: renderer.py:311-313,404-406 (python doubles, fp32 tensors); one value for the batch, or one per frame when the
+        // caller renders several single-frame calls of the script as one batch (wave-uniform scalar work either way)
+        const double dist = (double)p.dist[p.dist_per_frame ? b : 0];
+        const float t_start = (float)(dist - 0.45), t_end = (float)(dist + 0.6);
+        const float t_step = (t_end - t_start) / (float)(NS - 1);
+        const float t_delta = (float)(((dist + 0.6) - (dist - 0.45)) / (double)(NS - 1));
         const float* planes_b = p.planes + (int64_t)b * 3 * p.PH * p.PW * 32;
         const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
         const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
@@ -677,6 +678,7 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
     p.box_scale = 2.f / box_warp;
     p.B = B; p.R = R; p.PH = plane_h; p.PW = plane_w;
     p.white_back = (flags & IA_RENDER_WHITE_BACK) != 0; p.channel_major = (flags & IA_RENDER_RGB_CHANNEL_MAJOR) != 0;
+    p.dist_per_frame = (flags & IA_RENDER_DIST_PER_FRAME) != 0;
     p.rgb = rgb; p.depth = depth; p.wsum = wsum; p.minmax = minmax_scratch;
     p.dbg_z_fine = dbg_z_fine; p.dbg_inds = dbg_inds; p.dbg_order = dbg_order; p.dbg_w_coarse = dbg_w_coarse;
     p.dbg_sigma_coarse = dbg_sigma_coarse;
@@ -684,7 +686,7 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
     hipStream_t s = (hipStream_t)stream;
     static_assert(LDS_FLOATS * sizeof(float) <= 160 * 1024, "one workgroup must fit a CU's LDS");
     const auto kernel = plane_h == plane_w ? render_rays_kernel<true> : render_rays_kernel<false>;
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_FLOATS * sizeof(float)));
+    if (const int rs = ia::reserve_lds((const void*)kernel, (size_t)(LDS_FLOATS * sizeof(float)), "render_rays")) return rs;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), LDS_FLOATS * sizeof(float), s, p);
     int st = ia::check_launch("ia_render_rays");
     if (st != IA_OK) return st;

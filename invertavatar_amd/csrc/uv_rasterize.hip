@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void uv_splat_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void uv_resolve_kernel(const float* __restrict__ verts, const int* __restrict__ tris, const float* __restrict__ attrs,
-                                                        const unsigned long long* __restrict__ zbuf, float* __restrict__ out, UvGeo g) {
+                                                        const unsigned long long* __restrict__ zbuf, float* __restrict__ out, UvGeo g, int binarize) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)g.B * g.ch * g.cw) return;
     const int xx = (int)(i % g.cw), yy = (int)((i / g.cw) % g.ch), b = (int)(i / ((int64_t)g.cw * g.ch));
@@ -125,14 +125,14 @@ __global__ __launch_bounds__(256) void uv_resolve_kernel(const float* __restrict
         u = au * rm; vv = av * rm; m = am * rm;
     }
     float* o = out + i * 3;
-    o[0] = u; o[1] = vv; o[2] = m < 0.5f ? 0.f : 1.f;                  // (:82)
+    o[0] = u; o[1] = vv; o[2] = !binarize ? m : (m < 0.5f ? 0.f : 1.f);    // (:82; a caller that resizes first thresholds afterwards, :78-82)
 }
 
 }  // namespace
 
 extern "C" int ia_uv_rasterize(const float* verts, const int* tris, const float* face_attrs, void* zbuf_scratch, float* uvcoords_image,
                                int B, int V, int F, int raster_size, int crop_left, int crop_top, int crop_w, int crop_h, float blur_radius,
-                               void* stream) {
+                               int binarize_mask, void* stream) {
     IA_REQUIRE(verts && tris && face_attrs && zbuf_scratch && uvcoords_image, "null pointer argument");
     IA_REQUIRE(B > 0 && V > 0 && F > 0 && raster_size > 0, "empty input");
     IA_REQUIRE(crop_left >= 0 && crop_top >= 0 && crop_w > 0 && crop_h > 0 && crop_left + crop_w <= raster_size && crop_top + crop_h <= raster_size,
@@ -144,6 +144,6 @@ extern "C" int ia_uv_rasterize(const float* verts, const int* tris, const float*
     auto* zb = static_cast<unsigned long long*>(zbuf_scratch);
     hipLaunchKernelGGL(uv_clear_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, zb, npix);
     hipLaunchKernelGGL(uv_splat_kernel, dim3((unsigned)((nface + 255) / 256)), dim3(256), 0, s, verts, tris, zb, g);
-    hipLaunchKernelGGL(uv_resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, verts, tris, face_attrs, zb, uvcoords_image, g);
+    hipLaunchKernelGGL(uv_resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, verts, tris, face_attrs, zb, uvcoords_image, g, binarize_mask);
     return ia::check_launch("ia_uv_rasterize");
 }

@@ -76,17 +76,18 @@ class UVRasterizer:
         tv = transformed_vertices.float().contiguous()
         b, v, _ = tv.shape
         left, top, cw, ch = self.crop_param
+        resize = res is not None and res != ch
         if tv.is_cuda:
             out = torch.empty(b, ch, cw, 3, device=tv.device, dtype=torch.float32)
             zbuf = torch.empty(b * ch * cw, device=tv.device, dtype=torch.int64)
             with torch.cuda.device(tv.device):
                 st = _lib.load().ia_uv_rasterize(tv.data_ptr(), self.tris.data_ptr(), self.face_uvcoords.data_ptr(), zbuf.data_ptr(), out.data_ptr(),
                                                  b, v, self.tris.shape[0], self.render_res, left, top, cw, ch, float(self.blur_radius),
-                                                 _lib.stream_ptr(tv.device))
+                                                 0 if resize else 1, _lib.stream_ptr(tv.device))
             _lib.check(st, 'ia_uv_rasterize')
         else:
             raise RuntimeError('UVRasterizer.rasterize: the UV rasteriser is a device kernel (the reference requires CUDA pytorch3d here too)')
-        if res is not None and res != ch:
+        if resize:      # the reference interpolates the CONTINUOUS mask channel and thresholds once, after the resize (:78-82)
             img = out.permute(0, 3, 1, 2)
             img = torch.nn.functional.interpolate(img, size=(res, res), mode='bilinear', align_corners=False)
             out = img.permute(0, 2, 3, 1).contiguous()

@@ -35,11 +35,10 @@ def fill_group(t, n_src):
 
 
 @torch.no_grad()
-def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=False, hook=None, chain_results=False):
+def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=False, hook=None):
     """images [S,3,512,512] in [-1,1], uvs [S,6,256,256] (x['uv']), cams [S,25], uvcoords [S,256,256,3].  S in {1, 2, 4} or a
     multiple of 4.  `hook(group_index)` may return a context manager entered around each AR_eval_forward (tests pin the
-    renderer's random draws with it).  chain_results=True feeds each group the features updated by the previous one instead of
-    the e4e features (a variant the golden fixture encoder_fewshot.npz was recorded with).  Returns (ws, {'w','texture','static'}, r_list)."""
+    renderer's random draws with it).  Returns (ws, {'w','texture','static'} of the LAST group, r_list)."""
     s = images.shape[0]
     assert s in (1, 2, 4) or s % 4 == 0, f'{s} source frames: the script pads to a multiple of 4 first (:135-136)'
     images, uvs, cams, uvcoords = (fill_group(t, s) for t in (images, uvs, cams, uvcoords))
@@ -58,7 +57,7 @@ def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=Fal
         try:
             # (every group starts from the e4e features: the script passes e4e_results=e4e_results each time, :187)
             updated, r_list = net.AR_eval_forward({'image': images[sel], 'uv': uvs[sel]}, cams[sel], {'uvcoords_image': uvcoords[sel]},
-                                                  ws, r_list, e4e_results=updated if chain_results else results, return_fake=False)
+                                                  ws, r_list, e4e_results=results, return_fake=False)
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
@@ -67,8 +66,10 @@ def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=Fal
 
 @torch.no_grad()
 def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=None, neural_rendering_resolution=None):
-    """Drive loop (:206-219) over cams [F,25] / uvcoords [F,256,256,3] in calls of `batch` frames (the script uses 1).
+    """Drive loop (:206-219) over cams [F,25] / uvcoords [F,256,256,3] in calls of `batch` frames (the script uses 1; with
+    batch > 1 every frame keeps the depth range of its own call: per-frame `ray_dist`, frame_parallel.per_frame_ray_dist).
     Returns (images [F,3,H,W], mosaics or None): mosaics are the uint8 [gt | rendered] pictures when `gt` [F,3,H,W] is given."""
+    from .frame_parallel import per_frame_ray_dist
     g = net.generator
     n = cams.shape[0]
     imgs, mosaics = [], ([] if gt is not None else None)
@@ -83,6 +84,8 @@ def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=No
             kw['jitter'] = jitter[lo:hi]
         if neural_rendering_resolution is not None:
             kw['neural_rendering_resolution'] = neural_rendering_resolution
+        if b > 1:
+            kw['ray_dist'] = per_frame_ray_dist(cams[lo:hi])
         out = g.synthesis_withTexture(ws_b, tex, cams[lo:hi], {'uvcoords_image': uvcoords[lo:hi]}, noise_mode='const', static_feats=sta,
                                       evaluation=True, **kw)
         imgs.append(out['image'])

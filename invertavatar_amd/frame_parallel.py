@@ -26,6 +26,14 @@ def global_ray_dist(c):
     return torch.norm(cam2world[:, :3, 3].float(), dim=-1).mean().reshape(1)
 
 
+def per_frame_ray_dist(c):
+    """|camera origin| of every frame, [N]: the `dist` each frame gets when the script renders it in a call of its own
+    (eval_seq.py:206-212, B = 1: the batch mean of renderer.py:311 is then the frame's own value).  Passed as `ray_dist` it lets a
+    rank render its block of drive frames in one batched call with the per-call results."""
+    cam2world = c[:, -25:][:, :16].reshape(-1, 4, 4)
+    return torch.norm(cam2world[:, :3, 3].float(), dim=-1).contiguous()
+
+
 def render_sharded(generator, ws, c, mesh_condition, rank=0, world_size=1, jitter=None, gather=True, **synthesis_kwargs):
     """Render frames [lo, hi) of the batch on this rank and all-gather the images.
 

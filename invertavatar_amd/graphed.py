@@ -68,6 +68,53 @@ class GraphedSynthesis:
         return self.out
 
 
+class GraphedDrive:
+    """hipGraph of the drive loop's call (eval_seq.py:212): ``synthesis_withTexture`` on FIXED identity features (ws, texture and
+    static feature pyramids of the inversion result, expanded to `batch`), replayed per block of drive frames after staging that
+    block's cameras / UV maps / jitter (and `ray_dist`: [1] batch-global or [batch] per frame, see frame_parallel)."""
+
+    def __init__(self, generator, ws, texture_feats, static_feats, batch=1, neural_rendering_resolution=128, warmup=3, ray_dist_elems=0,
+                 **synthesis_kwargs):
+        self.g = generator
+        self.nrr = neural_rendering_resolution
+        self.kwargs = dict(noise_mode='const', evaluation=True)
+        self.kwargs.update(synthesis_kwargs)
+        dev = ws.device
+        self.ws = ws.expand(batch, -1, -1).contiguous()
+        self.tex = [t.expand(batch, -1, -1, -1).contiguous() for t in texture_feats]
+        self.sta = [t.expand(batch, -1, -1, -1).contiguous() for t in static_feats]
+        self.c = torch.zeros(batch, 25, device=dev)
+        self.uv = torch.zeros(batch, 256, 256, 3, device=dev)
+        self.jitter = torch.zeros(batch, self.nrr * self.nrr, 48, device=dev)
+        assert ray_dist_elems in (0, 1, batch), ray_dist_elems
+        self.ray_dist = torch.zeros(ray_dist_elems, device=dev) if ray_dist_elems else None
+        self.graph = None
+        self.out = None
+        self._warmup = warmup
+        self._scratch = {}
+
+    def _call(self):
+        return self.g.synthesis_withTexture(self.ws, self.tex, self.c, {'uvcoords_image': self.uv}, static_feats=self.sta,
+                                            neural_rendering_resolution=self.nrr, jitter=self.jitter, ray_dist=self.ray_dist, **self.kwargs)
+
+    capture = GraphedSynthesis.capture
+    _capture = GraphedSynthesis._capture
+
+    @torch.no_grad()
+    def __call__(self, c, uvcoords_image, jitter, ray_dist=None):
+        if (ray_dist is None) != (self.ray_dist is None):
+            raise ValueError('ray_dist must be passed exactly when the graph was built with ray_dist_elems > 0')
+        from . import hipops
+        pairs = [(c[:, -25:], self.c), (uvcoords_image, self.uv), (jitter.reshape(self.jitter.shape), self.jitter)]
+        if ray_dist is not None:
+            pairs.append((ray_dist.reshape(self.ray_dist.shape), self.ray_dist))
+        hipops.stage_inputs(pairs)
+        if self.graph is None:
+            self.capture()
+        self.graph.replay()
+        return self.out
+
+
 class FramePipeline:
     """`depth` captured frames in flight: frame k is replayed on stream k % depth with its own static buffers, so the
     latency-bound parts of consecutive frames (low-resolution layers, renderer sampling phases) fill each other's idle

@@ -212,6 +212,8 @@ class SplitAct:
     planes = 2 hi / lo pairs (fp32-equivalent consumers), planes = 1 one rounded fp16 plane (fp16-operand consumers: the
     fp16-storage form); already multiplied by the styles of the layer `consumer` (any object; None = unscaled)."""
 
+    requires_grad = False      # (forward-only: lets the autograd eligibility checks treat it like a detached tensor)
+
     def __init__(self, data, channels, consumer=None):
         self.data, self.channels, self.consumer = data, channels, consumer
         b, self.planes, c8, h, w, _ = data.shape
@@ -392,6 +394,9 @@ def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_mult
     if three != 3 or c != 32:
         raise RuntimeError(f'planes must be [B,3,H,W,32] channels-last, got {tuple(planes_cl.shape)}')
     r = rays_o.shape[1]
+    if dist.numel() not in (1, b):
+        raise RuntimeError(f'dist must have 1 or B = {b} elements, got {dist.numel()}')
+    dist_per_frame = dist.numel() == b and b > 1
     if tuple(jitter.shape[:3]) != (b, r, n_coarse):
         raise RuntimeError(f'jitter must be [B,R,{n_coarse}(,1)], got {tuple(jitter.shape)}')
     dev = planes_cl.device
@@ -410,7 +415,7 @@ def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_mult
     traffic = 4.0 * (planes_cl.numel() + 2 * rays_o.numel() + jitter.numel() + b * r * 34)
     with torch.cuda.device(dev), _Timed('render_rays', flops, traffic):
         st = lib.ia_render_rays(_p(planes_cl), _p(rays_o), _p(rays_d), _p(jitter), _p(dist), _p(w0), _p(b0), _p(w1), _p(b1),
-                                float(lr_multiplier), float(box_warp), int(bool(white_back)) | (2 if channel_major else 0), b, r, ph, pw,
+                                float(lr_multiplier), float(box_warp), int(bool(white_back)) | (2 if channel_major else 0) | (4 if dist_per_frame else 0), b, r, ph, pw,
                                 int(n_coarse),
                                 int(n_importance), _p(rgb), _p(depth), _p(wsum), _p(scratch), _p(aux.get('z_fine')),
                                 _p(aux.get('inds')), _p(aux.get('order')), _p(aux.get('w_coarse')), _p(aux.get('sigma_coarse')),

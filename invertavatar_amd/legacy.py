@@ -3,7 +3,8 @@
 A reference pickle stores every ``@persistence.persistent_class`` object as a call
 ``torch_utils.persistence._reconstruct_persistent_obj(meta)`` with ``meta = {type: 'class', version, module_src, class_name,
 state}`` (torch_utils/persistence.py:112-123, :186-207): the reference re-creates the object by EXECUTING the pickled module
-source.  This loader never executes pickled source: it reads the same byte stream, keeps ``class_name`` / ``_init_args`` /
+source.  This loader never executes pickled SOURCE (globals other than this package's classes, torch.nn layers and the
+tensor / ndarray reconstruction helpers are refused, see _SAFE_GLOBALS; a pickle is still untrusted input): it reads the same byte stream, keeps ``class_name`` / ``_init_args`` /
 ``_init_kwargs`` / parameters / buffers of each persistent object in a ``PickledModule`` shell, and then builds THIS backend's
 class of the same name from the recorded constructor arguments and loads the tensors by name -- the documented upgrade recipe of
 the reference (persistence.py:84-90, reenact_avatar_next3d.py:158-161: ``G_new = TriPlaneGenerator(*G.init_args,
@@ -141,7 +142,29 @@ class _Unpickler(pickle.Unpickler):
         try:    # classes pickled by reference to a module path of the reference repository: this package mirrors the paths
             return getattr(importlib.import_module(f'{_PACKAGE}.{module}'), name)
         except (ImportError, AttributeError):
+            pass
+        # Everything else must be on the allow-list of reconstruction helpers a network pickle legitimately needs: a pickle that
+        # names any other global (os.system, builtins.eval, subprocess ...) is refused instead of resolved.
+        own = module == _PACKAGE or module.startswith(_PACKAGE + '.')       # (pickles written by this backend itself)
+        layers = module.startswith('torch.nn.modules.')                       # plain torch.nn layers inside non-persistent networks
+        if own or layers or (module, name) in _SAFE_GLOBALS or (module in ('torch', 'torch.storage') and name.endswith('Storage')):
             return super().find_class(module, name)
+        raise pickle.UnpicklingError(f'global {module}.{name} is not on the allow-list of the network-pickle loader')
+
+
+_SAFE_GLOBALS = {
+    ('collections', 'OrderedDict'), ('builtins', 'set'), ('builtins', 'frozenset'), ('builtins', 'slice'), ('builtins', 'complex'),
+    ('builtins', 'bytearray'), ('builtins', 'range'),
+    ('torch._utils', '_rebuild_tensor'), ('torch._utils', '_rebuild_tensor_v2'), ('torch._utils', '_rebuild_parameter'),
+    ('torch._utils', '_rebuild_parameter_with_state'), ('torch._utils', '_rebuild_device_tensor_from_numpy'),
+    ('torch.storage', '_load_from_bytes'), ('torch', 'Size'), ('torch', 'device'), ('torch', 'dtype'), ('torch', 'Tensor'),
+    ('torch.nn.parameter', 'Parameter'), ('torch._tensor', '_rebuild_from_type_v2'),
+    ('torch', 'float32'), ('torch', 'float16'), ('torch', 'float64'), ('torch', 'bfloat16'), ('torch', 'int64'), ('torch', 'int32'),
+    ('torch', 'int16'), ('torch', 'int8'), ('torch', 'uint8'), ('torch', 'bool'),
+    ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'), ('numpy.core.multiarray', 'scalar'),
+    ('numpy._core.multiarray', 'scalar'), ('numpy', 'ndarray'), ('numpy', 'dtype'),
+    ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer'),
+}
 
 
 def load_network_pkl(f, force_fp16=False):

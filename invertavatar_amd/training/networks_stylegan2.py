@@ -355,6 +355,21 @@ class SynthesisLayer(torch.nn.Module):
             return None
         return split_for._pre[0] if split_for._takes_split_input(out_res, noise_mode, half_ops) else None
 
+    def _split_input(self, x, styles, planes):
+        """This layer's input as the SplitAct ia_conv2d_mfma_sx reads (`planes` fp16 planes of x * styles).  A SplitAct that was
+        made for this layer with that plane count is taken as it is; a SplitAct made for this layer with ANOTHER plane count
+        already carries the styles and is only re-split; an unscaled one is scaled here; one made for a different layer is a
+        producer / consumer mismatch and refused (its values are multiplied by somebody else's styles)."""
+        carried = x if isinstance(x, hipops.SplitAct) else getattr(x, '_ia_split', None)
+        if carried is not None and carried.consumer is self and carried.planes == planes:
+            return carried
+        if isinstance(x, hipops.SplitAct):
+            if x.consumer is self:
+                return hipops.act_split(x.float().contiguous(), None, consumer=self, planes=planes)
+            if x.consumer is not None:
+                raise RuntimeError('a SplitAct scaled for another layer reached this layer (producer/consumer out of sync)')
+        return hipops.act_split(x.float().contiguous(), styles.float().contiguous(), consumer=self, planes=planes)
+
     def _fused_device_forward(self, x, styles, noise_mode, act_gain, act_clamp, demod=None, half_ops=False, split_for=None, keep_f32=True,
                               next_half_ops=None):
         """conv + demod + noise + bias + lrelu + clamp on the MFMA path (one or two launches).
@@ -372,9 +387,7 @@ class SynthesisLayer(torch.nn.Module):
             wk = self._packed.get_half(self.weight) if half_ops else self._packed.get_split(self.weight)
             if demod is None:
                 demod = hipops.modconv_demod(styles.float().contiguous(), self._packed.get(self.weight)[1])
-            carried = x if isinstance(x, hipops.SplitAct) else getattr(x, '_ia_split', None)
-            xs = carried if (carried is not None and carried.consumer is self and carried.planes == planes) else \
-                hipops.act_split(x.float().contiguous(), styles.float().contiguous(), consumer=self, planes=planes)
+            xs = self._split_input(x, styles, planes)
             nz = self.noise_const.reshape(-1) if const_noise else None
             ns = self.noise_strength.detach().float().reshape(1) if const_noise else None
             bias = self.bias.detach().float()
@@ -398,7 +411,9 @@ class SynthesisLayer(torch.nn.Module):
                 return out[0]
             return out
         if isinstance(x, hipops.SplitAct):
-            raise RuntimeError('a SplitAct reached a layer that cannot consume it (producer/consumer eligibility out of sync)')
+            if x.consumer is not None:     # (scaled by some layer's styles: the fp32 values cannot be recovered exactly)
+                raise RuntimeError('a SplitAct reached a layer that cannot consume it (producer/consumer eligibility out of sync)')
+            x = x.float()
         wk, wsq = self._packed.get(self.weight)
         if (half_ops or SPLIT_FP16_PRODUCTS) and hipops.conv_h_supported(self.in_channels, self.out_channels, x.shape[2], x.shape[3], 3,
                                                                         self.up == 2):
@@ -453,9 +468,7 @@ class SynthesisLayer(torch.nn.Module):
         wk = self._packed.get_half(self.weight) if half_ops else self._packed.get_split(self.weight)
         if demod is None:
             demod = hipops.modconv_demod(styles.float().contiguous(), self._packed.get(self.weight)[1])
-        carried = x if isinstance(x, hipops.SplitAct) else getattr(x, '_ia_split', None)
-        xs = carried if (carried is not None and carried.consumer is self and carried.planes == planes) else \
-            hipops.act_split(x.float().contiguous(), styles.float().contiguous(), consumer=self, planes=planes)
+        xs = self._split_input(x, styles, planes)
         const_noise = self.use_noise and noise_mode == 'const'
         nz = self.noise_const.reshape(-1) if const_noise else None
         ns = self.noise_strength.detach().float().reshape(1) if const_noise else None
@@ -587,6 +600,10 @@ class SynthesisBlock(torch.nn.Module):
             self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2,
                                     resample_filter=resample_filter, channels_last=self.channels_last)
 
+    def _half_ops(self, device, force_fp32=False):
+        """True when this block's 3x3 convolutions run with fp16 operands (one-plane SplitAct in and out)."""
+        return bool(self.use_fp16 and not force_fp32 and device.type == 'cuda' and not FP16_BLOCKS_COMPUTE_FP32)
+
     def forward(self, x, img, ws, condition=None, force_fp32=False, fused_modconv=None, update_emas=False, _next_conv=None, _next_half=None,
                 _x_unused=False, _img_stream=None, _img_wait=None, **layer_kwargs):
         """`_next_conv`: the layer that consumes this block's x (the next block's conv0), given by the owning network on the device
@@ -596,7 +613,7 @@ class SynthesisBlock(torch.nn.Module):
         _ = update_emas
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
         w_iter = iter(ws.unbind(dim=1))
-        half_ops = self.use_fp16 and not force_fp32 and ws.device.type == 'cuda' and not FP16_BLOCKS_COMPUTE_FP32
+        half_ops = self._half_ops(ws.device, force_fp32)
         force_fp32 = True      # storage stays fp32 on this backend (CPU: as the reference, :437)
         if half_ops:
             layer_kwargs = dict(layer_kwargs, half_ops=True)
@@ -758,13 +775,19 @@ class SynthesisNetwork(torch.nn.Module):
         x = img = None
         self._prepare_styles(ws)
         for res, cur_ws in zip(self.block_resolutions, self._split_ws(ws)):
-            x, img = getattr(self, f'b{res}')(x, img, cur_ws, _next_conv=self._next_conv(res), **block_kwargs)
+            x, img = getattr(self, f'b{res}')(x, img, cur_ws, _next_conv=self._next_conv(res), _next_half=self._next_half(res, ws, block_kwargs),
+                                              **block_kwargs)
         return img
 
     def _next_conv(self, res):
         """conv0 of the block after `res` (the consumer of this block's features), or None for the last block."""
         nxt = getattr(self, f'b{res * 2}', None)
         return getattr(nxt, 'conv0', None)
+
+    def _next_half(self, res, ws, block_kwargs):
+        """Does the block after `res` run its convolutions with fp16 operands?  (None: there is no next block.)"""
+        nxt = getattr(self, f'b{res * 2}', None)
+        return None if nxt is None else nxt._half_ops(ws.device, block_kwargs.get('force_fp32', False))
 
     def extra_repr(self):
         return (f'w_dim={self.w_dim:d}, num_ws={self.num_ws:d}, img_resolution={self.img_resolution:d}, '

@@ -19,13 +19,14 @@ from ..training.networks_stylegan2 import (normalize_2nd_moment, modulated_conv2
                                            MappingNetwork, SynthesisLayer, ToRGBLayer, SynthesisBlock)
 
 
-def _paste(cond, x, fused, consumer=None):
+def _paste(cond, x, fused, consumer=None, noise_mode='random', half_ops=False):
     """cond[:, :-1] * a + x * (1 - a), a = cond[:, -1:] (reference :537-540).  `consumer`: the one layer that reads the result (the next
-    block's conv0); when it takes split input the blend is written in that format only (hipops.SplitAct)."""
+    block's conv0); when it takes split input -- under THIS call's noise mode; ia_cond_blend_split writes the two-plane hi / lo form,
+    so not for a consumer that runs with fp16 operands (`half_ops`) -- the blend is written in that format only (hipops.SplitAct)."""
     if fused and cond.dtype == torch.float32 and (x.shape[2] * x.shape[3]) % 4 == 0:
         from invertavatar_amd import hipops
         if (consumer is not None and consumer._pre is not None and x.shape[1] % 8 == 0 and consumer.in_channels == x.shape[1]
-                and consumer._takes_split_input(x.shape[2])):
+                and not half_ops and consumer._takes_split_input(x.shape[2], noise_mode, False)):
             return hipops.cond_blend_split(cond.contiguous(), x.contiguous(), consumer._pre[0], consumer)
         return hipops.cond_blend(cond.contiguous(), x.contiguous())
     a = cond[:, -1:]
@@ -43,7 +44,8 @@ class SynthesisNetwork(_base.SynthesisNetwork):
         for idx, (res, cur_ws) in enumerate(zip(self.block_resolutions, self._split_ws(ws))):
             if idx > first:
                 break
-            x, img = getattr(self, f'b{res}')(x, img, cur_ws, None, _next_conv=self._next_conv(res), **block_kwargs)
+            x, img = getattr(self, f'b{res}')(x, img, cur_ws, None, _next_conv=self._next_conv(res), _next_half=self._next_half(res, ws, block_kwargs),
+                                              **block_kwargs)
         return x, img, first
 
     def forward(self, ws, cond_list, return_list, feat_conditions=None, return_imgs=False, out_res=(32, 256), _head=None, _tap=None,
@@ -62,7 +64,8 @@ class SynthesisNetwork(_base.SynthesisNetwork):
                     continue
                 x, img = _head[0], _head[1]                         # resume after the pre-computed head
             else:
-                x, img = getattr(self, f'b{res}')(x, img, cur_ws, cond, _next_conv=self._next_conv(res), **block_kwargs)
+                x, img = getattr(self, f'b{res}')(x, img, cur_ws, cond, _next_conv=self._next_conv(res),
+                                                  _next_half=self._next_half(res, ws, block_kwargs), **block_kwargs)
             if idx < first:
                 continue
             # On the device inference path nothing downstream writes x / img in place (every fused layer allocates its
@@ -79,7 +82,8 @@ class SynthesisNetwork(_base.SynthesisNetwork):
                 if idx == first:   # face region copied straight into the skip image
                     img = _paste(cond_list[0], img, fused)
                 if idx < last:     # ... and into the features of the next block's input
-                    x = _paste(cond_list[1 + idx - first], x, fused, self._next_conv(res))
+                    x = _paste(cond_list[1 + idx - first], x, fused, self._next_conv(res), block_kwargs.get('noise_mode', 'random'),
+                               bool(self._next_half(res, ws, block_kwargs)))
         if return_list:
             feats.append(img)
             return feats

@@ -336,11 +336,11 @@ class TriPlaneGenerator(torch.nn.Module):
 
     def synthesis_withTexture(self, ws, texture_feats, c, mesh_condition, static_feats=None, neural_rendering_resolution=None,
                               update_emas=False, cache_backbone=False, use_cached_backbone=False, evaluation=False, jitter=None,
-                              **synthesis_kwargs):
+                              ray_dist=None, **synthesis_kwargs):
         # same orchestration as synthesis(): mouth fill + rays on the side stream, face-backbone head on its own stream
-        mouth = self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, None))
+        # (`ray_dist`: see ImportanceRenderer_bsMotion.forward -- 1 value for the batch or one per frame)
+        mouth = self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, ray_dist))
         face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
-        ray_dist = None
         side_rays = _state(self).side_rays
         if side_rays is not None:
             origins, dirs, nrr, ray_dist = side_rays

@@ -185,11 +185,15 @@ class ImportanceRenderer_bsMotion(_RendererBase):
                 and options.get('density_noise', 0) == 0 and _is_osg_decoder(decoder) and not torch.is_grad_enabled())
 
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, evaluation=False, jitter=None, dist=None):
-        """`dist` (1-element tensor) overrides the batch mean of |ray origin|: a sharded batch passes the value of the
-        whole batch so that the depth range does not depend on the sharding."""
+        """`dist` overrides the batch mean of |ray origin| (:311).  One element: a sharded batch passes the value of the whole batch
+        so that the depth range does not depend on the sharding.  B elements: frame b uses dist[b] -- a batch of frames that the
+        caller's script renders one call each (eval_seq.py:206-212) keeps the per-call results."""
         if jitter is None:
             jitter, self._jitter = self._jitter, None
         b, r, _ = ray_origins.shape
+        per_frame = dist is not None and dist.numel() == b and b > 1
+        if dist is not None and not per_frame and dist.numel() != 1:
+            raise ValueError(f'dist must have 1 or B = {b} elements, got {dist.numel()}')
         n_coarse = rendering_options['depth_resolution']
         if evaluation and self._fused_ok(planes, decoder, ray_origins, rendering_options):
             if jitter is None:
@@ -198,7 +202,7 @@ class ImportanceRenderer_bsMotion(_RendererBase):
             jitter = jitter.to(device=planes.device, dtype=torch.float32).reshape(b, r, n_coarse).contiguous()
             if dist is None:
                 dist = torch.norm(ray_origins, dim=-1).mean().reshape(1)  # stays on the device: no host sync
-            dist = dist.to(device=planes.device, dtype=torch.float32).reshape(1)
+            dist = dist.to(device=planes.device, dtype=torch.float32).reshape(-1).contiguous()
             lr_mul = float(decoder.net[0].bias_gain)
             planes_cl = planes.permute(0, 1, 3, 4, 2)          # free when the planes already live channels-last
             if not planes_cl.is_contiguous():
@@ -209,6 +213,10 @@ class ImportanceRenderer_bsMotion(_RendererBase):
                                       box_warp=rendering_options['box_warp'], white_back=rendering_options.get('white_back', False),
                                       channel_major=True)     # [B,R,32] view of a [B,32,R] image: the caller's permute is free
         # torch definition (CPU tensors, training, non-standard options)
+        if per_frame:      # one reference-shaped call per frame (the depth clamp bounds are then per frame too, as in those calls)
+            parts = [self.forward(planes[k:k + 1], decoder, ray_origins[k:k + 1], ray_directions[k:k + 1], rendering_options, evaluation,
+                                  None if jitter is None else jitter[k:k + 1], dist.reshape(-1)[k:k + 1]) for k in range(b)]
+            return tuple(torch.cat(t, 0) for t in zip(*parts))
         self.plane_axes = self.plane_axes.to(ray_origins.device)
         dist = torch.norm(ray_origins, dim=-1).mean().item() if dist is None else float(dist.reshape(-1)[0].item())
         depths = self.sample_stratified(ray_origins, dist - 0.45, dist + 0.6, n_coarse, rendering_options['disparity_space_sampling'],

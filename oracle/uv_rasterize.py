@@ -74,12 +74,18 @@ def render_after_rasterize(face_attrs, pix_to_face, bary):
     return np.concatenate([vals.transpose(2, 0, 1), vis[None].astype(np.float32)], 0)
 
 
-def make_driven_rendering(verts, tris, face_attrs, size=512, crop=(128, 114, 256, 256), blur_radius=1e-6):
-    """uvcoords_image [crop_h, crop_w, 3] for one frame (FaceVerse/renderer.py:66-84 with res == crop size)."""
+def make_driven_rendering(verts, tris, face_attrs, size=512, crop=(128, 114, 256, 256), blur_radius=1e-6, res=None):
+    """uvcoords_image [res, res, 3] for one frame (FaceVerse/renderer.py:66-84): crop, then -- when `res` differs from the crop
+    size -- bilinear interpolation of all channels INCLUDING the continuous mask (:78-79), and the threshold last (:82)."""
     face, bary = rasterize(verts, tris, size, blur_radius)
     rend = render_after_rasterize(face_attrs, face, bary)
     rend = rend * (rend[-1:] * rend[-2:-1])
     left, top, cw, ch = crop
-    uv = rend[:, top:top + ch, left:left + cw].transpose(1, 2, 0)[..., :3].copy()
+    rend = rend[:, top:top + ch, left:left + cw]
+    if res is not None and res != ch:
+        import torch
+        rend = torch.nn.functional.interpolate(torch.from_numpy(np.ascontiguousarray(rend))[None], size=(res, res), mode='bilinear',
+                                               align_corners=False)[0].numpy()
+    uv = rend.transpose(1, 2, 0)[..., :3].copy()
     uv[..., 2] = (uv[..., 2] >= 0.5).astype(np.float32)
     return uv

@@ -379,23 +379,39 @@ def set_eval_seq_modes(net):
     return net
 
 
-def run_few_shot(net, nrr=32):
-    """encode -> two AR_eval_forward groups with carried GRU state -> one drive frame (eval_seq.py:168-212)."""
+def run_few_shot(net, nrr=32, nrr_drive2=128):
+    """eval_seq.py:168-212 as the script runs it on 8 sources (default arguments): encode the first source, features of
+    that identity, then num_iter = 2 groups of four taken INTERLEAVED (``[idx::num_iter]``, :183-186), every group started from the
+    e4e features (``e4e_results=e4e_results``, :187) with the ConvGRU states carried; the drive loop uses the LAST group's result.
+    Two drive frames: one at the inversion's neural rendering resolution and one at `nrr_drive2` (the deployed 128)."""
     net.generator.neural_rendering_resolution = nrr
     groups, drive = encoder_inputs(nrr)
+    src = {k: torch.cat([grp[k] for grp in groups]) for k in groups[0]}
     g = net.generator
-    ws = net.encode(groups[0]['image'][:1])
-    tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
-    sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, noise_mode='const')
-    res, r_list = {'w': ws, 'texture': tex, 'static': sta}, [None, None]
-    for grp in groups:
-        with fixed_randomness(grp['jitter']):
-            res, r_list = net.AR_eval_forward({'image': grp['image'], 'uv': grp['uv']}, grp['c'], {'uvcoords_image': grp['uvcoords']},
-                                              ws, r_list, res)
+    ws = net.encode(src['image'][:1])
+    tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
+    sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
+    e4e, r_list = {'w': ws, 'texture': tex, 'static': sta}, [None, None]
+    num_iter = src['image'].shape[0] // 4
+    for idx in range(num_iter):
+        sel = slice(idx, None, num_iter)
+        with fixed_randomness(src['jitter'][sel]):
+            res, r_list = net.AR_eval_forward({'image': src['image'][sel], 'uv': src['uv'][sel]}, src['c'][sel],
+                                              {'uvcoords_image': src['uvcoords'][sel]}, ws, r_list, e4e_results=e4e, return_fake=False)
     with fixed_randomness(drive['jitter']):
         out = g.synthesis_withTexture(ws, res['texture'], drive['c'], {'uvcoords_image': drive['uvcoords']}, noise_mode='const',
                                       static_feats=res['static'], evaluation=True)
-    return ws, res, r_list, out['image']
+    d2 = drive_frame2(nrr_drive2)
+    with fixed_randomness(d2['jitter']):
+        out2 = g.synthesis_withTexture(ws, res['texture'], d2['c'], {'uvcoords_image': d2['uvcoords']}, noise_mode='const',
+                                       static_feats=res['static'], evaluation=True, neural_rendering_resolution=nrr_drive2)
+    g.neural_rendering_resolution = nrr
+    return ws, res, r_list, out['image'], out2['image']
+
+
+def drive_frame2(nrr=128):
+    fr = [47]
+    return dict(c=synthetic.camera_labels(fr), uvcoords=synthetic.uv_conditions(fr), jitter=synthetic.jitter(fr, nrr * nrr))
 
 
 def gen_encoder():
@@ -404,7 +420,7 @@ def gen_encoder():
     net = inversionNet(generator=g, encoding_triplane=True, encoding_texture=True).requires_grad_(False)
     synthetic.fill_encoder_parameters(net)
     set_eval_seq_modes(net)
-    ws, res, r_list, image = run_few_shot(net)
+    ws, res, r_list, image, image2 = run_few_shot(net)
     def thin(name, t):      # spatial sub-sampling with the stride recorded in the key: <name>_s<stride>
         stride = 1
         while t[..., ::stride, ::stride].numel() > 50000:
@@ -412,6 +428,9 @@ def gen_encoder():
         arrays[f'{name}_s{stride}'] = t[..., ::stride, ::stride]
     arrays = dict(ws=ws)
     thin('drive_image', image)
+    thin('drive_image_nrr128', image2)
+    arrays['drive_image_nrr128_crop'] = image2[:, :, 192:320, 192:320]
+    arrays['drive_image_nrr128_blockmean'] = block_means(image2)
     for i, t in enumerate(res['texture']):
         thin(f'texture{i}', t)
     for i, t in enumerate(res['static']):

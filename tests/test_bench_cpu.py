@@ -1,0 +1,37 @@
+"""bench.py's N > 1 code path (RCCL-free rehearsal): two ranks over gloo on CPU tensors run the SAME make_step / timed / all-gather /
+JSON code the driver's 8-GPU run executes.  Small width, nrr 32: plumbing, not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def run_bench(port, *flags, nproc=2, timeout=900):
+    env = dict(os.environ, OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', str(nproc), *flags]
+    r = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+CPU = ('--device', 'cpu', '--dist-backend', 'gloo', '--width', 'small', '--nrr', '32', '--steps', '1', '--warmup', '0')
+
+
+def test_bench_two_ranks_reenact_workload_over_gloo():
+    out = run_bench(29631, *CPU, '--frames-per-rank', '1')
+    assert out['n_gpus'] == 2 and out['steps'] == 1 and out['scaling'] == 'weak' and out['value'] > 0
+    assert out['config']['global_batch'] == 2 and 'all_gather' in out['config']['collective']
+    assert out['value'] == pytest.approx(2 * 1 / (out['ms_per_step'] * 1e-3), rel=1e-3)        # whole-job frames / max-over-ranks time
+
+
+def test_bench_two_ranks_drive_workload_over_gloo():
+    out = run_bench(29633, *CPU, '--frames-per-rank', '2', '--workload', 'drive', '--drive-frames', '8')
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['value'] > 0
+    assert 'configs[4]' in out['config']['workload'] and out['config']['identity_features'] == 'backbone'

@@ -1,0 +1,98 @@
+"""BASELINE configs[4] on the device: few-shot ConvGRU inversion of 8 source frames (the script's flow) -> identity features -> drive
+frames through synthesis_withTexture in calls of 8 with the SR head in its deployed fp16 precision; and the N > 1 path of bench.py
+rehearsed with two ranks sharing the one GPU over gloo."""
+import os
+
+import pytest
+import torch
+
+from invertavatar_amd import synthetic
+from conftest import max_abs
+
+pytestmark = pytest.mark.gpu
+
+TOL_BATCH = 2e-5           # B = 8 call vs the same frames one call each (HIP vs HIP: summation order of batch-shaped launches only)
+TOL_RGB_FP16_SR = 4e-3     # fp16 SR head vs the fp32 head on the same features (tests/test_generator_gpu.py has the derivation)
+
+
+@pytest.fixture(scope='module')
+def inverted():
+    """Full-width generator with sr_num_fp16_res = 4 + the inversion network; features from the harness' default (script) flow."""
+    from invertavatar_amd import eval_seq
+    from invertavatar_amd.encoder_inversion.models.uvnet import inversionNet
+    from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+    from encoder_common import source_batch
+    g = TriPlaneGenerator(**synthetic.generator_kwargs('full', sr_num_fp16_res=4)).eval().requires_grad_(False)
+    synthetic.fill_parameters(g)
+    net = inversionNet(generator=g, encoding_triplane=True, encoding_texture=True).requires_grad_(False)
+    synthetic.fill_encoder_parameters(net)
+    net = eval_seq.set_eval_seq_modes(net.cuda())
+    g.neural_rendering_resolution = 32                       # (the inversion's own renders; the drive frames below use 128)
+    src = source_batch('cuda')
+    ws, res, _ = eval_seq.few_shot_inversion(net, src['image'], src['uv'], src['c'], src['uvcoords'])
+    return net, ws, res
+
+
+def _drive_inputs(frames, nrr):
+    return (synthetic.camera_labels(frames).cuda(), synthetic.uv_conditions(frames).cuda(), synthetic.jitter(frames, nrr * nrr).squeeze(-1).cuda())
+
+
+def test_config4_drive_block_of_eight_fp16_sr_on_inverted_features(inverted):
+    from invertavatar_amd import eval_seq
+    from invertavatar_amd.frame_parallel import per_frame_ray_dist
+    from invertavatar_amd.graphed import GraphedDrive
+    from invertavatar_amd.training import networks_stylegan2 as sg2
+    net, ws, res = inverted
+    nrr, frames = 128, [40, 47, 61, 90, 120, 155, 200, 233]
+    c, uv, jit = _drive_inputs(frames, nrr)
+    saved, sg2.FP16_BLOCKS_COMPUTE_FP32 = sg2.FP16_BLOCKS_COMPUTE_FP32, False
+    try:
+        with torch.no_grad():
+            one, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=1, neural_rendering_resolution=nrr)     # the script: B = 1
+            blk, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=8, neural_rendering_resolution=nrr)     # one call of 8
+            graphed = GraphedDrive(net.generator, ws, res['texture'], res['static'], batch=8, neural_rendering_resolution=nrr, ray_dist_elems=8)
+            rep = graphed(c, uv, jit, per_frame_ray_dist(c))['image'].clone()
+            sg2.FP16_BLOCKS_COMPUTE_FP32 = True                                                                               # fp32 head, same features
+            f32, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=8, neural_rendering_resolution=nrr)
+    finally:
+        sg2.FP16_BLOCKS_COMPUTE_FP32 = saved
+    assert blk.shape == (8, 3, 512, 512) and torch.isfinite(blk).all()
+    d_batch, d_graph, d_f32 = max_abs(blk, one), max_abs(rep, blk), max_abs(blk, f32)
+    print(f'configs[4] drive block: B=8 vs 8 x B=1 {d_batch:.2e}, graph vs eager {d_graph:.2e}, fp16 SR vs fp32 SR {d_f32:.2e}')
+    assert d_batch <= TOL_BATCH
+    assert d_graph == 0.0                                    # the captured call replays the eager call bit for bit
+    assert 0.0 < d_f32 <= TOL_RGB_FP16_SR                    # (> 0: the fp16 mode really ran)
+    assert max_abs(blk[0], blk[1]) > 1e-2                    # different drive frames differ
+
+
+def test_synthesis_with_random_noise_mode_runs_on_the_device_path():
+    """noise_mode='random' (the default of G(z, c, v)) must not hand a SplitAct to a layer that takes the
+    random-noise branch.  With every noise_strength at zero the random-noise route equals the const-noise route."""
+    from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+    g = TriPlaneGenerator(**synthetic.generator_kwargs('small')).eval().requires_grad_(False)
+    synthetic.fill_parameters(g)
+    for name, p in g.named_parameters():
+        if name.endswith('noise_strength'):
+            p.zero_()
+    g = g.cuda()
+    frames, nrr = [3, 77], 32
+    c, uv, jit = _drive_inputs(frames, nrr)
+    with torch.no_grad():
+        ws = g.mapping(synthetic.latent(5, 2).cuda(), synthetic.conditioning_camera().cuda().expand(2, -1), truncation_psi=0.7, truncation_cutoff=14)
+        kw = dict(neural_rendering_resolution=nrr, evaluation=False, jitter=jit, return_featmap=True)
+        a = g.synthesis(ws, c, {'uvcoords_image': uv}, noise_mode='random', **kw)['triplane']       # (the renderer draws its own samples
+        b = g.synthesis(ws, c, {'uvcoords_image': uv}, noise_mode='const', **kw)['triplane']        # without evaluation: compare the planes)
+        out = g(synthetic.latent(5, 2).cuda(), c, {'uvcoords_image': uv}, neural_rendering_resolution=nrr)      # defaults: noise_mode random
+    assert torch.isfinite(out['image']).all() and out['image'].shape == (2, 3, 512, 512)
+    assert max_abs(a, b) <= 2e-4, max_abs(a, b)
+
+
+@pytest.mark.parametrize('workload,extra', [('reenact', ()), ('drive', ('--features', 'backbone', '--drive-frames', '8'))])
+def test_bench_n_gt_1_path_two_ranks_on_one_gpu(workload, extra):
+    """bench.py --gpus 2 with both ranks on cuda:0 and the collectives over gloo: device tensors, captured graphs with the
+    batch-global / per-frame ray_dist input, the all-gather and the max-over-ranks timing all execute (RCCL itself is the driver's)."""
+    from test_bench_cpu import run_bench
+    out = run_bench(29641 if workload == 'reenact' else 29643, '--dist-backend', 'gloo', '--width', 'full', '--steps', '2', '--warmup', '1',
+                    '--frames-per-rank', '2', '--workload', workload, *extra, timeout=1500)
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['value'] > 0
+    assert out['config']['launch'].startswith('hipGraph replay'), out['config']['launch']

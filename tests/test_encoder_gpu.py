@@ -5,14 +5,21 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+TOL_FEATURES = 2e-3      # relative to max(1, max |ref|): features / GRU states after two train-mode-BatchNorm UNet passes
+TOL_DRIVE_RGB = 1e-3     # BASELINE: rendered RGB within 1e-3 of the reference
+
 
 def test_few_shot_inversion_matches_reference(golden):
-    from encoder_common import build_inversion_net, run_few_shot, compare_with_fixture
+    """H2: the harness' DEFAULT path = the script's own flow (interleaved groups, e4e features into every group,
+    eval_seq.py:183-187) against the fixture the reference recorded with that flow; two drive frames (nrr 32 and nrr 128)."""
+    from encoder_common import build_inversion_net, run_few_shot, fixture_deviations
     net = build_inversion_net('full').cuda()
-    ws, res, r_list, image = run_few_shot(net, 'cuda')
-    worst = compare_with_fixture(golden('encoder_fewshot.npz'), ws, res, r_list, image, tol=2e-3)
-    print(f'few-shot inversion: worst relative deviation {worst:.2e}')
-    assert image.shape == (1, 3, 512, 512)
+    ws, res, r_list, image, image2 = run_few_shot(net, 'cuda')
+    dev = fixture_deviations(golden('encoder_fewshot.npz'), ws, res, r_list, image, image2)
+    print('few-shot inversion, deviation per recorded tensor:', {k: float(f'{v:.2e}') for k, v in dev.items()})
+    assert image.shape == (1, 3, 512, 512) and image2.shape == (1, 3, 512, 512)
+    bad = {k: v for k, v in dev.items() if v > (TOL_DRIVE_RGB if k.startswith('drive_image') else TOL_FEATURES)}
+    assert not bad, bad
 
 
 @pytest.mark.parametrize('prelu', [False, True])

@@ -115,3 +115,19 @@ sys.stdout.buffer.write(pickle.dumps(dict(G=g, G_ema=g, D=None)))
     ref = TriPlaneGenerator(**synthetic.generator_kwargs('small')).eval().requires_grad_(False)
     synthetic.fill_parameters(ref)
     assert all(torch.equal(a, b) for a, b in zip(ref.state_dict().values(), new.state_dict().values()))
+
+
+def test_pickle_naming_a_foreign_global_is_refused():
+    """the unpickler resolves only allow-listed globals -- a crafted pickle cannot reach os.system & co."""
+    import io
+    import os
+    import pickle
+    import pytest
+    from invertavatar_amd import legacy
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('true',))
+    blob = pickle.dumps({'G_ema': Evil()})
+    with pytest.raises(pickle.UnpicklingError, match='allow-list'):
+        legacy.load_network_pkl(io.BytesIO(blob))

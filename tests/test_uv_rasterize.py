@@ -83,3 +83,19 @@ def test_rasterized_condition_drives_the_generator():
     assert img[..., :2].abs().max().item() <= 1.0 + 1e-6
     half = ras.make_driven_rendering_from_vertices(torch.from_numpy(verts).cuda(), res=128)
     assert half.shape == (1, 128, 128, 3) and set(half[..., 2].unique().tolist()) <= {0.0, 1.0}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('res', [128, 192])
+def test_uv_rasterizer_resized_output_thresholds_after_the_resize(res):
+    """ADVICE r2: with res != 256 the reference interpolates the continuous mask and thresholds once, afterwards (renderer.py:78-82);
+    binarising at 256^2 first moves the silhouette by up to a pixel."""
+    from invertavatar_amd.data_preprocess.FaceVerse.renderer import UVRasterizer
+    verts, tris, uv, mask = synthetic_mesh(40, 5)
+    ras = UVRasterizer(tris, uv, mask, 'cuda')
+    tv = ras.project(torch.from_numpy(verts).cuda())
+    got = ras.rasterize(tv, res=res).cpu().numpy()[0]
+    want = OU.make_driven_rendering(tv.cpu().numpy()[0], tris, ras.face_uvcoords.cpu().numpy()[0], res=res)
+    assert got.shape == (res, res, 3)
+    assert np.array_equal(got[..., 2], want[..., 2]), int((got[..., 2] != want[..., 2]).sum())
+    assert np.abs(got - want).max() <= 2e-5
