@@ -53,13 +53,19 @@ def test_config4_drive_block_of_eight_fp16_sr_on_inverted_features(inverted):
             graphed = GraphedDrive(net.generator, ws, res['texture'], res['static'], batch=8, neural_rendering_resolution=nrr, ray_dist_elems=8)
             rep = graphed(c, uv, jit, per_frame_ray_dist(c))['image'].clone()
             sg2.FP16_BLOCKS_COMPUTE_FP32 = True                                                                               # fp32 head, same features
+            one32, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=1, neural_rendering_resolution=nrr)
             f32, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=8, neural_rendering_resolution=nrr)
     finally:
         sg2.FP16_BLOCKS_COMPUTE_FP32 = saved
     assert blk.shape == (8, 3, 512, 512) and torch.isfinite(blk).all()
-    d_batch, d_graph, d_f32 = max_abs(blk, one), max_abs(rep, blk), max_abs(blk, f32)
-    print(f'configs[4] drive block: B=8 vs 8 x B=1 {d_batch:.2e}, graph vs eager {d_graph:.2e}, fp16 SR vs fp32 SR {d_f32:.2e}')
-    assert d_batch <= TOL_BATCH
+    d_batch32, d_batch16, d_graph, d_f32 = max_abs(f32, one32), max_abs(blk, one), max_abs(rep, blk), max_abs(blk, f32)
+    print(f'configs[4] drive block: B=8 vs 8 x B=1 {d_batch32:.2e} (fp32 head) / {d_batch16:.2e} (fp16 head), graph vs eager {d_graph:.2e}, '
+          f'fp16 SR vs fp32 SR {d_f32:.2e}')
+    # Batching changes the summation order of the batch-shaped launches only: 2e-5 with the fp32 head.  With the fp16 head those
+    # last-bit differences meet the fp16 rounding of every stored activation (a value next to a rounding boundary lands on the other
+    # side: 2^-11 relative), so the batched and the one-frame calls agree to the fp16 mode's own tolerance, not to 2e-5.
+    assert d_batch32 <= TOL_BATCH
+    assert d_batch16 <= TOL_RGB_FP16_SR
     assert d_graph == 0.0                                    # the captured call replays the eager call bit for bit
     assert 0.0 < d_f32 <= TOL_RGB_FP16_SR                    # (> 0: the fp16 mode really ran)
     assert max_abs(blk[0], blk[1]) > 1e-2                    # different drive frames differ

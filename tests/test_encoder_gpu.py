@@ -5,8 +5,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL_FEATURES = 2e-3      # relative to max(1, max |ref|): features / GRU states after two train-mode-BatchNorm UNet passes
-TOL_DRIVE_RGB = 1e-3     # BASELINE: rendered RGB within 1e-3 of the reference
+TOL_FEATURES = 5e-5      # relative to max(1, max |ref|): features / GRU states after two train-mode-BatchNorm UNet passes (measured r03: <= 3.4e-6)
+TOL_DRIVE_RGB = 1e-4     # BASELINE asks 1e-3 on rendered RGB; measured r03: 4.8e-6 at nrr 128, 2.4e-6 at nrr 32
 
 
 def test_few_shot_inversion_matches_reference(golden):
