@@ -19,6 +19,7 @@
 // Replaces, like ia_conv2d_mfma, modulated_conv2d -> conv2d_resample -> conv2d / conv_transpose2d (+ bias_act) of the reference
 // (training/networks_stylegan2.py:34-91, torch_utils/ops/conv2d_resample.py:114-136).
 #include "conv_common.h"
+#include <cstdlib>
 
 // Compile-time ablations for tools/ablate_conv_split.sh (never set in the product build): 1 = no DMA after the first chunk of a
 // segment, 2 = no MFMAs (operand reads kept alive), 3 = no operand reads (MFMAs on stale registers), 4 = no output stores.
@@ -31,7 +32,44 @@
 
 namespace {
 
+constexpr size_t kLdsBytes = 160 * 1024;     // per CU on gfx950
+
 typedef __attribute__((address_space(3))) char lds_char;
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from a buffer resource into LDS at lds_addr + 16 * lane (out-of-range lanes write zeros).
+// Issued as inline assembly on purpose: for the builtin form the compiler's wait-count pass cannot tell which LDS stage a later
+// ds_read touches and inserts `s_waitcnt vmcnt(0)` in front of the first operand read of every chunk, which drains the whole ring
+// (seen in the ISA of the first ring build).  The kernel orders its reads behind the DMA itself: wait_vmcnt + s_barrier.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // (m0 is a reserved register: naming it as clobbered is the point)
+__device__ __forceinline__ void dma_piece(u32x4 rsrc, unsigned lds_addr, int voffset, int soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+__device__ __forceinline__ u32x4 buffer_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);      // stride 0: raw buffer, byte offsets
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate).  Loads -- LDS-DMA included -- return in order, so
+// "at most n outstanding" means everything issued before the youngest n has landed.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (__builtin_amdgcn_readfirstlane(n)) {
+#define IA_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define IA_W8(k) IA_W(k) IA_W(k + 1) IA_W(k + 2) IA_W(k + 3) IA_W(k + 4) IA_W(k + 5) IA_W(k + 6) IA_W(k + 7)
+        IA_W8(1) IA_W8(9) IA_W8(17) IA_W8(25) IA_W8(33) IA_W8(41) IA_W8(49) IA_W(57) IA_W(58) IA_W(59) IA_W(60) IA_W(61) IA_W(62) IA_W(63)
+#undef IA_W8
+#undef IA_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
 
 // fp32 NCHW (times an optional per-(batch, channel) style) -> split planes.  One thread = one pixel of one 8-channel group.
 __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ x, const float* __restrict__ styles, h16x8* __restrict__ out,
@@ -204,12 +242,13 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     const int tile_base = SK ? g.T_dp : 0;
     const int HW = g.H * g.W;
     const int plane_bytes = (g.I / 8) * HW * 16;
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16x8*>(xs) + (int64_t)b * NP * (g.I / 8) * HW, 0, NP * plane_bytes, 0x00020000);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16x8*>(wk), 0, NP * NT * (g.I / 8) * g.O * 16, 0x00020000);
-    lds_char* const lds_base = (lds_char*)lds;
+    const u32x4 rs_x = buffer_rsrc(xs + (int64_t)b * NP * (g.I / 8) * HW, (unsigned)(NP * plane_bytes));
+    const u32x4 rs_w = buffer_rsrc(wk, (unsigned)(NP * NT * (g.I / 8) * g.O * 16));
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_char*)lds;
 
-    // the all-zero tap of every plane, in both stages (the DMA never writes there)
-    for (int i = tid; i < 2 * NP * BO; i += NTHREADS) {
+    // the all-zero tap of every plane, in every stage of the ring (the DMA never writes there)
+    const int NS = g.stages;                           // LDS stages of the DMA ring (>= 2): chunks ch+1 .. ch+NS-1 are in flight under chunk ch
+    for (int i = tid; i < NS * NP * BO; i += NTHREADS) {
         const int stg = i / (NP * BO), r = i - stg * NP * BO, pl = r / BO, o = r - pl * BO;
         *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + stg * stage_bytes + ((pl * NTP + NT) * BO + o) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -277,32 +316,55 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     // every DMA of one chunk into one LDS stage.  (The voffset argument goes through a plain local: hipcc 7.2 silently drops the HOST
     // stub of a kernel template that passes an element of a template-sized array straight to the raw_ptr_buffer_load_lds builtin
     // -- the .so then fails to load with an undefined kernel symbol.)
-#define IA_ISSUE_DMA(chunk, stage)                                                                                                      \
+    // Slice `sl` of `nsl` of the chunk's pieces (piece q of this wave's list -- weights first, then patch -- belongs to slice q % nsl);
+    // nsl = 1 issues the whole chunk.
+#define IA_ISSUE_DMA_SLICE(chunk, stage, sl, nsl)                                                                                       \
     do {                                                                                                                               \
-        lds_char* st_ = lds_base + (stage) * stage_bytes;                                                                              \
+        const unsigned st_ = lds_base + (stage) * stage_bytes;                                                                         \
         const int wso_ = (chunk) * g.O * 16, pso_ = (chunk) * HW * 16;                                                                 \
         _Pragma("unroll") for (int j = 0; j < JW; ++j) {                                                                               \
             const int gidx = j * NWAVES + wave;                                                                                        \
-            if (gidx < WG) {                                                                                                           \
+            if (j % (nsl) == (sl) && gidx < WG) {                                                                                      \
                 const int row = (gidx * 64) / BO, o = gidx * 64 - row * BO, pl = row / NT, tap = row - pl * NT;                        \
                 const int vo_ = w_voff[j];                                                                                             \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, st_ + ((pl * NTP + tap) * BO + o) * 16, 16, vo_, wso_, 0, 0);           \
+                dma_piece(rs_w, st_ + ((pl * NTP + tap) * BO + o) * 16, vo_, wso_);                                                    \
             }                                                                                                                          \
         }                                                                                                                              \
         _Pragma("unroll") for (int j = 0; j < JP; ++j) {                                                                               \
             const int gidx = j * NWAVES + wave;                                                                                        \
             const int vo_ = p_voff[j];                                                                                                 \
-            if (gidx < PG) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, st_ + (WSLOTS + gidx * 64) * 16, 16, vo_, pso_, 0, 0);       \
+            if ((JW + j) % (nsl) == (sl) && gidx < PG) dma_piece(rs_x, st_ + (WSLOTS + gidx * 64) * 16, vo_, pso_);                    \
         }                                                                                                                              \
     } while (0)
+#define IA_ISSUE_DMA(chunk, stage) IA_ISSUE_DMA_SLICE(chunk, stage, 0, 1)
 
+    // DMA instructions this wave issues per chunk (wave-uniform): what one chunk adds to its vmcnt
+    int n_dma = 0;
+#pragma unroll
+    for (int j = 0; j < JW; ++j) n_dma += (j * NWAVES + wave < WG) ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < JP; ++j) n_dma += (j * NWAVES + wave < PG) ? 1 : 0;
+    // The previous segment's epilogue loads / stores are drained with a wait the compiler can SEE (vmcnt(0), gfx9 encoding): its
+    // wait-count pass cannot look inside the inline-assembly DMA, so anything it still believes pending when it meets a register
+    // re-use in the K loop would be waited for with vmcnt(0) there -- draining the ring on every chunk.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();                         // the previous segment's readers (and the zero-tap stores) are done
-    IA_ISSUE_DMA(c_lo, 0);
+    int issued = c_lo;                       // next chunk to issue; chunk c lives in stage (c - c_lo) % NS
+    for (int k = 0; k < NS - 1 && issued < c_hi; ++k, ++issued) IA_ISSUE_DMA(issued, k);
     int cur = 0;
     for (int ch = c_lo; ch < c_hi; ++ch) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMAs of chunk `ch` have landed ...
-        if (IA_ABLATE < 7 || ch == c_lo) __syncthreads();     // ... and everybody's; the other stage has no readers left
-        if (!IA_AB_NODMA && ch + 1 < c_hi) IA_ISSUE_DMA(ch + 1, cur ^ 1);
+        wait_vmcnt((issued - ch - 1) * n_dma);                // this wave's DMAs of chunk `ch` have landed (younger chunks stay in flight) ...
+        __builtin_amdgcn_s_barrier();                         // ... and everybody's; the stage of chunk ch - 1 has no readers left
+        asm volatile("" ::: "memory");                        // (s_barrier alone is no compiler fence: keep the operand reads below it)
+        // The chunk that goes into the stage just freed.  Issued either here in one burst, or (g.spread) a slice after each k-step's
+        // MFMAs: a piece costs its wave 60-185 issue cycles, and right after the barrier every wave of the SIMD would pay them at the
+        // same time with the matrix pipe idle; spread out, one wave's pieces run under the other wave's MFMAs.
+        const bool fill = !IA_AB_NODMA && issued < c_hi;
+        const int fill_chunk = issued, fill_stage = cur == 0 ? NS - 1 : cur - 1;
+        if (fill) {
+            if (!g.spread) IA_ISSUE_DMA(fill_chunk, fill_stage);
+            ++issued;
+        }
         const h16x8* wh = reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(lds) + cur * stage_bytes);
         const h16x8* ph = wh + WSLOTS;
         // five k-steps: the 8 channels of a pair of taps (lanes 0-31 the first tap, lanes 32-63 the second).  Operand reads run one
@@ -358,8 +420,12 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
                 for (int fp = 0; fp < FP; ++fp)          // hi * hi
                     acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][fo], b_buf[c_][fp], acc[ph_][fo][fp], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (fill && g.spread) {
+                IA_ISSUE_DMA_SLICE(fill_chunk, fill_stage, s, kPairs);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        cur ^= 1;
+        cur = cur + 1 == NS ? 0 : cur + 1;
     }
 
 #pragma unroll
@@ -397,13 +463,29 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     }
   }   // segments of this worker
 #undef IA_ISSUE_DMA
+#undef IA_ISSUE_DMA_SLICE
 }
 
 template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP>
-int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const Geo& g, const Epi& e, hipStream_t s) {
-    constexpr int BO = 32 * FO * WO;
-    const size_t lds = (size_t)2 * (NP * 10 * BO + NP * g.patch_cap) * 16;
-    if (lds > 160 * 1024) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
+int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const Geo& g_in, const Epi& e, hipStream_t s) {
+    constexpr int BO = 32 * FO * WO, NWAVES = WO * WP;
+    const size_t stage = (size_t)(NP * 10 * BO + NP * g_in.patch_cap) * 16;
+    if (2 * stage > kLdsBytes) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", 2 * stage);
+    // Ring depth.  Measured on MI355X (tools/bench_conv_layers.py, r03): with the ring really running ahead (no compiler-inserted
+    // drain, see dma_piece) 3 .. 6 stages change no layer by more than the run-to-run noise -- the DMA's latency was never the
+    // exposed part -- while the 4-wave tiles lose 35-55 % when a deep ring takes the LDS of the second workgroup of their CU.
+    // So: two stages; more only on request (IA_RING_STAGES), bounded by the LDS and by the 6-bit vmcnt counter ((stages - 1)
+    // chunks of DMA instructions are outstanding per wave).
+    Geo g = g_in;
+    const int per_wave = (NP * 9 * BO / 64 + NWAVES - 1) / NWAVES + JP;
+    int ns = 2;
+    if (const char* ev = getenv("IA_RING_STAGES")) {      // experiment switch (tools/): force the ring depth where it fits
+        const int want = atoi(ev);
+        if (want >= 2 && (size_t)want * stage <= kLdsBytes && (want - 1) * per_wave <= 63) ns = want;
+    }
+    g.stages = ns;
+    if (const char* ev = getenv("IA_DMA_SPREAD")) g.spread = atoi(ev);
+    const size_t lds = stage * ns;
     int st = IA_OK;
     if (g.T_dp > 0) {
         if constexpr (!TR) {

@@ -46,3 +46,17 @@ with torch.no_grad():
                            jitter=jit, return_featmap=True)['triplane']
     o, d, nrr = gen._rays(cams, 128)
     timeit('render + SR', lambda: gen._render(ws, planes, o, d, nrr, True, jit, dict(noise_mode='const')))
+    # the super-resolution head alone, and the planes stage (everything in front of the renderer) alone
+    feat = gen._render(ws, planes, o, d, nrr, True, jit, dict(noise_mode='const'))[3]
+    rgb = feat[:, :3].contiguous()
+    timeit('SR head', lambda: gen.superresolution(rgb, feat, ws, noise_mode=gen.rendering_kwargs['superresolution_noise_mode']))
+
+    def planes_only():
+        mouth = gen._start_mouth_fill({'uvcoords_image': uvs}, rays=(cams, 128, None))
+        head = gen._start_face_head(ws, False, dict(noise_mode='const'))
+        t, s_, pending = gen._two_backbones(ws, False, dict(noise_mode='const'), partial=True)
+        pl = gen._planes(ws, t, s_, {'uvcoords_image': uvs}, False, dict(noise_mode='const'), mouth=mouth, face_head=head, pending=pending)
+        torch.cuda.current_stream().wait_stream(pending[0])
+        return pl
+    timeit('planes (3 backbones + raster)', planes_only)
+    timeit('face backbone after head', lambda: gen._planes(ws, tex, sta, {'uvcoords_image': uvs}, False, dict(noise_mode='const')))
