@@ -179,6 +179,20 @@ int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed,
  */
 int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B, int I, int O, void* stream);
 
+/*
+ * The same fused convolution for the SMALL 3x3 layers of a synthesis network (4^2 .. 16^2 blocks and the 16^2 -> 32^2
+ * up-sampling layer: H * W <= 256, I % 32 == 0, O % 16 == 0) in ONE launch without scratch: 16 channel x 16 point tiles on
+ * v_mfma_f32_16x16x4_f32, the K loop of a tile split over the 8 waves of its workgroup and added through LDS in wave order
+ * (deterministic); operands straight from global memory.  Arguments, arithmetic (fp32 operands, fp32 accumulation) and the
+ * transposed form's contract are those of ia_conv2d_mfma with ksize 3 and no residual; replaces the same reference chain
+ * (training/networks_stylegan2.py:34-91, torch_utils/ops/conv2d_resample.py:114-136) and, against ia_conv2d_mfma on these shapes,
+ * the stream-K slabs and the fix-up launch.  ia_conv2d_small_supported returns 1 for shapes it takes.
+ */
+int ia_conv2d_small_supported(int I, int O, int H, int W, int transposed);
+int ia_conv2d_small(const float* x, const float* wk, const float* styles, const float* demod, const float* noise,
+                    const float* noise_strength, const float* bias, float* y, int B, int I, int O, int H, int W,
+                    int transposed, int act, float alpha, float gain, float clamp, void* stream);
+
 #define IA_RENDER_WHITE_BACK 1
 #define IA_RENDER_RGB_CHANNEL_MAJOR 2
 #define IA_RENDER_DIST_PER_FRAME 4

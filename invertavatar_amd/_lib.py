@@ -31,6 +31,8 @@ _SIGNATURES = {
     'ia_conv2d_mfma': [c_void_p] * 10 + [ctypes.c_size_t] + [c_int] * 8 + [c_float, c_float, c_float, c_int, c_void_p],
     'ia_conv2d_mfma_h': [c_void_p] * 10 + [ctypes.c_size_t] + [c_int] * 8 + [c_float, c_float, c_float, c_int, c_void_p],
     'ia_conv2d_mfma_s': [c_void_p] * 2 + [c_int] + [c_void_p] * 8 + [ctypes.c_size_t] + [c_int] * 8 + [c_float, c_float, c_float, c_int, c_void_p],
+    'ia_conv2d_small_supported': [c_int] * 5,
+    'ia_conv2d_small': [c_void_p] * 8 + [c_int] * 7 + [c_float, c_float, c_float, c_void_p],
     'ia_conv2d_plan': [c_int] * 8 + [ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_size_t)],
     'ia_modconv_demod': [c_void_p] * 3 + [c_int] * 3 + [c_void_p],
     'ia_render_rays': [c_void_p] * 9 + [c_float, c_float, c_int] + [c_int] * 6 + [c_void_p] * 9 + [c_void_p],

@@ -131,13 +131,43 @@ def _scratch_buffer(device, nbytes):
     return buf
 
 
+SMALL_CONV = True      # 3x3 layers up to 16^2 (and 16^2 -> 32^2): one ia_conv2d_small launch instead of stream-K kernel + fix-up
+
+
+def conv2d_small(x, wk, styles=None, demod=None, noise=None, noise_strength=None, bias=None, transposed=False, act='linear', alpha=0.2,
+                 gain=1.0, clamp=None):
+    """ia_conv2d_small: the fused 3x3 convolution for the small layers (same contract as conv2d_mfma with ksize 3, no residual)."""
+    _f32c(x, 'x')
+    _f32c(wk, 'wk')
+    b, i, h, w = x.shape
+    taps, wi, o = wk.shape
+    if taps != 9 or wi != i:
+        raise RuntimeError(f'packed weight {tuple(wk.shape)} does not match 3x3, in-channels {i}')
+    for name, t in (('styles', styles), ('demod', demod), ('noise', noise), ('bias', bias)):
+        if t is not None:
+            _f32c(t, name)
+    oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (h, w)
+    y = torch.empty(b, o, oh, ow, device=x.device, dtype=torch.float32)
+    flops = 2.0 * b * h * w * i * o * 9
+    traffic = 4.0 * (x.numel() + wk.numel() + y.numel())
+    with torch.cuda.device(x.device), _Timed('conv2d_small_t' if transposed else 'conv2d_small', flops, traffic, f'B{b} I{i} O{o} {h}x{w}'):
+        st = _lib.load().ia_conv2d_small(_p(x), _p(wk), _p(styles), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(y), b, i, o, h, w,
+                                         int(transposed), ACT_ID[act], float(alpha), float(gain), float(-1 if clamp is None else clamp),
+                                         _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_conv2d_small')
+    return y
+
+
 def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None, bias=None, residual=None,
                 ksize=3, transposed=False, act='linear', alpha=0.2, gain=1.0, clamp=None, ksplit=None):
     """One fused StyleGAN2 convolution (see ia_conv2d_mfma in include/ia_hip.h).  A float16 `wk` (pack_conv_weight_h)
-    selects the fp16-operand form ia_conv2d_mfma_h."""
+    selects the fp16-operand form ia_conv2d_mfma_h.  Small fp32 3x3 layers go to ia_conv2d_small (SMALL_CONV)."""
     _f32c(x, 'x')
     b, i, h, w = x.shape
     half_ops = wk.dtype == torch.float16
+    if (SMALL_CONV and not half_ops and ksize == 3 and residual is None and ksplit is None and wk.dim() == 3
+            and _lib.load().ia_conv2d_small_supported(i, wk.shape[2], h, w, int(transposed))):
+        return conv2d_small(x, wk, styles, demod, noise, noise_strength, bias, transposed, act, alpha, gain, clamp)
     split = half_ops and wk.dim() == 5
     if half_ops:
         if not (wk.is_cuda and wk.is_contiguous() and wk.dim() in (4, 5) and wk.shape[-1] == 8 and (not split or wk.shape[0] == 2)):
