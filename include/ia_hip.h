@@ -205,6 +205,9 @@ int ia_conv2d_small(const float* x, const float* wk, const float* styles, const 
  *   planes_cl : [B, 3, plane_h, plane_w, 32] float32 -- the tri-planes in CHANNELS-LAST order (the reference's
  *               [B, 3, 32, H, W] permuted so that a texel's 32 channels are one 128-byte line)
  *   rays_o/d  : [B, R, 3];  jitter : [B, R, 48] in [0,1), the stratified-sampling noise of renderer.py:406
+ *   u_importance : NULL = evaluation mode, the importance pass inverts the CDF on the grid linspace(0, 1, 48) (renderer.py:450);
+ *               else [B, R, 48] uniform draws in [0,1) (the torch.rand of renderer.py:453), SORTED ascending per ray (the inverse
+ *               CDF is monotone, so the fine depths then come out sorted and the merged order equals torch.sort of :361)
  *   dist      : device scalar = mean |ray origin| over the WHOLE batch (renderer.py:311); ray_start/end are
  *               derived from it in-kernel exactly as :313 does in Python doubles
  *   w0,b0,w1,b1 : OSGDecoder parameters net.0.weight [64,32], net.0.bias [64], net.2.weight [33,64], net.2.bias [33]
@@ -223,7 +226,7 @@ int ia_conv2d_small(const float* x, const float* wk, const float* styles, const 
  *          coarse weights [B,R,47], coarse densities [B,R,48]
  */
 int ia_render_rays(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
-                   const float* dist, const float* w0, const float* b0, const float* w1, const float* b1,
+                   const float* u_importance, const float* dist, const float* w0, const float* b0, const float* w1, const float* b1,
                    float lr_multiplier, float box_warp, int flags,
                    int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
                    float* rgb, float* depth, float* wsum, float* minmax_scratch,

@@ -47,6 +47,7 @@ struct Params {
     const float* rays_o;          // [B][R][3]
     const float* rays_d;          // [B][R][3]
     const float* jitter;          // [B][R][48]
+    const float* u_imp;           // [B][R][48] sorted uniform draws of the importance pass, or null: linspace(0, 1, 48)
     const float* dist;            // device scalar: batch mean of |ray origin| (renderer.py:311); [B] with dist_per_frame
     const float* w0; const float* b0; const float* w1; const float* b1;   // decoder parameters, reference layout
     float w0_gain, w1_gain, b_gain;
@@ -278,7 +279,7 @@ __device__ __forceinline__ double lane_value(double x, int l) {      // wave-uni
 
 // Smoothed inverse-CDF importance resampling of one ray, all in per-wave LDS scratch.
 //   in : tc[48] coarse depths, wc[47] coarse weights        out: tf[48] fine depths, returns ind for lane < 48
-__device__ __forceinline__ int importance_resample(float* scr, int lane) {
+__device__ __forceinline__ int importance_resample(float* scr, int lane, const float* u_row = nullptr) {
     float* tc = scr; float* wc = scr + 2 * NS; float* av = scr + 3 * NS; float* pdf = scr + 4 * NS;
     float* cdf = scr + 5 * NS; float* bins = scr + 6 * NS; float* tf = scr + 7 * NS;
     // max_pool1d(2,1,pad 1) then avg_pool1d(2,1), + 0.01 (renderer.py:421-423); bins = depth midpoints (:425)
@@ -325,7 +326,9 @@ __device__ __forceinline__ int importance_resample(float* scr, int lane) {
     int ind = 0;
     if (lane < NS) {
         const float ustep = 1.0f / (float)(NS - 1);
-        const float u = linspace_at(0.f, 1.f, ustep, lane, NS);
+        // evaluation: the deterministic grid linspace(0, 1, 48) (renderer.py:450); otherwise the caller's uniform draws (:453), which
+        // it hands over sorted so that the fine depths come out sorted like the grid's
+        const float u = u_row ? u_row[lane] : linspace_at(0.f, 1.f, ustep, lane, NS);
         // searchsorted(right=True) on the non-decreasing cdf[0..45]: number of entries <= u, by bisection
         int lo = 0, hi = NS - 2;                      // the count lies in [lo, hi]
 #pragma unroll
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         }
         wave_sync();
         // ---- importance resampling + merge
-        const int ind = importance_resample(scr, lane);
+        const int ind = importance_resample(scr, lane, p.u_imp ? p.u_imp + (int64_t)ray * NS : nullptr);
         int pos_c, pos_f;
         merge_sorted(scr, lane, pos_c, pos_f);
         if (lane < NS) {
@@ -656,7 +659,7 @@ extern "C" int ia_render_rays_grid(int B, int R) {
 }
 
 extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
-                              const float* dist, const float* w0, const float* b0, const float* w1, const float* b1,
+                              const float* u_importance, const float* dist, const float* w0, const float* b0, const float* w1, const float* b1,
                               float lr_multiplier, float box_warp, int flags,
                               int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
                               float* rgb, float* depth, float* wsum, float* minmax_scratch,
@@ -672,7 +675,7 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
     IA_REQUIRE(plane_h < (1 << 23) && plane_w < (1 << 23) && (int64_t)3 * plane_h * plane_w * 128 < ((int64_t)1 << 32),
                "planes of one batch element must stay below 4 GiB (32-bit texel offsets)");
     Params p;
-    p.planes = planes_cl; p.rays_o = rays_o; p.rays_d = rays_d; p.jitter = jitter; p.dist = dist;
+    p.planes = planes_cl; p.rays_o = rays_o; p.rays_d = rays_d; p.jitter = jitter; p.u_imp = u_importance; p.dist = dist;
     p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
     p.w0_gain = lr_multiplier / sqrtf(32.f); p.w1_gain = lr_multiplier / sqrtf(64.f); p.b_gain = lr_multiplier;
     p.box_scale = 2.f / box_warp;

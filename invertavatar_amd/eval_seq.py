@@ -34,11 +34,55 @@ def fill_group(t, n_src):
     return torch.cat([t] * (4 // n_src), dim=0)
 
 
+class GraphedGroupUpdate:
+    """hipGraph of one ``AR_eval_forward`` call on a group of T source frames (uvnet.py:160-203): ~1 100 launches (two IR-SE50 UNets
+    with ConvGRU decoders, two generator passes) that eager PyTorch issues in ~45 ms of host time for ~15 ms of GPU work.  The
+    group's frames are staged into static buffers, the ConvGRU states live in static buffers that the captured call updates in
+    place (a first group starts from zeros: ``h = zeros`` is what the cell does with ``r = None``, unet_encoders.py:44-46), and the
+    renderer's random draws go through the captured generator state like any CUDA-graph-safe op.  Results are the graph's static
+    output tensors: valid until the next replay."""
+
+    def __init__(self, net, ws, e4e_results, group, warmup=2):
+        self.net, self.ws, self.e4e = net, ws, e4e_results
+        self.inputs = [t.clone() for t in group]                   # images, uvs, cams, uvcoords of one group
+        images, uvs, cams, uvc = self.inputs
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                              # warm-up (library kernel selection, allocator) + state shapes
+            for _ in range(warmup):
+                _, r = net.AR_eval_forward({'image': images, 'uv': uvs}, cams, {'uvcoords_image': uvc}, ws, [None, None],
+                                           e4e_results=e4e_results, return_fake=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.state = [[torch.zeros_like(h) for h in unet_states] for unet_states in r]
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            out, new = net.AR_eval_forward({'image': images, 'uv': uvs}, cams, {'uvcoords_image': uvc}, ws,
+                                           [list(unet_states) for unet_states in self.state], e4e_results=e4e_results, return_fake=False)
+            for old_states, new_states in zip(self.state, new):
+                for h_old, h_new in zip(old_states, new_states):
+                    h_old.copy_(h_new)
+        self.out = out
+
+    def reset(self):
+        for unet_states in self.state:
+            for h in unet_states:
+                h.zero_()
+
+    def __call__(self, group):
+        for dst, src in zip(self.inputs, group):
+            dst.copy_(src)
+        self.graph.replay()
+        return self.out, self.state
+
+
 @torch.no_grad()
-def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=False, hook=None):
+def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=False, hook=None, graphed=None):
     """images [S,3,512,512] in [-1,1], uvs [S,6,256,256] (x['uv']), cams [S,25], uvcoords [S,256,256,3].  S in {1, 2, 4} or a
     multiple of 4.  `hook(group_index)` may return a context manager entered around each AR_eval_forward (tests pin the
-    renderer's random draws with it).  Returns (ws, {'w','texture','static'} of the LAST group, r_list)."""
+    renderer's random draws with it).  `graphed`: a dict the caller keeps (cache of GraphedGroupUpdate per identity) -- the groups
+    are then replayed as one hipGraph each instead of ~1 100 eager launches (device tensors, no hook; results are the graph's static
+    tensors, valid until the cache is used again).  Returns (ws, {'w','texture','static'} of the LAST group, r_list)."""
     s = images.shape[0]
     assert s in (1, 2, 4) or s % 4 == 0, f'{s} source frames: the script pads to a multiple of 4 first (:135-136)'
     images, uvs, cams, uvcoords = (fill_group(t, s) for t in (images, uvs, cams, uvcoords))
@@ -49,6 +93,20 @@ def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=Fal
     results, r_list = {'w': ws, 'texture': tex, 'static': sta}, [None, None]
     num_iter = max(images.shape[0] // 4, 1)
     updated = results
+    if graphed is not None and hook is None and images.is_cuda:
+        first = slice(0, 4) if sequential_sampling else slice(0, None, num_iter)
+        step = graphed.get('group')
+        if step is None:
+            step = graphed['group'] = GraphedGroupUpdate(net, ws, results, (images[first], uvs[first], cams[first], uvcoords[first]))
+        else:      # same network, new identity: the graph reads ws / the e4e features from the tensors it was captured with
+            step.ws.copy_(ws)
+            for dst, src in zip(step.e4e['texture'] + step.e4e['static'], tex + sta):
+                dst.copy_(src)
+        step.reset()
+        for idx in range(num_iter):
+            sel = slice(4 * idx, 4 * (idx + 1)) if sequential_sampling else slice(idx, None, num_iter)
+            updated, r_list = step((images[sel], uvs[sel], cams[sel], uvcoords[sel]))
+        return ws, updated, r_list
     for idx in range(num_iter):
         sel = slice(4 * idx, 4 * (idx + 1)) if sequential_sampling else slice(idx, None, num_iter)
         ctx = hook(idx) if hook is not None else None

@@ -413,7 +413,7 @@ def planes_channels_last(planes):
 
 
 def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_multiplier=1.0, box_warp=1.0, white_back=False,
-                n_coarse=48, n_importance=48, debug=False, channel_major=False):
+                n_coarse=48, n_importance=48, debug=False, channel_major=False, u_importance=None):
     """Fused importance renderer (see ia_render_rays).  Returns (rgb [B,R,32], depth [B,R,1], wsum [B,R,1][, aux]).
     channel_major=True stores rgb as [B,32,R] (the feature image the super-resolution head reads) and returns the [B,R,32] VIEW of
     it: same values and shape, and `rgb.permute(0, 2, 1).reshape(B, 32, nrr, nrr)` is then contiguous without a copy."""
@@ -429,6 +429,8 @@ def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_mult
     dist_per_frame = dist.numel() == b and b > 1
     if tuple(jitter.shape[:3]) != (b, r, n_coarse):
         raise RuntimeError(f'jitter must be [B,R,{n_coarse}(,1)], got {tuple(jitter.shape)}')
+    if u_importance is not None and (_f32c(u_importance, 'u_importance').numel() != b * r * n_importance):
+        raise RuntimeError(f'u_importance must hold B * R * {n_importance} sorted uniform draws')
     dev = planes_cl.device
     lib = _lib.load()
     rgb = torch.empty(b, 32, r, device=dev).permute(0, 2, 1) if channel_major else torch.empty(b, r, 32, device=dev)
@@ -444,7 +446,7 @@ def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_mult
     flops = b * r * 96 * 2.0 * (32 * 64 + 64 * 33)
     traffic = 4.0 * (planes_cl.numel() + 2 * rays_o.numel() + jitter.numel() + b * r * 34)
     with torch.cuda.device(dev), _Timed('render_rays', flops, traffic):
-        st = lib.ia_render_rays(_p(planes_cl), _p(rays_o), _p(rays_d), _p(jitter), _p(dist), _p(w0), _p(b0), _p(w1), _p(b1),
+        st = lib.ia_render_rays(_p(planes_cl), _p(rays_o), _p(rays_d), _p(jitter), _p(u_importance), _p(dist), _p(w0), _p(b0), _p(w1), _p(b1),
                                 float(lr_multiplier), float(box_warp), int(bool(white_back)) | (2 if channel_major else 0) | (4 if dist_per_frame else 0), b, r, ph, pw,
                                 int(n_coarse),
                                 int(n_importance), _p(rgb), _p(depth), _p(wsum), _p(scratch), _p(aux.get('z_fine')),

@@ -195,11 +195,18 @@ class ImportanceRenderer_bsMotion(_RendererBase):
         if dist is not None and not per_frame and dist.numel() != 1:
             raise ValueError(f'dist must have 1 or B = {b} elements, got {dist.numel()}')
         n_coarse = rendering_options['depth_resolution']
-        if evaluation and self._fused_ok(planes, decoder, ray_origins, rendering_options):
+        if self._fused_ok(planes, decoder, ray_origins, rendering_options):
+            # evaluation: deterministic importance grid.  Otherwise (the inversion's renders, uvnet.py:180) the uniform draws of
+            # sample_pdf (:453, same call shape), handed to the kernel sorted: the inverse CDF is monotone, so the set of fine samples
+            # and, ties aside, the merged order are those of the reference's unsorted draws + torch.sort.
             if jitter is None:
                 # same call shape as the reference's torch.rand_like(depths_coarse) (renderer.py:406)
                 jitter = torch.rand_like(torch.empty((b, r, n_coarse, 1), device=planes.device))
             jitter = jitter.to(device=planes.device, dtype=torch.float32).reshape(b, r, n_coarse).contiguous()
+            u_imp = None
+            if not evaluation:      # (drawn after the jitter, as the reference's generator sees the two calls)
+                u_imp = torch.rand(b * r, rendering_options['depth_resolution_importance'], device=planes.device).sort(dim=-1).values
+                u_imp = u_imp.to(torch.float32).contiguous()
             if dist is None:
                 dist = torch.norm(ray_origins, dim=-1).mean().reshape(1)  # stays on the device: no host sync
             dist = dist.to(device=planes.device, dtype=torch.float32).reshape(-1).contiguous()
@@ -211,7 +218,8 @@ class ImportanceRenderer_bsMotion(_RendererBase):
                                       jitter, dist, decoder.net[0].weight.detach(), decoder.net[0].bias.detach(),
                                       decoder.net[2].weight.detach(), decoder.net[2].bias.detach(), lr_multiplier=lr_mul,
                                       box_warp=rendering_options['box_warp'], white_back=rendering_options.get('white_back', False),
-                                      channel_major=True)     # [B,R,32] view of a [B,32,R] image: the caller's permute is free
+                                      channel_major=True,     # [B,R,32] view of a [B,32,R] image: the caller's permute is free
+                                      u_importance=u_imp)
         # torch definition (CPU tensors, training, non-standard options)
         if per_frame:      # one reference-shaped call per frame (the depth clamp bounds are then per frame too, as in those calls)
             parts = [self.forward(planes[k:k + 1], decoder, ray_origins[k:k + 1], ray_directions[k:k + 1], rendering_options, evaluation,

@@ -107,8 +107,9 @@ def ray_march(colors, densities, depths, white_back=False):
     return rgb * 2 - 1, depth, weights
 
 
-def sample_pdf_det(bins, weights, n_importance, eps=1e-5):
-    """Deterministic inverse-CDF sampling.  Reference: renderer.py:430-469.
+def sample_pdf_det(bins, weights, n_importance, eps=1e-5, u=None):
+    """Inverse-CDF sampling.  Reference: renderer.py:430-469: deterministic grid (det=True, :450), or -- `u`
+    [n_rays, n_importance] given -- the injected uniform draws of the det=False branch (:453, torch.rand).
 
     Returns samples and the integer buffers (inds, below, above).
     """
@@ -117,7 +118,7 @@ def sample_pdf_det(bins, weights, n_importance, eps=1e-5):
     pdf = w / torch.sum(w, -1, keepdim=True)
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
-    u = torch.linspace(0, 1, n_importance).expand(n_rays, n_importance).contiguous()
+    u = torch.linspace(0, 1, n_importance).expand(n_rays, n_importance).contiguous() if u is None else u.contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below = torch.clamp_min(inds - 1, 0)
     above = torch.clamp_max(inds, n_w)
@@ -136,13 +137,13 @@ def smooth_weights(weights):
     return w + 0.01
 
 
-def sample_importance(z_vals, weights, n_importance):
+def sample_importance(z_vals, weights, n_importance, u=None):
     """Reference: renderer.py:410-428.  z_vals [B,R,S,1], weights [B,R,S-1,1]."""
     b, r, s, _ = z_vals.shape
     z = z_vals.reshape(b * r, s)
     w = smooth_weights(weights.reshape(b * r, -1))
     z_mid = 0.5 * (z[:, :-1] + z[:, 1:])
-    samples, inds, below, above, cdf = sample_pdf_det(z_mid, w[:, 1:-1], n_importance)
+    samples, inds, below, above, cdf = sample_pdf_det(z_mid, w[:, 1:-1], n_importance, u=u)
     return samples.reshape(b, r, n_importance, 1), dict(inds=inds, below=below, above=above, cdf=cdf)
 
 
@@ -160,8 +161,9 @@ def coarse_depths(rays_o, n_coarse, jitter):
 
 
 def render(planes, dec, rays_o, rays_d, jitter, n_coarse=48, n_fine=48, box_warp=1.0, white_back=False,
-           return_aux=False):
-    """ImportanceRenderer_bsMotion.forward, evaluation=True.  Reference: renderer.py:309-351."""
+           return_aux=False, u=None):
+    """ImportanceRenderer_bsMotion.forward.  Reference: renderer.py:309-351.  evaluation=True by default; `u` [B*R, n_fine] = the
+    uniform draws of evaluation=False (in the order torch.rand returns them: unsorted)."""
     b, r, _ = rays_o.shape
     z_c, (start, end) = coarse_depths(rays_o, n_coarse, jitter)
     xyz = (rays_o.unsqueeze(-2) + z_c * rays_d.unsqueeze(-2)).reshape(b, -1, 3)
@@ -169,7 +171,7 @@ def render(planes, dec, rays_o, rays_d, jitter, n_coarse=48, n_fine=48, box_warp
     col_c = col_c.reshape(b, r, n_coarse, -1)
     den_c = den_c.reshape(b, r, n_coarse, 1)
     _, _, w_c = ray_march(col_c, den_c, z_c, white_back)
-    z_f, ibuf = sample_importance(z_c, w_c, n_fine)
+    z_f, ibuf = sample_importance(z_c, w_c, n_fine, u=u)
     xyz = (rays_o.unsqueeze(-2) + z_f * rays_d.unsqueeze(-2)).reshape(b, -1, 3)
     col_f, den_f = osg_decoder(dec, sample_from_planes(planes, xyz, box_warp))
     col_f = col_f.reshape(b, r, n_fine, -1)

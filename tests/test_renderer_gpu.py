@@ -130,3 +130,31 @@ def test_ray_sampler_kernel():
     ro, rd = OR.ray_sampler_zxc(cams[:, :16].view(-1, 4, 4), cams[:, 16:25].view(-1, 3, 3), 64)
     o, d = hipops.ray_sampler(cams.cuda(), 64)
     assert max_abs(o.cpu(), ro) == 0 and max_abs(d.cpu(), rd) <= 2e-6
+
+
+def test_fused_renderer_with_random_importance_draws_vs_oracle():
+    """evaluation=False (the inversion's renders, uvnet.py:180): the importance pass inverts the CDF at uniform draws (renderer.py:453).
+    The kernel takes them SORTED; the oracle, like the reference, takes them as drawn and sorts all 96 depths afterwards -- same
+    samples, same composite."""
+    b, nrr = 2, 16
+    frames = [5, 130]
+    planes = rnd(21, b, 3, 32, 64, 64)
+    c = synthetic.camera_labels(frames)
+    ro, rd = OR.ray_sampler_zxc(c[:, :16].reshape(-1, 4, 4), c[:, 16:25].reshape(-1, 3, 3), nrr)
+    jit = synthetic.jitter(frames, nrr * nrr)
+    u = torch.from_numpy(np.random.RandomState(7).rand(b * nrr * nrr, 48).astype(np.float32))
+    dec = _decoder()
+    ref_rgb, ref_depth, ref_w = OR.render(planes, dec, ro, rd, jit, u=u)
+    dev = 'cuda'
+    dist = torch.norm(ro, dim=-1).mean().reshape(1).to(dev)
+    rgb, depth, wsum = hipops.render_rays(hipops.planes_channels_last(planes.to(dev)), ro.to(dev).contiguous(), rd.to(dev).contiguous(),
+                                          jit.to(dev).reshape(b, nrr * nrr, 48).contiguous(), dist, dec['net.0.weight'].to(dev),
+                                          dec['net.0.bias'].to(dev), dec['net.2.weight'].to(dev), dec['net.2.bias'].to(dev),
+                                          u_importance=u.sort(dim=-1).values.contiguous().to(dev))
+    assert max_abs(rgb.cpu(), ref_rgb) <= 1e-4 and max_abs(wsum.cpu(), ref_w) <= 1e-4
+    finite = torch.isfinite(ref_depth)
+    assert max_abs(depth.cpu()[finite], ref_depth[finite]) <= 2e-4
+    det_rgb, _, _ = hipops.render_rays(hipops.planes_channels_last(planes.to(dev)), ro.to(dev).contiguous(), rd.to(dev).contiguous(),
+                                       jit.to(dev).reshape(b, nrr * nrr, 48).contiguous(), dist, dec['net.0.weight'].to(dev),
+                                       dec['net.0.bias'].to(dev), dec['net.2.weight'].to(dev), dec['net.2.bias'].to(dev))
+    assert max_abs(det_rgb.cpu(), rgb.cpu()) > 1e-4            # the draws are really used
