@@ -318,8 +318,11 @@ int ia_ray_sampler(const float* cam, int cam_stride, float* rays_o, float* rays_
  * ia_act_split is the stand-alone producer; ia_fir_tail_split and ia_conv2d_mfma_sx emit the format from their epilogues.
  * planes = 2 is the format above; planes = 1 keeps plane 0 only, rounded once (hi = fp16(v), saturating): the operand format of the
  * fp16 blocks (ia_conv2d_mfma_h arithmetic) and the fp16-STORAGE form of their activations, xs[b][c/8][y][x][c%8], 2 bytes / element.
+ * shift [B,C] or NULL: v = x * styles + shift -- an eval-mode BatchNorm folded into the staging of the convolution that follows it
+ * (inversion encoders, encoder_inversion/models/helpers.py:102-124: BatchNorm2d -> Conv2d 3x3; the zero padding then applies to
+ * the normalised tensor, as in the reference).
  */
-int ia_act_split(const float* x, const float* styles, void* xs, int planes, int B, int C, int H, int W, void* stream);
+int ia_act_split(const float* x, const float* styles, const float* shift, void* xs, int planes, int B, int C, int H, int W, void* stream);
 
 /*
  * ia_conv2d_mfma_s on split-format activations: same layer semantics, tiles, ksplit / scratch (ia_conv2d_plan with form = 3) and
@@ -332,11 +335,14 @@ int ia_act_split(const float* x, const float* styles, void* xs, int planes, int 
  *   y           : [B,O,OH,OW] fp32 or NULL (stride-1 form only: a layer whose result is consumed only in split format)
  *   ys, ys_planes : the result in split format (ys_planes planes), multiplied by styles_next [B,O] (the styles of the consuming layer; NULL = 1), or
  *                 NULL; stride-1 form only (the transposed form's (2H+1)^2 image goes through ia_fir_tail_split)
+  * prelu_alpha : NULL, or [O] per-output-channel negative slopes used by IA_ACT_LRELU in place of `alpha` (torch.nn.PReLU of the
+ *               inversion encoders' residual units, helpers.py:105).  With demod = BatchNorm scale and bias = BatchNorm shift (per output
+ *               channel) the epilogue is conv -> BatchNorm(eval) -> PReLU of those networks; styles / noise stay NULL.
  */
 int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
                       const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                       const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
-                      int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream);
+                      int transposed, int act, float alpha, const float* prelu_alpha, float gain, float clamp, int ksplit, void* stream);
 
 /*
  * ia_upfirdn2d_bias_act for the 4x4 filter at up = 1 (the FIR + noise + bias + activation tail of an up-sampling SynthesisLayer,

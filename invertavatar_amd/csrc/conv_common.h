@@ -65,6 +65,8 @@ struct Epi {
     float* rgb_out = nullptr;           // [B][rgb_n][OH*OW]
     float rgb_clamp = -1.f;
     int rgb_n = 0;
+    // optional per-output-channel negative slopes of the leaky ReLU ([O]; PReLU of the inversion encoders): replaces `alpha`
+    const float* alpha_vec = nullptr;
 };
 constexpr int kMaxRgb = 4;
 
@@ -126,7 +128,7 @@ __device__ __forceinline__ float epilogue(float v, int b, int o, int64_t pix, in
     if (e.demod) v *= e.demod[b * g.O + o];
     if (e.noise) v = fmaf(e.noise[pix], ns, v);
     if (e.bias) v += e.bias[o];
-    if (e.act == IA_ACT_LRELU) v = v > 0.f ? v : v * e.alpha;
+    if (e.act == IA_ACT_LRELU) v = v > 0.f ? v : v * (e.alpha_vec ? e.alpha_vec[o] : e.alpha);
     v *= e.gain;
     if (e.clamp >= 0.f) v = fminf(fmaxf(v, -e.clamp), e.clamp);
     if (e.residual) v += e.residual[((int64_t)b * g.O + o) * ohw + pix];

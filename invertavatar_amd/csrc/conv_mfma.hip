@@ -487,7 +487,7 @@ void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo
         if (form == 3 && npts >= kSplitWideTransposedPoints && npts < 2 * kSplitWideTransposedPoints) { *bp = 256; *waves = 8; }
     }
     else if (O <= 32) { *bo = 32; *bp = 256; }
-    else if (ksize == 3 && O >= 128 && O % 4 == 0 && npts >= kWidePoints && worst_patch(npts, W, 256, 3, false) <= kPatchFloats) {
+    else if (ksize == 3 && (O >= 128 || (O >= 64 && form == 3)) && O % 4 == 0 && npts >= kWidePoints && worst_patch(npts, W, 256, 3, false) <= kPatchFloats) {
         *bo = 128; *bp = 256; *waves = 8;
     }
     else { *bo = 128; *bp = 128; }

@@ -72,8 +72,8 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 // fp32 NCHW (times an optional per-(batch, channel) style) -> split planes.  One thread = one pixel of one 8-channel group.
-__global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ x, const float* __restrict__ styles, h16x8* __restrict__ out,
-                                                       int B, int C, int64_t HW, int planes) {
+__global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ x, const float* __restrict__ styles, const float* __restrict__ shift,
+                                                       h16x8* __restrict__ out, int B, int C, int64_t HW, int planes) {
     const int C8 = C / 8;
     const int64_t total = (int64_t)B * C8 * HW, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
             const int c = c8 * 8 + cc;
             float v = x[((int64_t)b * C + c) * HW + pix];
             if (styles) v *= styles[b * C + c];
+            if (shift) v += shift[b * C + c];
             if (planes == 2) { _Float16 h, l; ia::split_f16(v, h, l); hi[cc] = h; lo[cc] = l; }
             else hi[cc] = ia::round_f16(v);
         }
@@ -539,14 +540,14 @@ int launch_sx(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
 
 }  // namespace
 
-extern "C" int ia_act_split(const float* x, const float* styles, void* xs, int planes, int B, int C, int H, int W, void* stream) {
+extern "C" int ia_act_split(const float* x, const float* styles, const float* shift, void* xs, int planes, int B, int C, int H, int W, void* stream) {
     IA_REQUIRE(planes == 1 || planes == 2, "planes: 2 = hi / lo pair, 1 = one fp16 plane");
     IA_REQUIRE(x && xs, "null pointer argument");
     IA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "empty tensor");
     IA_REQUIRE(C % 8 == 0, "the split format stores channels in groups of 8 (C = %d)", C);
     IA_REQUIRE((int64_t)B * C * H * W <= INT32_MAX, "tensor is too large");
     const int64_t work = (int64_t)B * (C / 8) * H * W;
-    hipLaunchKernelGGL(act_split_kernel, dim3(ia::streaming_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, styles,
+    hipLaunchKernelGGL(act_split_kernel, dim3(ia::streaming_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, styles, shift,
                        static_cast<h16x8*>(xs), B, C, (int64_t)H * W, planes);
     return ia::check_launch("ia_act_split");
 }
@@ -560,7 +561,8 @@ struct RgbArgs { const float* w; const float* styles; const float* bias; const f
 static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
                         const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                         const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
-                        int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream, const RgbArgs& rgb) {
+                        int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream, const RgbArgs& rgb,
+                        const float* prelu_alpha = nullptr) {
     IA_REQUIRE(xs && wk_split && (y || ys || rgb.out), "xs, wk and at least one output must be device pointers");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
     IA_REQUIRE(I % 8 == 0 && O % 8 == 0, "the split form needs I %% 8 == 0 and O %% 8 == 0");
@@ -596,6 +598,7 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
     g.patch_cap = 0;
     g.acc_scale = ldexpf(1.f, -wk_exp);
     Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp, ys, styles_next, ys_planes};
+    e.alpha_vec = prelu_alpha;
     if (rgb.out) {
         IA_REQUIRE(rgb.w && rgb.n >= 1 && rgb.n <= kMaxRgb, "the fused ToRGB takes 1 .. %d output channels and its packed weight", kMaxRgb);
         e.rgb_w = rgb.w; e.rgb_styles = rgb.styles; e.rgb_bias = rgb.bias; e.rgb_res = rgb.res; e.rgb_out = rgb.out; e.rgb_n = rgb.n; e.rgb_clamp = rgb.clamp;
@@ -620,9 +623,11 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
 extern "C" int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
                                  const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                                  const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
-                                 int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream) {
+                                 int transposed, int act, float alpha, const float* prelu_alpha, float gain, float clamp, int ksplit, void* stream) {
+    IA_REQUIRE(!prelu_alpha || act == IA_ACT_LRELU, "prelu_alpha are the per-channel slopes of IA_ACT_LRELU");
     return conv_sx_impl(xs, planes, wk_split, wk_exp, demod, noise, noise_strength, bias, residual, y, ys, ys_planes, styles_next, scratch, scratch_bytes,
-                        B, I, O, H, W, transposed, act, alpha, gain, clamp, ksplit, stream, RgbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1.f});
+                        B, I, O, H, W, transposed, act, alpha, gain, clamp, ksplit, stream, RgbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1.f},
+                        prelu_alpha);
 }
 
 extern "C" int ia_conv2d_mfma_sx_rgb(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,

@@ -83,11 +83,18 @@ def irse50_trunk(inp_ch):
     return input_layer, body
 
 
+HIP_TRUNK = True      # eval-mode residual units on device tensors: their 3x3 convolutions through ia_conv2d_mfma_sx (trunk_hip.py)
+
+
 def run_trunk(body, x, taps):
     """Run the residual units and collect the activations after the unit indices in `taps`."""
+    from . import trunk_hip
     found = {}
     for i, unit in enumerate(body._modules.values()):
-        x = unit(x)
+        if HIP_TRUNK and isinstance(unit, (bottleneck_IR, bottleneck_IR_SE)) and trunk_hip.unit_supported(unit, x):
+            x = trunk_hip.unit_forward(unit, x)
+        else:
+            x = unit(x)
         if i in taps:
             found[i] = x
     return x, [found[i] for i in taps]

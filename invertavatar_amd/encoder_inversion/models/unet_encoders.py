@@ -15,6 +15,9 @@ import torch.nn.functional as F
 from .helpers import irse50_trunk, run_trunk
 
 
+HIP_GRU_CONVS = True      # ConvGRU cells from 32^2 up: their convolutions through ia_conv2d_mfma_sx instead of the library
+
+
 class ConvGRU(torch.nn.Module):
     """r, z = sigmoid(conv([x, h]));  c = tanh(conv([x, r*h]));  h' = (1-z) h + z c   (:8-49)."""
 
@@ -30,13 +33,36 @@ class ConvGRU(torch.nn.Module):
         return (x.is_cuda and x.dtype == torch.float32 and (x.shape[-1] * x.shape[-2]) % 4 == 0
                 and not (torch.is_grad_enabled() and (x.requires_grad or self.ih[0].weight.requires_grad)))
 
+    def _hip_convs(self, x):
+        """The cell's two 3x3 convolutions on ia_conv2d_mfma_sx (fp32 products from fp16 hi / lo pairs) instead of the library:
+        from 32^2 up (the 8-wave tile needs 1024 points), channel counts in units of 8.  Packed weights are cached per cell."""
+        conv_ih = self.ih[0]
+        c2, h, w = conv_ih.in_channels, x.shape[-2], x.shape[-1]
+        if not (HIP_GRU_CONVS and conv_ih.kernel_size == (3, 3) and conv_ih.padding == (1, 1) and c2 % 16 == 0 and self.channels >= 64
+                and h * w >= 1024 and w <= 320):
+            return None
+        from ... import _runtime, hipops
+        st = _runtime.state(self)
+        conv_hh = self.hh[0]
+        key = tuple((t.data_ptr(), t._version) for t in (conv_ih.weight, conv_hh.weight)) + (conv_ih.weight.device,)
+        if getattr(st, 'gru_key', None) != key:
+            st.gru_w = (hipops.pack_conv_weight_split(conv_ih.weight.detach().float()), hipops.pack_conv_weight_split(conv_hh.weight.detach().float()))
+            st.gru_key = key
+        return st.gru_w
+
     def _step_fused(self, xh, x, h, x_next):
         """xh = cat[x, h] (made by the previous step's update launch).  Returns (h', cat[x_next, h'] or None)."""
         from ... import hipops
         conv_ih, conv_hh, act = self.ih[0], self.hh[0], self.hh[1]
-        gates_pre = F.conv2d(xh, conv_ih.weight, conv_ih.bias, padding=conv_ih.padding)
-        xrh = hipops.convgru_gates(gates_pre, x, h)
-        cand_pre = F.conv2d(xrh, conv_hh.weight, conv_hh.bias, padding=conv_hh.padding)
+        packed = self._hip_convs(x)
+        if packed is not None:
+            gates_pre = hipops.conv2d_mfma_sx(hipops.act_split(xh), packed[0], bias=conv_ih.bias.detach().float())
+            xrh = hipops.convgru_gates(gates_pre, x, h)
+            cand_pre = hipops.conv2d_mfma_sx(hipops.act_split(xrh), packed[1], bias=conv_hh.bias.detach().float())
+        else:
+            gates_pre = F.conv2d(xh, conv_ih.weight, conv_ih.bias, padding=conv_ih.padding)
+            xrh = hipops.convgru_gates(gates_pre, x, h)
+            cand_pre = F.conv2d(xrh, conv_hh.weight, conv_hh.bias, padding=conv_hh.padding)
         prelu_w = act.weight.detach().float().contiguous() if isinstance(act, nn.PReLU) else None
         return hipops.convgru_update(gates_pre, cand_pre, h, prelu_w, x_next)
 
@@ -84,6 +110,9 @@ class DoubleConv(nn.Module):
             nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1), nn.PReLU(out_channels), nn.PReLU(out_channels))
 
     def forward(self, x):
+        from . import trunk_hip
+        if HIP_GRU_CONVS and trunk_hip.double_conv_supported(self, x):
+            return trunk_hip.double_conv_forward(self, x)
         return self.double_conv(x)
 
 
@@ -198,7 +227,13 @@ class TriPlaneSFTfeat_Encoder(_UNetBase):
                                                                      nn.Conv2d(ch, out, 3, 1, 1)))
 
     def _sft(self, res, t):
-        return torch.stack([getattr(self, f'condition_scale{res}')(t), getattr(self, f'condition_shift{res}')(t)])
+        from . import trunk_hip
+        scale, shift = getattr(self, f'condition_scale{res}'), getattr(self, f'condition_shift{res}')
+        if HIP_GRU_CONVS and trunk_hip.conv_lrelu_conv_supported(scale, t) and trunk_hip.conv_lrelu_conv_supported(shift, t):
+            from ... import hipops
+            ts = hipops.act_split(t.contiguous())
+            return torch.stack([trunk_hip.conv_lrelu_conv_forward(scale, ts), trunk_hip.conv_lrelu_conv_forward(shift, ts)])
+        return torch.stack([scale(t), shift(t)])
 
     def forward(self, x, r_list=None):
         T = 1

@@ -76,24 +76,53 @@ class GraphedGroupUpdate:
         return self.out, self.state
 
 
+class GraphedEncode:
+    """hipGraph of ``net.encode`` on one source frame (e4e: an IR-SE50 trunk at batch 1 + 14 style heads, ~500 launches that eager
+    PyTorch issues in 9 ms for 6 ms of GPU work)."""
+
+    def __init__(self, net, image, warmup=2):
+        self.image = image.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                net.encode(self.image)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.ws = net.encode(self.image)
+
+    def __call__(self, image):
+        self.image.copy_(image)
+        self.graph.replay()
+        return self.ws.clone()
+
+
 @torch.no_grad()
 def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=False, hook=None, graphed=None):
     """images [S,3,512,512] in [-1,1], uvs [S,6,256,256] (x['uv']), cams [S,25], uvcoords [S,256,256,3].  S in {1, 2, 4} or a
     multiple of 4.  `hook(group_index)` may return a context manager entered around each AR_eval_forward (tests pin the
-    renderer's random draws with it).  `graphed`: a dict the caller keeps (cache of GraphedGroupUpdate per identity) -- the groups
-    are then replayed as one hipGraph each instead of ~1 100 eager launches (device tensors, no hook; results are the graph's static
-    tensors, valid until the cache is used again).  Returns (ws, {'w','texture','static'} of the LAST group, r_list)."""
+    renderer's random draws with it).  `graphed`: a dict the caller keeps as a cache of captured graphs (device tensors, no hook):
+    the e4e encode is then replayed as one hipGraph (host-bound eagerly: 9 -> 6 ms), and with ``graphed['group_graph'] = True`` the
+    groups too (GraphedGroupUpdate; they are GPU-bound, measured 68 ms eager vs 73 ms replayed for the whole inversion, so off by
+    default; their results are the graph's static tensors, valid until the cache is used again).  Returns (ws, {'w','texture','static'} of the LAST group, r_list)."""
     s = images.shape[0]
     assert s in (1, 2, 4) or s % 4 == 0, f'{s} source frames: the script pads to a multiple of 4 first (:135-136)'
     images, uvs, cams, uvcoords = (fill_group(t, s) for t in (images, uvs, cams, uvcoords))
     g = net.generator
-    ws = net.encode(images[:1])
+    if graphed is not None and hook is None and images.is_cuda:
+        if 'encode' not in graphed:
+            graphed['encode'] = GraphedEncode(net, images[:1])
+        ws = graphed['encode'](images[:1])
+    else:
+        ws = net.encode(images[:1])
     tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
     sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
     results, r_list = {'w': ws, 'texture': tex, 'static': sta}, [None, None]
     num_iter = max(images.shape[0] // 4, 1)
     updated = results
-    if graphed is not None and hook is None and images.is_cuda:
+    if graphed is not None and graphed.get('group_graph', False) and hook is None and images.is_cuda:
         first = slice(0, 4) if sequential_sampling else slice(0, None, num_iter)
         step = graphed.get('group')
         if step is None:

@@ -258,22 +258,24 @@ class SplitAct:
         return v.permute(0, 1, 4, 2, 3).reshape(b, c8 * 8, h, w)
 
 
-def act_split(x, styles=None, consumer=None, planes=2):
-    """fp32 NCHW (x styles [B,C]) -> SplitAct (see ia_act_split)."""
+def act_split(x, styles=None, consumer=None, planes=2, shift=None):
+    """fp32 NCHW (x styles [B,C] + shift [B,C]) -> SplitAct (see ia_act_split)."""
     _f32c(x, 'x')
     b, c, h, w = x.shape
     if c % 8:
         raise RuntimeError('the split format needs channels % 8 == 0')
     out = torch.empty(b, planes, c // 8, h, w, 8, device=x.device, dtype=torch.float16)
     with torch.cuda.device(x.device), _Timed('act_split', 0.0, (4.0 + 2.0 * planes) * x.numel()):
-        st = _lib.load().ia_act_split(_p(x), _p(None if styles is None else _f32c(styles, 'styles')), _p(out), int(planes), b, c, h, w,
+        st = _lib.load().ia_act_split(_p(x), _p(None if styles is None else _f32c(styles, 'styles')),
+                                      _p(None if shift is None else _f32c(shift, 'shift')), _p(out), int(planes), b, c, h, w,
                                       _lib.stream_ptr(x.device))
     _lib.check(st, 'ia_act_split')
     return SplitAct(out, c, consumer)
 
 
 def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=None, residual=None, transposed=False, act='linear',
-                   alpha=0.2, gain=1.0, clamp=None, want_f32=True, split_for=None, styles_next=None, ksplit=None, split_planes=2):
+                   alpha=0.2, gain=1.0, clamp=None, want_f32=True, split_for=None, styles_next=None, ksplit=None, split_planes=2, prelu=None,
+                   want_split=None):
     """ia_conv2d_mfma_sx: 3x3 convolution of a SplitAct (already multiplied by this layer's styles).  Returns the fp32 result,
     a SplitAct for `split_for` (multiplied by styles_next, `split_planes` planes), or the pair (y, ys) when both are asked for.
     A two-plane input takes weights from pack_conv_weight_split, a one-plane input those of pack_conv_weight_h."""
@@ -287,7 +289,10 @@ def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=Non
     o = wk.shape[-2]
     if wk.shape[-4] != 9 or wk.shape[-3] * 8 != i:
         raise RuntimeError(f'packed weight {tuple(wk.shape)} does not match 3x3, in-channels {i}')
-    want_split = split_for is not None or styles_next is not None
+    if want_split is None:
+        want_split = split_for is not None or styles_next is not None
+    if prelu is not None and (_f32c(prelu, 'prelu').numel() != o or act != 'lrelu'):
+        raise RuntimeError('prelu: [O] per-channel slopes, with act="lrelu"')
     if transposed and (want_split or not want_f32):
         raise RuntimeError('the transposed form only writes the fp32 image')
     for name, t in (('demod', demod), ('noise', noise), ('bias', bias), ('residual', residual), ('styles_next', styles_next)):
@@ -313,7 +318,7 @@ def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=Non
                                         f'B{b} I{i} O{o} {h}x{w} G{ksplit} ' + ('f16x3 dma' if xs.planes == 2 else 'f16 dma')):
         st = lib.ia_conv2d_mfma_sx(_p(xs.data), int(xs.planes), _p(wk), int(getattr(wk, 'wk_exp', 0)), _p(demod), _p(noise), _p(noise_strength),
                                    _p(bias), _p(residual), _p(y), _p(ys), int(split_planes), _p(styles_next), _p(scratch), nbytes, b, i, o, h, w, int(transposed), ACT_ID[act],
-                                   float(alpha), float(gain), float(-1 if clamp is None else clamp), int(ksplit), _lib.stream_ptr(dev))
+                                   float(alpha), _p(prelu), float(gain), float(-1 if clamp is None else clamp), int(ksplit), _lib.stream_ptr(dev))
     _lib.check(st, 'ia_conv2d_mfma_sx')
     out_s = SplitAct(ys, o, split_for) if want_split else None
     if want_f32 and want_split:

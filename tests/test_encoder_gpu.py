@@ -38,3 +38,80 @@ def test_convgru_cell_kernels_match_the_torch_cell(prelu):
     assert (got.cpu() - want).abs().max().item() <= 2e-5 and (got_h.cpu() - want_h).abs().max().item() <= 2e-5
     one, _ = dev(x[:, 0].cuda(), h0.cuda())
     assert (one.cpu() - want[:, 0]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize('in_c,depth,stride,res', [(64, 64, 2, 64), (64, 128, 2, 48), (128, 128, 1, 32), (256, 256, 1, 32)])
+def test_residual_unit_on_hip_convolutions_matches_torch(in_c, depth, stride, res):
+    """bottleneck_IR_SE in eval mode: BatchNorm folded into the staging / epilogue of ia_conv2d_mfma_sx, PReLU in the epilogue,
+    stride 2 by sub-sampling -- against the module's own torch.nn forward in fp64 on the CPU (helpers.py:102-124)."""
+    from invertavatar_amd.encoder_inversion.models import helpers, trunk_hip
+    torch.manual_seed(in_c + depth + stride)
+    unit = helpers.bottleneck_IR_SE(in_c, depth, stride).requires_grad_(False).eval()
+    for m in unit.modules():                       # non-trivial BatchNorm statistics and PReLU slopes
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.5); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3)
+        if isinstance(m, torch.nn.PReLU):
+            m.weight.uniform_(0.05, 0.4)
+    x = torch.randn(3, in_c, res, res)
+    want = unit.double()(x.double()).float()
+    unit = unit.float().cuda()
+    with torch.no_grad():
+        assert trunk_hip.unit_supported(unit, x.cuda())
+        got = trunk_hip.unit_forward(unit, x.cuda()).cpu()
+        lib = unit(x.cuda()).cpu()                     # the library route, for scale
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item() / max(want.abs().max().item(), 1.0)
+    err_lib = (lib - want).abs().max().item() / max(want.abs().max().item(), 1.0)
+    print(f'unit {in_c}->{depth} s{stride} @{res}: HIP {err:.2e}, library fp32 {err_lib:.2e} (relative to max |ref|, vs fp64)')
+    assert err <= 2e-5
+    unit.train()
+    with torch.no_grad():
+        assert not trunk_hip.unit_supported(unit, x.cuda())      # batch statistics: the unit's own forward
+
+
+def test_convgru_cell_with_hip_convolutions_matches_the_torch_cell():
+    """From 32^2 up the cell's two convolutions run on ia_conv2d_mfma_sx (unet_encoders.ConvGRU._hip_convs): against the same
+    module on the CPU (unet_encoders.py:8-49), 4-frame series, carried state."""
+    from invertavatar_amd.encoder_inversion.models.unet_encoders import ConvGRU
+    torch.manual_seed(5)
+    cell = ConvGRU(64).requires_grad_(False)
+    x = torch.randn(1, 4, 64, 32, 40) * 0.5
+    h0 = torch.randn(1, 64, 32, 40) * 0.5
+    want, want_h = cell(x, h0.clone(), seq2seq=True)
+    dev = cell.cuda()
+    with torch.no_grad():
+        assert dev._hip_convs(x[:, 0].cuda()) is not None
+        got, got_h = dev(x.cuda(), h0.cuda(), seq2seq=True)
+    assert (got.cpu() - want).abs().max().item() <= 2e-5 and (got_h.cpu() - want_h).abs().max().item() <= 2e-5
+
+
+def test_decoder_double_conv_and_sft_heads_on_hip_convolutions():
+    """DoubleConv in TRAIN mode (batch statistics over the 4 frames of a group, eval_seq.py:92) and a CS-SFT head pair, through
+    ia_conv2d_mfma_sx, against the same modules on the CPU in fp64; the BatchNorm's running statistics move as torch's do."""
+    from invertavatar_amd.encoder_inversion.models import trunk_hip
+    from invertavatar_amd.encoder_inversion.models.unet_encoders import DoubleConv
+    torch.manual_seed(11)
+    dc = DoubleConv(72, 64).requires_grad_(False).train()
+    for m in dc.modules():
+        if isinstance(m, torch.nn.PReLU):
+            m.weight.uniform_(-0.2, 0.5)                       # both signs: the composite slope of PReLU(PReLU(.)) has two cases
+    x = torch.randn(4, 72, 32, 36) * 1.5 + 0.3
+    ref_mod = __import__('copy').deepcopy(dc).double()
+    want = ref_mod(x.double()).float()
+    dev = dc.cuda()
+    with torch.no_grad():
+        assert trunk_hip.double_conv_supported(dev, x.cuda())
+        got = dev(x.cuda()).cpu()
+    assert (got - want).abs().max().item() <= 3e-5 * max(want.abs().max().item(), 1.0)
+    bn_dev, bn_ref = dev.double_conv[0], ref_mod.double_conv[0]
+    assert (bn_dev.running_mean.cpu() - bn_ref.running_mean.float()).abs().max().item() <= 1e-5
+    assert (bn_dev.running_var.cpu() - bn_ref.running_var.float()).abs().max().item() <= 1e-5
+    head = torch.nn.Sequential(torch.nn.Conv2d(96, 96, 3, 1, 1), torch.nn.LeakyReLU(0.2, True), torch.nn.Conv2d(96, 64, 3, 1, 1)).requires_grad_(False)
+    t = torch.randn(1, 96, 64, 64)
+    want = __import__('copy').deepcopy(head).double()(t.double()).float()
+    head = head.cuda()
+    with torch.no_grad():
+        assert trunk_hip.conv_lrelu_conv_supported(head, t.cuda())
+        from invertavatar_amd import hipops
+        got = trunk_hip.conv_lrelu_conv_forward(head, hipops.act_split(t.cuda())).cpu()
+    assert (got - want).abs().max().item() <= 3e-5 * max(want.abs().max().item(), 1.0)

@@ -58,6 +58,42 @@ def main():
                 off, r_list[0] = timed('group: texture UNet (IR-SE50 + ConvGRU decoder)', lambda: net.unet_encoder.texture_unet(uv_in.unsqueeze(0), r_list=r_list[0], return_list=True))
                 sft, r_list[1] = timed('group: tri-plane UNet (IR-SE50 + ConvGRU decoder + SFT heads)', lambda: net.unet_encoder.triplane_unet(tri_in.unsqueeze(0), r_list=r_list[1]))
                 timed('group: static backbone with CS-SFT conditions', lambda: g.backbone.synthesis(ws, cond_list=None, return_list=True, feat_conditions=sft, noise_mode='const'))
+        if '--graph-stages' in sys.argv:      # pure GPU time of each stage: captured once, replayed
+            def gtime(name, fn):
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    fn()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    fn()
+                gr.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    gr.replay()
+                torch.cuda.synchronize()
+                print(f'  graph replay  {name:58s} {(time.perf_counter() - t0) / 5 * 1e3:7.2f} ms', flush=True)
+            sel = slice(0, None, 2)
+            x = {'image': images[sel], 'uv': uvs[sel]}
+            T = 4
+            over = lambda feats: [f.expand(T, -1, -1, -1) for f in feats]   # noqa: E731
+            gtime('encode (e4e, 1 frame)', lambda: net.encode(images[:1]))
+            gtime('synthesis_withTexture (4 frames)', lambda: g.synthesis_withTexture(ws.expand(T, -1, -1), over(tex), cams[sel], {'uvcoords_image': uvc[sel]},
+                                                                                       static_feats=over(sta), noise_mode='const'))
+            y0 = g.synthesis_withTexture(ws.expand(T, -1, -1), over(tex), cams[sel], {'uvcoords_image': uvc[sel]}, static_feats=over(sta), noise_mode='const')
+            delta = y0['image'] - x['image'][:, :3]
+            uv_in = net.get_unet_uvinput(x['uv'], delta)
+            tri_in = torch.cat([x['image'][:, :3], delta], dim=-3)
+            tu, pu = net.unet_encoder.texture_unet, net.unet_encoder.triplane_unet
+            gtime('texture UNet: trunk', lambda: tu._encode(uv_in))
+            feats_t = tu._encode(uv_in)
+            gtime('texture UNet: decoder + heads', lambda: tu._heads(feats_t, T, [None] * 4))
+            gtime('tri-plane UNet: whole', lambda: pu(tri_in.unsqueeze(0), r_list=None))
+            sft_, _ = pu(tri_in.unsqueeze(0), r_list=None)
+            gtime('static backbone with CS-SFT', lambda: g.backbone.synthesis(ws, cond_list=None, return_list=True, feat_conditions=sft_, noise_mode='const'))
         print('stage                                                            GPU ms   host ms   (last of 3 repetitions)')
         tot = [0.0, 0.0]
         for name, vals in stages.items():
@@ -67,7 +103,7 @@ def main():
             tot[0] += gpu; tot[1] += host
             print(f'{name:64s} {gpu:7.2f}  {host:7.2f}   x{per_rep}')
         print(f'{"sum":64s} {tot[0]:7.2f}  {tot[1]:7.2f}')
-        for label, cache in (('eager', None), ('graphed groups', {})):
+        for label, cache in (('eager', None), ('graphed encode', {}), ('graphed encode + groups', {'group_graph': True})):
             for rep in range(3):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
