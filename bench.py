@@ -188,16 +188,25 @@ def capture(gen, wl, batch, **kw):
 
 
 def pmc_traffic(family):
-    """HBM bytes per launch of the dominant kernel family from the committed PMC collection (rocprofv3 --pmc FETCH_SIZE /
-    --pmc WRITE_SIZE, separate passes over this same command with --eager; tools/pmc_frame.sh).  Counters cannot be read
-    from inside this process, so the figure comes from profiles/ (file named per round); None when it is absent."""
+    """HBM-side bytes per logical launch of the dominant kernel family from the committed PMC collection (rocprofv3 --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE, separate passes over this same command with --eager; tools/profile_round.sh + tools/pmc_traffic_summary.py, which
+    applies the guide's gfx950 FETCH_SIZE correction and sums over the SAME launches as `algorithmic_bytes_per_launch`).  Counters
+    cannot be read from inside this process, so the figure comes from profiles/ (file named per round); it is used only when the file
+    was measured on THIS tree's kernels (digest of csrc/ + include/).  Returns (bytes or None, note)."""
     if family != 'conv2d_mfma' or not os.path.exists(PMC_FILE):
-        return None
+        return None, 'no PMC collection for this family under profiles/'
     try:
+        from invertavatar_amd import build
         with open(PMC_FILE) as fh:
-            return round(json.load(fh)['_summary']['conv_family_per_logical_launch_mb'] * 1e6)
-    except (KeyError, ValueError, OSError):
-        return None
+            summ = json.load(fh)['_summary']
+        if summ.get('csrc_digest') != build.source_digest():
+            return None, f'{os.path.basename(PMC_FILE)} was measured on other kernel sources (digest {summ.get("csrc_digest")}): not used'
+        fam = summ['fp16_pair_family']
+        return int(fam['traffic_bytes_per_logical_launch']), (
+            f'{os.path.basename(PMC_FILE)}: (2 x FETCH_SIZE + WRITE_SIZE) of conv_split_kernel + its fix-ups / {fam["logical_launches_per_frame"]} '
+            f'launches per frame; uncorrected {fam["traffic_bytes_per_logical_launch_uncorrected"]}')
+    except (KeyError, ValueError, OSError) as exc:
+        return None, f'unreadable PMC summary: {exc}'
 
 
 def _profiled_frames(gen, wl, frames, single_stream):
@@ -240,7 +249,7 @@ def roofline_leg(gen, wl, frames=3):
         out = dict(bound='mfma', kernel='conv2d_mfma (3x3 layers >= 32^2: fp32 products from fp16 hi/lo pairs, 3 x v_mfma_f32_32x32x16_f16)',
                    achieved=round(3 * alg, 2), peak=PEAK_FP16_MFMA_TFLOPS, unit='TFLOP/s', frac=round(3 * alg / PEAK_FP16_MFMA_TFLOPS, 4),
                    frac_algorithmic=round(alg / PEAK_FP16_MFMA_TFLOPS, 4), mfma_util=round(3 * alg / PEAK_FP16_MFMA_TFLOPS, 4),
-                   algorithmic_f32_tflops=round(alg, 2), traffic=pmc_traffic(dom),
+                   algorithmic_f32_tflops=round(alg, 2), traffic=pmc_traffic(dom)[0], traffic_source=pmc_traffic(dom)[1],
                    algorithmic_bytes_per_launch=round(split['bytes'] / split['launches']),
                    launches_per_frame=split['launches'] // frames, avg_launch_us=round(split['ms'] * 1e3 / split['launches'], 2),
                    algorithmic_gflop_per_frame=round(split['flops'] / frames / 1e9, 1),
@@ -249,7 +258,7 @@ def roofline_leg(gen, wl, frames=3):
                                           frac_of_f32_mfma_peak=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)))
     else:
         out = dict(bound='mfma', kernel=dom, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                   frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom), launches_per_frame=d['launches'] // frames,
+                   frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom)[0], traffic_source=pmc_traffic(dom)[1], launches_per_frame=d['launches'] // frames,
                    avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2), algorithmic_gflop_per_frame=round(d['flops'] / frames / 1e9, 1))
     others = {}
     for k, f in fam.items():

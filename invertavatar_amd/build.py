@@ -41,6 +41,11 @@ def headers():
     return sorted(hs)
 
 
+def source_digest():
+    """Digest of every kernel source + header + the compile flags: stamps measurement files (profiles/) with the code they measured."""
+    return _digest(sources() + headers())
+
+
 def build(verbose=False, force=False):
     """Compile every csrc/*.hip for gfx950 and link libia_hip.so.  Returns its path."""
     hipcc = _hipcc()

@@ -231,7 +231,17 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int wo = wave / WP, wp = wave % WP;
-    const int b = blockIdx.y, worker = blockIdx.x;
+    const int b = blockIdx.y;
+    int worker = blockIdx.x;
+    if (!SK && g.xcd_bands) {
+        // Whole-tile launches: workgroups go to the 8 XCDs round-robin, and a tile's input window overlaps its neighbours' (a stride-1
+        // tile is one or two image rows + halo rows).  Give XCD x the contiguous band of tiles [start(x), start(x+1)) instead of every
+        // eighth tile, so that a halo row is fetched into ONE L2 instead of three (the tile order inside the band follows the dispatch
+        // order, so the bands advance together).
+        const int T = gridDim.x, per = T / ia::kNumXCD, rem = T - per * ia::kNumXCD;
+        const int x = worker % ia::kNumXCD, j = worker / ia::kNumXCD;
+        worker = x * per + (x < rem ? x : rem) + j;
+    }
     const int npts = g.GH * g.GW;
     const int cap = g.patch_cap;                       // patch positions reserved per plane (multiple of 64)
     const int PG = NP * cap / 64;                      // patch DMA instructions per chunk
@@ -486,6 +496,8 @@ int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     }
     g.stages = ns;
     if (const char* ev = getenv("IA_DMA_SPREAD")) g.spread = atoi(ev);
+    g.xcd_bands = (g.B == 1 || g.T_dp % ia::kNumXCD == 0) ? 1 : 0;      // (the linear workgroup id of batch element b starts at b * T_dp)
+    if (const char* ev = getenv("IA_XCD_BANDS")) g.xcd_bands = g.xcd_bands && atoi(ev);
     const size_t lds = stage * ns;
     int st = IA_OK;
     if (g.T_dp > 0) {

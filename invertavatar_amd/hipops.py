@@ -131,7 +131,14 @@ def _scratch_buffer(device, nbytes):
     return buf
 
 
-SMALL_CONV = True      # 3x3 layers up to 16^2 (and 16^2 -> 32^2): one ia_conv2d_small launch instead of stream-K kernel + fix-up
+import os as _os
+
+# ia_conv2d_small (3x3 layers up to 16^2 and 16^2 -> 32^2 in one launch, no fix-up) is OFF by default: alone it matches or beats the
+# stream-K kernel + fix-up per layer (15 vs 20 us at 4^2, 34 vs 41 at 16^2), but inside a frame its hundreds of 16 x 16 tiles re-read
+# operands from L2 next to the other networks' large layers: same-box A/B 296 vs 303 frames/s (r03, tools/ab_frame.py).
+# IA_SMALL_CONV=1 enables it (kept for batch-1 callers that run one network at a time).
+SMALL_CONV = _os.environ.get('IA_SMALL_CONV', '0') == '1'
+SMALL_CONV_MAX_BATCH = int(_os.environ.get('IA_SMALL_CONV_MAX_BATCH', '2'))      # (a batch-8 call: 352 vs 375 frames/s with it)
 
 
 def conv2d_small(x, wk, styles=None, demod=None, noise=None, noise_strength=None, bias=None, transposed=False, act='linear', alpha=0.2,
@@ -165,7 +172,7 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     _f32c(x, 'x')
     b, i, h, w = x.shape
     half_ops = wk.dtype == torch.float16
-    if (SMALL_CONV and not half_ops and ksize == 3 and residual is None and ksplit is None and wk.dim() == 3
+    if (SMALL_CONV and b <= SMALL_CONV_MAX_BATCH and not half_ops and ksize == 3 and residual is None and ksplit is None and wk.dim() == 3
             and _lib.load().ia_conv2d_small_supported(i, wk.shape[2], h, w, int(transposed))):
         return conv2d_small(x, wk, styles, demod, noise, noise_strength, bias, transposed, act, alpha, gain, clamp)
     split = half_ops and wk.dim() == 5

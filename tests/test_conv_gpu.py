@@ -407,7 +407,7 @@ SMALL_CASES = [  # B, I, O, res, up
 
 @pytest.mark.parametrize('b,i,o,res,up', SMALL_CASES)
 def test_small_layer_kernel_vs_oracle_and_vs_the_tiled_kernel(b, i, o, res, up):
-    """The layer through ia_conv2d_small (hipops.SMALL_CONV, the default route of these shapes) against the oracle's modulated
+    """The layer through ia_conv2d_small (hipops.SMALL_CONV) against the oracle's modulated
     convolution, and against the stream-K + fix-up route it replaces (same fp32 arithmetic, another summation order)."""
     assert hipops._lib.load().ia_conv2d_small_supported(i, o, res, res, int(up == 2)) == 1
     x, w = rnd(1, b, i, res, res), rnd(2, o, i, 3, 3)
@@ -415,18 +415,19 @@ def test_small_layer_kernel_vs_oracle_and_vs_the_tiled_kernel(b, i, o, res, up):
     out = res * up
     noise, bias = rnd(4, out, out), rnd(5, o) * 0.2
     ref = _layer_ref(x, w, styles, noise, 0.1, bias, up, clamp=2.0)
-    assert hipops.SMALL_CONV
-    got = _layer_hip(x, w, styles, noise, 0.1, bias, up, clamp=2.0).cpu()
-    hipops.SMALL_CONV = False
+    saved, saved_b = hipops.SMALL_CONV, hipops.SMALL_CONV_MAX_BATCH
+    hipops.SMALL_CONV, hipops.SMALL_CONV_MAX_BATCH = False, 8
     try:
         tiled = _layer_hip(x, w, styles, noise, 0.1, bias, up, clamp=2.0).cpu()
-    finally:
         hipops.SMALL_CONV = True
+        got = _layer_hip(x, w, styles, noise, 0.1, bias, up, clamp=2.0).cpu()
+        again = _layer_hip(x, w, styles, noise, 0.1, bias, up, clamp=2.0).cpu()
+    finally:
+        hipops.SMALL_CONV, hipops.SMALL_CONV_MAX_BATCH = saved, saved_b
     scale = max(ref.abs().max().item(), 1.0)
     assert got.shape == ref.shape
     assert max_abs(got, ref) <= 3e-5 * scale, (max_abs(got, ref), scale)
     assert max_abs(got, tiled) <= 3e-5 * scale
-    again = _layer_hip(x, w, styles, noise, 0.1, bias, up, clamp=2.0).cpu()
     assert torch.equal(again, got)                        # fixed summation order: run-to-run identical
 
 

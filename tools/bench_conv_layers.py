@@ -39,7 +39,7 @@ def main():
         line = f'I={i:4d} O={o:4d} res={r:4d} tr={tr}'
         for sname in sweeps:
             # a sweep entry is "default" or comma-separated ENV=VALUE pairs, e.g. IA_RING_STAGES=2,IA_DMA_SPREAD=1
-            for k in ('IA_RING_STAGES', 'IA_DMA_SPREAD'):
+            for k in ('IA_RING_STAGES', 'IA_DMA_SPREAD', 'IA_XCD_BANDS'):
                 os.environ.pop(k, None)
             if sname != 'default':
                 for kv in sname.split(','):
