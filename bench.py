@@ -25,7 +25,7 @@ Extra legs on rank 0 at N == 1 (all outside the timed region):
   roofline     -- per-launch HIP-event timing of the dominant kernel family over extra eager frames
   cpu_baseline -- the CPU oracle (restatement of the reference's pure-PyTorch op path) timed on the host cores on a bounded
                   sample of the same workload; the SAME frames give `max_abs_rgb_vs_oracle` (second half of the metric)
-  f32_mfma_only / sr_fp16 / drive_loop / batch8 / encoder -- variants reported beside the headline, never as `value`
+  f32_mfma_only / sr_fp16 / drive_loop / batch8 / encoder / oneshot -- variants reported beside the headline, never as `value`
 """
 import argparse
 import json
@@ -386,6 +386,11 @@ def extra_legs(result, gen, wl, args):
     guarded('drive_loop', lambda: drive_loop_leg(gen, wl, args))
     guarded('batch8', batch8)
     guarded('encoder', encoder)
+
+    def oneshot():
+        from invertavatar_amd.encoder_bench import oneshot_leg
+        return oneshot_leg(gen)
+    guarded('oneshot', oneshot)
 
 
 def sr_fp16_generator(gen, width):

@@ -422,6 +422,25 @@ int ia_convgru_update(const float* gates_pre, const float* cand_pre, const float
                       const float* x_next, float* xh_next, int B, int C, int H, int W, void* stream);
 
 /*
+ * Multi-head self-attention in one launch: out = softmax(Q K^T * scale) V per (batch, head), without the [N, M] score matrix.
+ * Replaces Attention.forward of the transformer-refined UNet decoders between the projections
+ * (encoder_inversion/models/mmseg/mix_transformer.py:83-116 with sr_ratio 1: two batched matmuls, the softmax over [N, M] and
+ * the head permutes).  fp32 operands and accumulation (v_mfma_f32_32x32x2_f32), online softmax, fixed summation order.
+ *   q   : [B, N, heads * head_dim] float32 (the output of the q projection; head h = columns [h * head_dim, (h + 1) * head_dim))
+ *   k, v: [B, M, heads * head_dim] views with their own batch / row strides (the reference's fused kv projection is [B, M, 2 C]:
+ *         k = columns [0, C), v = columns [C, 2 C), row stride 2 C)
+ *   out : [B, N, heads * head_dim] float32 = (attn @ v).transpose(1, 2).reshape(B, N, C) of the reference
+ *   strides in floats, multiples of 4; head_dim must be 256 (the 1024-dim / 4-head blocks) and N * M <= 131072 (the 8^2 / 16^2 token
+ *   grids of the first two decoder stages, where the ATen sequence is launch-bound: 21 vs 66 us, 65 vs 139 us; beyond that the
+ *   library GEMMs are faster and the caller keeps them): others -> IA_ERR_UNSUPPORTED (ia_attention_supported tells)
+ */
+int ia_attention_supported(int head_dim, int N, int M);
+int ia_attention(const float* q, const float* k, const float* v, float* out, int B, int heads, int N, int M, int head_dim,
+                 int64_t q_batch_stride, int64_t q_row_stride, int64_t k_batch_stride, int64_t k_row_stride,
+                 int64_t v_batch_stride, int64_t v_row_stride, int64_t out_batch_stride, int64_t out_row_stride,
+                 float scale, void* stream);
+
+/*
  * Driver-side UV rasteriser: projected FaceVerse mesh -> uvcoords_image, the mesh condition of TriPlaneGenerator.synthesis.
  * Replaces Faceverse_manager.make_driven_rendering from the rasteriser call on (data_preprocess/FaceVerse/renderer.py:66-82:
  * pytorch3d MeshRasterizer, ortho camera K = [-1,-1,0,0], T = [0,0,10], faces_per_pixel 1 -> render_after_rasterize

@@ -51,6 +51,8 @@ _SIGNATURES = {
     'ia_filtered_lrelu': [c_void_p] * 5 + [c_int] * 17 + [c_float] * 3 + [c_int, c_void_p],
     'ia_convgru_gates': [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
     'ia_convgru_update': [c_void_p] * 7 + [c_int] * 4 + [c_void_p],
+    'ia_attention_supported': [c_int] * 3,
+    'ia_attention': [c_void_p] * 4 + [c_int] * 5 + [c_int64] * 8 + [c_float, c_void_p],
     'ia_uv_rasterize': [c_void_p] * 5 + [c_int] * 8 + [c_float, c_int, c_void_p],
     'ia_layout_grid_u8': [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     'ia_stage_inputs': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), _i64p, c_int, c_void_p],

@@ -46,3 +46,37 @@ def encoder_leg(gen, n_sources=8, n_drive=32):
                          '(synthesis_withTexture, B=1 per call), eager launches, generator in train() mode as eval_seq.py leaves it',
                 inversion_ms=round(inv_ms, 2), drive_ms=round(drive_ms, 2), drive_frames_per_s=round(n_drive / (drive_ms * 1e-3), 2),
                 clip_frames_per_s=round(n_drive / wall, 2), finite=ok)
+
+
+def oneshot_leg(gen, n_drive=8):
+    """SURVEY 8(f)4 as a timed flow: the improved one-shot inversion of eval_updated_os.py (uvnet_new.inversionNet: e4e + two IR-SE50
+    UNets with transformer-refined decoders, everything in eval() mode) on one source frame, then `n_drive` drive frames."""
+    from . import eval_updated_os
+    from .encoder_inversion.models.uvnet_new import inversionNet as OneShotNet
+    was_training = gen.training
+    net = OneShotNet(generator=gen, encoding_triplane=True, encoding_texture=True).eval().requires_grad_(False)
+    synthetic.fill_encoder_parameters(net)
+    net = net.cuda()
+    gen.neural_rendering_resolution = NRR
+    try:
+        src = [12]
+        image, uv = synthetic.source_frames(9, 1).cuda(), synthetic.source_uv(19, src).cuda()
+        cam, uvc = synthetic.camera_labels(src).cuda(), synthetic.uv_conditions(src).cuda()
+        drive = list(range(40, 40 + n_drive))
+        d_c, d_uv = synthetic.camera_labels(drive).cuda(), synthetic.uv_conditions(drive).cuda()
+        for _ in range(3):      # (first runs: allocations, library kernel selection)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ws, res = eval_updated_os.one_shot_inversion(net, image, uv, cam, uvc)
+            torch.cuda.synchronize()
+            inv_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        imgs, _ = eval_seq.drive_sequence(net, ws, res, d_c, d_uv, neural_rendering_resolution=NRR)
+        torch.cuda.synchronize()
+        drive_ms = (time.perf_counter() - t0) * 1e3
+        ok = bool(torch.isfinite(imgs).all().item())
+    finally:
+        gen.train(was_training)
+    return dict(workload='SURVEY 8(f)4: eval_updated_os.py one-shot inversion (uvnet_new: e4e + 2 IR-SE50 UNets with 13 + 12 transformer '
+                         f'blocks, attention through ia_attention) of 1 source frame + {n_drive} drive frames, eager launches',
+                inversion_ms=round(inv_ms, 2), drive_frames_per_s=round(n_drive / (drive_ms * 1e-3), 2), finite=ok)

@@ -11,6 +11,9 @@ import torch
 import torch.nn as nn
 
 
+HIP_ATTENTION = True      # device inference: softmax(QK^T)V of the 1024-dim / 4-head blocks through ia_attention
+
+
 def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
@@ -102,7 +105,13 @@ class Attention(nn.Module):
         src = x
         if self.sr_ratio > 1:
             src = self.norm(self.sr(x.permute(0, 2, 1).reshape(B, C, H, W)).reshape(B, C, -1).permute(0, 2, 1))
-        k, v = self.kv(src).reshape(B, -1, 2, heads, hd).permute(2, 0, 3, 1, 4)
+        kv = self.kv(src)
+        if (HIP_ATTENTION and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not (self.training and self.attn_drop.p > 0)):
+            from .... import _lib, hipops
+            if _lib.load().ia_attention_supported(hd, N, kv.shape[1]):      # one launch: no [N, M] score matrix, no head permutes
+                out = hipops.attention(self.q(x).contiguous(), kv.contiguous(), heads, self.scale)
+                return self.proj_drop(self.proj(out))
+        k, v = kv.reshape(B, -1, 2, heads, hd).permute(2, 0, 3, 1, 4)
         attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1))
         return self.proj_drop(self.proj((attn @ v).transpose(1, 2).reshape(B, N, C)))
 

@@ -680,3 +680,22 @@ def stage_inputs(pairs):
         with torch.cuda.device(dev):
             st = _lib.load().ia_stage_inputs(srcs, dsts, nbytes, n, _lib.stream_ptr(dev))
         _lib.check(st, 'ia_stage_inputs')
+
+
+def attention(q, kv, heads, scale):
+    """softmax(Q K^T * scale) V per head in one launch (see ia_attention).  q [B,N,C], kv [B,M,2C] (k = kv[..., :C], v = kv[..., C:]);
+    returns [B,N,C]."""
+    _f32c(q, 'q')
+    _f32c(kv, 'kv')
+    b, n, c = q.shape
+    m = kv.shape[1]
+    if kv.shape[0] != b or kv.shape[2] != 2 * c or c % heads:
+        raise RuntimeError(f'attention: q {tuple(q.shape)} / kv {tuple(kv.shape)} / {heads} heads do not fit together')
+    out = torch.empty_like(q)
+    k, v = kv[..., :c], kv[..., c:]
+    with torch.cuda.device(q.device), _Timed('attention', 4.0 * b * n * m * c, 4.0 * (q.numel() + kv.numel() + out.numel()), f'B{b} N{n} M{m} C{c}'):
+        st = _lib.load().ia_attention(_p(q), k.data_ptr(), v.data_ptr(), _p(out), b, heads, n, m, c // heads, q.stride(0), q.stride(1),
+                                      kv.stride(0), kv.stride(1), kv.stride(0), kv.stride(1), out.stride(0), out.stride(1), float(scale),
+                                      _lib.stream_ptr(q.device))
+    _lib.check(st, 'ia_attention')
+    return out
