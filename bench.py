@@ -310,6 +310,17 @@ def cpu_baseline_leg(gen, wl, frames):
         base['product_cpu_route'] = dict(value=round(2 / (time.perf_counter() - t0), 4), unit='frames/s', cores=cores,
                                          sample='2 frames after 1 warm-up frame',
                                          survey_container_8_cores=0.34)
+        # the same route at n = 8 threads (the survey container's core count) and on every logical core of this box
+        by_threads = {}
+        for n_thr in sorted({8, os.cpu_count() or cores}):
+            torch.set_num_threads(n_thr)
+            call(sets[0])
+            t0 = time.perf_counter()
+            call(sets[1])
+            by_threads[str(n_thr)] = round(1 / (time.perf_counter() - t0), 4)
+        torch.set_num_threads(cores)
+        base['product_cpu_route']['frames_per_s_by_threads'] = by_threads
+        base['product_cpu_route']['logical_cores_of_this_box'] = os.cpu_count()
     except Exception as exc:   # noqa: BLE001
         base['product_cpu_route'] = f'failed: {exc}'
     return base, dict(max_abs_rgb_vs_oracle=float(f'{err_rgb:.3e}'), max_abs_raw_rgb_vs_oracle=float(f'{err_raw:.3e}'),

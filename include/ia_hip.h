@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 1
+#define IA_HIP_ABI_VERSION 2      /* r03: ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -469,6 +469,16 @@ int ia_uv_rasterize(const float* verts, const int* tris, const float* face_attrs
  * Bit-exact with the reference's torch expression (one multiply, one add, clamp, truncation).
  */
 int ia_layout_grid_u8(const float* img, uint8_t* out, int B, int C, int H, int W, int grid_w, int grid_h, int chw_to_hwc, void* stream);
+
+/*
+ * Range check of the split format (debug / test aid).  The hi plane saturates at +-65504 (ia_act_split and every epilogue that writes
+ * the format clamp x * style there: ia_common.h split_f16); a value that hit the clamp is no longer the fp32 number the consumer
+ * should multiply.  Counts the elements of plane 0 whose magnitude is the fp16 maximum.
+ *   xs : split tensor [B][planes][C/8][H*W][8] fp16;  count : device uint32 (overwritten)
+ * The generator's activations stay far below the bound (|x * style| < 10^3 on the synthetic and on trained checkpoints); the tests
+ * assert a zero count over a full-width frame, and hipops.CHECK_SPLIT_RANGE makes every producer check itself.
+ */
+int ia_split_saturation_count(const void* xs, int planes, int B, int C, int H, int W, unsigned int* count, void* stream);
 
 /*
  * Input side of a captured frame: n <= 8 device-to-device segment copies in ONE launch (src[k] -> dst[k], nbytes[k] bytes).

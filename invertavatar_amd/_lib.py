@@ -17,6 +17,8 @@ _lib = None
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _i64p = ctypes.POINTER(ctypes.c_int64)
 
+ABI_VERSION = 2      # IA_HIP_ABI_VERSION of include/ia_hip.h
+
 DTYPE_ID = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
 
 # name -> argtypes, mirroring include/ia_hip.h
@@ -44,6 +46,7 @@ _SIGNATURES = {
     'ia_rasterize_level': [c_void_p] * 4 + [c_int64, c_void_p] + [c_int] * 9 + [c_void_p],
     'ia_blend_planes': [c_void_p] * 3 + [c_int64, c_void_p] + [c_int] * 5 + [c_void_p],
     'ia_cond_blend': [c_void_p] * 3 + [c_int] * 4 + [c_void_p],
+    'ia_split_saturation_count': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'ia_act_split': [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
     'ia_conv2d_mfma_sx': [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 7 + [c_int] + [c_void_p] * 2 + [ctypes.c_size_t] + [c_int] * 7 + [c_float, c_void_p, c_float, c_float] + [c_int, c_void_p],
     'ia_fir_tail_split': [c_void_p] * 8 + [c_int] * 10 + [c_float, c_int, c_float, c_float, c_float, c_void_p],
@@ -86,8 +89,8 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_size_t if name == 'ia_last_error' else c_int
-        if lib.ia_version() != 1:
-            raise RuntimeError(f'libia_hip.so ABI version {lib.ia_version()} != 1; rebuild with python -m invertavatar_amd.build')
+        if lib.ia_version() != ABI_VERSION:
+            raise RuntimeError(f'libia_hip.so ABI version {lib.ia_version()} != {ABI_VERSION}; rebuild with python -m invertavatar_amd.build')
         _lib = lib
         return lib
 

@@ -94,6 +94,19 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
     }
 }
 
+// Elements of the hi plane that sit on the fp16 maximum: values the split clamped (see ia_split_saturation_count).
+__global__ __launch_bounds__(256) void split_saturation_kernel(const unsigned short* __restrict__ xs, int64_t per_batch_hi, int64_t batch_stride,
+                                                              int B, unsigned int* __restrict__ count) {
+    unsigned int mine = 0;
+    const int64_t total = (int64_t)B * per_batch_hi, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t b = i / per_batch_hi, e = i - b * per_batch_hi;
+        mine += ((xs[b * batch_stride + e] & 0x7fffu) == 0x7bffu) ? 1u : 0u;      // |hi| == 65504
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);                  // (integer adds commute: the count is deterministic)
+}
+
 // Accumulator tile -> fp32 NCHW (y, optional) and/or split planes (e.ys, optional); stride-1 form.
 template <int FO, int FP, int WO, int WP>
 __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], float* __restrict__ y, const Geo& g, const Epi& e,
@@ -562,6 +575,17 @@ extern "C" int ia_act_split(const float* x, const float* styles, const float* sh
     hipLaunchKernelGGL(act_split_kernel, dim3(ia::streaming_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, styles, shift,
                        static_cast<h16x8*>(xs), B, C, (int64_t)H * W, planes);
     return ia::check_launch("ia_act_split");
+}
+
+extern "C" int ia_split_saturation_count(const void* xs, int planes, int B, int C, int H, int W, unsigned int* count, void* stream) {
+    IA_REQUIRE(xs && count, "null pointer argument");
+    IA_REQUIRE((planes == 1 || planes == 2) && B > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "not a split tensor shape");
+    const int64_t per_plane = (int64_t)C * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(count, 0, sizeof(unsigned int), s) != hipSuccess) return ia::fail(IA_ERR_LAUNCH, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(split_saturation_kernel, dim3(ia::streaming_grid((int64_t)B * per_plane, 256)), dim3(256), 0, s,
+                       static_cast<const unsigned short*>(xs), per_plane, (int64_t)planes * per_plane, B, count);
+    return ia::check_launch("ia_split_saturation_count");
 }
 
 // (make_plan / tile selection live in conv_mfma.hip: both forms of a layer share tiles, worker counts and slab sizes)

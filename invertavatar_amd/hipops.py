@@ -244,6 +244,21 @@ def conv1x1(x, wk, styles=None, bias=None, residual=None, clamp=None):
     return y
 
 
+# Debug switch: every producer of a SplitAct counts the elements its hi / lo split clamped at +-65504 (ia_split_saturation_count) and
+# raises when there are any -- the range contract of the fp16-pair convolutions, otherwise silent (one sync per producer: tests only).
+CHECK_SPLIT_RANGE = False
+
+
+def split_saturation_count(sa):
+    """Elements of the SplitAct's hi plane that sit on the fp16 maximum (a device -> host sync)."""
+    b, c, h, w = sa.shape
+    cnt = torch.zeros(1, device=sa.data.device, dtype=torch.int32)
+    with torch.cuda.device(sa.data.device):
+        st = _lib.load().ia_split_saturation_count(_p(sa.data), int(sa.planes), b, c, h, w, _p(cnt), _lib.stream_ptr(sa.data.device))
+    _lib.check(st, 'ia_split_saturation_count')
+    return int(cnt.item())
+
+
 class SplitAct:
     """An activation stored as fp16 planes [B, planes, C/8, H, W, 8] (the input format of ia_conv2d_mfma_sx, see include/ia_hip.h):
     planes = 2 hi / lo pairs (fp32-equivalent consumers), planes = 1 one rounded fp16 plane (fp16-operand consumers: the
@@ -256,6 +271,10 @@ class SplitAct:
         b, self.planes, c8, h, w, _ = data.shape
         self.shape = (b, channels, h, w)
         self.device, self.dtype = data.device, torch.float32      # stands in for an fp32 activation
+        if CHECK_SPLIT_RANGE and not torch.cuda.is_current_stream_capturing():
+            n = split_saturation_count(self)
+            if n:
+                raise OverflowError(f'{n} activations of a {self.shape} split tensor were clamped at +-65504 (fp16 range of the hi plane)')
 
     def float(self):     # inverse of the split (tests / fallbacks): hi + lo * 2^-11, channel groups unfolded
         v = self.data[:, 0].float()

@@ -287,3 +287,25 @@ def test_sr_head_fused_torgb_equals_two_launches(golden, full):
     finally:
         sg2.FUSED_TORGB, hipops.PROFILE = saved, None
     assert max_abs(imgs[True], imgs[False]) <= 1e-5, max_abs(imgs[True], imgs[False])
+
+
+def test_split_format_range_contract_holds_over_a_full_width_frame_and_trips_when_broken():
+    """the hi / lo split clamps x * style at +-65504 silently.  With hipops.CHECK_SPLIT_RANGE every producer of
+    the format counts its clamped elements: zero over a full-width frame at the bench configuration, non-zero for an activation
+    pushed out of range."""
+    g = _build('full')
+    frames, nrr = [3], 128
+    ws = g.mapping(synthetic.latent(0, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14)
+    hipops.CHECK_SPLIT_RANGE = True
+    try:
+        with torch.no_grad():
+            out = g.synthesis(ws, synthetic.camera_labels(frames).cuda(), {'uvcoords_image': synthetic.uv_conditions(frames).cuda()},
+                              neural_rendering_resolution=nrr, noise_mode='const', evaluation=True, jitter=synthetic.jitter(frames, nrr * nrr).cuda())
+        assert torch.isfinite(out['image']).all()
+        x = torch.randn(1, 64, 32, 32, device='cuda')
+        assert hipops.split_saturation_count(hipops.act_split(x)) == 0
+        x[0, 5, 7, 9] = 7.0e4
+        with pytest.raises(OverflowError, match='clamped'):
+            hipops.act_split(x)
+    finally:
+        hipops.CHECK_SPLIT_RANGE = False
