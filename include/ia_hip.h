@@ -422,6 +422,17 @@ int ia_convgru_update(const float* gates_pre, const float* cand_pre, const float
                       const float* x_next, float* xh_next, int B, int C, int H, int W, void* stream);
 
 /*
+ * Squeeze-and-excitation gate + residual add of an IR-SE50 unit:  out = v * sigmoid(W2 relu(W1 mean_hw(v))) + shortcut.
+ * Replaces SEModule.forward and the add of bottleneck_IR_SE.forward (encoder_inversion/models/helpers.py:84-100, :121-124).
+ *   v, shortcut : float32 [B, C, H, W] VIEWS given by 4 strides each (floats; batch, channel, row, column) -- the stride-2 output of
+ *                 the unit's second convolution and MaxPool2d(1, s) shortcuts are strided views of larger tensors
+ *   w1 [R, C], w2 [C, R] : the two bias-free 1x1 convolutions (R = C / reduction <= 64);  pooled_scratch : B * C floats
+ *   out : [B, C, H, W] contiguous
+ */
+int ia_se_gate(const float* v, const int64_t* v_strides, const float* shortcut, const int64_t* shortcut_strides, const float* w1,
+               const float* w2, float* pooled_scratch, float* out, int B, int C, int R, int H, int W, void* stream);
+
+/*
  * Multi-head self-attention in one launch: out = softmax(Q K^T * scale) V per (batch, head), without the [N, M] score matrix.
  * Replaces Attention.forward of the transformer-refined UNet decoders between the projections
  * (encoder_inversion/models/mmseg/mix_transformer.py:83-116 with sr_ratio 1: two batched matmuls, the softmax over [N, M] and

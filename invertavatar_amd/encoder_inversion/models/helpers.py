@@ -93,6 +93,8 @@ def run_trunk(body, x, taps):
     for i, unit in enumerate(body._modules.values()):
         if HIP_TRUNK and isinstance(unit, (bottleneck_IR, bottleneck_IR_SE)) and trunk_hip.unit_supported(unit, x):
             x = trunk_hip.unit_forward(unit, x)
+        elif HIP_TRUNK and isinstance(unit, bottleneck_IR_SE) and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
+            x = trunk_hip.se_tail(unit, unit.res_layer[:5](x), x)      # library convolutions / BatchNorm, fused gate + shortcut + add
         else:
             x = unit(x)
         if i in taps:

@@ -73,8 +73,26 @@ def unit_forward(unit, x):
     v = hipops.conv2d_mfma_sx(us, p.w2, demod=p.a2.unsqueeze(0).expand(b, -1).contiguous(), bias=p.c2, act='linear')
     if stride == 2:
         v = v[:, :, ::2, ::2]
-    res = unit.res_layer[5](v) if len(unit.res_layer) > 5 else v            # SEModule (bottleneck_IR has none)
-    return res + unit.shortcut_layer(x)
+    return se_tail(unit, v, x)
+
+
+def se_tail(unit, v, x):
+    """SEModule gate + shortcut + add of a residual unit (helpers.py:84-100, :121-124) in two launches (ia_se_gate); `v`: the residual
+    branch in front of the gate (may be a strided view).  Units without a gate, CPU tensors and autograd take the ATen ops."""
+    se = unit.res_layer[5] if len(unit.res_layer) > 5 else None
+    short = unit.shortcut_layer
+    if (se is not None and v.is_cuda and v.dtype == torch.float32 and not torch.is_grad_enabled() and se.fc1.out_channels <= 64
+            and se.fc1.bias is None and se.fc2.bias is None):
+        if isinstance(short, torch.nn.MaxPool2d) and short.kernel_size == 1:      # MaxPool2d(1, s) = the input sub-sampled
+            s_ = short.stride if isinstance(short.stride, int) else short.stride[0]
+            sc = x[:, :, ::s_, ::s_]
+        else:
+            sc = short(x)
+        c = v.shape[1]
+        return hipops.se_gate(v, sc, se.fc1.weight.detach().float().reshape(-1, c).contiguous(),
+                              se.fc2.weight.detach().float().reshape(c, -1).contiguous())
+    res = se(v) if se is not None else v
+    return res + short(x)
 
 
 # ------------------------------------------------------------------ plain 3x3 convolutions of the UNet decoders / heads

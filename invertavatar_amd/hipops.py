@@ -718,3 +718,20 @@ def attention(q, kv, heads, scale):
                                       _lib.stream_ptr(q.device))
     _lib.check(st, 'ia_attention')
     return out
+
+
+def se_gate(v, shortcut, w1, w2):
+    """v * sigmoid(w2 relu(w1 mean_hw(v))) + shortcut (see ia_se_gate).  v, shortcut: fp32 [B,C,H,W] views (any strides);
+    w1 [R,C], w2 [C,R]."""
+    b, c, h, w = v.shape
+    if not (v.is_cuda and v.dtype == torch.float32 and shortcut.dtype == torch.float32 and tuple(shortcut.shape) == (b, c, h, w)):
+        raise RuntimeError('se_gate: v and shortcut must be float32 device tensors of one shape')
+    r = w1.shape[0]
+    _f32c(w1, 'w1'); _f32c(w2, 'w2')
+    out = torch.empty(b, c, h, w, device=v.device, dtype=torch.float32)
+    pooled = torch.empty(b * c, device=v.device, dtype=torch.float32)
+    with torch.cuda.device(v.device):
+        st = _lib.load().ia_se_gate(v.data_ptr(), _lib.strides64(v), shortcut.data_ptr(), _lib.strides64(shortcut), _p(w1), _p(w2), _p(pooled),
+                                    _p(out), b, c, r, h, w, _lib.stream_ptr(v.device))
+    _lib.check(st, 'ia_se_gate')
+    return out
