@@ -27,6 +27,8 @@ def fam(name):
     base = n.split('<')[0].split('(')[0]
     if base == 'conv_mfma_kernel':
         return 'conv_mfma_kernel<HM=%s>' % n.split('>')[0].split(',')[-1].strip()
+    if base == 'conv_fixup_kernel':      # keep the tile family (TR, FO, FP, WO, WP): WO = 2 are the fix-ups of the fp16-pair kernels
+        return 'conv_fixup_kernel<%s>' % n.split('<')[1].split('>')[0].replace(' ', '')
     return base
 summary = {}
 for s in ('fetch', 'write', 'sq'):
