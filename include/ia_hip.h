@@ -382,6 +382,22 @@ int ia_conv1x1(const float* x, const float* wk, const float* styles, const float
                int B, int I, int O, int H, int W, float clamp, void* stream);
 
 /*
+ * ToRGB layer AND the skip-image branch of its block in one launch:
+ *   y = clamp((w * styles) (*) x + bias) + (residual | upsample2d(skip))
+ * Replaces ToRGBLayer.forward (training/networks_stylegan2.py:353-362) + `img = upfirdn2d.upsample2d(img, resample_filter)` +
+ * `img = img.add_(y)` of SynthesisBlock.forward (:454-457; upsample2d = torch_utils/ops/upfirdn2d.py:315-350: zero insertion x2,
+ * padding [2,1,2,1], the 4x4 filter, gain 4).  Same arguments as ia_conv1x1, plus skip [B,O,H/2,W/2] (or NULL) with its resample
+ * filter skip_filter [4,4] (upfirdn2d.setup_filter([1,3,3,1])); residual and skip are exclusive.  Every load of a wave (128 input
+ * channels x 32 pixels, its weights and styles) is in flight before the first MFMA, wider layers split their channels over the waves
+ * of a workgroup; the up-sampling evaluates the 2 x 2 non-zero taps per output pixel in ia_upfirdn2d's order (bit-identical image).
+ * C_in in {128, 256, 512, 1024}, C_out <= 96, H and W even when skip is given; else IA_ERR_UNSUPPORTED (callers use ia_conv1x1 +
+ * ia_upfirdn2d).  ia_torgb_supported answers that question without a launch (1 = covered).  One launch, no scratch.
+ */
+int ia_torgb_supported(int I, int O, int H, int W, int with_skip);
+int ia_torgb(const float* x, const float* wk, const float* styles, const float* bias, const float* residual, const float* skip,
+             const float* skip_filter, float* y, int B, int I, int O, int H, int W, float clamp, void* stream);
+
+/*
  * ia_cond_blend with the result in SPLIT format (ia_act_split) for the one layer that consumes it, multiplied by that layer's
  * styles [B,C] (NULL = 1): ys = split((cond[:, :C] * a + x * (1 - a)) * styles_next), a = cond[:, C]
  * (training_avatar_texture/networks_stylegan2_new.py:539-540 feeding the next block's conv0).  C % 8 == 0.

@@ -43,6 +43,8 @@ _SIGNATURES = {
     'ia_fill_mouth': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'ia_conv2d_mfma_sx_rgb': [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6 + [c_int] + [c_void_p] * 6 + [c_int, c_float] + [c_int] * 6 + [c_float] * 3 + [c_void_p],
     'ia_conv1x1': [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p],
+    'ia_torgb_supported': [c_int] * 5,
+    'ia_torgb': [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p],
     'ia_rasterize_level': [c_void_p] * 4 + [c_int64, c_void_p] + [c_int] * 9 + [c_void_p],
     'ia_blend_planes': [c_void_p] * 3 + [c_int64, c_void_p] + [c_int] * 5 + [c_void_p],
     'ia_cond_blend': [c_void_p] * 3 + [c_int] * 4 + [c_void_p],

@@ -150,6 +150,137 @@ __global__ __launch_bounds__(64 * KS) void conv1x1_kernel(C1Params p) {
         }
 }
 
+
+// ---- ia_torgb: the same layer with every load of a wave in flight at once, and the skip image's up-sampling in the epilogue -------------
+//
+// conv1x1_kernel keeps 8 channel pairs (8 KB) in flight per wave and walks its channels in 8 - 32 dependent load -> MFMA rounds: at
+// one frame per call the 22 ToRGB launches of a frame are latency chains (18 - 40 us each for 0.5 .. 33 MB).  Here a wave owns 32
+// pixels x 128 input channels (64 channel pairs): all 64 activation loads, 64 weight loads and the styles are issued before the first
+// MFMA -- one memory round trip -- and the input channels of a 256 / 512-channel layer are split over KS = 2 / 4 waves that meet in LDS
+// (fixed order).  A workgroup is always 8 waves: 8 / KS pixel fragments.  The epilogue adds either a residual image or
+// upsample2d(skip) -- the 2x up-sampling of the previous block's image with the 4x4 resample filter (upfirdn2d.upsample2d :341-350:
+// zero insertion, padding [2,1,2,1], gain 4) evaluated at the output pixel: of the 16 taps the 2 x 2 that fall on real samples, in the
+// order and with the fused multiply-adds of ia_upfirdn2d (the other 12 multiply zeros there), so the image is bit-identical to the
+// two-launch route's -- and the separate upfirdn2d launch per block disappears.
+struct TParams {
+    const float* x;          // [B][I][P]
+    const float* wk;         // [I][O]
+    const float* styles;     // [B][I] or null
+    const float* bias;       // [O] or null
+    const float* residual;   // [B][O][P] or null (added after the clamp)
+    const float* skip;       // [B][O][H/2][W/2] or null: up-sampled 2x and added after the clamp
+    const float* filt;       // [4][4] resample filter of the skip up-sampling
+    float* y;                // [B][O][P]
+    int I, O, H, W;
+    int64_t P;
+    float clamp;             // < 0: none
+};
+
+constexpr int kTU = 32;      // channel pairs per register block (two blocks are in flight)
+
+template <int KS>
+__global__ __launch_bounds__(512) void torgb_kernel(TParams p) {
+    constexpr int NG = 8 / KS;                                   // pixel fragments per workgroup
+    __shared__ float s_red[KS > 1 ? 8 * 16 * 64 : 1];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, half = lane >> 5;
+    const int grp = wave / KS, ks = wave - grp * KS;
+    const int b = blockIdx.y, o0 = blockIdx.z * 32;
+    const int64_t pix = ((int64_t)blockIdx.x * NG + grp) * 32 + l31;
+    const bool pvalid = pix < p.P, ovalid = o0 + l31 < p.O;
+    const int kw = p.I / KS, k_begin = ks * kw;                  // this wave's input channels: 64 or 128 of them
+    const float* xp = p.x + ((int64_t)b * p.I + k_begin + half) * p.P + (pvalid ? pix : 0);
+    const float* wp = p.wk + (int64_t)(k_begin + half) * p.O + o0 + (ovalid ? l31 : 0);
+    // styles of the wave's channels: lane l holds those of channels l and 64 + l; a pair's two values are read back with v_readlane
+    float sv0 = 1.f, sv1 = 1.f;
+    if (p.styles) {
+        const float* sp = p.styles + (int64_t)b * p.I + k_begin;
+        sv0 = sp[lane];
+        if (kw > 64) sv1 = sp[64 + lane];
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    float xa[kTU], wa[kTU], xb[kTU], wb[kTU];
+    auto load_block = [&](float (&xv)[kTU], float (&wv)[kTU], int k0) {
+#pragma unroll
+        for (int u = 0; u < kTU; ++u) {
+            const int k = k0 + 2 * u;                            // this lane's channel: k_begin + k + half
+            xv[u] = pvalid ? xp[(int64_t)k * p.P] : 0.f;
+            wv[u] = ovalid ? wp[(int64_t)k * p.O] : 0.f;
+        }
+    };
+    auto mma_block = [&](const float (&xv)[kTU], const float (&wv)[kTU], float sv) {
+#pragma unroll
+        for (int u = 0; u < kTU; ++u) {
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), 2 * u));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), 2 * u + 1));
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u] * (half ? s1 : s0), xv[u], acc, 0, 0, 0);      // (w * s) * x, the reference's order
+        }
+    };
+    load_block(xa, wa, 0);
+    if (kw > 64) load_block(xb, wb, 64);
+    mma_block(xa, wa, sv0);
+    if (kw > 64) mma_block(xb, wb, sv1);
+
+    // C/D map of the 32x32 MFMA: row (output channel) = (r&3) + 8*(r>>2) + 4*half, column (pixel) = l31.  With KS > 1 the KS waves
+    // of a pixel fragment leave their sums in LDS and wave ks finishes registers [ks * 16/KS, (ks+1) * 16/KS), adding in wave order.
+    constexpr int NR = 16 / KS;
+    float v[NR];
+    if constexpr (KS > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            float s = s_red[((grp * KS) * 16 + ks * NR + j) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < KS; ++w) s += s_red[((grp * KS + w) * 16 + ks * NR + j) * 64 + lane];
+            v[j] = s;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) v[j] = acc[j];
+    }
+    if (!pvalid) return;
+    // the 2 x 2 real taps of the up-sampling at this pixel: rows my + t with weights ky[t], columns mx + u with kx[u]
+    int soff[4];
+    float sk[4];
+    const int Ws = p.W >> 1, Hs = p.H >> 1;
+    if (p.skip) {
+        const int oy = (int)(pix / p.W), ox = (int)(pix - (int64_t)oy * p.W);
+        const int my = ((oy + (oy & 1)) >> 1) - 1, mx = ((ox + (ox & 1)) >> 1) - 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int iy = (oy & 1) + 2 * t, ix = (ox & 1) + 2 * u;          // tap index in the 4x4 filter (before the flip)
+                const bool in = my + t >= 0 && my + t < Hs && mx + u >= 0 && mx + u < Ws;
+                soff[2 * t + u] = in ? (my + t) * Ws + mx + u : 0;
+                sk[2 * t + u] = in ? p.filt[(3 - iy) * 4 + (3 - ix)] * 4.f : 0.f;
+            }
+    }
+    float* yb = p.y + (int64_t)b * p.O * p.P + pix;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = ks * NR + j;
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o >= p.O) continue;
+        float s = v[j] + (p.bias ? p.bias[o] : 0.f);
+        if (p.clamp >= 0.f) s = fminf(fmaxf(s, -p.clamp), p.clamp);
+        if (p.residual) s += p.residual[((int64_t)b * p.O + o) * p.P + pix];
+        if (p.skip) {
+            const float* sb = p.skip + ((int64_t)b * p.O + o) * Hs * Ws;
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a = fmaf(sb[soff[q]], sk[q], a);
+            s += a;
+        }
+        yb[(int64_t)o * p.P] = s;
+    }
+}
+
 template <int V>
 void launch_ks(int ksplit, dim3 grid, hipStream_t s, const C1Params& p) {
     switch (ksplit) {
@@ -184,4 +315,36 @@ extern "C" int ia_conv1x1(const float* x, const float* wk, const float* styles, 
     if (v == 4) launch_ks<4>(ksplit, grid, s, p);
     else launch_ks<2>(ksplit, grid, s, p);
     return ia::check_launch("ia_conv1x1");
+}
+
+extern "C" int ia_torgb_supported(int I, int O, int H, int W, int with_skip) {
+    if (O > 96 || !(I == 128 || I == 256 || I == 512 || I == 1024)) return 0;
+    if (with_skip && ((H | W) & 1)) return 0;
+    return 1;
+}
+
+extern "C" int ia_torgb(const float* x, const float* wk, const float* styles, const float* bias, const float* residual, const float* skip,
+                        const float* skip_filter, float* y, int B, int I, int O, int H, int W, float clamp, void* stream) {
+    IA_REQUIRE(x && wk && y, "x, wk and y must be device pointers");
+    IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
+    IA_REQUIRE(!(residual && skip), "either a residual image or a skip image to up-sample, not both");
+    IA_REQUIRE(!skip || skip_filter, "the skip image needs its 4x4 resample filter");
+    if (!ia_torgb_supported(I, O, H, W, skip != nullptr))
+        return ia::fail(IA_ERR_UNSUPPORTED, "ia_torgb covers C_out <= 96, C_in 128 / 256 / 512 / 1024 and even H, W with a skip image (got C_in %d, C_out %d, %d x %d)", I, O, H, W);
+    IA_REQUIRE(B <= 65535, "batch too large for one launch");
+    const int64_t P = (int64_t)H * W;
+    // 128 input channels per wave; a single 32-pixel fragment (4^2 images) splits 512+ channels over all 8 waves instead
+    int ks = I / 128;
+    if (P <= 32 && I == 512) ks = 8;
+    TParams p{x, wk, styles, bias, residual, skip, skip_filter, y, I, O, H, W, P, clamp};
+    const int ng = 8 / ks;
+    const dim3 grid((unsigned)((P + 32 * ng - 1) / (32 * ng)), (unsigned)B, (unsigned)((O + 31) / 32));
+    const hipStream_t s = (hipStream_t)stream;
+    switch (ks) {
+        case 8: hipLaunchKernelGGL((torgb_kernel<8>), grid, dim3(512), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((torgb_kernel<4>), grid, dim3(512), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((torgb_kernel<2>), grid, dim3(512), 0, s, p); break;
+        default: hipLaunchKernelGGL((torgb_kernel<1>), grid, dim3(512), 0, s, p); break;
+    }
+    return ia::check_launch("ia_torgb");
 }

@@ -34,6 +34,8 @@
 // machine (e.g. the (H+1)x(W+1) point grids of the transposed form: 524 equal workgroups on 512 slots ran as two rounds)
 // and gives low-resolution layers, which have only a handful of tiles, a fine-grained K split.
 #include "conv_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -502,13 +504,31 @@ static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transpos
     Plan p;
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
     tile_dims(O, H, W, ksize, transposed, form, &p.bo, &p.bp, &p.cc, &p.waves);
+    bool force_whole = false;
+    if (const char* ev = form == 3 ? getenv("IA_SX_TILE") : nullptr) {      // experiment switch (tools/): "bo,bp" = whole tiles of that family
+        int bo = 0, bp = 0;
+        if (sscanf(ev, "%d,%d", &bo, &bp) == 2 && bp == 256 && (bo == 32 || bo == 64 || bo == 128) && !(transposed && bo == 128) &&
+            worst_patch(npts, transposed ? W + 1 : W, 256, 3, transposed) <= kPatchFloats) {
+            p.bo = bo; p.bp = bp; p.waves = 8; force_whole = true;
+        }
+    }
+    // Stride-1 3x3 layers of the split-DMA form that are smaller than the machine (512 -> 512 @64^2, 256 -> 256 @128^2 at one frame per
+    // call): 32-channel x 256-point tiles, every tile whole, instead of 128 x 256 tiles cut between stream-K workers -- as soon as those
+    // tiles give every CU one.  No slabs, no fix-up launch; a tile's weight rows (9 KB per chunk) are a quarter of the wide tile's.
+    // Measured r03 (tools/bench_conv_layers.py, B = 1): 102.8 -> 76.2 us @64^2, 74.1 -> 67.3 us @128^2; 1024-point layers
+    // (64 narrow tiles) stay on stream-K: 39 vs 64 us.
+    if (form == 3 && !force_whole && !transposed && ksize == 3 && p.waves == 8 && O % 32 == 0 && !getenv("IA_NO_NARROW_TILES")) {
+        const int64_t t_wide = (int64_t)B * ((npts + 255) / 256) * ((O + 127) / 128), t_narrow = (int64_t)B * ((npts + 255) / 256) * (O / 32);
+        if (t_wide < ia::kNumCU && t_narrow >= ia::kNumCU) { p.bo = 32; p.bp = 256; force_whole = true; }
+    }
+    if (const char* ev = form == 3 ? getenv("IA_SX_WHOLE") : nullptr) force_whole = force_whole || atoi(ev) != 0;      // experiment switch
     p.TO = (O + p.bo - 1) / p.bo;
     p.T = ((npts + p.bp - 1) / p.bp) * p.TO;
     p.C = (I + p.cc - 1) / p.cc;
     const int slots = (p.waves == 8 ? 1 : 2) * ia::kNumCU;           // workgroups per CU of the tile family
     const int Gb = slots / B > 0 ? slots / B : 1;                    // slots of one batch element
     const int rounds = p.T / Gb, R = p.T - rounds * Gb;
-    if (R == 0 || rounds >= 8 || (rounds >= 1 && 4 * R >= 3 * Gb)) {
+    if (force_whole || R == 0 || rounds >= 8 || (rounds >= 1 && 4 * R >= 3 * Gb)) {
         p.T_dp = p.T; p.G = 0;                                       // whole (or nearly whole) rounds of whole tiles
     } else {
         p.T_dp = rounds * Gb;

@@ -235,10 +235,12 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NWAVES = WO * WP, NTHREADS = NWAVES * 64;
     constexpr int PAD = TR ? 0 : KS / 2;
     constexpr int NACC = NPH * FO * FP * 16;
-    constexpr int WSLOTS = NP * NTP * BO;             // 16-byte slots of the weight region of a stage: [plane][tap (+ zero tap)][BO]
-    constexpr int WG = NP * NT * BO / 64;              // weight DMA instructions per chunk (64 slots each), spread over the waves
+    constexpr int WSLOTS = NP * NTP * BO;             // 16-byte slots of the weight region of a stage: [plane][tap][BO], then one all-zero row per plane
+    constexpr int WG = (NP * NT * BO + 63) / 64;       // weight DMA instructions per chunk (64 slots each), spread over the waves
     constexpr int JW = (WG + NWAVES - 1) / NWAVES;
-    static_assert(BO % 64 == 0, "a DMA instruction fills 64 consecutive slots of one (plane, tap) row");
+    static_assert(WG * 64 <= WSLOTS, "a DMA instruction fills 64 consecutive slots of the [plane][tap][BO] rows (a last partial one ends in the zero rows)");
+    // LDS row of (plane, tap): the DMA'd rows are contiguous (a 64-slot piece may span two rows of a 32-channel tile), the zero taps follow
+    auto wrow = [](int pl, int tap) { return tap == kZeroTap ? NP * NT + pl : pl * NT + tap; };
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     const int NS = g.stages;                           // LDS stages of the DMA ring (>= 2): chunks ch+1 .. ch+NS-1 are in flight under chunk ch
     for (int i = tid; i < NS * NP * BO; i += NTHREADS) {
         const int stg = i / (NP * BO), r = i - stg * NP * BO, pl = r / BO, o = r - pl * BO;
-        *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + stg * stage_bytes + ((pl * NTP + NT) * BO + o) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + stg * stage_bytes + ((NP * NT + pl) * BO + o) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
   for (int64_t u = u_begin; u < u_end;) {
@@ -322,9 +324,9 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     int w_voff[JW], p_voff[JP];
 #pragma unroll
     for (int j = 0; j < JW; ++j) {
-        const int e_ = min((j * NWAVES + wave) * 64 + lane, NP * NT * BO - 1);
+        const int e_ = (j * NWAVES + wave) * 64 + lane;                      // (slots past the last row: zeros into the zero rows)
         const int row = e_ / BO, o = e_ - row * BO;                         // row = plane*NT + tap
-        w_voff[j] = ((row * (g.I / 8)) * g.O + min(o0 + o, g.O - 1)) * 16;
+        w_voff[j] = e_ < NP * NT * BO ? ((row * (g.I / 8)) * g.O + min(o0 + o, g.O - 1)) * 16 : kOutside;
     }
 #pragma unroll
     for (int j = 0; j < JP; ++j) {
@@ -349,9 +351,8 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
         _Pragma("unroll") for (int j = 0; j < JW; ++j) {                                                                               \
             const int gidx = j * NWAVES + wave;                                                                                        \
             if (j % (nsl) == (sl) && gidx < WG) {                                                                                      \
-                const int row = (gidx * 64) / BO, o = gidx * 64 - row * BO, pl = row / NT, tap = row - pl * NT;                        \
                 const int vo_ = w_voff[j];                                                                                             \
-                dma_piece(rs_w, st_ + ((pl * NTP + tap) * BO + o) * 16, vo_, wso_);                                                    \
+                dma_piece(rs_w, st_ + gidx * 64 * 16, vo_, wso_);                                                                      \
             }                                                                                                                          \
         }                                                                                                                              \
         _Pragma("unroll") for (int j = 0; j < JP; ++j) {                                                                               \
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                for (int fo = 0; fo < FO; ++fo) a[pl * FO + fo] = wh[(pl * NTP + tap) * BO + (wo * FO + fo) * 32 + l31];
+                for (int fo = 0; fo < FO; ++fo) a[pl * FO + fo] = wh[wrow(pl, tap) * BO + (wo * FO + fo) * 32 + l31];
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
 #undef IA_ISSUE_DMA_SLICE
 }
 
-template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP>
+template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP, bool WHOLE = false>
 int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const Geo& g_in, const Epi& e, hipStream_t s) {
     constexpr int BO = 32 * FO * WO, NWAVES = WO * WP;
     const size_t stage = (size_t)(NP * 10 * BO + NP * g_in.patch_cap) * 16;
@@ -514,7 +515,7 @@ int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     const size_t lds = stage * ns;
     int st = IA_OK;
     if (g.T_dp > 0) {
-        if constexpr (!TR) {
+        if constexpr (!TR && !WHOLE) {
             if (e.rgb_out) {      // (the fused ToRGB epilogue is its own instantiation: it costs the plain kernel registers otherwise)
                 auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, false, true>;
                 if (const int rs = ia::reserve_lds((const void*)k, (size_t)(lds), "conv_split")) return rs;
@@ -527,7 +528,9 @@ int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
         hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma_sx");
     }
-    if (st == IA_OK && g.T > g.T_dp) {
+    if constexpr (WHOLE) {
+        if (g.T > g.T_dp) return ia::fail(IA_ERR_UNSUPPORTED, "this tile family runs whole tiles only");
+    } else if (st == IA_OK && g.T > g.T_dp) {
         auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, true>;
         if (const int rs = ia::reserve_lds((const void*)k, (size_t)(lds), "conv_split")) return rs;
         hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
@@ -544,7 +547,7 @@ int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     return st;
 }
 
-template <int NP, bool TR, int FO, int FP, int WO, int WP>
+template <int NP, bool TR, int FO, int FP, int WO, int WP, bool WHOLE = false>
 int launch_sx(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const Geo& g_in, const Epi& e, hipStream_t s) {
     constexpr int BP = 32 * FP * WP, NWAVES = WO * WP;
     Geo g = g_in;
@@ -558,9 +561,9 @@ int launch_sx(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d positions exceeds the LDS budget", worst);
     g.patch_cap = (worst + 63) & ~63;
     const int per_wave = (NP * g.patch_cap / 64 + NWAVES - 1) / NWAVES;
-    if (per_wave <= 2) return launch_jp<NP, TR, FO, FP, WO, WP, 2>(xs, wk, y, scratch, g, e, s);
-    if (per_wave <= 4) return launch_jp<NP, TR, FO, FP, WO, WP, 4>(xs, wk, y, scratch, g, e, s);
-    return launch_jp<NP, TR, FO, FP, WO, WP, 8>(xs, wk, y, scratch, g, e, s);
+    if (per_wave <= 2) return launch_jp<NP, TR, FO, FP, WO, WP, 2, WHOLE>(xs, wk, y, scratch, g, e, s);
+    if (per_wave <= 4) return launch_jp<NP, TR, FO, FP, WO, WP, 4, WHOLE>(xs, wk, y, scratch, g, e, s);
+    return launch_jp<NP, TR, FO, FP, WO, WP, 8, WHOLE>(xs, wk, y, scratch, g, e, s);
 }
 
 }  // namespace
@@ -619,6 +622,9 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
     if (st_plan != IA_OK) return st_plan;
     const bool wide = waves == 8;
     IA_REQUIRE(wide || (transposed && bo == 64), "the split form covers 3x3 layers on the two-stage tiles (large stride-1 layers, stride-2 transposed)");
+    const bool narrow = wide && bp == 256 && (bo == 32 || (bo == 64 && !transposed));      // whole-tile families of the mid-sized layers
+    IA_REQUIRE(!narrow || g.T_dp == g.T, "the narrow tile families run whole tiles only");
+    if (rgb.out && narrow) return ia::fail(IA_ERR_UNSUPPORTED, "the fused ToRGB needs the 128-channel tile");
     if (rgb.out && (transposed || g.TO != 1 || g.T_dp != g.T))
         return ia::fail(IA_ERR_UNSUPPORTED, "the fused ToRGB needs a stride-1 layer whose tiles hold every output channel and run in whole rounds "
                         "(O %d, %d channel tiles, %d of %d tiles in whole rounds)", O, g.TO, g.T_dp, g.T);
@@ -643,11 +649,16 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
     const h16x8* x8 = static_cast<const h16x8*>(xs);
     const h16x8* w8 = static_cast<const h16x8*>(wk_split);
     if (planes == 1) {
+        if (narrow && bo == 32 && !transposed) return launch_sx<1, false, 1, 1, 1, 8, true>(x8, w8, y, scratch, g, e, s);
+        IA_REQUIRE(!narrow, "one-plane operands: the narrow tile family covers the 32-channel stride-1 tile only");
         if (transposed && bp == 256) return launch_sx<1, true, 1, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
         if (transposed && bp == 128) return launch_sx<1, true, 1, 2, 2, 2>(x8, w8, y, scratch, g, e, s);
         if (transposed) return launch_sx<1, true, 1, 1, 2, 2>(x8, w8, y, scratch, g, e, s);
         return launch_sx<1, false, 2, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
     }
+    if (narrow && bo == 32 && transposed) return launch_sx<2, true, 1, 1, 1, 8, true>(x8, w8, y, scratch, g, e, s);
+    if (narrow && bo == 32) return launch_sx<2, false, 1, 1, 1, 8, true>(x8, w8, y, scratch, g, e, s);
+    if (narrow) return launch_sx<2, false, 1, 2, 2, 4, true>(x8, w8, y, scratch, g, e, s);
     if (transposed && bp == 256) return launch_sx<2, true, 1, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
     if (transposed && bp == 128) return launch_sx<2, true, 1, 2, 2, 2>(x8, w8, y, scratch, g, e, s);
     if (transposed) return launch_sx<2, true, 1, 1, 2, 2>(x8, w8, y, scratch, g, e, s);

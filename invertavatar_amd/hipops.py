@@ -244,6 +244,38 @@ def conv1x1(x, wk, styles=None, bias=None, residual=None, clamp=None):
     return y
 
 
+def torgb_supported(i, o, h, w, with_skip=False):
+    """Shapes ia_torgb covers (see include/ia_hip.h)."""
+    return o <= 96 and i in (128, 256, 512, 1024) and not (with_skip and (h % 2 or w % 2))
+
+
+def torgb(x, wk, styles=None, bias=None, residual=None, skip=None, skip_filter=None, clamp=None):
+    """ToRGB layer + the skip-image branch in one launch (see ia_torgb): clamp((wk * styles) (*) x + bias) + residual, or
+    + upsample2d(skip, skip_filter) with skip [B, O, H/2, W/2] and the [4, 4] resample filter."""
+    _f32c(x, 'x')
+    _f32c(wk, 'wk')
+    b, i, h, w = x.shape
+    o = wk.shape[-1]
+    if wk.numel() != i * o:
+        raise RuntimeError(f'wk has {wk.numel()} elements, expected {i} x {o}')
+    if residual is not None and skip is not None:
+        raise RuntimeError('either a residual image or a skip image, not both')
+    for t, name, n in ((styles, 'styles', b * i), (bias, 'bias', o), (residual, 'residual', b * o * h * w),
+                       (skip, 'skip', b * o * (h // 2) * (w // 2)), (skip_filter, 'skip_filter', 16)):
+        if t is not None and (_f32c(t, name).numel() != n):
+            raise RuntimeError(f'{name} has {t.numel()} elements, expected {n}')
+    if skip is not None and skip_filter is None:
+        raise RuntimeError('skip needs skip_filter (the [4, 4] resample filter)')
+    y = torch.empty(b, o, h, w, device=x.device, dtype=torch.float32)
+    flops = 2.0 * b * h * w * i * o
+    traffic = 4.0 * (x.numel() + wk.numel() + y.numel() + (residual.numel() if residual is not None else 0) + (skip.numel() if skip is not None else 0))
+    with torch.cuda.device(x.device), _Timed('conv1x1', flops, traffic, f'B{b} I{i} O{o} {h}x{w} torgb'):
+        st = _lib.load().ia_torgb(_p(x), _p(wk), _p(styles), _p(bias), _p(residual), _p(skip), _p(skip_filter), _p(y), b, i, o, h, w,
+                                  float(-1 if clamp is None else clamp), _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_torgb')
+    return y
+
+
 # Debug switch: every producer of a SplitAct counts the elements its hi / lo split clamped at +-65504 (ia_split_saturation_count) and
 # raises when there are any -- the range contract of the fp16-pair convolutions, otherwise silent (one sync per producer: tests only).
 CHECK_SPLIT_RANGE = False
@@ -358,7 +390,8 @@ def conv_sx_rgb_supported(b, i, o, h, w):
         return False
     plan_s, plan_bytes = ctypes.c_int(0), ctypes.c_size_t(0)
     st = _lib.load().ia_conv2d_plan(b, i, o, h, w, 3, 0, 3, ctypes.byref(plan_s), ctypes.byref(plan_bytes))
-    return st == 0 and plan_s.value == 0 and h * w >= 8192
+    # (whole rounds of the 128-channel x 256-point tile: a layer with fewer of those than CUs runs on the 32-channel tile family or stream-K)
+    return st == 0 and plan_s.value == 0 and h * w >= 8192 and b * ((h * w + 255) // 256) >= 256
 
 
 def conv2d_mfma_sx_rgb(xs, wk, rgb_wk, rgb_styles=None, rgb_bias=None, rgb_residual=None, rgb_clamp=None, demod=None, noise=None,

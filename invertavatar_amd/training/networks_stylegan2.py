@@ -18,6 +18,8 @@ reference does.  The discriminator classes of the reference file are training-on
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -36,6 +38,7 @@ FP16_BLOCKS_COMPUTE_FP32 = True
 # (tests/test_conv_gpu.py) and twice as fast.  False keeps every layer on v_mfma_f32_32x32x2_f32.
 FUSED_TORGB = True               # a block whose x nobody reads (last SR block): ToRGB evaluated in conv1's epilogue (ia_conv2d_mfma_sx_rgb)
 STREAMING_TORGB = True           # ToRGB layers through ia_conv1x1 (one streaming launch) instead of the tiled ia_conv2d_mfma form
+FUSED_TORGB_SKIP = os.environ.get('IA_FUSED_TORGB_SKIP', '1') == '1'          # ... and, where ia_torgb covers the shape, with the skip image's up-sampling + add in the same launch
 SPLIT_FP16_PRODUCTS = True
 
 # ... and where the INPUT can be had as fp16 hi/lo planes (hipops.SplitAct: written by the producing layer's epilogue, or by
@@ -536,10 +539,17 @@ class ToRGBLayer(torch.nn.Module):
             wk, _ = self._packed.get(self.weight, scale=self.weight_gain)
             pre, self._pre = self._pre, None
             styles = pre[0] if pre is not None else self.affine(w).float().contiguous()
+            x = x.float().contiguous()
+            if (FUSED_TORGB_SKIP and STREAMING_TORGB and residual is None
+                    and hipops.torgb_supported(x.shape[1], wk.shape[-1], x.shape[2], x.shape[3], skip is not None)
+                    and (skip is None or (resample_filter is not None and tuple(resample_filter.shape) == (4, 4) and skip.dtype == torch.float32
+                                          and skip.shape[2] * 2 == x.shape[2] and skip.shape[3] * 2 == x.shape[3]))):
+                # conv + bias + clamp + upsample2d(skip) + add in one launch (ia_torgb)
+                return hipops.torgb(x, wk, styles, bias=self.bias.detach().float(), skip=None if skip is None else skip.contiguous(),
+                                    skip_filter=None if skip is None else resample_filter.float().contiguous(), clamp=self.conv_clamp)
             if skip is not None:
                 residual = upfirdn2d.upsample2d(skip, resample_filter)
             res = None if residual is None else residual.float().contiguous()
-            x = x.float().contiguous()
             if STREAMING_TORGB and hipops.conv1x1_supported(x.shape[1], wk.shape[-1], x.shape[2], x.shape[3]):
                 return hipops.conv1x1(x, wk, styles, bias=self.bias.detach().float(), residual=res, clamp=self.conv_clamp)
             return hipops.conv2d_mfma(x, wk, styles, None,

@@ -28,7 +28,7 @@ def test_bench_two_ranks_reenact_workload_over_gloo():
     out = run_bench(29631, *CPU, '--frames-per-rank', '1')
     assert out['n_gpus'] == 2 and out['steps'] == 1 and out['scaling'] == 'weak' and out['value'] > 0
     assert out['config']['global_batch'] == 2 and 'all_gather' in out['config']['collective']
-    assert out['value'] == pytest.approx(2 * 1 / (out['ms_per_step'] * 1e-3), rel=1e-3)        # whole-job frames / max-over-ranks time
+    assert out['value'] == pytest.approx(2 * 1 / (out['ms_per_step'] * 1e-3), rel=1e-3, abs=6e-4)        # whole-job frames / max-over-ranks time (3 printed decimals)
 
 
 def test_bench_two_ranks_drive_workload_over_gloo():

@@ -55,8 +55,12 @@ def test_conv_planner_host_logic():
     for res in (4, 8, 16):
         workers, nbytes = _plan(1, 512, 512, res, res)
         assert workers == 128 and nbytes > 0, (res, workers)
-    assert _plan(1, 512, 512, 64, 64, form=3)[0] == 128
-    assert _plan(1, 256, 256, 128, 128, form=3)[0] == 256           # 128^2 keeps the whole machine
+    assert _plan(1, 512, 512, 64, 64, form=2)[0] == 128
+    assert _plan(1, 256, 256, 128, 128, form=2)[0] == 256           # 128^2 keeps the whole machine
+    # split-DMA form: stride-1 layers smaller than the machine whose 32-channel x 256-point tiles give every CU one run whole tiles
+    assert _plan(1, 512, 512, 64, 64, form=3) == (0, 0) and _plan(1, 256, 256, 128, 128, form=3) == (0, 0)
+    assert _plan(1, 512, 512, 32, 32, form=3)[0] == 128             # 64 narrow tiles would leave 3/4 of the CUs idle: stream-K stays
+    assert _plan(8, 512, 512, 64, 64, form=3) == (0, 0)             # (a batch of 8 already fills whole rounds of wide tiles)
     for shape in ((1, 128, 128, 512, 512), (1, 256, 256, 256, 256), (1, 128, 128, 256, 256)):
         assert _plan(*shape, form=3) == (0, 0), shape               # whole rounds of whole tiles: no workers, no scratch
     assert _plan(8, 512, 512, 16, 16)[0] <= 64                      # 512 slots shared by 8 batch elements
@@ -67,6 +71,11 @@ def test_conv_planner_host_logic():
 
 def test_streaming_torgb_shape_rules():
     from invertavatar_amd import hipops
+    assert hipops.torgb_supported(512, 96, 4, 4, True) and hipops.torgb_supported(128, 3, 512, 512) and hipops.torgb_supported(1024, 8, 6, 10, True)
+    assert not hipops.torgb_supported(64, 32, 8, 8) and not hipops.torgb_supported(128, 128, 8, 8) and not hipops.torgb_supported(128, 32, 7, 8, True)
+    lib = _lib.load()
+    for args in ((512, 96, 4, 4, 1), (128, 3, 512, 512, 0), (64, 32, 8, 8, 0), (128, 128, 8, 8, 0), (128, 32, 7, 8, 1), (128, 32, 7, 8, 0), (384, 32, 8, 8, 0)):
+        assert bool(lib.ia_torgb_supported(*args)) == hipops.torgb_supported(args[0], args[1], args[2], args[3], bool(args[4])), args
     assert hipops.conv1x1_supported(512, 96, 4, 4) and hipops.conv1x1_supported(128, 3, 512, 512)
     assert not hipops.conv1x1_supported(48, 8, 8, 8)                # C_in % 32
     assert not hipops.conv1x1_supported(64, 128, 8, 8)              # C_out > 96

@@ -364,6 +364,38 @@ def test_conv1x1_streaming_matches_torch(b, i, o, h, w):
     assert max_abs(plain.double(), torch.einsum('bihw,oi->bohw', x.double(), wgt.double()[:, :, 0, 0])) <= 2e-5
 
 
+@pytest.mark.parametrize('b,i,o,h,w', [(1, 512, 32, 4, 4), (1, 512, 96, 8, 8), (2, 512, 32, 16, 16), (1, 512, 96, 32, 32), (1, 512, 32, 64, 64),
+                                       (1, 256, 96, 128, 128), (2, 128, 32, 256, 256), (1, 128, 3, 512, 512), (1, 1024, 8, 6, 10), (1, 256, 5, 2, 2)])
+def test_torgb_with_fused_skip_upsampling(b, i, o, h, w):
+    """ia_torgb (ToRGB + upsample2d(previous image) + add in one launch) against the reference's op order in torch fp64, against the
+    two-launch route it replaces (ia_conv1x1 + ia_upfirdn2d: the same up-sampled image bit for bit), and with a plain residual."""
+    from conftest import rnd
+    from invertavatar_amd.torch_utils.ops import upfirdn2d
+    x, wgt = rnd(1, b, i, h, w).cuda(), (rnd(2, o, i, 1, 1) / i ** 0.5).cuda()
+    styles, bias, skip = (rnd(3, b, i) * 0.3 + 1).cuda(), rnd(4, o).cuda(), rnd(5, b, o, h // 2, w // 2).cuda()
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).cuda()
+    wk = hipops.pack_conv_weight(wgt)
+    clamp = 1.5
+    assert hipops.torgb_supported(i, o, h, w, True)
+    up = upfirdn2d.upsample2d(skip, f)
+    conv = torch.einsum('bihw,boi->bohw', x.double(), wgt.double()[None, :, :, 0, 0] * styles.double()[:, None, :])
+    conv = (conv + bias.double()[None, :, None, None]).clamp(-clamp, clamp)
+    got = hipops.torgb(x, wk, styles, bias=bias, skip=skip, skip_filter=f, clamp=clamp)
+    assert got.shape == conv.shape and max_abs(got.double(), conv + up.double()) <= 2e-5, max_abs(got.double(), conv + up.double())
+    # the up-sampled image alone (zero weights): bit-identical to ia_upfirdn2d's
+    only_up = hipops.torgb(x, torch.zeros_like(wk), None, skip=skip, skip_filter=f)
+    assert torch.equal(only_up, up)
+    res = rnd(6, b, o, h, w).cuda()
+    got_r = hipops.torgb(x, wk, styles, bias=bias, residual=res, clamp=clamp)
+    assert max_abs(got_r.double(), conv + res.double()) <= 2e-5
+    if hipops.conv1x1_supported(i, o, h, w):
+        assert max_abs(got_r, hipops.conv1x1(x, wk, styles, bias=bias, residual=res, clamp=clamp)) <= 2e-5
+    plain = hipops.torgb(x, wk)                                     # no styles / bias / skip / clamp
+    assert max_abs(plain.double(), torch.einsum('bihw,oi->bohw', x.double(), wgt.double()[:, :, 0, 0])) <= 2e-5
+    with pytest.raises(RuntimeError, match='ia_torgb covers'):
+        hipops.torgb(torch.zeros(1, 48, 8, 8, device='cuda'), torch.zeros(1, 48, 8, device='cuda'))
+
+
 def test_conv1x1_rejects_unsupported_shapes():
     x = torch.zeros(1, 48, 8, 8, device='cuda')
     with pytest.raises(RuntimeError, match='ia_conv1x1 covers'):

@@ -37,17 +37,27 @@ def main():
         xs = hipops.act_split(x, st)
         fl = 2.0 * batch * r * r * 9 * i * o
         line = f'I={i:4d} O={o:4d} res={r:4d} tr={tr}'
+        ref = None
         for sname in sweeps:
-            # a sweep entry is "default" or comma-separated ENV=VALUE pairs, e.g. IA_RING_STAGES=2,IA_DMA_SPREAD=1
-            for k in ('IA_RING_STAGES', 'IA_DMA_SPREAD', 'IA_XCD_BANDS'):
+            # a sweep entry is "default" or '+'-separated ENV=VALUE pairs, e.g. IA_RING_STAGES=2+IA_DMA_SPREAD=1
+            for k in ('IA_RING_STAGES', 'IA_DMA_SPREAD', 'IA_XCD_BANDS', 'IA_SX_TILE', 'IA_SX_WHOLE', 'IA_NO_NARROW_TILES'):
                 os.environ.pop(k, None)
             if sname != 'default':
-                for kv in sname.split(','):
+                for kv in sname.split('+'):
                     k, v = kv.split('=')
                     os.environ[k] = v
+            try:
+                y = hipops.conv2d_mfma_sx(xs, wk, transposed=bool(tr))
+            except RuntimeError as err:      # (a forced tile family that does not cover this shape)
+                line += f' | {"n/a":>7s}    ' + str(err)[:40]
+                total[sname] += float('nan')
+                continue
+            if ref is None:
+                ref = y
+            dev = float((y - ref).abs().max() / ref.abs().max())
             us = bench(lambda: hipops.conv2d_mfma_sx(xs, wk, transposed=bool(tr)))
             total[sname] += us * per_frame
-            line += f' | {us:7.1f} us {fl / us / 1e6:6.1f} TF {3 * fl / us / 1e6 / 2500:.3f}'
+            line += f' | {us:7.1f} us {fl / us / 1e6:6.1f} TF {3 * fl / us / 1e6 / 2500:.3f} d={dev:.1e}'
         print(line, flush=True)
     print('sweeps: ' + ' | '.join(sweeps))
     print('per frame (us): ' + ', '.join(f'{k}: {v:.0f}' for k, v in total.items()))
