@@ -221,12 +221,46 @@ __global__ __launch_bounds__(512) void torgb_kernel(TParams p) {
     };
     load_block(xa, wa, 0);
     if (kw > 64) load_block(xb, wb, 64);
-    mma_block(xa, wa, sv0);
-    if (kw > 64) mma_block(xb, wb, sv1);
 
+    // The epilogue's operands do not depend on the products: their loads go out now, behind the activations, and land under the MFMAs.
     // C/D map of the 32x32 MFMA: row (output channel) = (r&3) + 8*(r>>2) + 4*half, column (pixel) = l31.  With KS > 1 the KS waves
     // of a pixel fragment leave their sums in LDS and wave ks finishes registers [ks * 16/KS, (ks+1) * 16/KS), adding in wave order.
     constexpr int NR = 16 / KS;
+    // the 2 x 2 real taps of the up-sampling at this pixel: rows my + t with weights ky[t], columns mx + u with kx[u]
+    int soff[4];
+    float sk[4];
+    const int Ws = p.W >> 1, Hs = p.H >> 1;
+    if (p.skip) {
+        const int64_t pp = pvalid ? pix : 0;
+        const int oy = (int)(pp / p.W), ox = (int)(pp - (int64_t)oy * p.W);
+        const int my = ((oy + (oy & 1)) >> 1) - 1, mx = ((ox + (ox & 1)) >> 1) - 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int iy = (oy & 1) + 2 * t, ix = (ox & 1) + 2 * u;          // tap index in the 4x4 filter (before the flip)
+                const bool in = my + t >= 0 && my + t < Hs && mx + u >= 0 && mx + u < Ws;
+                soff[2 * t + u] = in ? (my + t) * Ws + mx + u : 0;
+                sk[2 * t + u] = in ? p.filt[(3 - iy) * 4 + (3 - ix)] * 4.f : 0.f;
+            }
+    }
+    float e_bias[NR], e_res[NR], e_tap[NR][4];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = ks * NR + j;
+        const int o = min(o0 + (r & 3) + 8 * (r >> 2) + 4 * half, p.O - 1);
+        e_bias[j] = p.bias ? p.bias[o] : 0.f;
+        e_res[j] = (p.residual && pvalid) ? p.residual[((int64_t)b * p.O + o) * p.P + pix] : 0.f;
+        if (p.skip) {
+            const float* sb = p.skip + ((int64_t)b * p.O + o) * Hs * Ws;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e_tap[j][q] = sb[soff[q]];
+        }
+    }
+
+    mma_block(xa, wa, sv0);
+    if (kw > 64) mma_block(xb, wb, sv1);
+
     float v[NR];
     if constexpr (KS > 1) {
 #pragma unroll
@@ -241,40 +275,22 @@ __global__ __launch_bounds__(512) void torgb_kernel(TParams p) {
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) v[j] = acc[j];
+        for (int j = 0; j < NR; ++j) v[j] = acc[ks * NR + j];
     }
     if (!pvalid) return;
-    // the 2 x 2 real taps of the up-sampling at this pixel: rows my + t with weights ky[t], columns mx + u with kx[u]
-    int soff[4];
-    float sk[4];
-    const int Ws = p.W >> 1, Hs = p.H >> 1;
-    if (p.skip) {
-        const int oy = (int)(pix / p.W), ox = (int)(pix - (int64_t)oy * p.W);
-        const int my = ((oy + (oy & 1)) >> 1) - 1, mx = ((ox + (ox & 1)) >> 1) - 1;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int iy = (oy & 1) + 2 * t, ix = (ox & 1) + 2 * u;          // tap index in the 4x4 filter (before the flip)
-                const bool in = my + t >= 0 && my + t < Hs && mx + u >= 0 && mx + u < Ws;
-                soff[2 * t + u] = in ? (my + t) * Ws + mx + u : 0;
-                sk[2 * t + u] = in ? p.filt[(3 - iy) * 4 + (3 - ix)] * 4.f : 0.f;
-            }
-    }
     float* yb = p.y + (int64_t)b * p.O * p.P + pix;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int r = ks * NR + j;
         const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (o >= p.O) continue;
-        float s = v[j] + (p.bias ? p.bias[o] : 0.f);
+        float s = v[j] + e_bias[j];
         if (p.clamp >= 0.f) s = fminf(fmaxf(s, -p.clamp), p.clamp);
-        if (p.residual) s += p.residual[((int64_t)b * p.O + o) * p.P + pix];
+        if (p.residual) s += e_res[j];
         if (p.skip) {
-            const float* sb = p.skip + ((int64_t)b * p.O + o) * Hs * Ws;
             float a = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a = fmaf(sb[soff[q]], sk[q], a);
+            for (int q = 0; q < 4; ++q) a = fmaf(e_tap[j][q], sk[q], a);
             s += a;
         }
         yb[(int64_t)o * p.P] = s;
@@ -333,9 +349,9 @@ extern "C" int ia_torgb(const float* x, const float* wk, const float* styles, co
         return ia::fail(IA_ERR_UNSUPPORTED, "ia_torgb covers C_out <= 96, C_in 128 / 256 / 512 / 1024 and even H, W with a skip image (got C_in %d, C_out %d, %d x %d)", I, O, H, W);
     IA_REQUIRE(B <= 65535, "batch too large for one launch");
     const int64_t P = (int64_t)H * W;
-    // 128 input channels per wave; a single 32-pixel fragment (4^2 images) splits 512+ channels over all 8 waves instead
+    // 128 input channels per wave; 512-channel layers on small images (up to 64^2: few pixel fragments) split over all 8 waves instead
     int ks = I / 128;
-    if (P <= 32 && I == 512) ks = 8;
+    if (P <= 4096 && I == 512) ks = 8;
     TParams p{x, wk, styles, bias, residual, skip, skip_filter, y, I, O, H, W, P, clamp};
     const int ng = 8 / ks;
     const dim3 grid((unsigned)((P + 32 * ng - 1) / (32 * ng)), (unsigned)B, (unsigned)((O + 31) / 32));

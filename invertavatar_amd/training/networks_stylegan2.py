@@ -38,6 +38,9 @@ FP16_BLOCKS_COMPUTE_FP32 = True
 # (tests/test_conv_gpu.py) and twice as fast.  False keeps every layer on v_mfma_f32_32x32x2_f32.
 FUSED_TORGB = True               # a block whose x nobody reads (last SR block): ToRGB evaluated in conv1's epilogue (ia_conv2d_mfma_sx_rgb)
 STREAMING_TORGB = True           # ToRGB layers through ia_conv1x1 (one streaming launch) instead of the tiled ia_conv2d_mfma form
+# ia_torgb re-reads the activations once per block of 32 output channels with 8-wave workgroups: past this many pixels x channel blocks
+# the 64-thread workgroups of ia_conv1x1 (+ ia_upfirdn2d) share the machine better with the convolutions of the other streams
+TORGB_MAX_WORK = int(os.environ.get('IA_TORGB_MAX_WORK', 49152))
 FUSED_TORGB_SKIP = os.environ.get('IA_FUSED_TORGB_SKIP', '1') == '1'          # ... and, where ia_torgb covers the shape, with the skip image's up-sampling + add in the same launch
 SPLIT_FP16_PRODUCTS = True
 
@@ -541,6 +544,7 @@ class ToRGBLayer(torch.nn.Module):
             styles = pre[0] if pre is not None else self.affine(w).float().contiguous()
             x = x.float().contiguous()
             if (FUSED_TORGB_SKIP and STREAMING_TORGB and residual is None
+                    and x.shape[2] * x.shape[3] * ((wk.shape[-1] + 31) // 32) <= TORGB_MAX_WORK
                     and hipops.torgb_supported(x.shape[1], wk.shape[-1], x.shape[2], x.shape[3], skip is not None)
                     and (skip is None or (resample_filter is not None and tuple(resample_filter.shape) == (4, 4) and skip.dtype == torch.float32
                                           and skip.shape[2] * 2 == x.shape[2] and skip.shape[3] * 2 == x.shape[3]))):
