@@ -26,6 +26,9 @@
 #ifndef IA_ABLATE
 #define IA_ABLATE 0
 #endif
+#ifndef IA_PAIR_TAPS
+#define IA_PAIR_TAPS 1
+#endif
 #define IA_AB_NODMA (IA_ABLATE == 1 || IA_ABLATE >= 5)
 #define IA_AB_NOREAD (IA_ABLATE == 3 || IA_ABLATE >= 5)
 #define IA_AB_NOSTORE (IA_ABLATE == 4 || IA_ABLATE >= 5)
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NWAVES = WO * WP, NTHREADS = NWAVES * 64;
     constexpr int PAD = TR ? 0 : KS / 2;
     constexpr int NACC = NPH * FO * FP * 16;
+    constexpr bool PAIR = !SK && IA_ABLATE == 0 && IA_PAIR_TAPS;      // (stream-K ranges may cut a pair of chunks: they keep the zero tap)
     constexpr int WSLOTS = NP * NTP * BO;             // 16-byte slots of the weight region of a stage: [plane][tap][BO], then one all-zero row per plane
     constexpr int WG = (NP * NT * BO + 63) / 64;       // weight DMA instructions per chunk (64 slots each), spread over the waves
     constexpr int JW = (WG + NWAVES - 1) / NWAVES;
@@ -377,6 +381,15 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     int issued = c_lo;                       // next chunk to issue; chunk c lives in stage (c - c_lo) % NS
     for (int k = 0; k < NS - 1 && issued < c_hi; ++k, ++issued) IA_ISSUE_DMA(issued, k);
     int cur = 0;
+    // PAIR (whole-tile launches): the odd tap out of a chunk's nine (tap 8; tap 4 in the transposed form) does not meet an all-zero tap
+    // in its k-step -- 10 % of the MFMAs multiplying zeros -- but the same tap of the NEXT chunk: lanes 0-31 read their operands at the
+    // even chunk of a pair and keep them, lanes 32-63 read theirs at the odd chunk into the same registers (exec-masked LDS reads),
+    // and the k-step runs once per pair: 9 k-steps per 16 input channels instead of 10.  Only the order of the fp32 additions changes.
+    h16x8 a_hold[NP * FO], b_hold[NP * FP];
+#pragma unroll
+    for (int q = 0; q < NP * FO; ++q) a_hold[q] = h16x8{};
+#pragma unroll
+    for (int q = 0; q < NP * FP; ++q) b_hold[q] = h16x8{};
     for (int ch = c_lo; ch < c_hi; ++ch) {
         wait_vmcnt((issued - ch - 1) * n_dma);                // this wave's DMAs of chunk `ch` have landed (younger chunks stay in flight) ...
         __builtin_amdgcn_s_barrier();                         // ... and everybody's; the stage of chunk ch - 1 has no readers left
@@ -407,49 +420,80 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
 #pragma unroll
                 for (int fp = 0; fp < FP; ++fp) bv[pl * FP + fp] = ph[pl * cap + bpos[fp] + tof];
         };
+        const int par = (ch - c_lo) & 1;                       // position of this chunk in its pair
+        const bool run_odd_tap = !PAIR || par == 1 || ch == c_hi - 1;
+        auto load_hold = [&]() {                                 // the odd tap's operands of this chunk, into this chunk's half of the lanes
+            constexpr int tap8 = pair_t0(TR, kPairs - 1);
+            if (half == par) {
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int fo = 0; fo < FO; ++fo) a_hold[pl * FO + fo] = wh[wrow(pl, tap8) * BO + (wo * FO + fo) * 32 + l31];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp) b_hold[pl * FP + fp] = ph[pl * cap + bpos[fp] + toff[tap8]];
+            } else if (par == 0 && ch == c_hi - 1) {             // a last chunk without a partner: its upper lanes multiply zeros
+#pragma unroll
+                for (int q = 0; q < NP * FO; ++q) a_hold[q] = h16x8{};
+#pragma unroll
+                for (int q = 0; q < NP * FP; ++q) b_hold[q] = h16x8{};
+            }
+        };
         if (!IA_AB_NOREAD || ch == c_lo) load_ops(0, a_buf[0], b_buf[0]);
 #pragma unroll
         for (int s = 0; s < kPairs; ++s) {
             const int c_ = s & 1;
             // the NEXT k-step's operand reads are issued before this k-step's MFMAs and pinned there (sched_barrier): their LDS
             // latency then hides under 12 x 32 MFMA cycles; left to itself the scheduler sinks them to just before their use
-            if ((!IA_AB_NOREAD || ch == c_lo) && s + 1 < kPairs) load_ops(s + 1, a_buf[(s + 1) & 1], b_buf[(s + 1) & 1]);
+            if constexpr (PAIR) {
+                if (s + 2 < kPairs) load_ops(s + 1, a_buf[(s + 1) & 1], b_buf[(s + 1) & 1]);
+                else if (s + 2 == kPairs) load_hold();
+            } else if ((!IA_AB_NOREAD || ch == c_lo) && s + 1 < kPairs) load_ops(s + 1, a_buf[(s + 1) & 1], b_buf[(s + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+            if (PAIR && s == kPairs - 1 && !run_odd_tap) {        // the even chunk of a pair: its odd tap waits for the partner's
+                if (fill && g.spread) IA_ISSUE_DMA_SLICE(fill_chunk, fill_stage, s, kPairs);
+                continue;
+            }
+            const h16x8 (&a_use)[NP * FO] = (PAIR && s == kPairs - 1) ? a_hold : a_buf[c_];
+            const h16x8 (&b_use)[NP * FP] = (PAIR && s == kPairs - 1) ? b_hold : b_buf[c_];
 #if IA_ABLATE == 2
 #pragma unroll
-            for (int q = 0; q < NP * FO; ++q) asm volatile("" ::"v"(a_buf[c_][q]));
+            for (int q = 0; q < NP * FO; ++q) asm volatile("" ::"v"(a_use[q]));
 #pragma unroll
-            for (int q = 0; q < NP * FP; ++q) asm volatile("" ::"v"(b_buf[c_][q]));
+            for (int q = 0; q < NP * FP; ++q) asm volatile("" ::"v"(b_use[q]));
             continue;
 #endif
             const int ph_ = pair_phase(TR, s);
             if constexpr (NP == 2) {
                 h16x8 a_sc[FO];                        // weight high parts at 2^-11: they meet the activation's low parts (scaled by 2^11)
 #pragma unroll
-                for (int fo = 0; fo < FO; ++fo) a_sc[fo] = IA_ABLATE >= 6 ? a_buf[c_][fo] : a_buf[c_][fo] * (_Float16)(1.0f / kLoScale);
+                for (int fo = 0; fo < FO; ++fo) a_sc[fo] = IA_ABLATE >= 6 ? a_use[fo] : a_use[fo] * (_Float16)(1.0f / kLoScale);
                 // three products per fragment pair, product-major: consecutive MFMAs write different accumulators
 #pragma unroll
                 for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
                     for (int fp = 0; fp < FP; ++fp)      // lo * hi
-                        acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][(NP - 1) * FO + fo], b_buf[c_][fp], acc[ph_][fo][fp], 0, 0, 0);
+                        acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_use[(NP - 1) * FO + fo], b_use[fp], acc[ph_][fo][fp], 0, 0, 0);
 #pragma unroll
                 for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
                     for (int fp = 0; fp < FP; ++fp)      // (hi * 2^-11) * (lo * 2^11)
-                        acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[fo], b_buf[c_][(NP - 1) * FP + fp], acc[ph_][fo][fp], 0, 0, 0);
+                        acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[fo], b_use[(NP - 1) * FP + fp], acc[ph_][fo][fp], 0, 0, 0);
             }
 #pragma unroll
             for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
                 for (int fp = 0; fp < FP; ++fp)          // hi * hi
-                    acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_buf[c_][fo], b_buf[c_][fp], acc[ph_][fo][fp], 0, 0, 0);
+                    acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_use[fo], b_use[fp], acc[ph_][fo][fp], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (fill && g.spread) {
                 IA_ISSUE_DMA_SLICE(fill_chunk, fill_stage, s, kPairs);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // (the kept operands were read from the stage that is refilled after the next barrier: they are in registers before it)
+        if constexpr (PAIR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         cur = cur + 1 == NS ? 0 : cur + 1;
     }
 
