@@ -238,7 +238,9 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     constexpr int BO = 32 * FO * WO, BP = 32 * FP * WP, NWAVES = WO * WP, NTHREADS = NWAVES * 64;
     constexpr int PAD = TR ? 0 : KS / 2;
     constexpr int NACC = NPH * FO * FP * 16;
-    constexpr bool PAIR = !SK && IA_ABLATE == 0 && IA_PAIR_TAPS;      // (stream-K ranges may cut a pair of chunks: they keep the zero tap)
+    // (pairs are formed inside a segment, so a stream-K range of any length works; the transposed tiles are not MFMA-bound and have no
+    // registers to spare for the kept operands: measured no gain on 256 -> 128 @256^2)
+    constexpr bool PAIR = !TR && IA_ABLATE == 0 && IA_PAIR_TAPS;
     constexpr int WSLOTS = NP * NTP * BO;             // 16-byte slots of the weight region of a stage: [plane][tap][BO], then one all-zero row per plane
     constexpr int WG = (NP * NT * BO + 63) / 64;       // weight DMA instructions per chunk (64 slots each), spread over the waves
     constexpr int JW = (WG + NWAVES - 1) / NWAVES;

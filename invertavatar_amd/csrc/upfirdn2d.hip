@@ -251,6 +251,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled_pipe(const T* __restrict_
 // registers, and after the eighth channel every thread holds the 8 channels of its 4 pixels: 1 KB contiguous per wave, plane
 // and row.  Optionally the fp32 NCHW result is written as well (callers that still need it, e.g. the CS-SFT modulation).
 typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+#ifndef IA_FIR_SETS
+#define IA_FIR_SETS 2
+#endif
+constexpr int kFirSets = IA_FIR_SETS;      // channels in flight per workgroup (register sets); measured r03 on the 256^2 / 512^2 layers: 2: 40.4 / 77.2 us, 3: 42.3 / 79.1, 4: 44.5 / 77.9
 __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y,
                                                             h16x8_t* __restrict__ ys, const float* __restrict__ styles_next, Geo g, int flip, Tail tail, int planes) {
     constexpr int FS = 4;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __rest
     }
     // two channels in flight per workgroup (register sets v[0], v[1]): with one, a workgroup waits out a full memory round trip per
     // channel and eight workgroups per CU do not keep enough bytes in flight for the HBM stream
-    float v[2][NLD];
+    float v[kFirSets][NLD];
     auto fetch = [&](int ch, int set) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) v[set][j] = g_off[j] >= 0 ? xb[(int64_t)ch * in_plane + g_off[j]] : 0.f;
@@ -289,10 +293,11 @@ __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __rest
     const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * RPT;
     const int ox = ox0 + tx;
     const float t_ns = tail.noise ? (tail.noise_strength ? *tail.noise_strength : 1.f) : 0.f;
-    fetch(0, 0);
-    fetch(1, 1);
+    // channel c travels in register set c % kFirSets; channels ch + 1 .. ch + kFirSets stay in flight under the filter of channel ch
+#pragma unroll
+    for (int c = 0; c < kFirSets; ++c) fetch(c, c);
     commit(0, 0);
-    fetch(2, 0);
+    fetch(kFirSets, 0);
     __syncthreads();
     float kf[FS * FS];
 #pragma unroll
@@ -327,8 +332,8 @@ __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __rest
             if (planes == 2) { _Float16 h, l; ia::split_f16(t, h, l); hi[r][ch] = h; lo[r][ch] = l; }
             else hi[r][ch] = ia::round_f16(t);
         }
-        if (ch + 1 < 8) commit(buf ^ 1, (ch + 1) & 1);            // (its last readers passed the barrier of the previous channel)
-        if (ch + 3 < 8) fetch(ch + 3, (ch + 1) & 1);              // channels ch + 2 and ch + 3 stay in flight under the next filter
+        if (ch + 1 < 8) commit(buf ^ 1, (ch + 1) % kFirSets);     // (its last readers passed the barrier of the previous channel)
+        if (ch + 1 + kFirSets < 8) fetch(ch + 1 + kFirSets, (ch + 1) % kFirSets);
         __syncthreads();
     }
     if (ox >= g.out_w) return;

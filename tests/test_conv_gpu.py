@@ -324,8 +324,9 @@ def test_cond_blend_split_equals_cond_blend_then_split():
 
 @pytest.mark.parametrize('i,o,h,w,tr', [(128, 128, 64, 64, False), (256, 128, 48, 80, False), (64, 64, 65, 65, True), (32, 256, 128, 128, True)])
 def test_one_plane_dma_convolution_equals_the_fp16_operand_form(i, o, h, w, tr):
-    """The fp16-storage form (one fp16 plane in, one product per k-step) is the arithmetic of ia_conv2d_mfma_h: same bits, with the
-    activation stored as 2 bytes per element; its split second output is the rounded fp16 plane of (result * styles_next)."""
+    """The fp16-storage form (one fp16 plane in, one product per k-step) is the arithmetic of ia_conv2d_mfma_h (same products, equal to
+    summation-order level), with the activation stored as 2 bytes per element; its split second output is the rounded fp16 plane of
+    (result * styles_next)."""
     g = torch.Generator(device='cuda').manual_seed(5 + i + h)
     x = torch.randn(2, i, h, w, device='cuda', generator=g) * 2
     wt = torch.randn(o, i, 3, 3, device='cuda', generator=g)
@@ -344,8 +345,9 @@ def test_one_plane_dma_convolution_equals_the_fp16_operand_form(i, o, h, w, tr):
     kw = dict(demod=d, bias=bias, act='lrelu', gain=1.3, clamp=256.0)
     want = hipops.conv2d_mfma(x, wk, styles=s, ksize=3, **kw)
     got, got_s = hipops.conv2d_mfma_sx(xs, wk, styles_next=sn, split_planes=1, **kw)
-    assert torch.equal(got, want)
-    assert got_s.planes == 1 and torch.equal(got_s.data[:, 0].permute(0, 1, 4, 2, 3).reshape(want.shape), (want * sn[:, :, None, None]).half())
+    # (the DMA form pairs the odd tap of a chunk with the next chunk's: the same products in another order)
+    assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+    assert got_s.planes == 1 and torch.equal(got_s.data[:, 0].permute(0, 1, 4, 2, 3).reshape(want.shape), (got * sn[:, :, None, None]).half())
 
 
 @pytest.mark.parametrize('b,i,o,h,w', [(1, 512, 32, 64, 64), (1, 256, 96, 128, 128), (2, 128, 3, 256, 256), (1, 128, 96, 256, 256),
