@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 2      /* r03: ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 3      /* 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -369,6 +369,28 @@ int ia_conv2d_mfma_sx_rgb(const void* xs, int planes, const void* wk_split, int 
                           const float* rgb_wk, const float* rgb_styles, const float* rgb_bias, const float* rgb_residual, float* rgb_out,
                           int rgb_channels, float rgb_clamp, int B, int I, int O, int H, int W, int act, float alpha, float gain, float clamp,
                           void* stream);
+
+/*
+ * An up-sampling SynthesisLayer with FEW input channels as ONE stride-1 launch: the transposed convolution (stride 2) and the 4x4
+ * resample FIR that follows it are linear, so their composition is, per output phase (py, px), a 3x3 convolution of the INPUT image
+ * with the weights  W'[py,px][dy,dx] = gain * sum_{i,ky: py+i-1-ky = 2dy} sum_{j,kx: px+j-1-kx = 2dx} F[i,j] * w[ky,kx]  (F the
+ * flipped filter).  The layer then is a stride-1 convolution with 4 x O output channels -- row ((py * O/32 + o/32) * 2 + px) * 32 +
+ * o % 32, so that a wave holds both horizontal phases of its channels -- whose epilogue stores point (r, c) of phase (py, px) at
+ * pixel (2r + py, 2c + px): four times the products, but no (2H+1) x (2W+1) fp32 image, no FIR launch
+ * and no stream-K tail -- a win when the K loop is short (the 32 -> 256 @128^2 layer of the SR head: 2.4 GFLOP that moved 200 MB).
+ * Replaces modulated_conv2d(up=2) -> conv2d_resample (conv_transpose2d, stride 2) -> upfirdn2d(pad [1,1,1,1], gain 4) -> noise ->
+ * bias_act of SynthesisLayer.forward (training/networks_stylegan2.py:296-305, torch_utils/ops/conv2d_resample.py:114-131) for such
+ * layers; results agree with the two-launch route to fp32 rounding (the same sums in another association).
+ *   xs        : split input [B, planes, I/8, H, W, 8], already multiplied by the layer's styles (ia_act_split)
+ *   wk_split  : pack_conv_weight_split / _h layout of the COMPOSED weight [4*O, I, 3, 3] (row order above), wk_exp its exponent
+ *   demod [B,O], noise [2H*2W], noise_strength, bias [O], styles_next [B,O]: per REAL channel / OUTPUT pixel, any may be NULL
+ *   y [B,O,2H,2W] fp32 and / or ys [B, ys_planes, O/8, 2H, 2W, 8] split (at least one)
+ * O % 32 == 0 and the 4*O-channel layer must run in whole 128-channel tiles (ia_conv2d_plan(B, I, 4*O, H, W, 3, 0, 3) gives 0
+ * workers, at least one such tile per CU); else IA_ERR_UNSUPPORTED (callers use ia_conv2d_mfma_sx(transposed) + ia_fir_tail_split).
+ */
+int ia_upconv2d_fir_sx(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
+                       const float* noise_strength, const float* bias, float* y, void* ys, int ys_planes, const float* styles_next,
+                       int B, int I, int O, int H, int W, int act, float alpha, float gain, float clamp, void* stream);
 
 /*
  * ToRGB layer as a streaming kernel: y = clamp((w * styles) (*) x + bias) + residual for a 1x1 modulated convolution without

@@ -68,6 +68,10 @@ struct Epi {
     int rgb_n = 0;
     // optional per-output-channel negative slopes of the leaky ReLU ([O]; PReLU of the inversion encoders): replaces `alpha`
     const float* alpha_vec = nullptr;
+    // depth-to-space store (conv_split.hip, ia_upconv2d_fir_sx): the layer's O channels are 4 output PHASES x O/4 real channels
+    // (phase-major), and point (r, c) of phase (py, px) is pixel (2r + py, 2c + px) of a 2H x 2W image; demod / bias / noise /
+    // styles_next are indexed by the real channel and the output pixel
+    int d2s = 0;
 };
 constexpr int kMaxRgb = 4;
 

@@ -111,33 +111,74 @@ __global__ __launch_bounds__(256) void split_saturation_kernel(const unsigned sh
 }
 
 // Accumulator tile -> fp32 NCHW (y, optional) and/or split planes (e.ys, optional); stride-1 form.
+// The per-channel terms of the epilogue (demodulation coefficient, bias, the consumer's style) are the same for every pixel of the tile:
+// they are staged once per tile in LDS (`lds_f`, the K loop's stage memory, free by now) and read back as float4 per register quad.
+// Reading them from global memory per element -- 3 loads for each of a lane's 64 values -- made the epilogue of a tile a chain of
+// ~200 L1 round trips: 31 us of a 106 us layer with a short K loop (1024 <- 32 channels @128^2), 10 - 20 us on the large layers.
 template <int FO, int FP, int WO, int WP>
 __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], float* __restrict__ y, const Geo& g, const Epi& e,
-                                                int b, int o0, int p0, int tid) {
+                                                int b, int o0, int p0, int tid, float* lds_f) {
+    constexpr int BO = 32 * FO * WO, NTHREADS = WO * WP * 64;
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int wo = wave / WP, wp = wave % WP;
     const int npts = g.GH * g.GW;
     const int64_t ohw = (int64_t)g.OH * g.OW;
     const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
-    float* yb = y ? y + ((int64_t)b * g.O) * ohw : nullptr;
+    const int OR = e.d2s ? g.O / 4 : g.O;                      // real channels
+    const int NB = OR / 32;
+    float* c_dm = lds_f;                                         // [BO] demodulation (1 if none)
+    float* c_bs = lds_f + BO;                                    // [BO] bias (0 if none)
+    float* c_sn = lds_f + 2 * BO;                                // [BO] styles of the consumer (1 if none)
+    __syncthreads();                                             // the K loop's last operand reads are done
+    for (int t = tid; t < BO; t += NTHREADS) {
+        // real channel of tile row t (depth-to-space: rows are groups of 32 = (row phase, block of 32 real channels, column phase))
+        const int o = e.d2s ? ((((o0 >> 5) + (t >> 5)) >> 1) % NB) * 32 + (t & 31) : o0 + t;
+        const bool ok = o < OR;
+        c_dm[t] = (e.demod && ok) ? e.demod[b * OR + o] : 1.f;
+        c_bs[t] = (e.bias && ok) ? e.bias[o] : 0.f;
+        c_sn[t] = (e.styles_next && ok) ? e.styles_next[b * OR + o] : 1.f;
+    }
+    __syncthreads();
+    const bool lrelu = e.act == IA_ACT_LRELU;
+    const int OW2 = 2 * g.GW;
+    const int64_t ohw_out = e.d2s ? 4 * ohw : ohw;
+    float* yb = y ? y + ((int64_t)b * OR) * ohw_out : nullptr;
 #pragma unroll
     for (int fp = 0; fp < FP; ++fp) {
         const int p = p0 + (wp * FP + fp) * 32 + l31;
         if (p >= npts) continue;
+        const int r = e.d2s ? p / g.GW : 0, c = p - r * g.GW;
 #pragma unroll
-        for (int fo = 0; fo < FO; ++fo)
+        for (int fo = 0; fo < FO; ++fo) {
+            // output pixel and first real channel of this fragment
+            const int grp = (o0 >> 5) + wo * FO + fo;
+            const int64_t pix = e.d2s ? (int64_t)(2 * r + ((grp >> 1) / NB)) * OW2 + 2 * c + (grp & 1) : (int64_t)p;
+            const int o_frag = e.d2s ? ((grp >> 1) % NB) * 32 : o0 + (wo * FO + fo) * 32;
+            const float nz = e.noise ? e.noise[pix] : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                      // register quad q: channels 8q + 4*half + (0..3) of the fragment
-                const int o_first = o0 + (wo * FO + fo) * 32 + 8 * q + 4 * half;
-                float v[4];
+                const int trow = (wo * FO + fo) * 32 + 8 * q + 4 * half, o_first = o_frag + 8 * q + 4 * half;
+                const float4 dm4 = *reinterpret_cast<const float4*>(c_dm + trow), bs4 = *reinterpret_cast<const float4*>(c_bs + trow);
+                const float4 sn4 = *reinterpret_cast<const float4*>(c_sn + trow);
+                const float dm[4] = {dm4.x, dm4.y, dm4.z, dm4.w}, bs[4] = {bs4.x, bs4.y, bs4.z, bs4.w}, sn[4] = {sn4.x, sn4.y, sn4.z, sn4.w};
+                float v[4], t[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int o = o_first + k;
-                    v[k] = o < g.O ? epilogue(acc[0][fo][fp][4 * q + k], b, o, p, ohw, g, e, ns) : 0.f;
-                    if (yb && o < g.O) yb[(int64_t)o * ohw + p] = v[k];
+                    float a = acc[0][fo][fp][4 * q + k] * dm[k];                       // (the order of epilogue(): demod, noise, bias, ...)
+                    if (e.noise) a = fmaf(nz, ns, a);
+                    a += bs[k];
+                    if (lrelu) a = a > 0.f ? a : a * (e.alpha_vec ? e.alpha_vec[min(o, OR - 1)] : e.alpha);
+                    a *= e.gain;
+                    if (e.clamp >= 0.f) a = fminf(fmaxf(a, -e.clamp), e.clamp);
+                    if (e.residual && o < OR) a += e.residual[((int64_t)b * OR + o) * ohw_out + pix];
+                    v[k] = o < OR ? a : 0.f;
+                    t[k] = v[k] * sn[k];
+                    if (yb && o < OR) yb[(int64_t)o * ohw_out + pix] = v[k];
                 }
-                if (e.ys && o_first + 3 < g.O) split_store4(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, p, v);
+                if (e.ys && o_first + 3 < OR) split_store4(e.ys, nullptr, e.ys_planes, b, OR, ohw_out, o_first, pix, t);
             }
+        }
     }
 }
 
@@ -521,7 +562,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     } else if (!SK || (c_lo == 0 && c_hi == g.C)) {
         if constexpr (TR) store_tile<TR, FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
         else if constexpr (RGB) store_tile_rgb<FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid, lds);
-        else store_tile_dual<FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
+        else store_tile_dual<FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid, lds);
     } else if constexpr (SK) {
         const int slot = (tile_l == first_tile) ? 0 : 1;
         float4* slab = reinterpret_cast<float4*>(slabs + (((int64_t)b * g.G + worker) * 2 + slot) * ((int64_t)NACC * NTHREADS)) + tid;
@@ -647,7 +688,7 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
                         const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                         const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
                         int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream, const RgbArgs& rgb,
-                        const float* prelu_alpha = nullptr) {
+                        const float* prelu_alpha = nullptr, int d2s = 0) {
     IA_REQUIRE(xs && wk_split && (y || ys || rgb.out), "xs, wk and at least one output must be device pointers");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
     IA_REQUIRE(I % 8 == 0 && O % 8 == 0, "the split form needs I %% 8 == 0 and O %% 8 == 0");
@@ -663,6 +704,8 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
     g.GH = transposed ? H + 1 : H; g.GW = transposed ? W + 1 : W;
     g.OH = transposed ? 2 * H + 1 : H; g.OW = transposed ? 2 * W + 1 : W;
     IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
+    IA_REQUIRE(!d2s || (!transposed && O % 32 == 0 && residual == nullptr && !rgb.out && !prelu_alpha),
+               "the depth-to-space store takes a stride-1 layer of 4 x O/4 channels without residual / fused ToRGB");
     int bo, bp, waves, slab_floats;
     const int st_plan = ia_conv2d_plan_tiles(B, I, O, H, W, 3, transposed, 3, &bo, &bp, &waves, &g.T, &g.TO, &g.C, &g.T_dp, &slab_floats);
     if (st_plan != IA_OK) return st_plan;
@@ -687,6 +730,10 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
     g.acc_scale = ldexpf(1.f, -wk_exp);
     Epi e{demod, noise, noise_strength, bias, residual, act, alpha, gain, clamp, ys, styles_next, ys_planes};
     e.alpha_vec = prelu_alpha;
+    e.d2s = d2s;
+    if (d2s && (bo != 128 || O % 128 != 0 || g.T_dp != g.T))
+        return ia::fail(IA_ERR_UNSUPPORTED, "depth-to-space store: needs whole 128-channel tiles (4 x %d channels, %d-channel tiles, %d of %d tiles whole)",
+                        O / 4, bo, g.T_dp, g.T);
     if (rgb.out) {
         IA_REQUIRE(rgb.w && rgb.n >= 1 && rgb.n <= kMaxRgb, "the fused ToRGB takes 1 .. %d output channels and its packed weight", kMaxRgb);
         e.rgb_w = rgb.w; e.rgb_styles = rgb.styles; e.rgb_bias = rgb.bias; e.rgb_res = rgb.res; e.rgb_out = rgb.out; e.rgb_n = rgb.n; e.rgb_clamp = rgb.clamp;
@@ -731,4 +778,13 @@ extern "C" int ia_conv2d_mfma_sx_rgb(const void* xs, int planes, const void* wk_
     IA_REQUIRE(rgb_out && rgb_wk, "rgb_out and rgb_wk must be device pointers");
     return conv_sx_impl(xs, planes, wk_split, wk_exp, demod, noise, noise_strength, bias, nullptr, y, ys, ys_planes, styles_next, nullptr, 0,
                         B, I, O, H, W, 0, act, alpha, gain, clamp, 0, stream, RgbArgs{rgb_wk, rgb_styles, rgb_bias, rgb_residual, rgb_out, rgb_channels, rgb_clamp});
+}
+
+extern "C" int ia_upconv2d_fir_sx(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,
+                                  const float* noise_strength, const float* bias, float* y, void* ys, int ys_planes, const float* styles_next,
+                                  int B, int I, int O, int H, int W, int act, float alpha, float gain, float clamp, void* stream) {
+    IA_REQUIRE(O > 0 && (int64_t)4 * O <= INT32_MAX / 4, "empty tensor");
+    return conv_sx_impl(xs, planes, wk_split, wk_exp, demod, noise, noise_strength, bias, nullptr, y, ys, ys_planes, styles_next, nullptr, 0,
+                        B, I, 4 * O, H, W, 0, act, alpha, gain, clamp, 0, stream, RgbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1.f},
+                        nullptr, 1);
 }

@@ -19,6 +19,11 @@
 // write the three planes channels-last [B,3,256,256,32].
 #include "ia_common.h"
 
+// Compile-time ablations (tools/, never in the product build): bit 0 = no static-crop loads, bit 1 = no texture walk
+#ifndef IA_RAST_ABLATE
+#define IA_RAST_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int kSrc = 256;                  // UV / alpha maps are 256 x 256 (triplane_v20.py:114,322)
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
     // add entries first, first + step, ... (< n) of the walk list for channels c .. c+CV-1
     auto walk = [&](int c, int first, int step, int n, float (&acc)[4][PXB]) {
         const float* tc = texb + c;
+        if (IA_RAST_ABLATE & 2) return;
         if (CV == 4) {
 #pragma unroll 8
             for (int e = first; e < n; e += step) {
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256) void rasterize_level_kernel(RastParams p) {
 #pragma unroll
                         for (int i = 0; i < kSCols; ++i) {
                             if (i < s_nc) {
-                                const float v = row[i];
+                                const float v = (IA_RAST_ABLATE & 1) ? 0.f : row[i];
 #pragma unroll
                                 for (int k = 0; k < PXB; ++k) h[k] = fmaf(v, swx[k][i], h[k]);
                             }

@@ -138,6 +138,7 @@ import os as _os
 # operands from L2 next to the other networks' large layers: same-box A/B 296 vs 303 frames/s (r03, tools/ab_frame.py).
 # IA_SMALL_CONV=1 enables it (kept for batch-1 callers that run one network at a time).
 SMALL_CONV = _os.environ.get('IA_SMALL_CONV', '0') == '1'
+SMALL_CONV_MAX_RES = int(_os.environ.get('IA_SMALL_CONV_MAX_RES', '16'))       # (input resolution; 8 keeps the 16^2 layers, its heaviest launches, on the tiled route)
 SMALL_CONV_MAX_BATCH = int(_os.environ.get('IA_SMALL_CONV_MAX_BATCH', '2'))      # (a batch-8 call: 352 vs 375 frames/s with it)
 
 
@@ -172,7 +173,7 @@ def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None,
     _f32c(x, 'x')
     b, i, h, w = x.shape
     half_ops = wk.dtype == torch.float16
-    if (SMALL_CONV and b <= SMALL_CONV_MAX_BATCH and not half_ops and ksize == 3 and residual is None and ksplit is None and wk.dim() == 3
+    if (SMALL_CONV and b <= SMALL_CONV_MAX_BATCH and h <= SMALL_CONV_MAX_RES and not half_ops and ksize == 3 and residual is None and ksplit is None and wk.dim() == 3
             and _lib.load().ia_conv2d_small_supported(i, wk.shape[2], h, w, int(transposed))):
         return conv2d_small(x, wk, styles, demod, noise, noise_strength, bias, transposed, act, alpha, gain, clamp)
     split = half_ops and wk.dim() == 5
@@ -468,6 +469,76 @@ def fir_tail_split(x, f, noise=None, noise_strength=None, bias=None, styles_next
                                            float(alpha), float(act_gain), float(-1 if clamp is None else clamp), _lib.stream_ptr(x.device))
     _lib.check(st, 'ia_fir_tail_split')
     out = SplitAct(ys, c, split_for)
+    return (y, out) if want_f32 else out
+
+
+def compose_upfir_weight(w, f, gain=4.0):
+    """[O, I, 3, 3] weight of an up-sampling layer + its [4, 4] resample filter -> [4*O, I, 3, 3]: per output phase (py, px) the 3x3
+    kernel on the INPUT image that equals conv_transpose2d(stride 2) followed by upfirdn2d(f, padding [1,1,1,1], gain)
+    (see ia_upconv2d_fir_sx).  Row ((py * O/32 + o // 32) * 2 + px) * 32 + o % 32."""
+    w = w.detach().double()
+    f = torch.as_tensor(f).double().to(w.device)
+    if tuple(f.shape) != (4, 4) or tuple(w.shape[2:]) != (3, 3):
+        raise RuntimeError('compose_upfir_weight: 3x3 weight and 4x4 filter')
+    F = f.flip([0, 1])                                   # upfirdn2d applies the flipped filter (a true convolution)
+    o, i = w.shape[:2]
+    out = torch.zeros(4, o, i, 3, 3, dtype=torch.float64, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for a in range(4):
+                for ky in range(3):
+                    ny = py + a - 1 - ky
+                    if ny % 2:
+                        continue
+                    for b_ in range(4):
+                        for kx in range(3):
+                            nx = px + b_ - 1 - kx
+                            if nx % 2:
+                                continue
+                            out[2 * py + px, :, :, ny // 2 + 1, nx // 2 + 1] += gain * F[a, b_] * w[:, :, ky, kx]
+    if o % 32:
+        raise RuntimeError('compose_upfir_weight: out_channels % 32 == 0')
+    # row order (py, block of 32 channels, px, channel in block): the two horizontal phases of a block are neighbours (see the kernel's store)
+    out = out.view(2, 2, o // 32, 32, i, 3, 3).permute(0, 2, 1, 3, 4, 5, 6)
+    return out.reshape(4 * o, i, 3, 3).float()
+
+
+def upconv_fir_supported(b, i, o, h, w):
+    """Layers ia_upconv2d_fir_sx covers: the composed 4*O-channel stride-1 layer runs in whole tiles that divide O."""
+    if i % 8 or o % 128:
+        return False
+    plan_s, plan_bytes = ctypes.c_int(0), ctypes.c_size_t(0)
+    st = _lib.load().ia_conv2d_plan(b, i, 4 * o, h, w, 3, 0, 3, ctypes.byref(plan_s), ctypes.byref(plan_bytes))
+    # whole rounds of the 128-channel x 256-point tile (a layer with fewer of those than CUs runs on the 32-channel tiles or stream-K)
+    return st == 0 and plan_s.value == 0 and h * w >= 1024 and w <= 512 and b * ((h * w + 255) // 256) * (4 * o // 128) >= 256
+
+
+def upconv_fir_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=None, styles_next=None, act='linear', alpha=0.2, gain=1.0,
+                  clamp=None, want_f32=False, split_for=None, split_planes=2):
+    """ia_upconv2d_fir_sx: an up-sampling layer (transposed convolution + resample FIR + noise + bias + activation) of a SplitAct as one
+    stride-1 launch on the COMPOSED weight (pack of compose_upfir_weight).  Returns the SplitAct of the [B, O, 2H, 2W] result for
+    `split_for` (multiplied by styles_next), or (y, SplitAct) with want_f32."""
+    if not isinstance(xs, SplitAct):
+        raise RuntimeError('xs must be a SplitAct')
+    b, i, h, w = xs.shape
+    o4 = wk.shape[-2]
+    if o4 % 4 or wk.shape[-4] != 9 or wk.shape[-3] * 8 != i:
+        raise RuntimeError(f'packed composed weight {tuple(wk.shape)} does not match 3x3, in-channels {i}, 4 x O rows')
+    o = o4 // 4
+    for name, t, n in (('demod', demod, b * o), ('noise', noise, 4 * h * w), ('bias', bias, o), ('styles_next', styles_next, b * o)):
+        if t is not None and _f32c(t, name).numel() != n:
+            raise RuntimeError(f'{name} has {t.numel()} elements, expected {n}')
+    dev = xs.data.device
+    y = torch.empty(b, o, 2 * h, 2 * w, device=dev, dtype=torch.float32) if want_f32 else None
+    ys = torch.empty(b, split_planes, o // 8, 2 * h, 2 * w, 8, device=dev, dtype=torch.float16)
+    flops = 2.0 * b * h * w * i * o * 9          # (algorithmic: the transposed convolution's; 4x of it is executed)
+    traffic = 2.0 * (xs.data.numel() + wk.numel()) + 2.0 * ys.numel() + (4.0 * y.numel() if want_f32 else 0.0)
+    with torch.cuda.device(dev), _Timed('conv2d_mfma_t', flops, traffic, f'B{b} I{i} O{o} {h}x{w} composed up-FIR'):
+        st = _lib.load().ia_upconv2d_fir_sx(_p(xs.data), int(xs.planes), _p(wk), int(getattr(wk, 'wk_exp', 0)), _p(demod), _p(noise),
+                                            _p(noise_strength), _p(bias), _p(y), _p(ys), int(split_planes), _p(styles_next), b, i, o, h, w,
+                                            ACT_ID[act], float(alpha), float(gain), float(-1 if clamp is None else clamp), _lib.stream_ptr(dev))
+    _lib.check(st, 'ia_upconv2d_fir_sx')
+    out = SplitAct(ys, o, split_for)
     return (y, out) if want_f32 else out
 
 

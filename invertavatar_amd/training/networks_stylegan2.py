@@ -41,6 +41,10 @@ STREAMING_TORGB = True           # ToRGB layers through ia_conv1x1 (one streamin
 # ia_torgb re-reads the activations once per block of 32 output channels with 8-wave workgroups: past this many pixels x channel blocks
 # the 64-thread workgroups of ia_conv1x1 (+ ia_upfirdn2d) share the machine better with the convolutions of the other streams
 TORGB_MAX_WORK = int(os.environ.get('IA_TORGB_MAX_WORK', 49152))
+# Up-sampling layers with at most this many input channels run as one stride-1 launch on the weight composed with the resample filter
+# (ia_upconv2d_fir_sx: 4x the products, no (2H+1)^2 fp32 image, no FIR launch): the 32 -> 256 @128^2 layer of the SR head
+COMPOSED_UPFIR = os.environ.get('IA_COMPOSED_UPFIR', '1') == '1'
+COMPOSED_UPFIR_MAX_IN = int(os.environ.get('IA_COMPOSED_UPFIR_MAX_IN', 32))
 FUSED_TORGB_SKIP = os.environ.get('IA_FUSED_TORGB_SKIP', '1') == '1'          # ... and, where ia_torgb covers the shape, with the skip image's up-sampling + add in the same launch
 SPLIT_FP16_PRODUCTS = True
 
@@ -81,6 +85,16 @@ class _PackedWeights(_runtime.DeviceCache):
             self.wk_s = hipops.pack_conv_weight_split(weight.detach().float())
             self.wk_s_key = self.key
         return self.wk_s
+
+    def get_upfir(self, weight, resample_filter, half):
+        """Packing of the weight composed with the resample filter (hipops.compose_upfir_weight) for ia_upconv2d_fir_sx."""
+        self.get(weight)
+        key = (self.key, resample_filter.data_ptr(), resample_filter._version, bool(half))
+        if getattr(self, 'wk_uf_key', None) != key:
+            wc = hipops.compose_upfir_weight(weight, resample_filter)
+            self.wk_uf = hipops.pack_conv_weight_h(wc) if half else hipops.pack_conv_weight_split(wc)
+            self.wk_uf_key = key
+        return self.wk_uf
 
     def get_half(self, weight):
         """fp16 packing for ia_conv2d_mfma_h (made on first use)."""
@@ -404,6 +418,12 @@ class SynthesisLayer(torch.nn.Module):
                 out = hipops.conv2d_mfma_sx(xs, wk, demod, nz, ns, bias, act=self.activation, gain=act_gain, clamp=act_clamp,
                                             want_f32=keep_f32 or sn is None, split_for=split_for if sn is not None else None, styles_next=sn,
                                             split_planes=out_planes)
+            elif (COMPOSED_UPFIR and sn is not None and self.in_channels <= COMPOSED_UPFIR_MAX_IN and tuple(self.resample_filter.shape) == (4, 4)
+                  and hipops.upconv_fir_supported(xs.shape[0], self.in_channels, self.out_channels, in_res, in_res)):
+                # few input channels: transposed convolution + FIR + tail as ONE stride-1 launch on the composed weight
+                out = hipops.upconv_fir_sx(xs, self._packed.get_upfir(self.weight, self.resample_filter, half_ops), demod, nz, ns, bias, styles_next=sn,
+                                           act=self.activation, gain=act_gain, clamp=act_clamp, want_f32=keep_f32, split_for=split_for,
+                                           split_planes=out_planes)
             else:
                 t = hipops.conv2d_mfma_sx(xs, wk, demod, transposed=True)
                 if sn is None:

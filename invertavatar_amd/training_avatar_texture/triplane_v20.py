@@ -30,6 +30,7 @@ from .volumetric_rendering.ray_sampler import RaySampler, RaySampler_zxc  # noqa
 
 BBOX_256 = [57, 185, 64, 192]   # face region of the frontal plane, in 256^2 pixels (triplane_v20.py:114)
 N_COND_LEVELS_USED = 4          # cond_list entries the face backbone consumes
+CL_COPIES_ON_TEXTURE_STREAM = __import__('os').environ.get('IA_CL_ON_TEX', '1') == '1'   # False: the rasteriser's stream makes them (ia_rasterize_level's own copy)
 SINGLE_STREAM = False           # True: no side streams (every launch of a frame in program order on the caller's stream); used by
                                 # bench.py to time kernels without neighbours from other streams
 
@@ -150,7 +151,8 @@ class TriPlaneGenerator(torch.nn.Module):
                     tex_cl[k] = hipops.channels_last_copy(t)
 
         def tap_tex(feats):
-            make_cl(feats)
+            if CL_COPIES_ON_TEXTURE_STREAM:
+                make_cl(feats)
             ev_tex[len(feats)].record(t_stream)
         t_stream.wait_stream(main)
         with torch.cuda.stream(t_stream):

@@ -286,6 +286,47 @@ def test_split_dma_convolution_equals_the_register_staged_form(i, o, h, w, tr, b
     assert torch.equal(only_s.data, got_s.data)
 
 
+@pytest.mark.parametrize('b,i,o,res,planes', [(1, 32, 256, 128, 2), (2, 16, 256, 64, 2), (1, 8, 128, 128, 2), (1, 32, 256, 128, 1)])
+def test_composed_upfir_layer_equals_the_two_launch_route(b, i, o, res, planes):
+    """ia_upconv2d_fir_sx (transposed convolution + resample FIR + noise + bias + lrelu as ONE stride-1 launch on the composed weight,
+    depth-to-space store) against the two launches it replaces (ia_conv2d_mfma_sx transposed + ia_fir_tail_split) and against fp64."""
+    from invertavatar_amd.torch_utils.ops import upfirdn2d
+    g = torch.Generator(device='cuda').manual_seed(3 + i + res)
+    x = torch.randn(b, i, res, res, device='cuda', generator=g) * 2
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g)
+    s = torch.rand(b, i, device='cuda', generator=g) + 0.5
+    sn = torch.rand(b, o, device='cuda', generator=g) + 0.5
+    bias = torch.randn(o, device='cuda', generator=g)
+    noise = torch.randn(4 * res * res, device='cuda', generator=g)
+    ns = torch.full((1,), 0.3, device='cuda')
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).cuda()
+    d = hipops.modconv_demod(s, hipops.weight_sq_sum(wt))
+    xs = hipops.act_split(x, s, planes=planes)
+    assert hipops.upconv_fir_supported(b, i, o, res, res)
+    pack = hipops.pack_conv_weight_split if planes == 2 else hipops.pack_conv_weight_h
+    t = hipops.conv2d_mfma_sx(xs, pack(wt), demod=d, transposed=True)
+    kw = dict(act='lrelu', clamp=None)
+    want, want_s = hipops.fir_tail_split(t, f, noise, ns, bias, styles_next=sn, out_hw=(2 * res, 2 * res), pad0=(1, 1), fir_gain=4.0,
+                                         act_gain=2 ** 0.5, want_f32=True, planes=planes, **kw)
+    got, got_s = hipops.upconv_fir_sx(xs, pack(hipops.compose_upfir_weight(wt, f)), d, noise, ns, bias, styles_next=sn, gain=2 ** 0.5,
+                                      want_f32=True, split_planes=planes, **kw)
+    scale = want.abs().max().item()
+    tol = 3e-6 if planes == 2 else 2e-3          # (one fp16 plane: the composed weight is rounded to fp16 once instead of the factors)
+    assert got.shape == want.shape and (got - want).abs().max().item() <= tol * scale, ((got - want).abs().max().item(), scale)
+    assert got_s.planes == planes and (got_s.float() - want_s.float()).abs().max().item() <= max(tol, 2e-3 if planes == 1 else 0) * scale * 1.5
+    if planes == 2:
+        xv = (xs.float()).double()               # the operands the kernels see
+        tt = torch.nn.functional.conv_transpose2d(xv, wt.double().transpose(0, 1), stride=2) * d.double()[:, :, None, None]
+        fir = torch.nn.functional.conv2d(torch.nn.functional.pad(tt, [1, 1, 1, 1]).reshape(b * o, 1, 2 * res + 3, 2 * res + 3),
+                                         (4 * f.double().flip([0, 1]))[None, None]).reshape(b, o, 2 * res, 2 * res)
+        ref = fir + (noise.double() * 0.3).view(1, 1, 2 * res, 2 * res)
+        ref = torch.nn.functional.leaky_relu(ref + bias.double()[None, :, None, None], 0.2) * 2 ** 0.5
+        assert (got.double() - ref).abs().max().item() <= 3e-6 * scale
+    clamped = hipops.upconv_fir_sx(xs, pack(hipops.compose_upfir_weight(wt, f)), d, noise, ns, bias, styles_next=None, act='lrelu', gain=2 ** 0.5,
+                                   clamp=0.5 * scale, want_f32=True, split_planes=planes)[0]
+    assert torch.equal(clamped, got.clamp(-0.5 * scale, 0.5 * scale))
+
+
 @pytest.mark.parametrize('c,res,batch', [(16, 32, 2), (32, 64, 1), (8, 256, 1), (128, 128, 1)])
 def test_fir_tail_split_equals_fir_tail_then_split(c, res, batch):
     """ia_fir_tail_split = ia_upfirdn2d_bias_act (same sums, bit for bit) followed by the split of (result * styles_next)."""
