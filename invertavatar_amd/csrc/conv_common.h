@@ -3,6 +3,9 @@
 // the accumulator-tile store and the stream-K fix-up kernel.
 #pragma once
 #include "ia_common.h"
+#ifndef IA_TR_SIMPLE_EPI
+#define IA_TR_SIMPLE_EPI 1      // 0: the transposed store evaluates the generic epilogue per element (A/B builds in tools/)
+#endif
 #include <type_traits>
 
 namespace {
@@ -166,6 +169,18 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
             // the two horizontal phases of a point are adjacent output pixels: one 8-byte store per (row phase, channel), so
             // that a half-wave writes 64 consecutive floats instead of every other one twice
             const int ox = 2 * pc;
+            // The transposed form's epilogue is the demodulation alone (FIR, noise, bias, activation follow in the FIR tail): its
+            // coefficients -- 16 per fragment, the same for all four phases -- are read once, ahead of the stores (read per element
+            // they are re-loaded after every store: the compiler cannot prove that y does not alias them).
+            const bool simple = IA_TR_SIMPLE_EPI && !e.noise && !e.bias && !e.residual && e.act == IA_ACT_LINEAR && e.clamp < 0.f && e.gain == 1.f;
+            float dmv[FO][16];
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    dmv[fo][r] = (simple && e.demod && o < g.O) ? e.demod[b * g.O + o] : 1.f;
+                }
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
                 const int oy = 2 * pr + py;
@@ -179,9 +194,9 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
                         const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                         if (o >= g.O) continue;
                         float* dst = yb + (int64_t)o * ohw + pix;
-                        const float v0 = epilogue(acc[2 * py][fo][fp][r], b, o, pix, ohw, g, e, ns);
+                        const float v0 = simple ? acc[2 * py][fo][fp][r] * dmv[fo][r] : epilogue(acc[2 * py][fo][fp][r], b, o, pix, ohw, g, e, ns);
                         if (pair) {
-                            const float v1 = epilogue(acc[2 * py + 1][fo][fp][r], b, o, pix + 1, ohw, g, e, ns);
+                            const float v1 = simple ? acc[2 * py + 1][fo][fp][r] * dmv[fo][r] : epilogue(acc[2 * py + 1][fo][fp][r], b, o, pix + 1, ohw, g, e, ns);
                             __builtin_memcpy(dst, &(const float2&)make_float2(v0, v1), 8);     // (rows of odd width: 4-byte aligned only)
                         } else dst[0] = v0;
                     }

@@ -35,6 +35,13 @@ def main():
         st = torch.rand(batch, i, device='cuda') + 0.5
         wk = hipops.pack_conv_weight_split(torch.randn(o, i, 3, 3, device='cuda'))
         xs = hipops.act_split(x, st)
+        # BENCH_EPI=1: with the epilogue terms the layers carry in a frame (demodulation; stride-1: + noise, bias, lrelu, split output)
+        kw = {}
+        if os.environ.get('BENCH_EPI') == '1':
+            kw = dict(demod=torch.rand(batch, o, device='cuda') + 0.5)
+            if not tr:
+                kw.update(noise=torch.randn(r * r, device='cuda'), noise_strength=torch.full((1,), 0.3, device='cuda'), bias=torch.randn(o, device='cuda'),
+                          act='lrelu', gain=2 ** 0.5, want_f32=False, styles_next=torch.rand(batch, o, device='cuda') + 0.5)
         fl = 2.0 * batch * r * r * 9 * i * o
         line = f'I={i:4d} O={o:4d} res={r:4d} tr={tr}'
         ref = None
@@ -47,7 +54,8 @@ def main():
                     k, v = kv.split('=')
                     os.environ[k] = v
             try:
-                y = hipops.conv2d_mfma_sx(xs, wk, transposed=bool(tr))
+                y = hipops.conv2d_mfma_sx(xs, wk, transposed=bool(tr), **kw)
+                y = y.float() if isinstance(y, hipops.SplitAct) else y
             except RuntimeError as err:      # (a forced tile family that does not cover this shape)
                 line += f' | {"n/a":>7s}    ' + str(err)[:40]
                 total[sname] += float('nan')
@@ -55,7 +63,7 @@ def main():
             if ref is None:
                 ref = y
             dev = float((y - ref).abs().max() / ref.abs().max())
-            us = bench(lambda: hipops.conv2d_mfma_sx(xs, wk, transposed=bool(tr)))
+            us = bench(lambda: hipops.conv2d_mfma_sx(xs, wk, transposed=bool(tr), **kw))
             total[sname] += us * per_frame
             line += f' | {us:7.1f} us {fl / us / 1e6:6.1f} TF {3 * fl / us / 1e6 / 2500:.3f} d={dev:.1e}'
         print(line, flush=True)
