@@ -197,12 +197,20 @@ __device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], f
     float* yb = y ? y + ((int64_t)b * g.O) * ohw : nullptr;
     float* ws = lds_f;                              // [kMaxRgb][BO]: ToRGB weight x style of the tile's channels
     float* red = lds_f + kMaxRgb * BO;              // [WO][WP][FP][kMaxRgb][32]
+    float* c_dm = red + WO * WP * FP * kMaxRgb * 32; // [BO] per-channel epilogue terms, staged once per tile (see store_tile_dual)
+    float* c_bs = c_dm + BO;
     __syncthreads();                                // the K loop's last operand reads are done
     for (int i = tid; i < kMaxRgb * BO; i += NTHREADS) {
         const int c = i / BO, o = o0 + i - c * BO;
         ws[i] = (c < e.rgb_n && o < g.O) ? e.rgb_w[o * e.rgb_n + c] * (e.rgb_styles ? e.rgb_styles[b * g.O + o] : 1.f) : 0.f;
     }
+    for (int t = tid; t < BO; t += NTHREADS) {
+        const int o = o0 + t;
+        c_dm[t] = (e.demod && o < g.O) ? e.demod[b * g.O + o] : 1.f;
+        c_bs[t] = (e.bias && o < g.O) ? e.bias[o] : 0.f;
+    }
     __syncthreads();
+    const bool lrelu = e.act == IA_ACT_LRELU;
     int pp[FP];
     bool valid[FP];
     float part[FP][kMaxRgb];
@@ -214,6 +222,9 @@ __device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], f
 #pragma unroll
         for (int c = 0; c < kMaxRgb; ++c) part[fp][c] = 0.f;
     }
+    float nz[FP];
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp) nz[fp] = e.noise ? e.noise[pp[fp]] : 0.f;
     // channel-major: the ToRGB weights of a channel are read once and meet that channel's value at every pixel of the lane
 #pragma unroll
     for (int fo = 0; fo < FO; ++fo)
@@ -229,7 +240,13 @@ __device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], f
                 for (int c = 0; c < kMaxRgb; ++c) wc[c] = ws[c * BO + ol + k];
 #pragma unroll
                 for (int fp = 0; fp < FP; ++fp) {
-                    v[fp][k] = o < g.O ? epilogue(acc[0][fo][fp][4 * q + k], b, o, pp[fp], ohw, g, e, ns) : 0.f;
+                    float a = acc[0][fo][fp][4 * q + k] * c_dm[ol + k];              // (the order of epilogue(): demod, noise, bias, ...)
+                    if (e.noise) a = fmaf(nz[fp], ns, a);
+                    a += c_bs[ol + k];
+                    if (lrelu) a = a > 0.f ? a : a * (e.alpha_vec ? e.alpha_vec[min(o, g.O - 1)] : e.alpha);
+                    a *= e.gain;
+                    if (e.clamp >= 0.f) a = fminf(fmaxf(a, -e.clamp), e.clamp);
+                    v[fp][k] = o < g.O ? a : 0.f;
                     if (yb && valid[fp] && o < g.O) yb[(int64_t)o * ohw + pp[fp]] = v[fp][k];
 #pragma unroll
                     for (int c = 0; c < kMaxRgb; ++c) part[fp][c] = fmaf(v[fp][k], wc[c], part[fp][c]);
