@@ -533,7 +533,7 @@ def upconv_fir_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=None
     ys = torch.empty(b, split_planes, o // 8, 2 * h, 2 * w, 8, device=dev, dtype=torch.float16)
     flops = 2.0 * b * h * w * i * o * 9          # (algorithmic: the transposed convolution's; 4x of it is executed)
     traffic = 2.0 * (xs.data.numel() + wk.numel()) + 2.0 * ys.numel() + (4.0 * y.numel() if want_f32 else 0.0)
-    with torch.cuda.device(dev), _Timed('conv2d_mfma_t', flops, traffic, f'B{b} I{i} O{o} {h}x{w} composed up-FIR'):
+    with torch.cuda.device(dev), _Timed('conv2d_mfma_t', flops, traffic, f'B{b} I{i} O{o} {h}x{w} ' + ('f16x3 dma' if xs.planes == 2 else 'f16 dma') + ' composed up-FIR'):
         st = _lib.load().ia_upconv2d_fir_sx(_p(xs.data), int(xs.planes), _p(wk), int(getattr(wk, 'wk_exp', 0)), _p(demod), _p(noise),
                                             _p(noise_strength), _p(bias), _p(y), _p(ys), int(split_planes), _p(styles_next), b, i, o, h, w,
                                             ACT_ID[act], float(alpha), float(gain), float(-1 if clamp is None else clamp), _lib.stream_ptr(dev))
