@@ -463,6 +463,7 @@ constexpr int kSmallPoints = 320;
 constexpr int kWidePoints = 1024;
 constexpr int kWideTransposedPoints = 32768;   // (H+1)(W+1): the 256^2 -> 512^2 layers
 constexpr int kSplitWideTransposedPoints = 4096;   // split-DMA form: the 8-wave transposed tile for 64^2 inputs
+constexpr int kSplitMinPoints = 64;                // split-DMA form: smallest point grid (8^2; 9^2 transposed)
 
 int worst_patch(int npts, int GW, int bp, int ksize, bool tr) {
     int worst = 0;
@@ -477,7 +478,12 @@ int worst_patch(int npts, int GW, int bp, int ksize, bool tr) {
 void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo, int* bp, int* cc, int* waves) {
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
     *waves = 4; *cc = kChunkConv;
-    if (npts <= kSmallPoints && O > 32) { *bo = 128; *bp = 32; }
+    // (form 3, r03: the 8^2 / 16^2 stride-1 layers and the 8^2 -> 16^2 / 16^2 -> 32^2 transposed ones run on the fp16-pair tiles too --
+    //  a quarter of the matrix-pipe time of the fp32 tile's 36 MFMAs per chunk, although an 8^2 image fills a quarter of the 256-point
+    //  tile; same-box frame A/B: 32^2 limit 340.4, 16^2 346.0 frames/s; on another box 16^2 327.0, 8^2 330.3, 4^2 332.2 (noise): 8^2)
+    static const int min_pts = getenv("IA_SX_MIN_POINTS") ? atoi(getenv("IA_SX_MIN_POINTS")) : kSplitMinPoints;      // (experiment switch)
+    const bool sx_small = form == 3 && ksize == 3 && npts >= min_pts;
+    if (npts <= kSmallPoints && O > 32 && !sx_small) { *bo = 128; *bp = 32; }
     else if (transposed) {
         // fp16-pair form on large images: two point fragments per wave (64ch x 128pt x 4 phases) -- one accumulator set leaves
         // the registers for it, and a k-step then reads 7 operand fragments for 6 MFMAs instead of 4 for 3
@@ -489,7 +495,7 @@ void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo
         if (form == 3 && npts >= kSplitWideTransposedPoints && npts < 2 * kSplitWideTransposedPoints) { *bp = 256; *waves = 8; }
     }
     else if (O <= 32) { *bo = 32; *bp = 256; }
-    else if (ksize == 3 && (O >= 128 || (O >= 64 && form == 3)) && O % 4 == 0 && npts >= kWidePoints && worst_patch(npts, W, 256, 3, false) <= kPatchFloats) {
+    else if (ksize == 3 && (O >= 128 || (O >= 64 && form == 3)) && O % 4 == 0 && (npts >= kWidePoints || sx_small) && worst_patch(npts, W, 256, 3, false) <= kPatchFloats) {
         *bo = 128; *bp = 256; *waves = 8;
     }
     else { *bo = 128; *bp = 128; }

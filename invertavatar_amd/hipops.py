@@ -7,6 +7,7 @@ import contextlib
 import contextvars
 import ctypes
 import math
+import os
 
 import torch
 
@@ -84,6 +85,23 @@ def conv_h_supported(i, o, h, w, ksize, transposed):
     if transposed:
         return (h + 1) * (w + 1) > 320
     return o >= 128 and h * w >= 1024 and w <= 512
+
+
+# Smallest images the split-DMA form (ia_conv2d_mfma_sx) takes: 8^2 / 16^2 stride-1 layers (one 128 x 256 tile per 128 channels, cut
+# between stream-K workers) and 8^2 -> 16^2 / 16^2 -> 32^2 transposed layers (9^2 / 17^2 points on the 64 x 64 tile); the 4^2 layers
+# stay on the fp32 tiles (no gain measured).  IA_SX_MIN_RES=32 restores the r02 limits (the library follows with IA_SX_MIN_POINTS).
+SX_MIN_RES = int(os.environ.get('IA_SX_MIN_RES', '8'))
+
+
+def conv_sx_supported(i, o, h, w, ksize, transposed):
+    """Shapes the split-DMA form covers: those of conv_h_supported, plus (r03) the SX_MIN_RES^2 layers."""
+    if conv_h_supported(i, o, h, w, ksize, transposed):
+        return True
+    if ksize != 3 or i % 8 or o % 8 or min(h, w) < SX_MIN_RES:
+        return False
+    if transposed:
+        return (h + 1) * (w + 1) >= (SX_MIN_RES + 1) ** 2
+    return o >= 128 and h * w >= SX_MIN_RES ** 2 and w <= 512
 
 
 def weight_sq_sum(w):

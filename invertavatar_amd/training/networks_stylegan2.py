@@ -366,7 +366,7 @@ class SynthesisLayer(torch.nn.Module):
         """True when this layer, fed a [*, in_channels, in_res, in_res] activation, runs on ia_conv2d_mfma_sx."""
         return ((SPLIT_FP16_PRODUCTS or half_ops) and USE_SPLIT_DMA and self.weight.shape[2] == 3 and self.in_channels % 8 == 0
                 and self.out_channels % 8 == 0 and not (self.use_noise and noise_mode == 'random') and self.activation in hipops.ACT_ID
-                and hipops.conv_h_supported(self.in_channels, self.out_channels, in_res, in_res, 3, self.up == 2))
+                and hipops.conv_sx_supported(self.in_channels, self.out_channels, in_res, in_res, 3, self.up == 2))
 
     def _consumer_styles(self, split_for, out_res, noise_mode, half_ops=False):
         """Styles of the layer that will consume this layer's result, if it can take it in split format (they were computed ahead
