@@ -505,7 +505,9 @@ void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo
 
 // Shared by the planner and the entry point: tile counts and the split between whole rounds and stream-K.
 struct Plan { int bo, bp, cc, waves, T, TO, C, T_dp, G, slab_floats; };
-constexpr int kSmallLayerWorkers = ia::kNumCU / 2, kSmallLayerPoints = 65 * 65;
+// (r03, with the 8^2 / 16^2 layers on the fp16-pair tiles and the shorter ToRGB launches: cap 128 / 64 / 48 / 32 workers = 321.8 / 326.4 /
+//  326.2 / 320.0 frames/s same-box, 96 / 192 / 256 = 329.6 / 326.7 / 321.5 against 330.3 and 333.3 for 128 and 64 on another box: 64)
+constexpr int kSmallLayerWorkers = ia::kNumCU / 4, kSmallLayerPoints = 65 * 65;
 static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int form) {
     Plan p;
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
@@ -525,7 +527,8 @@ static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transpos
     // (64 narrow tiles) stay on stream-K: 39 vs 64 us.
     if (form == 3 && !force_whole && !transposed && ksize == 3 && p.waves == 8 && O % 32 == 0 && !getenv("IA_NO_NARROW_TILES")) {
         const int64_t t_wide = (int64_t)B * ((npts + 255) / 256) * ((O + 127) / 128), t_narrow = (int64_t)B * ((npts + 255) / 256) * (O / 32);
-        if (t_wide < ia::kNumCU && t_narrow >= ia::kNumCU) { p.bo = 32; p.bp = 256; force_whole = true; }
+        static const int min_tiles = getenv("IA_NARROW_MIN_TILES") ? atoi(getenv("IA_NARROW_MIN_TILES")) : ia::kNumCU;      // (experiment switch)
+        if (t_wide < ia::kNumCU && t_narrow >= min_tiles) { p.bo = 32; p.bp = 256; force_whole = true; }
     }
     if (const char* ev = form == 3 ? getenv("IA_SX_WHOLE") : nullptr) force_whole = force_whole || atoi(ev) != 0;      // experiment switch
     p.TO = (O + p.bo - 1) / p.bo;
@@ -550,7 +553,8 @@ static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transpos
         // measured 272 -> 280-284 frames/s at batch 1 for 0.241 -> 0.222 single-stream MFMA utilisation of the fp16-pair family;
         // capping the 128^2 layers too gives 283-285 and 0.213.  At batch >= 4 the per-element share Gb is below the cap anyway.
         if (rounds == 0 && npts <= kSmallLayerPoints) {
-            const int64_t lim = p.T > kSmallLayerWorkers ? p.T : kSmallLayerWorkers;
+            static const int cap = getenv("IA_SMALL_LAYER_WORKERS") ? atoi(getenv("IA_SMALL_LAYER_WORKERS")) : kSmallLayerWorkers;      // (experiment switch)
+            const int64_t lim = p.T > cap ? p.T : cap;
             if (G > lim) G = lim;
         }
         if (G < 1) G = 1;

@@ -50,16 +50,16 @@ def _plan(b, i, o, h, w, ksize=3, transposed=0, form=0):
 
 def test_conv_planner_host_logic():
     """ia_conv2d_plan is host-only arithmetic: worker counts of the stream-K split (include/ia_hip.h).  Layers smaller than the machine
-    up to 64^2 are capped at half of the 256 CUs (one worker per tile if they have more tiles); layers that fill whole rounds of
+    up to 64^2 are capped at a quarter of the 256 CUs (one worker per tile if they have more tiles); layers that fill whole rounds of
     tiles have no stream-K part; the per-element share shrinks with the batch."""
     for res in (4, 8, 16):
         workers, nbytes = _plan(1, 512, 512, res, res)
-        assert workers == 128 and nbytes > 0, (res, workers)
-    assert _plan(1, 512, 512, 64, 64, form=2)[0] == 128
+        assert workers == 64 and nbytes > 0, (res, workers)
+    assert _plan(1, 512, 512, 64, 64, form=2)[0] == 64
     assert _plan(1, 256, 256, 128, 128, form=2)[0] == 256           # 128^2 keeps the whole machine
     # split-DMA form: stride-1 layers smaller than the machine whose 32-channel x 256-point tiles give every CU one run whole tiles
     assert _plan(1, 512, 512, 64, 64, form=3) == (0, 0) and _plan(1, 256, 256, 128, 128, form=3) == (0, 0)
-    assert _plan(1, 512, 512, 32, 32, form=3)[0] == 128             # 64 narrow tiles would leave 3/4 of the CUs idle: stream-K stays
+    assert _plan(1, 512, 512, 32, 32, form=3)[0] == 64              # 64 narrow tiles would leave 3/4 of the CUs idle: stream-K stays
     assert _plan(8, 512, 512, 64, 64, form=3) == (0, 0)             # (a batch of 8 already fills whole rounds of wide tiles)
     for shape in ((1, 128, 128, 512, 512), (1, 256, 256, 256, 256), (1, 128, 128, 256, 256)):
         assert _plan(*shape, form=3) == (0, 0), shape               # whole rounds of whole tiles: no workers, no scratch
