@@ -278,6 +278,14 @@ int ia_blend_planes(const float* stitch, const float* full_alpha, const float* s
                     float* planes_cl, int B, int y0, int y1, int x0, int x1, void* stream);
 
 /*
+ * Channels-last copy of a feature map, [B,C,H,W] -> [B,H,W,C] (float32, contiguous): the layout ia_rasterize_level gathers its
+ * texture level from (`tex_cl`).  Replaces the permute + contiguous copy the gather formulation of TriPlaneGenerator.rasterize
+ * (training_avatar_texture/triplane_v20.py:328-337: F.grid_sample over an NCHW texture) needs on this backend; 64 x 64 tiles through
+ * LDS, reads and writes in 256-byte runs.
+ */
+int ia_channels_last(const float* x, float* y, int B, int C, int H, int W, void* stream);
+
+/*
  * Paste of a rasterised condition over features or the skip image inside the face backbone
  * (training_avatar_texture/networks_stylegan2_new.py:537-540):  y = cond[:, :C] * a + x * (1 - a),  a = cond[:, C:C+1].
  *   cond : [B, C+1, H, W] float32 (last channel = alpha);  x, y : [B, C, H, W] float32;  H*W % 4 == 0.

@@ -47,6 +47,7 @@ _SIGNATURES = {
     'ia_torgb': [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p],
     'ia_rasterize_level': [c_void_p] * 4 + [c_int64, c_void_p] + [c_int] * 9 + [c_void_p],
     'ia_blend_planes': [c_void_p] * 3 + [c_int64, c_void_p] + [c_int] * 5 + [c_void_p],
+    'ia_channels_last': [c_void_p] * 2 + [c_int] * 4 + [c_void_p],
     'ia_cond_blend': [c_void_p] * 3 + [c_int] * 4 + [c_void_p],
     'ia_split_saturation_count': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'ia_act_split': [c_void_p] * 4 + [c_int] * 5 + [c_void_p],

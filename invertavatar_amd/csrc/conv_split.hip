@@ -97,6 +97,43 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
     }
 }
 
+// The same, four consecutive pixels per thread (H*W % 4 == 0): 16-byte loads, a quarter of the load instructions.
+__global__ __launch_bounds__(256) void act_split4_kernel(const float* __restrict__ x, const float* __restrict__ styles, const float* __restrict__ shift,
+                                                        h16x8* __restrict__ out, int B, int C, int64_t HW, int planes) {
+    const int C8 = C / 8;
+    const int64_t HW4 = HW / 4, total = (int64_t)B * C8 * HW4, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t p4 = i % HW4;
+        const int c8 = (int)((i / HW4) % C8), b = (int)(i / (HW4 * C8));
+        float4 xv[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) xv[cc] = reinterpret_cast<const float4*>(x + ((int64_t)b * C + c8 * 8 + cc) * HW)[p4];
+        h16x8 hi[4], lo[4];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int c = c8 * 8 + cc;
+            const float st = styles ? styles[b * C + c] : 1.f, sh = shift ? shift[b * C + c] : 0.f;
+            const float v4[4] = {xv[cc].x, xv[cc].y, xv[cc].z, xv[cc].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = v4[k];
+                if (styles) v *= st;
+                if (shift) v += sh;
+                if (planes == 2) { _Float16 h, l; ia::split_f16(v, h, l); hi[k][cc] = h; lo[k][cc] = l; }
+                else hi[k][cc] = ia::round_f16(v);
+            }
+        }
+        h16x8* dh = out + ((int64_t)(b * planes) * C8 + c8) * HW + 4 * p4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dh[k] = hi[k];
+        if (planes == 2) {
+            h16x8* dl = out + ((int64_t)(b * 2 + 1) * C8 + c8) * HW + 4 * p4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dl[k] = lo[k];
+        }
+    }
+}
+
 // Elements of the hi plane that sit on the fp16 maximum: values the split clamped (see ia_split_saturation_count).
 __global__ __launch_bounds__(256) void split_saturation_kernel(const unsigned short* __restrict__ xs, int64_t per_batch_hi, int64_t batch_stride,
                                                               int B, unsigned int* __restrict__ count) {
@@ -679,8 +716,12 @@ extern "C" int ia_act_split(const float* x, const float* styles, const float* sh
     IA_REQUIRE(C % 8 == 0, "the split format stores channels in groups of 8 (C = %d)", C);
     IA_REQUIRE((int64_t)B * C * H * W <= INT32_MAX, "tensor is too large");
     const int64_t work = (int64_t)B * (C / 8) * H * W;
-    hipLaunchKernelGGL(act_split_kernel, dim3(ia::streaming_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, styles, shift,
-                       static_cast<h16x8*>(xs), B, C, (int64_t)H * W, planes);
+    if (((int64_t)H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        hipLaunchKernelGGL(act_split4_kernel, dim3(ia::streaming_grid(work / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, styles, shift,
+                           static_cast<h16x8*>(xs), B, C, (int64_t)H * W, planes);
+    else
+        hipLaunchKernelGGL(act_split_kernel, dim3(ia::streaming_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, styles, shift,
+                           static_cast<h16x8*>(xs), B, C, (int64_t)H * W, planes);
     return ia::check_launch("ia_act_split");
 }
 

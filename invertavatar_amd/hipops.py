@@ -675,7 +675,15 @@ def cond_blend_split(cond, x, styles_next, consumer):
 
 
 def channels_last_copy(t):
-    """[B,C,H,W] -> contiguous [B,H,W,C] (the layout ia_rasterize_level gathers from)."""
+    """[B,C,H,W] -> contiguous [B,H,W,C] (the layout ia_rasterize_level gathers from): ia_channels_last for contiguous fp32 device
+    tensors (a tiled transpose: 25 -> ~8 us for 256 channels @128^2 against the strided Tensor.copy_), torch otherwise."""
+    if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4:
+        b, c, h, w = t.shape
+        out = torch.empty(b, h, w, c, device=t.device, dtype=torch.float32)
+        with torch.cuda.device(t.device):
+            st = _lib.load().ia_channels_last(_p(t), _p(out), b, c, h, w, _lib.stream_ptr(t.device))
+        _lib.check(st, 'ia_channels_last')
+        return out
     return t.permute(0, 2, 3, 1).contiguous()
 
 

@@ -133,3 +133,12 @@ def test_stage_inputs_copies_segments_in_one_launch():
     torch.cuda.synchronize()
     for s, d in zip(srcs, dsts):
         assert torch.equal(s, d)
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 32, 32), (2, 512, 64, 64), (1, 256, 128, 128), (1, 40, 7, 9)])
+def test_channels_last_copy_kernel(shape):
+    """ia_channels_last = permute(0, 2, 3, 1).contiguous(), bit for bit (ragged channel / pixel counts included)."""
+    from invertavatar_amd import hipops
+    x = torch.randn(*shape, device='cuda')
+    got = hipops.channels_last_copy(x)
+    assert got.is_contiguous() and torch.equal(got, x.permute(0, 2, 3, 1).contiguous())
