@@ -251,6 +251,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled_pipe(const T* __restrict_
 // registers, and after the eighth channel every thread holds the 8 channels of its 4 pixels: 1 KB contiguous per wave, plane
 // and row.  Optionally the fp32 NCHW result is written as well (callers that still need it, e.g. the CS-SFT modulation).
 typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+#ifndef IA_FIR_ABLATE
+#define IA_FIR_ABLATE 0      // tools/: bit 0 = one tap instead of 16 (LDS reads + FMAs), bit 1 = no global loads
+#endif
 #ifndef IA_FIR_SETS
 #define IA_FIR_SETS 2
 #endif
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __rest
     float v[kFirSets][NLD];
     auto fetch = [&](int ch, int set) {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) v[set][j] = g_off[j] >= 0 ? xb[(int64_t)ch * in_plane + g_off[j]] : 0.f;
+        for (int j = 0; j < NLD; ++j) v[set][j] = (g_off[j] >= 0 && !(IA_FIR_ABLATE & 2)) ? xb[(int64_t)ch * in_plane + g_off[j]] : 0.f;
     };
     auto commit = [&](int buf, int set) {
 #pragma unroll
@@ -317,10 +320,14 @@ __global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             float acc = 0.f;
+#if IA_FIR_ABLATE & 1
+            acc = in_lds[buf][(ty + r + 1) * IWP + tx + 1] * kf[5];
+#else
 #pragma unroll
             for (int a = 0; a < FS; ++a)
 #pragma unroll
                 for (int bb = 0; bb < FS; ++bb) acc = fmaf(in_lds[buf][(ty + r + a) * IWP + tx + bb], kf[a * FS + bb], acc);
+#endif
             if (tail.noise) acc = fmaf(nz[r], t_ns, acc);
             acc += t_bias;
             if (tail.act == IA_ACT_LRELU) acc = acc > 0.f ? acc : acc * tail.alpha;
