@@ -233,14 +233,21 @@ def roofline_leg(gen, wl, frames=3):
     _profiled_frames(gen, wl, 1, True)                     # (the first single-stream frame allocates that path's buffers)
     recs = _profiled_frames(gen, wl, frames, True)
     fam = {}
-    split = dict(ms=0.0, flops=0.0, bytes=0.0, launches=0)   # conv launches whose products are fp16 hi/lo pairs (3 MFMAs per k-step)
+    # conv launches whose products are fp16 hi/lo pairs (3 MFMAs per k-step).  `split`: the layers from 32^2 up -- the 25 launches per
+    # frame the figure has been quoted on since r01; `split_all`: those plus the 8^2 / 16^2 layers that joined the fp16-pair tiles in r03
+    # (stream-K fragments of a tile, latency-bound: they are in the PMC family, whose kernels cannot be told apart by layer).
+    split = dict(ms=0.0, flops=0.0, bytes=0.0, launches=0)
+    split_all = dict(ms=0.0, flops=0.0, bytes=0.0, launches=0)
     for name, flops, nbytes, e0, e1, desc in recs:
         key = 'conv2d_mfma' if name.startswith('conv2d_mfma') else name
         f = fam.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
         ms = e0.elapsed_time(e1)
         f['ms'] += ms; f['flops'] += flops; f['bytes'] += nbytes; f['launches'] += 1
         if key == 'conv2d_mfma' and 'f16x3' in desc:
-            split['ms'] += ms; split['flops'] += flops; split['bytes'] += nbytes; split['launches'] += 1
+            split_all['ms'] += ms; split_all['flops'] += flops; split_all['bytes'] += nbytes; split_all['launches'] += 1
+            hw = [t for t in desc.split() if 'x' in t and t.replace('x', '').isdigit()]
+            if hw and min(int(v) for v in hw[0].split('x')) >= 32:
+                split['ms'] += ms; split['flops'] += flops; split['bytes'] += nbytes; split['launches'] += 1
     dom = max(fam, key=lambda k: fam[k]['ms'])
     d = fam[dom]
     achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
@@ -253,6 +260,11 @@ def roofline_leg(gen, wl, frames=3):
                    algorithmic_bytes_per_launch=round(split['bytes'] / split['launches']),
                    launches_per_frame=split['launches'] // frames, avg_launch_us=round(split['ms'] * 1e3 / split['launches'], 2),
                    algorithmic_gflop_per_frame=round(split['flops'] / frames / 1e9, 1),
+                   all_fp16_pair_launches=dict(
+                       note='with the 8^2 / 16^2 layers (r03): the launch set of `traffic` (PMC kernel names do not separate layers)',
+                       launches_per_frame=split_all['launches'] // frames, avg_launch_us=round(split_all['ms'] * 1e3 / split_all['launches'], 2),
+                       mfma_util=round(3 * split_all['flops'] / (split_all['ms'] * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, 4),
+                       algorithmic_bytes_per_launch=round(split_all['bytes'] / split_all['launches'])),
                    whole_conv_family=dict(algorithmic_f32_tflops=round(achieved, 2), launches_per_frame=d['launches'] // frames,
                                           ms_per_frame=round(d['ms'] / frames, 3),
                                           frac_of_f32_mfma_peak=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)))
