@@ -94,3 +94,27 @@ def test_stage_inputs_host_tensors_take_the_copy_route():
     dst = [torch.zeros(3, 4), torch.zeros(2, 2)]
     hipops.stage_inputs(list(zip(src, dst)))
     assert all(torch.equal(s, d) for s, d in zip(src, dst))
+
+
+def test_compose_upfir_weight_equals_transposed_convolution_then_fir():
+    """hipops.compose_upfir_weight (host arithmetic of ia_upconv2d_fir_sx): conv2d with the composed weight + depth-to-space =
+    conv_transpose2d(stride 2) followed by upfirdn2d(filter, padding [1,1,1,1], gain 4), in fp64, for an asymmetric filter too."""
+    import torch
+    from invertavatar_amd import hipops
+    from invertavatar_amd.torch_utils.ops import upfirdn2d
+    torch.manual_seed(0)
+    x, w = torch.randn(2, 8, 9, 11, dtype=torch.float64), torch.randn(32, 8, 3, 3, dtype=torch.float64)
+    for f in (upfirdn2d.setup_filter([1, 3, 3, 1]).double(), torch.randn(4, 4, dtype=torch.float64)):
+        t = torch.nn.functional.conv_transpose2d(x, w.transpose(0, 1), stride=2)
+        # upfirdn2d(t, f, padding 1, gain 4) = correlation of the zero-padded image with the flipped filter
+        ref = torch.nn.functional.conv2d(torch.nn.functional.pad(t, [1, 1, 1, 1]).reshape(-1, 1, t.shape[2] + 2, t.shape[3] + 2),
+                                         (4 * f.flip([0, 1]))[None, None]).reshape(2, 32, 18, 22)
+        wc = hipops.compose_upfir_weight(w, f).double()          # rows ((py * O/32 + o // 32) * 2 + px) * 32 + o % 32
+        y = torch.nn.functional.conv2d(x, wc, padding=1).view(2, 2, 1, 2, 32, 9, 11)     # [b, py, block, px, o % 32, r, c]
+        y = y.permute(0, 2, 4, 5, 1, 6, 3).reshape(2, 32, 18, 22)
+        assert (y - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()      # (the composed weight is returned in fp32)
+    chk = upfirdn2d.upfirdn2d(torch.nn.functional.conv_transpose2d(x, w.transpose(0, 1), stride=2).float(),
+                              upfirdn2d.setup_filter([1, 3, 3, 1]), padding=[1, 1, 1, 1], gain=4)
+    wc = hipops.compose_upfir_weight(w, upfirdn2d.setup_filter([1, 3, 3, 1])).double()
+    y = torch.nn.functional.conv2d(x, wc, padding=1).view(2, 2, 1, 2, 32, 9, 11).permute(0, 2, 4, 5, 1, 6, 3).reshape(2, 32, 18, 22)
+    assert (y - chk.double()).abs().max().item() <= 1e-5 * chk.abs().max().item()       # and against the mirror's own upfirdn2d
