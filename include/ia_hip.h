@@ -334,7 +334,8 @@ int ia_act_split(const float* x, const float* styles, const float* shift, void* 
 
 /*
  * ia_conv2d_mfma_s on split-format activations: same layer semantics, tiles, ksplit / scratch (ia_conv2d_plan with form = 3) and
- * results of the same arithmetic (bit-identical wherever both forms use the same tile), but the operand split was done by the producer and both operands reach LDS by DMA
+ * results of the same arithmetic (the same products; since r03 the stride-1 kernels pair the odd tap of a chunk with the next chunk's
+ * instead of an all-zero tap, so the fp32 sums are added in another order: equal to summation-order level, 2e-6 of a layer's magnitude), but the operand split was done by the producer and both operands reach LDS by DMA
  * (buffer_load ... lds) instead of through registers.  Replaces the same reference chain as ia_conv2d_mfma
  * (training/networks_stylegan2.py:34-91, conv2d_resample.py:114-136) for the 3x3 layers of >= 32^2 (I % 8 == 0, O % 8 == 0).
  *   xs, planes  : input in split format, already multiplied by THIS layer's styles (there is no `styles` argument); planes = 2 with

@@ -3,7 +3,8 @@
 //
 // Same arithmetic as ia_conv2d_mfma_s (conv_mfma.hip, HM = 2): every fp32 product a*b is taken as
 // a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation, a = packed weights (hi, lo of w * 2^e),
-// b = style-scaled activation (hi, lo * 2^11); the results are bit-identical to that path.  What differs is where the split
+// b = style-scaled activation (hi, lo * 2^11): the same products as that path (the stride-1 kernels add them in another order since
+// they pair the odd tap of a chunk with the next chunk's, see PAIR below).  What differs is where the split
 // happens and how the operands reach LDS:
 //
 //   * the PRODUCER of an activation (the FIR tail of an up-sampling layer, the epilogue of the previous convolution, or the

@@ -258,7 +258,11 @@ typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
 #define IA_FIR_SETS 2
 #endif
 constexpr int kFirSets = IA_FIR_SETS;      // channels in flight per workgroup (register sets); measured r03 on the 256^2 / 512^2 layers: 2: 40.4 / 77.2 us, 3: 42.3 / 79.1, 4: 44.5 / 77.9
-__global__ __launch_bounds__(256) void fir_tail_split_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y,
+#ifndef IA_FIR_WAVES
+#define IA_FIR_WAVES 1      // minimum waves per SIMD asked of the register allocator (tools/).  108 VGPRs = 4 waves per SIMD; forcing 5 / 6 / 8
+                            // (96 / 80 / 64 VGPRs) measured 133 / 222 / 396 us against 73 on the 512^2 layer: the loads in flight need the registers
+#endif
+__global__ __launch_bounds__(256, IA_FIR_WAVES) void fir_tail_split_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y,
                                                             h16x8_t* __restrict__ ys, const float* __restrict__ styles_next, Geo g, int flip, Tail tail, int planes) {
     constexpr int FS = 4;
     constexpr int IH = TH + FS, IW = TW + FS, IWP = IW + 1, NLD = (IH * IW + 255) / 256;
