@@ -75,6 +75,13 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((v - (float)hi) * kSplitLoScale);
 }
 
+// Weight side of the pair form: hi = fp16(v), lo = fp16(v - hi), unscaled (the caller has scaled v so that both are normal numbers).
+__device__ __forceinline__ void split_f16_unscaled_lo(float v, _Float16& hi, _Float16& lo) {
+    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
 // One-plane form of the same format (fp16 operands, the arithmetic of the reference's fp16 blocks): the saturated value rounded once.
 __device__ __forceinline__ _Float16 round_f16(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
 

@@ -33,9 +33,18 @@
 // the 47-bin / 45-weight quirk of sample_importance are preserved.
 #include "ia_common.h"
 
+// IA_RENDER_F16_RGB = 1: the colour rows of layer 2 (half of the decoder's matrix work, no influence on the index buffers) form their
+// fp32 products from fp16 hi / lo pairs on v_mfma_f32_16x16x32_f16 (12 instructions of 16 pipe cycles instead of 32 of 32), issued as
+// inline assembly with their own wait states (the compiler's hazard handling around this instruction next to the fp32 MFMAs and
+// their VALU consumers produced run-to-run differences in r02).  Experimental: see DESIGN.md 4.2.
+#ifndef IA_RENDER_F16_RGB
+#define IA_RENDER_F16_RGB 0
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8r __attribute__((ext_vector_type(8)));
 
 constexpr int NS = 48;            // coarse samples == importance samples (depth_resolution[_importance])
 constexpr int NM = 2 * NS;        // merged
@@ -68,8 +77,8 @@ struct Params {
 
 // LDS image (floats)
 constexpr int A1_OFF = 0;                       // [4 tiles][8 ksteps][64 lanes]
-constexpr int A2_OFF = A1_OFF + 4 * 8 * 64;     // [2 tiles][16 ksteps][64 lanes]
-constexpr int WS_OFF = A2_OFF + 2 * 16 * 64;    // [16 ksteps][4 quarters]   density row of layer 2
+constexpr int A2_OFF = A1_OFF + 4 * 8 * 64;     // [2 tiles][16 ksteps][64 lanes]; IA_RENDER_F16_RGB: [3 variants][2 tiles][2 k-halves][64 lanes] x 8 halves
+constexpr int WS_OFF = A2_OFF + (IA_RENDER_F16_RGB ? 12 * 64 * 4 : 2 * 16 * 64);    // [16 ksteps][4 quarters]   density row of layer 2
 constexpr int B0_OFF = WS_OFF + 64;             // [64]
 constexpr int B1_OFF = B0_OFF + 64;             // [33] (+pad)
 constexpr int SCR_OFF = B1_OFF + 40;            // per-wave scratch
@@ -236,10 +245,80 @@ __device__ __forceinline__ float decoder_sigma(const float* __restrict__ lds, in
     return part + lds[B1_OFF];
 }
 
+#if IA_RENDER_F16_RGB
+// One product term of the pair form for both colour tiles and both k-halves: acc[U][j] += A_v[U][j] * B[j].  Four independent
+// accumulators, so no MFMA of a block depends on another; wait states around the block by hand (VALU-written operands before,
+// VALU readers of the accumulators after).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#ifndef IA_RENDER_F16_NOPS
+#define IA_RENDER_F16_NOPS 1      // 1: two s_nop 15 after every block; 0: one s_nop 15 after the last block only
+#endif
+template <bool LAST>
+__device__ __forceinline__ void rgb_pair_block(const h16x8r* __restrict__ A, int v, int lane, const h16x8r (&b)[2], f32x4 (&acc)[2][2]) {
+    const h16x8r a00 = A[((v * 2 + 0) * 2 + 0) * 64 + lane], a01 = A[((v * 2 + 0) * 2 + 1) * 64 + lane];
+    const h16x8r a10 = A[((v * 2 + 1) * 2 + 0) * 64 + lane], a11 = A[((v * 2 + 1) * 2 + 1) * 64 + lane];
+    if (IA_RENDER_F16_NOPS)
+        asm volatile("s_nop 4\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
+                     "v_mfma_f32_16x16x32_f16 %1, %5, %9, %1\n\t"
+                     "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"
+                     "v_mfma_f32_16x16x32_f16 %3, %7, %9, %3\n\t"
+                     "s_nop 15\n\t"
+                     "s_nop 15"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+                     : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b[0]), "v"(b[1]));
+    else if (LAST)
+        asm volatile("s_nop 1\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
+                     "v_mfma_f32_16x16x32_f16 %1, %5, %9, %1\n\t"
+                     "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"
+                     "v_mfma_f32_16x16x32_f16 %3, %7, %9, %3\n\t"
+                     "s_nop 15"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+                     : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b[0]), "v"(b[1]));
+    else
+        asm volatile("s_nop 1\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
+                     "v_mfma_f32_16x16x32_f16 %1, %5, %9, %1\n\t"
+                     "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"
+                     "v_mfma_f32_16x16x32_f16 %3, %7, %9, %3"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+                     : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b[0]), "v"(b[1]));
+}
+#pragma clang diagnostic pop
+#endif
+
 // Colours: output rows 1..32 of layer 2 on MFMA.  c[U][r] = channel 16U + 4q + r of this lane's sample.
 __device__ __forceinline__ void decoder_rgb(const float* __restrict__ lds, int lane, int q, const f32x4 (&h)[4], f32x4 (&c)[2]) {
     c[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     c[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if IA_RENDER_F16_RGB
+    // B operands: k-half j of this lane = hidden units 16T + 4q + r for T = 2j, 2j + 1 (8 values), as hi and lo * 2^11 halves
+    h16x8r bh[2], bl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 hi, lo;
+            ia::split_f16(h[2 * j + (e >> 2)][e & 3], hi, lo);
+            bh[j][e] = hi; bl[j][e] = lo;
+        }
+    const h16x8r* A = reinterpret_cast<const h16x8r*>(lds + A2_OFF);     // variants: 0 = hi, 1 = lo, 2 = hi * 2^-11 of w * 2^e
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int U = 0; U < 2; ++U)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[U][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    rgb_pair_block<false>(A, 1, lane, bh, acc);      // lo * hi
+    rgb_pair_block<false>(A, 2, lane, bl, acc);      // (hi * 2^-11) * (lo * 2^11)
+    rgb_pair_block<true>(A, 0, lane, bh, acc);       // hi * hi
+    const float back = lds[B1_OFF + 36];      // 2^-e
+#pragma unroll
+    for (int U = 0; U < 2; ++U)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[U][r] = (acc[U][0][r] + acc[U][1][r]) * back;
+#else
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -247,6 +326,7 @@ __device__ __forceinline__ void decoder_rgb(const float* __restrict__ lds, int l
 #pragma unroll
             for (int U = 0; U < 2; ++U)
                 c[U] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[A2_OFF + (U * 16 + T * 4 + r) * 64 + lane], h[T][r], c[U], 0, 0, 0);
+#endif
 #pragma unroll
     for (int U = 0; U < 2; ++U)
 #pragma unroll
@@ -385,10 +465,36 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         const int l = e & 63, t = (e >> 6) & 7, T = e >> 9;
         lds[A1_OFF + e] = p.w0[(16 * T + (l & 15)) * 32 + 8 * (l >> 4) + t] * p.w0_gain;
     }
+#if IA_RENDER_F16_RGB
+    {
+        // power of two that takes the largest colour weight to <= 32768 (fp16 range, denormal-free low parts; conv_split.hip's scheme)
+        float mx = 0.f;
+        for (int i = lane; i < 32 * 64; i += 64) mx = fmaxf(mx, fabsf(p.w1[64 + i] * p.w1_gain));
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        int ew = (mx > 0.f && mx < INFINITY) ? (int)floorf(log2f(32768.f / mx)) : 0;
+        ew = min(max(ew, -14), 30);
+        const float up = ldexpf(1.f, ew);
+        if (tid == 0) lds[B1_OFF + 36] = ldexpf(1.f, -ew);
+        h16x8r* A = reinterpret_cast<h16x8r*>(lds + A2_OFF);
+        for (int e = tid; e < 12 * 64; e += WAVES * 64) {
+            const int l = e & 63, frag = e >> 6, j = frag & 1, U = (frag >> 1) & 1, v = frag >> 2;
+            h16x8r out;
+#pragma unroll
+            for (int ee = 0; ee < 8; ++ee) {
+                const int unit = 16 * (2 * j + (ee >> 2)) + 4 * (l >> 4) + (ee & 3);
+                _Float16 hi, lo;
+                ia::split_f16_unscaled_lo(p.w1[(1 + 16 * U + (l & 15)) * 64 + unit] * p.w1_gain * up, hi, lo);
+                out[ee] = v == 0 ? hi : v == 1 ? lo : (_Float16)(hi * (_Float16)(1.f / 2048.f));
+            }
+            A[e] = out;
+        }
+    }
+#else
     for (int e = tid; e < 2 * 16 * 64; e += WAVES * 64) {
         const int l = e & 63, k = (e >> 6) & 15, U = e >> 10;     // k = T*4 + r
         lds[A2_OFF + e] = p.w1[(1 + 16 * U + (l & 15)) * 64 + 16 * (k >> 2) + 4 * (l >> 4) + (k & 3)] * p.w1_gain;
     }
+#endif
     if (tid < 64) {
         const int k = tid >> 2, qq = tid & 3;
         lds[WS_OFF + tid] = p.w1[16 * (k >> 2) + 4 * qq + (k & 3)] * p.w1_gain;
