@@ -286,6 +286,39 @@ def test_split_dma_convolution_equals_the_register_staged_form(i, o, h, w, tr, b
     assert torch.equal(only_s.data, got_s.data)
 
 
+@pytest.mark.parametrize('b,i,o,res,tr', [(1, 512, 512, 8, False), (2, 512, 512, 16, False), (1, 256, 128, 16, False), (1, 512, 512, 8, True),
+                                          (2, 512, 512, 16, True), (1, 64, 64, 16, True)])
+def test_split_dma_convolution_on_the_small_layers(b, i, o, res, tr):
+    """r03: the 8^2 / 16^2 layers run on the fp16-pair tiles too (wide tile cut between stream-K workers; 64 x 64 transposed tile):
+    against the fp64 convolution of the operands the kernel sees, with the epilogue and the split second output (stride 1)."""
+    assert hipops.conv_sx_supported(i, o, res, res, 3, tr)
+    g = torch.Generator(device='cuda').manual_seed(17 + i + res)
+    x = torch.randn(b, i, res, res, device='cuda', generator=g) * 2
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g)
+    s = torch.rand(b, i, device='cuda', generator=g) + 0.5
+    sn = torch.rand(b, o, device='cuda', generator=g) + 0.5
+    d = hipops.modconv_demod(s, hipops.weight_sq_sum(wt))
+    xs = hipops.act_split(x, s)
+    wk = hipops.pack_conv_weight_split(wt)
+    xv = xs.float().double()
+    if tr:
+        got = hipops.conv2d_mfma_sx(xs, wk, demod=d, transposed=True)
+        ref = torch.nn.functional.conv_transpose2d(xv, wt.double().transpose(0, 1), stride=2) * d.double()[:, :, None, None]
+        assert got.shape == ref.shape and (got.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+        assert torch.equal(got, hipops.conv2d_mfma_sx(xs, wk, demod=d, transposed=True))          # stream-K + fix-up: deterministic
+        return
+    bias = torch.randn(o, device='cuda', generator=g)
+    noise = torch.randn(res * res, device='cuda', generator=g)
+    ns = torch.full((1,), 0.3, device='cuda')
+    got, got_s = hipops.conv2d_mfma_sx(xs, wk, demod=d, noise=noise, noise_strength=ns, bias=bias, act='lrelu', gain=1.3, styles_next=sn)
+    ref = torch.nn.functional.conv2d(xv, wt.double(), padding=1) * d.double()[:, :, None, None] + (noise.double() * 0.3).view(1, 1, res, res)
+    ref = torch.nn.functional.leaky_relu(ref + bias.double()[None, :, None, None], 0.2) * 1.3
+    assert (got.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+    hi, lo = _split_reference(got, sn)
+    assert torch.equal(got_s.data[:, 0].permute(0, 1, 4, 2, 3).reshape(got.shape), hi)
+    assert torch.equal(got_s.data[:, 1].permute(0, 1, 4, 2, 3).reshape(got.shape), lo)
+
+
 @pytest.mark.parametrize('b,i,o,res,planes', [(1, 32, 256, 128, 2), (2, 16, 256, 64, 2), (1, 8, 128, 128, 2), (1, 32, 256, 128, 1)])
 def test_composed_upfir_layer_equals_the_two_launch_route(b, i, o, res, planes):
     """ia_upconv2d_fir_sx (transposed convolution + resample FIR + noise + bias + lrelu as ONE stride-1 launch on the composed weight,
