@@ -31,6 +31,9 @@ from .volumetric_rendering.ray_sampler import RaySampler, RaySampler_zxc  # noqa
 BBOX_256 = [57, 185, 64, 192]   # face region of the frontal plane, in 256^2 pixels (triplane_v20.py:114)
 N_COND_LEVELS_USED = 4          # cond_list entries the face backbone consumes
 CL_COPIES_ON_TEXTURE_STREAM = __import__('os').environ.get('IA_CL_ON_TEX', '1') == '1'   # False: the rasteriser's stream makes them (ia_rasterize_level's own copy)
+FACE_HEAD_AFTER_BACKBONES = __import__('os').environ.get('IA_FACE_HEAD_LATE', '0') == '1'   # launch order experiment (tools/ab_frame.py)
+LAUNCH_ORDER = __import__('os').environ.get('IA_LAUNCH_ORDER', 'default')                    # 'face_first', 'static_first'
+
 SINGLE_STREAM = False           # True: no side streams (every launch of a frame in program order on the caller's stream); used by
                                 # bench.py to time kernels without neighbours from other streams
 
@@ -154,6 +157,11 @@ class TriPlaneGenerator(torch.nn.Module):
             if CL_COPIES_ON_TEXTURE_STREAM:
                 make_cl(feats)
             ev_tex[len(feats)].record(t_stream)
+        static_feats = None
+        if partial and LAUNCH_ORDER == 'static_first':      # (launch-order experiment: the static backbone queued ahead of the texture one)
+            s_stream.wait_stream(main)
+            with torch.cuda.stream(s_stream):
+                static_feats = sta(_tap=(counts, lambda feats: ev_sta[len(feats)].record(s_stream)))
         t_stream.wait_stream(main)
         with torch.cuda.stream(t_stream):
             if partial:
@@ -162,9 +170,10 @@ class TriPlaneGenerator(torch.nn.Module):
                 texture_feats = tex()
                 make_cl(texture_feats)
         if partial:
-            s_stream.wait_stream(main)
-            with torch.cuda.stream(s_stream):
-                static_feats = sta(_tap=(counts, lambda feats: ev_sta[len(feats)].record(s_stream)))
+            if static_feats is None:
+                s_stream.wait_stream(main)
+                with torch.cuda.stream(s_stream):
+                    static_feats = sta(_tap=(counts, lambda feats: ev_sta[len(feats)].record(s_stream)))
             pending = (t_stream, s_stream, ev_tex, ev_sta)
         else:
             static_feats = sta()
@@ -318,14 +327,18 @@ class TriPlaneGenerator(torch.nn.Module):
     # ------------------------------------------------------------------ public synthesis entry points
     def synthesis(self, ws, c, mesh_condition, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
                   use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, ray_dist=None, **synthesis_kwargs):
+        face_head = self._start_face_head(ws, update_emas, synthesis_kwargs) if LAUNCH_ORDER == 'face_first' else None
         mouth = self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, ray_dist))
-        face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
+        if face_head is None and not FACE_HEAD_AFTER_BACKBONES:
+            face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
         side_rays = _state(self).side_rays
         if side_rays is not None:            # made on the side stream; joined with the mouth fill inside rasterize()
             origins, dirs, nrr, ray_dist = side_rays
         else:
             origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
         texture_feats, static_feats, pending = self._two_backbones(ws, update_emas, synthesis_kwargs, partial=True)
+        if FACE_HEAD_AFTER_BACKBONES:        # (queued behind the two backbones whose taps the rasteriser waits for)
+            face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
         planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, mouth=mouth,
                               face_head=face_head, pending=pending)
         image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist)
