@@ -132,22 +132,46 @@ def _materialize(obj):
 
 
 class _Unpickler(pickle.Unpickler):
+    """Resolves only (a) classes DEFINED in this package's mirror of the reference's module paths, (b) torch.nn layer classes,
+    (c) the reconstruction helpers of _SAFE_GLOBALS.  Names are never walked: protocol >= 4 lets a pickle name
+    'module', 'attr.attr.attr' and pickle.Unpickler.find_class follows the dots through whatever the module imported
+    ('invertavatar_amd.hipops', '_os.system'), so a dotted name is refused outright and a resolved object must be a class
+    whose __module__ lies below the prefix it was asked for (an imported `os`, `subprocess`, `importlib` never qualifies)."""
+
+    @staticmethod
+    def _class_defined_below(module, name, prefix):
+        try:
+            obj = getattr(importlib.import_module(module), name)
+        except (ImportError, AttributeError):
+            return None
+        owner = getattr(obj, '__module__', None)
+        if isinstance(obj, type) and isinstance(owner, str) and (owner == prefix or owner.startswith(prefix + '.')):
+            return obj
+        return None
+
     def find_class(self, module, name):
+        if '.' in name:
+            raise pickle.UnpicklingError(f'dotted global {module}:{name} is refused by the network-pickle loader')
         if module == 'torch_utils.persistence' and name == '_reconstruct_persistent_obj':
             return _reconstruct_persistent_obj
         if module == 'dnnlib.tflib.network':
             raise pickle.UnpicklingError('TensorFlow-era StyleGAN pickles are outside this backend (legacy.py:27-33 converts them in the reference)')
         if module.split('.')[0] == 'dnnlib':
-            return getattr(dnnlib.util, name)
-        try:    # classes pickled by reference to a module path of the reference repository: this package mirrors the paths
-            return getattr(importlib.import_module(f'{_PACKAGE}.{module}'), name)
-        except (ImportError, AttributeError):
-            pass
+            if name != 'EasyDict':
+                raise pickle.UnpicklingError(f'global {module}.{name} is not on the allow-list of the network-pickle loader')
+            return dnnlib.util.EasyDict
+        own = module == _PACKAGE or module.startswith(_PACKAGE + '.')       # (pickles written by this backend itself)
+        # classes pickled by reference to a module path of the reference repository: this package mirrors the paths
+        cls = self._class_defined_below(module if own else f'{_PACKAGE}.{module}', name, _PACKAGE)
+        if cls is not None:
+            return cls
+        if module.startswith('torch.nn.modules.'):                            # plain torch.nn layers inside non-persistent networks
+            cls = self._class_defined_below(module, name, 'torch.nn.modules')
+            if cls is not None and issubclass(cls, torch.nn.Module):
+                return cls
         # Everything else must be on the allow-list of reconstruction helpers a network pickle legitimately needs: a pickle that
         # names any other global (os.system, builtins.eval, subprocess ...) is refused instead of resolved.
-        own = module == _PACKAGE or module.startswith(_PACKAGE + '.')       # (pickles written by this backend itself)
-        layers = module.startswith('torch.nn.modules.')                       # plain torch.nn layers inside non-persistent networks
-        if own or layers or (module, name) in _SAFE_GLOBALS or (module in ('torch', 'torch.storage') and name.endswith('Storage')):
+        if (module, name) in _SAFE_GLOBALS or (module in ('torch', 'torch.storage') and name.endswith('Storage')):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f'global {module}.{name} is not on the allow-list of the network-pickle loader')
 
