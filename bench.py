@@ -284,6 +284,30 @@ def roofline_leg(gen, wl, frames=3):
     return out, others
 
 
+def host_physical_cores():
+    """Physical cores this process may run on: distinct (package, core) pairs of the CPUs in the affinity mask, capped by the
+    cgroup CPU quota.  SMT siblings and CPUs outside the mask / quota only oversubscribe the torch-CPU path (r03: 256 logical
+    CPUs = 147 s per frame)."""
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in cpus:
+        try:
+            base = f'/sys/devices/system/cpu/cpu{c}/topology/'
+            with open(base + 'physical_package_id') as f, open(base + 'core_id') as g:
+                cores.add((f.read().strip(), g.read().strip()))
+        except OSError:
+            cores.add(('cpu', str(c)))
+    n = max(1, len(cores))
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline_leg(gen, wl, frames):
     """The oracle (test infrastructure: CPU restatement of the reference's torch op path) on the host cores, on a bounded
     sample of the workload; the same frames rendered by the device path give max |dRGB| (BASELINE metric, second half).
@@ -292,47 +316,59 @@ def cpu_baseline_leg(gen, wl, frames):
     from oracle import generator as OG
     sd = {k: v.detach().cpu() for k, v in gen.state_dict().items()}
     ws_c = wl.ws.cpu()
-    cores = min(torch.get_num_threads(), 32)     # the torch-CPU path stops scaling (and oversubscribes) beyond ~32 threads
-    torch.set_num_threads(cores)
+    cores = host_physical_cores()                # all physical cores the process may run on, stated in the line
     sets = [(i + 1) % wl.n_sets for i in range(frames)]
 
     def oracle(s):
         return OG.synthesis(sd, ws_c, wl.cams[s].cpu(), wl.uvs[s].cpu(), wl.jits[s].cpu().unsqueeze(-1), nrr=NRR)
-    oracle(0)   # warm
-    t0 = time.perf_counter()
-    refs = [oracle(s) for s in sets]
-    dt = time.perf_counter() - t0
+
+    def oracle_rate(n_thr, n_frames):
+        """(frames/s, results) at n_thr threads: one warm-up frame, then n_frames timed; a warm-up frame slower than 12 s ends the
+        point there (the torch-CPU path stops scaling beyond ~32 threads: the bounded sample must stay bounded)."""
+        torch.set_num_threads(n_thr)
+        t0 = time.perf_counter()
+        oracle(0)
+        warm = time.perf_counter() - t0
+        if warm > 12.0:
+            return 1.0 / warm, None
+        t0 = time.perf_counter()
+        refs = [oracle(s) for s in sets[:n_frames]]
+        return n_frames / (time.perf_counter() - t0), refs
+    rate, refs = oracle_rate(cores, frames)
+    by_threads = {str(cores): round(rate, 4)}
+    for n_thr in sorted({8, 32} - {cores}):
+        if n_thr < cores:
+            r_n, refs_n = oracle_rate(n_thr, 1 if refs is not None else frames)
+            by_threads[str(n_thr)] = round(r_n, 4)
+            refs = refs if refs is not None else refs_n
+    torch.set_num_threads(cores)
     err_rgb = err_raw = 0.0
     for s, ref in zip(sets, refs):
         out = wl.eager(gen, s)
         err_rgb = max(err_rgb, (out['image'].cpu() - ref['image']).abs().max().item())
         err_raw = max(err_raw, (out['image_raw'].cpu() - ref['image_raw']).abs().max().item())
-    base = dict(value=round(frames / dt, 4), unit='frames/s', cores=cores, kind='port',
+    base = dict(value=round(rate, 4), unit='frames/s', cores=cores, kind='port',
                 sample=f'{frames} frames of the same workload (B=1, nrr={NRR}, 512^2 out, fp32) after 1 warm-up frame',
-                note='oracle/ restates the reference op by op for checking, not for speed; see product_cpu_route for the reference\'s own CPU route')
+                frames_per_s_by_threads=by_threads, logical_cores_of_this_box=os.cpu_count(),
+                note='cores = physical cores this process may run on; oracle/ restates the reference op by op for checking, not for '
+                     'speed; see product_cpu_route for the reference\'s own CPU route')
     try:   # the product's CPU formulation = the reference's pure-PyTorch route (not the measured product path)
         gen_c = TriPlaneGenerator(**gen.init_kwargs).eval().requires_grad_(False)
         gen_c.load_state_dict(sd)
         call = lambda s: gen_c.synthesis(ws_c, wl.cams[s].cpu(), {'uvcoords_image': wl.uvs[s].cpu()}, neural_rendering_resolution=NRR,   # noqa: E731
                                          noise_mode='const', evaluation=True, jitter=wl.jits[s].cpu())
-        call(0)
-        t0 = time.perf_counter()
-        for s in sets[:2]:
-            call(s)
-        base['product_cpu_route'] = dict(value=round(2 / (time.perf_counter() - t0), 4), unit='frames/s', cores=cores,
-                                         sample='2 frames after 1 warm-up frame',
-                                         survey_container_8_cores=0.34)
-        # the same route at n = 8 threads (the survey container's core count) and on every logical core of this box
         by_threads = {}
-        for n_thr in sorted({8, os.cpu_count() or cores}):
+        for n_thr in sorted({8, 32, cores}):     # SURVEY 8(d): n = 8 is the survey container's core count (0.34 frames/s there)
+            if n_thr > cores:
+                continue
             torch.set_num_threads(n_thr)
             call(sets[0])
             t0 = time.perf_counter()
-            call(sets[1])
+            call(sets[-1])
             by_threads[str(n_thr)] = round(1 / (time.perf_counter() - t0), 4)
         torch.set_num_threads(cores)
-        base['product_cpu_route']['frames_per_s_by_threads'] = by_threads
-        base['product_cpu_route']['logical_cores_of_this_box'] = os.cpu_count()
+        base['product_cpu_route'] = dict(value=by_threads[str(cores)], unit='frames/s', cores=cores, sample='1 frame after 1 warm-up frame',
+                                         survey_container_8_cores=0.34, frames_per_s_by_threads=by_threads)
     except Exception as exc:   # noqa: BLE001
         base['product_cpu_route'] = f'failed: {exc}'
     return base, dict(max_abs_rgb_vs_oracle=float(f'{err_rgb:.3e}'), max_abs_raw_rgb_vs_oracle=float(f'{err_raw:.3e}'),

@@ -254,6 +254,16 @@ int ia_importance_stage(const float* z_coarse, const float* w_coarse, float* z_f
 int ia_fill_mouth(const float* alpha, float* mouth, int B, int H, int W, void* stream);
 
 /*
+ * The soft mouth mask of fill_mouth(images, blur_mouth_edge=True) -- the function's default -- from ia_fill_mouth's result
+ * (renderer.py:732-736): copyImg = cv2.blur(cv2.erode(filled, ones(3,3), iterations=3), (5,5));  out = (255 - copyImg) / 255,
+ * where filled = 255 on reached pixels (mouth == 0) and alpha*255 elsewhere.  cv2 semantics restated (OpenCV 4.6 is not in
+ * this image: parity unpinned by reference tests): erosion border = +inf, box filter on CV_32F sums in double, multiplies by
+ * the double 1/25, rounds to float, border BORDER_REFLECT_101.
+ *   alpha, mouth, out : [B, H, W] float32 contiguous, H, W >= 3.
+ */
+int ia_mouth_edge_blur(const float* alpha, const float* mouth, float* out, int B, int H, int W, void* stream);
+
+/*
  * One pyramid level of TriPlaneGenerator.rasterize (training_avatar_texture/triplane_v20.py:328-337) in one pass:
  *     out[:, :C] = AA(grid_sample(texture, uv)) * AA(alpha) + AA(static[:, :, bbox]) * (1 - AA(alpha));  out[:, C] = AA(upper_alpha)
  * where AA = F.interpolate(bilinear, antialias=True) to res x res and grid_sample = bilinear / zeros / align_corners False.

@@ -41,6 +41,7 @@ _SIGNATURES = {
     'ia_render_rays_grid': [c_int, c_int],
     'ia_importance_stage': [c_void_p] * 5 + [c_int, c_void_p],
     'ia_fill_mouth': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    'ia_mouth_edge_blur': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'ia_conv2d_mfma_sx_rgb': [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6 + [c_int] + [c_void_p] * 6 + [c_int, c_float] + [c_int] * 6 + [c_float] * 3 + [c_void_p],
     'ia_conv1x1': [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p],
     'ia_torgb_supported': [c_int] * 5,

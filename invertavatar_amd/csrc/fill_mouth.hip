@@ -153,7 +153,74 @@ __global__ __launch_bounds__(kN) void fill_mouth256_kernel(const float* __restri
     }
 }
 
+// ---- blur_mouth_edge=True (renderer.py:732-734): copyImg = cv2.blur(cv2.erode(copyImg, ones(3,3), iterations=3), (5,5)) on the filled
+// float image (255 where the flood reached, alpha*255 elsewhere), then (255 - copyImg) / 255.  Three 3x3 erosions are one 7x7 minimum
+// (border pixels see +inf: cv2's morphologyDefaultBorderValue); the normalised 5x5 box filter of a CV_32F image sums in double and
+// multiplies by the double 1/25 before rounding to float (boxFilter: sumType CV_64F), border BORDER_REFLECT_101.
+// A workgroup owns a 32 x 32 output tile: filled image with a 5-pixel halo -> LDS, 7x7 minimum with a 2-pixel halo -> LDS, box sum.
+constexpr int kET = 32, kEH = kET + 10, kEM = kET + 4;
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void mouth_edge_kernel(const float* __restrict__ alpha, const float* __restrict__ mouth,
+                                                         float* __restrict__ out, int H, int W) {
+    __shared__ float filled[kEH * kEH];      // image coordinates (ty0 - 5 + r, tx0 - 5 + c); +inf outside the image
+    __shared__ float eroded[kEM * kEM];      // image coordinates (ty0 - 2 + r, tx0 - 2 + c)
+    const int64_t img = (int64_t)blockIdx.z * H * W;
+    const int ty0 = blockIdx.y * kET, tx0 = blockIdx.x * kET;
+    // The box filter reads the eroded image at reflected coordinates; with H, W >= 3 a reflected index stays within 2 pixels of the
+    // border it left, i.e. inside the tile's own halo range only for interior tiles -- so eroded[] is evaluated AT the reflected
+    // coordinate (its 7x7 window is fetched through `at`), never assumed to sit in the neighbouring slot.
+    auto at = [&](int y, int x) -> float {
+        if (y < 0 || y >= H || x < 0 || x >= W) return __builtin_inff();
+        const int64_t i = img + (int64_t)y * W + x;
+        return mouth[i] == 0.f ? 255.f : alpha[i] * 255.f;
+    };
+    for (int i = threadIdx.x; i < kEH * kEH; i += 256) filled[i] = at(ty0 - 5 + i / kEH, tx0 - 5 + i % kEH);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kEM * kEM; i += 256) {
+        const int r = i / kEM, c = i % kEM;
+        const int y = ty0 - 2 + r, x = tx0 - 2 + c;
+        const int yr = reflect101(y, H), xr = reflect101(x, W);
+        float m = __builtin_inff();
+        if (yr == y && xr == x) {
+            for (int dy = 0; dy < 7; ++dy)
+                for (int dx = 0; dx < 7; ++dx) m = fminf(m, filled[(r + dy) * kEH + c + dx]);
+        } else {                                  // a reflected border sample: its own window, from memory
+            for (int dy = -3; dy <= 3; ++dy)
+                for (int dx = -3; dx <= 3; ++dx) m = fminf(m, at(yr + dy, xr + dx));
+        }
+        eroded[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kET * kET; i += 256) {
+        const int r = i / kET, c = i % kET;
+        const int y = ty0 + r, x = tx0 + c;
+        if (y >= H || x >= W) continue;
+        double sum = 0.0;
+        for (int dx = 0; dx < 5; ++dx) {          // row sums first, then the column of row sums (RowSum / ColumnSum order; exact in double)
+            double col = 0.0;
+            for (int dy = 0; dy < 5; ++dy) col += (double)eroded[(r + dy) * kEM + c + dx];
+            sum += col;
+        }
+        const float blurred = (float)(sum * (1.0 / 25.0));
+        out[img + (int64_t)y * W + x] = (255.f - blurred) / 255.f;
+    }
+}
+
 }  // namespace
+
+extern "C" int ia_mouth_edge_blur(const float* alpha, const float* mouth, float* out, int B, int H, int W, void* stream) {
+    IA_REQUIRE(alpha && mouth && out, "null pointer argument");
+    IA_REQUIRE(B > 0 && H >= 3 && W >= 3, "mask must be at least 3 x 3");
+    hipLaunchKernelGGL(mouth_edge_kernel, dim3((W + kET - 1) / kET, (H + kET - 1) / kET, B), dim3(256), 0, (hipStream_t)stream,
+                       alpha, mouth, out, H, W);
+    return ia::check_launch("ia_mouth_edge_blur");
+}
 
 extern "C" int ia_fill_mouth(const float* alpha, float* mouth, int B, int H, int W, void* stream) {
     IA_REQUIRE(alpha && mouth, "null pointer argument");

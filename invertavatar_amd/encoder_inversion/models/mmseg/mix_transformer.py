@@ -101,7 +101,7 @@ class Attention(nn.Module):
     def forward(self, x, H, W):
         B, N, C = x.shape
         heads, hd = self.num_heads, C // self.num_heads
-        q = self.q(x).reshape(B, N, heads, hd).permute(0, 2, 1, 3)
+        qp = self.q(x)
         src = x
         if self.sr_ratio > 1:
             src = self.norm(self.sr(x.permute(0, 2, 1).reshape(B, C, H, W)).reshape(B, C, -1).permute(0, 2, 1))
@@ -109,8 +109,9 @@ class Attention(nn.Module):
         if (HIP_ATTENTION and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not (self.training and self.attn_drop.p > 0)):
             from .... import _lib, hipops
             if _lib.load().ia_attention_supported(hd, N, kv.shape[1]):      # one launch: no [N, M] score matrix, no head permutes
-                out = hipops.attention(self.q(x).contiguous(), kv.contiguous(), heads, self.scale)
+                out = hipops.attention(qp.contiguous(), kv.contiguous(), heads, self.scale)
                 return self.proj_drop(self.proj(out))
+        q = qp.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
         k, v = kv.reshape(B, -1, 2, heads, hd).permute(2, 0, 3, 1, 4)
         attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1))
         return self.proj_drop(self.proj((attn @ v).transpose(1, 2).reshape(B, N, C)))

@@ -53,7 +53,8 @@ def unit_supported(unit, x):
     conv1, conv2 = unit.res_layer[1], unit.res_layer[3]
     i, o = conv1.in_channels, conv1.out_channels
     h, w = x.shape[-2:]
-    return (conv1.kernel_size == (3, 3) and conv2.kernel_size == (3, 3) and conv1.stride == (1, 1) and conv2.stride in ((1, 1), (2, 2))
+    plain = all(c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == 'zeros' for c in (conv1, conv2))
+    return (plain and conv1.kernel_size == (3, 3) and conv2.kernel_size == (3, 3) and conv1.stride == (1, 1) and conv2.stride in ((1, 1), (2, 2))
             and conv1.bias is None and conv2.bias is None and i % 8 == 0 and o % 8 == 0 and o >= 64 and h * w >= 1024 and w <= 320
             and conv2.in_channels == o and conv2.out_channels == o)
 
@@ -99,7 +100,7 @@ def se_tail(unit, v, x):
 def conv_supported(conv, h, w):
     """A torch.nn.Conv2d(3x3, stride 1, padding 1) whose shape ia_conv2d_mfma_sx takes (8-wave tile: >= 1024 points, >= 64 outputs)."""
     return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
-            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros' and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0
             and conv.out_channels >= 64 and h * w >= 1024 and w <= 320)
 
 
@@ -141,11 +142,13 @@ def double_conv_forward(dc, x):
     b = x.shape[0]
     if bn.training or not bn.track_running_stats:
         var, mean = torch.var_mean(x, dim=(0, 2, 3), unbiased=False)
-        if bn.track_running_stats and bn.momentum is not None:      # the side effect of a train-mode call (torch.nn.BatchNorm2d)
+        if bn.track_running_stats and bn.running_mean is not None:  # the side effect of a train-mode call (torch.nn.BatchNorm2d)
             n = x.numel() / x.shape[1]
-            bn.running_mean.lerp_(mean, bn.momentum)
-            bn.running_var.lerp_(var * (n / max(n - 1, 1)), bn.momentum)
             bn.num_batches_tracked += 1
+            # momentum=None is the cumulative moving average: factor 1 / num_batches_tracked (torch/nn/modules/batchnorm.py)
+            factor = bn.momentum if bn.momentum is not None else 1.0 / bn.num_batches_tracked.to(mean.dtype)
+            bn.running_mean.lerp_(mean, factor)
+            bn.running_var.lerp_(var * (n / max(n - 1, 1)), factor)
     else:
         var, mean = bn.running_var, bn.running_mean
     a = bn.weight.detach().float() * torch.rsqrt(var.float() + bn.eps)

@@ -36,14 +36,15 @@ class ConvGRU(torch.nn.Module):
     def _hip_convs(self, x):
         """The cell's two 3x3 convolutions on ia_conv2d_mfma_sx (fp32 products from fp16 hi / lo pairs) instead of the library:
         from 32^2 up (the 8-wave tile needs 1024 points), channel counts in units of 8.  Packed weights are cached per cell."""
-        conv_ih = self.ih[0]
+        conv_ih, conv_hh = self.ih[0], self.hh[0]
         c2, h, w = conv_ih.in_channels, x.shape[-2], x.shape[-1]
-        if not (HIP_GRU_CONVS and conv_ih.kernel_size == (3, 3) and conv_ih.padding == (1, 1) and c2 % 16 == 0 and self.channels >= 64
+        plain = all(c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride == (1, 1) and c.dilation == (1, 1) and c.groups == 1
+                    and c.padding_mode == 'zeros' and c.bias is not None for c in (conv_ih, conv_hh))
+        if not (HIP_GRU_CONVS and plain and c2 % 16 == 0 and conv_hh.in_channels == c2 and self.channels >= 64
                 and h * w >= 1024 and w <= 320):
             return None
         from ... import _runtime, hipops
         st = _runtime.state(self)
-        conv_hh = self.hh[0]
         key = tuple((t.data_ptr(), t._version) for t in (conv_ih.weight, conv_hh.weight)) + (conv_ih.weight.device,)
         if getattr(st, 'gru_key', None) != key:
             st.gru_w = (hipops.pack_conv_weight_split(conv_ih.weight.detach().float()), hipops.pack_conv_weight_split(conv_hh.weight.detach().float()))

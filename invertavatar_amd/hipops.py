@@ -633,6 +633,17 @@ def fill_mouth(alpha):
     return mouth
 
 
+def mouth_edge_blur(alpha, mouth):
+    """alpha, mouth (= fill_mouth(alpha)) [B,1,H,W] -> the eroded + blurred mouth mask [B,1,H,W] (see ia_mouth_edge_blur)."""
+    _f32c(alpha, 'alpha'); _f32c(mouth, 'mouth')
+    b, one, h, w = alpha.shape
+    out = torch.empty_like(alpha)
+    with torch.cuda.device(alpha.device):
+        st = _lib.load().ia_mouth_edge_blur(_p(alpha), _p(mouth), _p(out), b * one, h, w, _lib.stream_ptr(alpha.device))
+    _lib.check(st, 'ia_mouth_edge_blur')
+    return out
+
+
 def rasterize_level(tex, uvcoords_image, upper_alpha, sta, bbox, res, tex_cl=None):
     """One level of TriPlaneGenerator.rasterize (see ia_rasterize_level).  tex [B,C,Rt,Rt]; sta NCHW (may be a channel
     slice of a wider tensor as long as channels/rows are dense); returns [B, C+1, res, res].  `tex_cl` is the level

@@ -235,14 +235,29 @@ class ImportanceRenderer_bsMotion(_RendererBase):
 def fill_mouth(images, blur_mouth_edge=True):
     """Close the mouth hole of a rasterised face mask: every background region NOT connected to the image
     corner becomes foreground.  images [B,1,H,W] in {0,1}.  Returns (filled alpha, mouth mask) (renderer.py:716-741).
-    Device tensors: ``ia_fill_mouth``; CPU tensors: breadth-first flood fill in NumPy."""
-    if blur_mouth_edge:
-        raise NotImplementedError('blur_mouth_edge=True (cv2.erode + cv2.blur) is not on the v20 generator path')
+    With ``blur_mouth_edge`` (the signature's default; the v20 generator passes False, triplane_v20.py:74,323) the returned mask is
+    eroded three times and box-blurred (:732-736).  Device tensors: ``ia_fill_mouth`` (+ ``ia_mouth_edge_blur``); CPU tensors: breadth-first
+    flood fill in NumPy (+ torch pooling)."""
     if images.is_cuda:
-        mouth = hipops.fill_mouth(images.float().contiguous())
+        alpha = images.float().contiguous()
+        mouth = hipops.fill_mouth(alpha)
+        soft = hipops.mouth_edge_blur(alpha, mouth) if blur_mouth_edge else mouth
     else:
         mouth = torch.stack([_flood_fill_cpu(img[0]) for img in images], 0).unsqueeze(1)
-    return (images + mouth).clip(0, 1), mouth
+        soft = _erode_blur_cpu(images.float(), mouth) if blur_mouth_edge else mouth
+    return (images + mouth).clip(0, 1), soft
+
+
+def _erode_blur_cpu(alpha, mouth):
+    """`cv2.blur(cv2.erode(filled, ones(3,3), iterations=3), (5,5))` then (255 - .)/255 (renderer.py:732-736) in torch: three 3x3
+    erosions = one 7x7 minimum (border = +inf), normalised 5x5 box filter with BORDER_REFLECT_101 summed in double and scaled by
+    the double 1/25 before rounding to float (cv::boxFilter on CV_32F).  OpenCV is not in this image: semantics restated."""
+    f = torch.nn.functional
+    filled = torch.where(mouth == 0, torch.full_like(alpha, 255.0), alpha * 255.0)
+    eroded = -f.max_pool2d(-filled, kernel_size=7, stride=1, padding=3)          # (max_pool2d pads with -inf: the border never wins)
+    padded = f.pad(eroded.double(), (2, 2, 2, 2), mode='reflect')                 # 'reflect' = BORDER_REFLECT_101
+    box = f.avg_pool2d(padded, kernel_size=5, stride=1, divisor_override=1)
+    return (255.0 - (box * (1.0 / 25.0)).float()) / 255.0
 
 
 def _flood_fill_cpu(alpha):

@@ -92,3 +92,45 @@ def test_generator_copies_and_pickles_after_a_forward_pass(small_generator):
         for other in (g2, g3, g4):
             assert torch.equal(other.synthesis(*args, **kw)['image'], ref)
     assert not any(k.startswith('_') and 'stream' in k for k in vars(g))
+
+
+def _soft_mouth_by_loops(alpha, mouth):
+    """fill_mouth's blur_mouth_edge branch (renderer.py:732-736) pixel by pixel: cv2.erode 3x3 three times (border = +inf), cv2.blur 5x5
+    (double sums, * double(1/25), -> float; BORDER_REFLECT_101), (255 - x) / 255 in float32."""
+    import numpy as np
+    h, w = alpha.shape
+    img = np.where(mouth == 0, np.float32(255), alpha * np.float32(255)).astype(np.float32)
+    for _ in range(3):
+        nxt = img.copy()
+        for y in range(h):
+            for x in range(w):
+                nxt[y, x] = img[max(0, y - 1):y + 2, max(0, x - 1):x + 2].min()
+        img = nxt
+    refl = lambda i, n: -i if i < 0 else (2 * (n - 1) - i if i >= n else i)     # noqa: E731
+    out = np.empty_like(img)
+    for y in range(h):
+        for x in range(w):
+            s = 0.0
+            for dy in range(-2, 3):
+                for dx in range(-2, 3):
+                    s += float(img[refl(y + dy, h), refl(x + dx, w)])
+            out[y, x] = (np.float32(255) - np.float32(s * (1.0 / 25.0))) / np.float32(255)
+    return out
+
+
+def test_fill_mouth_default_blurs_the_mouth_edge():
+    """`fill_mouth(images)` with the signature's default blur_mouth_edge=True used to raise."""
+    import numpy as np
+    from invertavatar_amd.training_avatar_texture.volumetric_rendering.renderer import fill_mouth
+    m = torch.ones(3, 1, 24, 28)
+    m[0, 0, 10, 12] = 0                                  # a one-pixel hole in the interior: 7x7 after erosion
+    m[1, 0, 1:4, 22:27] = 0                              # a hole next to the top-right corner: reflected border samples
+    m[2, 0, 8:16, 6:20] = 0.25 * torch.from_numpy(np.random.RandomState(2).rand(8, 14).astype(np.float32))    # fractional alphas
+    full, soft = fill_mouth(m.clone())
+    full_hard, hard = fill_mouth(m.clone(), blur_mouth_edge=False)
+    assert torch.equal(full, full_hard)                  # the composited alpha uses the unblurred mask (:738)
+    for b in range(3):
+        expect = _soft_mouth_by_loops(m[b, 0].numpy(), hard[b, 0].numpy())
+        assert np.array_equal(soft[b, 0].numpy(), expect), b
+    assert soft[0, 0, 10, 12] == 1 and soft[0, 0, 10, 15] == np.float32(1 - np.float32(255 * 10 / 25.0) / 255)   # 3 of 5 columns inside
+    assert soft[0, 0, 10, 18] == 0 and soft[0, 0, 4, 12] == 0 and soft[0, 0, 5, 12] == np.float32(0.2)

@@ -309,3 +309,24 @@ def test_split_format_range_contract_holds_over_a_full_width_frame_and_trips_whe
             hipops.act_split(x)
     finally:
         hipops.CHECK_SPLIT_RANGE = False
+
+
+def test_fill_mouth_default_blur_on_device_equals_the_cpu_route():
+    """fill_mouth(images) with blur_mouth_edge=True (the default, renderer.py:732-736): ia_mouth_edge_blur == the torch-CPU restatement of
+    cv2.erode x3 + cv2.blur 5x5 bit for bit (which tests/test_generator_cpu.py pins against a pixel-by-pixel evaluation)."""
+    import numpy as np
+    from invertavatar_amd.training_avatar_texture.volumetric_rendering.renderer import fill_mouth
+    yy, xx = torch.meshgrid(torch.arange(256), torch.arange(256), indexing='ij')
+    disc = ((xx - 128) ** 2 + (yy - 120) ** 2 < 90 ** 2).float()
+    disc[150:170, 100:156] = 0.0
+    edge = torch.ones(256, 256)
+    edge[1:6, 1:9] = 0; edge[250:255, 120:140] = 0; edge[100:140, 251:255] = 0          # holes whose blur reflects at three borders
+    soft = torch.from_numpy(np.random.RandomState(4).rand(256, 256).astype(np.float32)) * disc
+    big = torch.stack([disc, edge, soft])[:, None]
+    odd = torch.ones(2, 1, 45, 77)
+    odd[0, 0, 20:25, 30:50] = 0; odd[1, 0, 1:3, 70:76] = 0.5
+    for masks in (big, odd):
+        cpu_full, cpu_soft = fill_mouth(masks.clone())
+        dev_full, dev_soft = fill_mouth(masks.cuda())
+        assert torch.equal(dev_full.cpu(), cpu_full) and torch.equal(dev_soft.cpu(), cpu_soft)
+        assert 0 < (cpu_soft > 0).float().mean() < 1 and ((cpu_soft > 0) & (cpu_soft < 1)).any()
