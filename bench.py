@@ -77,8 +77,20 @@ def parse():
     ap.add_argument('--nrr', type=int, default=128, help='neural rendering resolution (BASELINE: 128)')
     ap.add_argument('--features', default='encoder', choices=['encoder', 'backbone'],
                     help='--workload drive: identity features from the few-shot inversion (configs[4]) or straight from the backbones')
+    ap.add_argument('--set', action='append', default=[], metavar='MODULE.ATTR=VALUE',
+                    help='tuning A/Bs (tools/ab_frame.py): set a module-level switch of invertavatar_amd before the model is built')
     ap.add_argument('--drive-frames', type=int, default=256, help='--workload drive: length of the drive sequence (BASELINE: 256)')
-    return ap.parse_args()
+    args = ap.parse_args()
+    for item in getattr(args, 'set'):
+        import ast
+        import importlib
+        target, value = item.split('=', 1)
+        mod, attr = target.rsplit('.', 1)
+        module = importlib.import_module('invertavatar_amd.' + mod)
+        if not hasattr(module, attr):
+            raise SystemExit(f'--set: invertavatar_amd.{mod} has no attribute {attr}')
+        setattr(module, attr, ast.literal_eval(value))
+    return args
 
 
 def setup_distributed(args):

@@ -390,6 +390,22 @@ int ia_conv2d_mfma_sx_rgb(const void* xs, int planes, const void* wk_split, int 
                           void* stream);
 
 /*
+ * The stride-2 transposed 3x3 convolution of an up-sampling SynthesisLayer (torch_utils/ops/conv2d_resample.py:114-131 ->
+ * conv_transpose2d; training/networks_stylegan2.py:296-305) on split-format activations, evaluated per output ROW phase on the
+ * stride-1 tile (128 channels x 256 / 128 points, two accumulator sets = the two column phases): the same products as
+ * ia_conv2d_mfma_sx(transposed = 1) -- 9 per input pixel and channel pair, the minimum -- and the same result image
+ *   y [B, O, 2H+1, 2W+1] float32 = demod[b][o] * conv_transpose2d(x * styles, w, stride 2)   (summation order differs),
+ * which ia_fir_tail_split / ia_upfirdn2d_bias_act turn into the layer's output.  (csrc/conv_up.hip)
+ *   xs       : activations as ia_act_split(planes = 2) stores them, already multiplied by this layer's styles
+ *   wk_split : the weights of pack_conv_weight_split ([2][9][I/8][O][8] fp16 of w * 2^wk_exp), the ones ia_conv2d_mfma_sx takes
+ *   scratch  : ia_upconv2d_rows_plan's byte count (partial sums of the thin edge grids: bottom row / last column of the image)
+ * Needs I % 16 == 0, O % 128 == 0, 16 <= H, W <= 1024: ia_upconv2d_rows_plan returns IA_ERR_UNSUPPORTED otherwise.
+ */
+int ia_upconv2d_rows_plan(int B, int I, int O, int H, int W, size_t* h_scratch_bytes);
+int ia_upconv2d_rows_sx(const void* xs, const void* wk_split, int wk_exp, const float* demod, float* y, float* scratch,
+                        size_t scratch_bytes, int B, int I, int O, int H, int W, void* stream);
+
+/*
  * An up-sampling SynthesisLayer with FEW input channels as ONE stride-1 launch: the transposed convolution (stride 2) and the 4x4
  * resample FIR that follows it are linear, so their composition is, per output phase (py, px), a 3x3 convolution of the INPUT image
  * with the weights  W'[py,px][dy,dx] = gain * sum_{i,ky: py+i-1-ky = 2dy} sum_{j,kx: px+j-1-kx = 2dx} F[i,j] * w[ky,kx]  (F the

@@ -53,6 +53,8 @@ _SIGNATURES = {
     'ia_split_saturation_count': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'ia_act_split': [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
     'ia_conv2d_mfma_sx': [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 7 + [c_int] + [c_void_p] * 2 + [ctypes.c_size_t] + [c_int] * 7 + [c_float, c_void_p, c_float, c_float] + [c_int, c_void_p],
+    'ia_upconv2d_rows_plan': [c_int] * 5 + [ctypes.POINTER(ctypes.c_size_t)],
+    'ia_upconv2d_rows_sx': [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t] + [c_int] * 5 + [c_void_p],
     'ia_upconv2d_fir_sx': [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 5 + [c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_float] * 3 + [c_void_p],
     'ia_fir_tail_split': [c_void_p] * 8 + [c_int] * 10 + [c_float, c_int, c_float, c_float, c_float, c_void_p],
     'ia_cond_blend_split': [c_void_p] * 4 + [c_int] * 4 + [c_void_p],

@@ -403,6 +403,40 @@ def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=Non
     return y if want_f32 else out_s
 
 
+def upconv_rows_supported(b, i, o, h, w):
+    """Shapes ia_upconv2d_rows_sx covers (the row-phase form of the transposed 3x3 convolution): asks the library."""
+    nbytes = ctypes.c_size_t(0)
+    return _lib.load().ia_upconv2d_rows_plan(int(b), int(i), int(o), int(h), int(w), ctypes.byref(nbytes)) == 0
+
+
+def upconv2d_rows_sx(xs, wk, demod=None):
+    """ia_upconv2d_rows_sx: stride-2 transposed 3x3 convolution of a two-plane SplitAct -> the demodulated [B, O, 2H+1, 2W+1] fp32 image
+    (what conv2d_mfma_sx(transposed=True) returns), evaluated per output row phase on the stride-1 tile."""
+    if not (isinstance(xs, SplitAct) and xs.planes == 2):
+        raise RuntimeError('xs must be a two-plane SplitAct')
+    if not (wk.dtype == torch.float16 and wk.dim() == 5 and wk.shape[0] == 2 and hasattr(wk, 'wk_exp')):
+        raise RuntimeError('wk must come from pack_conv_weight_split')
+    b, i, h, w = xs.shape
+    o = wk.shape[-2]
+    if wk.shape[-4] != 9 or wk.shape[-3] * 8 != i:
+        raise RuntimeError(f'packed weight {tuple(wk.shape)} does not match 3x3, in-channels {i}')
+    if demod is not None:
+        _f32c(demod, 'demod')
+    lib = _lib.load()
+    plan_bytes = ctypes.c_size_t(0)
+    _lib.check(lib.ia_upconv2d_rows_plan(b, i, o, h, w, ctypes.byref(plan_bytes)), 'ia_upconv2d_rows_plan')
+    dev = xs.data.device
+    y = torch.empty(b, o, 2 * h + 1, 2 * w + 1, device=dev, dtype=torch.float32)
+    scratch = _scratch_buffer(dev, plan_bytes.value)
+    flops = 2.0 * b * h * w * i * o * 9
+    traffic = 2.0 * (xs.data.numel() + wk.numel()) + 4.0 * y.numel()
+    with torch.cuda.device(dev), _Timed('conv2d_mfma_t', flops, traffic, f'B{b} I{i} O{o} {h}x{w} rows f16x3 dma'):
+        st = lib.ia_upconv2d_rows_sx(_p(xs.data), _p(wk), int(wk.wk_exp), _p(demod), _p(y), _p(scratch), plan_bytes.value, b, i, o, h, w,
+                                     _lib.stream_ptr(dev))
+    _lib.check(st, 'ia_upconv2d_rows_sx')
+    return y
+
+
 def conv_sx_rgb_supported(b, i, o, h, w):
     """Layers ia_conv2d_mfma_sx_rgb covers: stride-1 layers that run in whole rounds of tiles holding every output channel."""
     if o > 128 or i % 8 or o % 8:

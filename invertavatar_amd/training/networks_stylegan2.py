@@ -46,6 +46,10 @@ TORGB_MAX_WORK = int(os.environ.get('IA_TORGB_MAX_WORK', 65536))
 # (ia_upconv2d_fir_sx: 4x the products, no (2H+1)^2 fp32 image, no FIR launch): the 32 -> 256 @128^2 layer of the SR head
 COMPOSED_UPFIR = os.environ.get('IA_COMPOSED_UPFIR', '1') == '1'
 COMPOSED_UPFIR_MAX_IN = int(os.environ.get('IA_COMPOSED_UPFIR_MAX_IN', 32))
+# Up-sampling layers from UPCONV_ROWS_MIN_RES^2 inputs: the transposed convolution per output row phase on the stride-1 tile
+# (ia_upconv2d_rows_sx, csrc/conv_up.hip) instead of the four-phase tile of ia_conv2d_mfma_sx.
+UPCONV_ROWS = True
+UPCONV_ROWS_MIN_RES = 64
 FUSED_TORGB_SKIP = os.environ.get('IA_FUSED_TORGB_SKIP', '1') == '1'          # ... and, where ia_torgb covers the shape, with the skip image's up-sampling + add in the same launch
 SPLIT_FP16_PRODUCTS = True
 
@@ -426,7 +430,11 @@ class SynthesisLayer(torch.nn.Module):
                                            act=self.activation, gain=act_gain, clamp=act_clamp, want_f32=keep_f32, split_for=split_for,
                                            split_planes=out_planes)
             else:
-                t = hipops.conv2d_mfma_sx(xs, wk, demod, transposed=True)
+                if UPCONV_ROWS and planes == 2 and in_res >= UPCONV_ROWS_MIN_RES and hipops.upconv_rows_supported(
+                        xs.shape[0], self.in_channels, self.out_channels, in_res, in_res):
+                    t = hipops.upconv2d_rows_sx(xs, wk, demod)      # per output row phase on the stride-1 tile (csrc/conv_up.hip)
+                else:
+                    t = hipops.conv2d_mfma_sx(xs, wk, demod, transposed=True)
                 if sn is None:
                     return hipops.upfirdn2d_bias_act(t, self.resample_filter, nz, ns, bias, up=1, pad0=(1, 1), out_hw=(res, res),
                                                      fir_gain=4.0, act=self.activation, act_gain=act_gain, clamp=act_clamp)

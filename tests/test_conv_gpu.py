@@ -550,3 +550,47 @@ def test_small_layer_kernel_refuses_what_it_does_not_cover():
     wk = torch.zeros(9, 24, 16, device='cuda')
     with pytest.raises(RuntimeError, match='ia_conv2d_small covers'):
         hipops.conv2d_small(x, wk)
+
+
+@pytest.mark.parametrize('b,i,o,h,w', [(1, 32, 128, 64, 64), (2, 48, 256, 24, 40), (1, 16, 128, 16, 256), (1, 64, 128, 130, 128),
+                                       (1, 512, 256, 64, 64), (1, 256, 128, 128, 128), (3, 32, 128, 33, 17)])
+def test_row_phase_upconv_equals_the_four_phase_form_and_fp64(b, i, o, h, w):
+    """r04: ia_upconv2d_rows_sx -- the transposed 3x3 convolution per output row phase on the stride-1 tile (two accumulator sets, no
+    zero k-step) -- forms the same products as ia_conv2d_mfma_sx(transposed): equal to summation-order level, as close to the fp64
+    convolution of the operands the kernel sees, every pixel of the (2H+1) x (2W+1) image written (interior tiles, bottom row, last
+    column; whole tiles and K-split edge tiles), run-to-run identical."""
+    assert hipops.upconv_rows_supported(b, i, o, h, w)
+    g = torch.Generator(device='cuda').manual_seed(23 + i + h)
+    x = torch.randn(b, i, h, w, device='cuda', generator=g) * 2
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g)
+    s = torch.rand(b, i, device='cuda', generator=g) + 0.5
+    d = hipops.modconv_demod(s, hipops.weight_sq_sum(wt))
+    xs = hipops.act_split(x, s)
+    wk = hipops.pack_conv_weight_split(wt)
+    ref = torch.nn.functional.conv_transpose2d(xs.float().double(), wt.double().transpose(0, 1), stride=2) * d.double()[:, :, None, None]
+    scale = ref.abs().max().item()
+    poison = torch.full_like(ref, float('nan'), dtype=torch.float32)
+    got = hipops.upconv2d_rows_sx(xs, wk, demod=d)
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 3e-6 * scale, err / scale
+    if hipops.conv_sx_supported(i, o, h, w, 3, True):
+        four = hipops.conv2d_mfma_sx(xs, wk, demod=d, transposed=True)
+        assert (got - four).abs().max().item() <= 2e-6 * scale
+        assert err <= (four.double() - ref).abs().max().item() * 1.5 + 1e-7 * scale
+    again = hipops.upconv2d_rows_sx(xs, wk, demod=d)
+    assert torch.equal(got, again)
+    none = hipops.upconv2d_rows_sx(xs, wk)                      # without demodulation
+    ref1 = torch.nn.functional.conv_transpose2d(xs.float().double(), wt.double().transpose(0, 1), stride=2)
+    assert (none.double() - ref1).abs().max().item() <= 3e-6 * ref1.abs().max().item()
+    del poison
+
+
+def test_row_phase_upconv_refuses_what_it_does_not_cover():
+    assert not hipops.upconv_rows_supported(1, 24, 128, 64, 64)       # I % 16
+    assert not hipops.upconv_rows_supported(1, 32, 64, 64, 64)        # O % 128
+    assert not hipops.upconv_rows_supported(1, 32, 128, 8, 8)         # below 16^2
+    xs = hipops.act_split(torch.randn(1, 32, 32, 32, device='cuda'))
+    wk = hipops.pack_conv_weight_split(torch.randn(64, 32, 3, 3, device='cuda'))
+    with pytest.raises(RuntimeError, match='row-phase'):
+        hipops.upconv2d_rows_sx(xs, wk)

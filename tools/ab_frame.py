@@ -14,12 +14,16 @@ res = {c: [] for c in configs}
 for r in range(rounds):
     for c in configs:
         env = dict(os.environ)
+        sets = []
         if c != 'default':
             for kv in c.split(','):
                 k, v = kv.split('=')
-                env[k] = v
+                if '.' in k:          # module-level switch of invertavatar_amd: bench.py --set module.ATTR=value
+                    sets += ['--set', kv]
+                else:
+                    env[k] = v
         out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--no-extra', '--no-roofline', '--no-cpu-baseline', '--steps', '60',
-                              '--warmup', '10', *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                              '--warmup', '10', *sets, *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
         res[c].append(json.loads(line[0])['value'] if line else None)
         print(f'round {r} {c}: {res[c][-1]}', flush=True)
