@@ -265,20 +265,21 @@ __global__ __launch_bounds__(512, 2) void up_rows_kernel(const h16x8* __restrict
         const bool ok = j * NWAVES + wave < PG && pos < PSZ && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
         p_voff[j] = ok ? pl * plane_bytes + (cg * HW + iy * g.W + ix) * 16 : kOutside;
     }
-// pieces of one chunk into one LDS stage; `what`: 1 = the weight pieces, 2 = the patch pieces, 3 = both
-#define IA_UP_ISSUE(chunk, stage, what)                                                                                               \
+// pieces of one chunk into one LDS stage: slice `sl` of `nsl` of this wave's JW + JP pieces (weights first, then patch; piece q belongs to
+// slice q * nsl / (JW + JP)); nsl = 1 issues the whole chunk
+#define IA_UP_ISSUE(chunk, stage, sl, nsl)                                                                                            \
     do {                                                                                                                               \
         const unsigned st_ = __builtin_amdgcn_readfirstlane(lds_base + (stage) * stage_bytes);                                         \
-        const int wso_ = IA_UP_ABLATE == 5 ? 0 : __builtin_amdgcn_readfirstlane((chunk) * CPC * g.O * 16);                                                     \
-        const int pso_ = IA_UP_ABLATE == 6 ? 0 : __builtin_amdgcn_readfirstlane((chunk) * CPC * HW * 16);                                                      \
-        if ((what) & 1) {                                                                                                              \
-            _Pragma("unroll") for (int j = 0; j < JW; ++j) {                                                                           \
+        const int wso_ = (IA_UP_ABLATE == 5 || IA_UP_ABLATE == 7) ? 0 : __builtin_amdgcn_readfirstlane((chunk) * CPC * g.O * 16);                             \
+        const int pso_ = (IA_UP_ABLATE == 6 || IA_UP_ABLATE == 7) ? 0 : __builtin_amdgcn_readfirstlane((chunk) * CPC * HW * 16);                              \
+        _Pragma("unroll") for (int j = 0; j < JW; ++j) {                                                                               \
+            if (j * (nsl) / (JW + JP) == (sl)) {                                                                                       \
                 const int vo_ = w_voff[j];                                                                                             \
                 dma_piece(rs_w, st_ + (j * NWAVES + wave) * 64 * 16, vo_, wso_);                                                       \
             }                                                                                                                          \
         }                                                                                                                              \
-        if ((what) & 2) {                                                                                                              \
-            _Pragma("unroll") for (int j = 0; j < JP; ++j) {                                                                           \
+        _Pragma("unroll") for (int j = 0; j < JP; ++j) {                                                                               \
+            if ((JW + j) * (nsl) / (JW + JP) == (sl)) {                                                                                \
                 const int gidx = j * NWAVES + wave;                                                                                    \
                 const int vo_ = p_voff[j];                                                                                             \
                 dma_piece(rs_x, gidx < PG ? st_ + (WSLOTS + gidx * 64) * 16 : dummy_lds, vo_, pso_);                                   \
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void up_rows_kernel(const h16x8* __restrict
     // "at most k operations outstanding" with k younger DMAs issued implies the older chunk has landed, whatever the stores do.
     __syncthreads();
     int issued = c_lo;
-    for (int k = 0; k < NS - 1 && issued < c_hi; ++k, ++issued) IA_UP_ISSUE(issued, k, 3);
+    for (int k = 0; k < NS - 1 && issued < c_hi; ++k, ++issued) IA_UP_ISSUE(issued, k, 0, 1);
     wait_chunks_in_flight<n_dma>(issued - c_lo - 1);      // chunk c_lo: this wave's pieces have landed ...
     ia_barrier();                                         // ... and everybody's
     // ---- K loop, two wave groups in antiphase.  Waves w and w + 4 share a SIMD; group 1 (waves 4-7) runs ONE barrier interval behind
@@ -305,8 +306,9 @@ __global__ __launch_bounds__(512, 2) void up_rows_kernel(const h16x8* __restrict
     // eight waves in step (the structure of conv_split_kernel) both waves of a SIMD issue DMA / wait for their reads together and then
     // queue for the pipe together -- ablation (tools/ablate_conv_up.sh, 256 -> 128 @256^2): 152 us with, 96 us without the MFMAs, i.e.
     // nothing but the MFMAs' own 57 us was overlapped.  Every wave executes the same number of barriers (group 0 one more at the end).
-    //   hazards: a stage is refilled (chunk ch + NS - 1 into the stage of chunk ch - 1) during the LOAD segments of k-steps 1 and 2 of
-    //   chunk ch -- the lagging group finished its reads of chunk ch - 1 two intervals earlier; the wait for chunk ch + 1 sits in the LOAD
+    //   hazards: a stage is refilled (chunk ch + NS - 1 into the stage of chunk ch - 1) during the LOAD segments of chunk ch, a third of the
+    //   pieces per k-step -- every wave waits for its operand reads (lgkmcnt(0)) in front of the barrier that ends a LOAD segment, and the
+    //   leading group's first refill piece is issued behind the barrier at which the lagging group ended its last LOAD segment of chunk ch - 1; the wait for chunk ch + 1 sits in the LOAD
     //   segment of k-step 2, in front of the barrier after which the leading group starts reading it.
     if (grp) ia_barrier();
     int cur = 0;
@@ -333,9 +335,19 @@ __global__ __launch_bounds__(512, 2) void up_rows_kernel(const h16x8* __restrict
                 for (int fp = 0; fp < FP; ++fp) b_use[pl * FP + fp] = ph[pl * cap + bpos[fp] + boff[s]];
             // this wave's share of the refill DMA, behind its reads (70 - 200 issue cycles per piece: under the partner wave's MFMAs here;
             // at the end of the COMPUTE segment they delayed the barrier the partner waits at -- measured, 620 - 720 cycle intervals)
-            if (s == 1 && fill) IA_UP_ISSUE(fill_chunk, fill_stage, 1);
-            if (s == 2 && fill) { IA_UP_ISSUE(fill_chunk, fill_stage, 2); ++issued; }
-            if (s == 2 && ch + 1 < c_hi && IA_UP_ABLATE != 4) wait_chunks_in_flight<n_dma>(issued - ch - 2);      // chunk ch + 1 has landed (this wave's pieces)
+            // (the wait for chunk ch + 1 goes IN FRONT of this k-step's pieces: an s_waitcnt vmcnt directly behind freshly issued
+            //  buffer_load ... lds instructions stalled ~220 cycles although the pieces it waits for were three k-steps old -- trace builds)
+            if (s == 2 && ch + 1 < c_hi && IA_UP_ABLATE != 4) {
+                constexpr int kFirst2 = (2 * n_dma + 2) / 3;      // pieces of slices 0 and 1: q * 3 / n_dma < 2
+                const int full = issued - ch - 2;                  // chunks beyond ch + 1 whose pieces are all out (0 or 1)
+                if (fill) { if (full <= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFirst2) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_dma + kFirst2) : "memory"); }
+                else wait_chunks_in_flight<n_dma>(full);
+            }
+            if (fill) IA_UP_ISSUE(fill_chunk, fill_stage, s, 3);
+            if (s == 2 && fill) ++issued;
+            // the reads have RETURNED before the barrier: what follows it on the other wave group may refill the stage they came from
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             IA_STAMP(1);
             ia_barrier();
@@ -512,12 +524,12 @@ int plan_up(int B, int I, int O, int H, int W, UpPlan* out) {
     g.cap = (need + 127) & ~127;
     p.jp = (int)ia::ceil_div(2 * g.cap / 64, 8);
     const size_t stage = (size_t)(2 * 6 * 128 + 2 * g.cap) * 16;
-    if (2 * stage + 1024 > kLdsBytesUp || p.jp > 4) return IA_ERR_UNSUPPORTED;
+    if (3 * stage + 1024 > kLdsBytesUp || p.jp > 4) return IA_ERR_UNSUPPORTED;      // (the K loop's refill schedule needs three stages)
     // ring depth: the DMA of a chunk must land within (stages - 1) chunks of 36 - 72 MFMAs per SIMD: as deep as the LDS allows
     // (bounded by the 6-bit vmcnt: (stages - 1) x (3 + jp) instructions per wave outstanding)
     g.stages = (int)((kLdsBytesUp - 1024) / stage);
     if (g.stages > kUpMaxStages) g.stages = kUpMaxStages;
-    while (g.stages > 2 && (g.stages - 1) * (3 + p.jp) > 60) --g.stages;      // (3 + jp <= 7: four stages always pass)
+
     p.lds = stage * g.stages + 1024;       // (+ the dummy target of all-outside DMA pieces)
     p.scratch = (size_t)B * g.E * g.gpe * (2 * 2 * p.fp * 16) * 512 * sizeof(float);
     *out = p;
