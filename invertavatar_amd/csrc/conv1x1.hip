@@ -297,6 +297,104 @@ __global__ __launch_bounds__(512) void torgb_kernel(TParams p) {
     }
 }
 
+// ---- ToRGB proper: up to four output channels on a large image (the SR head's 256 -> 3 @256^2: 67 MB of activations for 0.1 GFLOP).
+// torgb_kernel pads the three channels to a 32-row MFMA fragment and fetches a pixel fragment with 4-byte loads, 32 pixels x 2 channels
+// per instruction: 0.33 TB/s on that layer (205 us, r03 frame trace).  This is a streaming kernel instead: a lane owns FOUR consecutive
+// pixels and reads them as one 16-byte load per input channel (a wave: 1 KB contiguous per channel), the products are plain FMAs against
+// (weight x style) rows kept in LDS (broadcast reads), the input channels are split over the KS waves of a workgroup -- every wave has
+// 2 x 8 loads in flight -- and the partial sums meet in LDS in wave order.  Wave o then finishes output channel o: bias, clamp,
+// residual or up-sampled skip image with the arithmetic of torgb_kernel (the up-sampled image stays bit-identical to ia_upfirdn2d's).
+constexpr int kFewO = 4, kFewU = 8;
+template <int KS>
+__global__ __launch_bounds__(64 * KS) void torgb_few_kernel(TParams p) {
+    static_assert(KS >= kFewO, "wave o finishes output channel o");
+    __shared__ float4 s_w[1024];                     // (w[k][0..3] * s[k]) per input channel
+    __shared__ float4 s_red[KS][kFewO][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int64_t pix0 = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    for (int k = tid; k < p.I; k += 64 * KS) {
+        const float st = p.styles ? p.styles[(int64_t)b * p.I + k] : 1.f;
+        float w4[kFewO];
+#pragma unroll
+        for (int o = 0; o < kFewO; ++o) w4[o] = o < p.O ? p.wk[(int64_t)k * p.O + o] * st : 0.f;      // (w * s), the reference's order
+        s_w[k] = make_float4(w4[0], w4[1], w4[2], w4[3]);
+    }
+    __syncthreads();
+    const int kw = p.I / KS, k0 = wave * kw;
+    const float* xp = p.x + ((int64_t)b * p.I + k0) * p.P + pix0;
+    float acc[kFewO][4];
+#pragma unroll
+    for (int o = 0; o < kFewO; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+    float4 xa[kFewU], xb[kFewU];
+    auto load_block = [&](float4 (&xv)[kFewU], int k) {
+#pragma unroll
+        for (int u = 0; u < kFewU; ++u) xv[u] = *reinterpret_cast<const float4*>(xp + (int64_t)(k + u) * p.P);
+    };
+    auto fma_block = [&](const float4 (&xv)[kFewU], int k) {
+#pragma unroll
+        for (int u = 0; u < kFewU; ++u) {
+            const float4 w = s_w[k0 + k + u];
+            const float wv[kFewO] = {w.x, w.y, w.z, w.w}, xj[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+            for (int o = 0; o < kFewO; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(wv[o], xj[j], acc[o][j]);
+        }
+    };
+    load_block(xa, 0);
+    for (int k = 0; k < kw; k += 2 * kFewU) {              // (kw is a multiple of 16: I in {128, 256, 512, 1024}, KS = 4)
+        load_block(xb, k + kFewU);
+        fma_block(xa, k);
+        if (k + 2 * kFewU < kw) load_block(xa, k + 2 * kFewU);
+        fma_block(xb, k + kFewU);
+    }
+#pragma unroll
+    for (int o = 0; o < kFewO; ++o) s_red[wave][o][lane] = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+    __syncthreads();
+    const int o = wave;
+    if (o >= p.O) return;
+    float4 t = s_red[0][o][lane];
+#pragma unroll
+    for (int w = 1; w < KS; ++w) { const float4 v = s_red[w][o][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    const float v4[4] = {t.x, t.y, t.z, t.w};
+    const float bias = p.bias ? p.bias[o] : 0.f;
+    const int64_t at = ((int64_t)b * p.O + o) * p.P + pix0;
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.residual) r4 = *reinterpret_cast<const float4*>(p.residual + at);
+    const float rj[4] = {r4.x, r4.y, r4.z, r4.w};
+    const int Ws = p.W >> 1, Hs = p.H >> 1;
+    const int oy = (int)(pix0 / p.W), ox0 = (int)(pix0 - (int64_t)oy * p.W);      // (W % 4 == 0: the four pixels share a row)
+    const float* sb = p.skip ? p.skip + ((int64_t)b * p.O + o) * Hs * Ws : nullptr;
+    float out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float sres = v4[j] + bias;
+        if (p.clamp >= 0.f) sres = fminf(fmaxf(sres, -p.clamp), p.clamp);
+        if (p.residual) sres += rj[j];
+        if (p.skip) {                 // the 2 x 2 real taps of the up-sampling at this pixel, in ia_upfirdn2d's order (see torgb_kernel)
+            const int ox = ox0 + j;
+            const int my = ((oy + (oy & 1)) >> 1) - 1, mx = ((ox + (ox & 1)) >> 1) - 1;
+            float a = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int iy = (oy & 1) + 2 * tt, ix = (ox & 1) + 2 * u;
+                    const bool in = my + tt >= 0 && my + tt < Hs && mx + u >= 0 && mx + u < Ws;
+                    const float tap = in ? sb[(my + tt) * Ws + mx + u] : 0.f;
+                    const float kk = in ? p.filt[(3 - iy) * 4 + (3 - ix)] * 4.f : 0.f;
+                    a = fmaf(tap, kk, a);
+                }
+            sres += a;
+        }
+        out[j] = sres;
+    }
+    *reinterpret_cast<float4*>(p.y + at) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 template <int V>
 void launch_ks(int ksplit, dim3 grid, hipStream_t s, const C1Params& p) {
     switch (ksplit) {
@@ -353,6 +451,12 @@ extern "C" int ia_torgb(const float* x, const float* wk, const float* styles, co
     int ks = I / 128;
     if (P <= 4096 && I == 512) ks = 8;
     TParams p{x, wk, styles, bias, residual, skip, skip_filter, y, I, O, H, W, P, clamp};
+    const hipStream_t s_ = (hipStream_t)stream;
+    if (O <= kFewO && P >= 16384 && P % 256 == 0 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+        (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0)) {      // ToRGB proper on a large image: the streaming form
+        hipLaunchKernelGGL((torgb_few_kernel<4>), dim3((unsigned)(P / 256), (unsigned)B), dim3(256), 0, s_, p);
+        return ia::check_launch("ia_torgb");
+    }
     const int ng = 8 / ks;
     const dim3 grid((unsigned)((P + 32 * ng - 1) / (32 * ng)), (unsigned)B, (unsigned)((O + 31) / 32));
     const hipStream_t s = (hipStream_t)stream;
