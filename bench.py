@@ -470,10 +470,12 @@ def sr_fp16_generator(gen, width):
     return gen16.to(DEV)
 
 
-def inversion_features(gen, n_sources=8, repeats=2):
+def inversion_features(gen, n_sources=8, repeats=2, rank=0, world=1):
     """BASELINE configs[4], first half: few-shot ConvGRU inversion of 8 source frames through the script's own flow
     (invertavatar_amd.eval_seq.few_shot_inversion: encode + 2 interleaved AR_eval_forward groups, module modes of eval_seq.py:91-97).
-    Every rank runs it (replicated: the identity is shared by all drive frames).  Returns (ws, results, milliseconds of the last run)."""
+    N = 1: every step on the one GPU.  N > 1: inversion_parallel.few_shot_inversion_sharded -- the source renders sharded by frame, the
+    texture / tri-plane UNet chains on ranks 0 / 1, one all-gather + one broadcast per chain owner.
+    Returns (ws, results, milliseconds of the last run: max over ranks)."""
     from invertavatar_amd import eval_seq
     from invertavatar_amd.encoder_inversion.models.uvnet import inversionNet
     net = inversionNet(generator=gen, encoding_triplane=True, encoding_texture=True).requires_grad_(False)
@@ -489,9 +491,19 @@ def inversion_features(gen, n_sources=8, repeats=2):
     for _ in range(repeats + (1 if cache is not None else 0)):      # (the first runs pay allocations, kernel selection, the capture)
         sync()
         t0 = time.perf_counter()
-        ws, res, _ = eval_seq.few_shot_inversion(net, images, uvs, cams, uvc, graphed=cache)
+        if world > 1:
+            from invertavatar_amd import inversion_parallel
+            torch.distributed.barrier()
+            ws, res, _ = inversion_parallel.few_shot_inversion_sharded(net, images, uvs, cams, uvc, rank=rank, world_size=world,
+                                                                       draws=inversion_parallel.seeded_draws(0, NRR * NRR))
+        else:
+            ws, res, _ = eval_seq.few_shot_inversion(net, images, uvs, cams, uvc, graphed=cache)
         sync()
         ms = (time.perf_counter() - t0) * 1e3
+    if world > 1:
+        worst = torch.tensor([ms], dtype=torch.float64, device=DEV)
+        torch.distributed.all_reduce(worst, op=torch.distributed.ReduceOp.MAX)
+        ms = float(worst.item())
     return ws, res, ms
 
 
@@ -513,7 +525,7 @@ def drive_main(args, rank, world):
         wl = Workload(gen, per, rank, world, n_sets=max(1, args.drive_frames // (per * world)))
         inversion_ms = None
         if features == 'encoder':
-            ws, res, inversion_ms = inversion_features(gen)
+            ws, res, inversion_ms = inversion_features(gen, rank=rank, world=world)
             tex, sta = res['texture'], res['static']
         else:
             ws = wl.ws
@@ -561,7 +573,7 @@ def drive_main(args, rank, world):
         n = args.drive_frames
         out['inversion_ms'] = round(inversion_ms, 2)
         out['clip'] = dict(frames=n, seconds=round(inversion_ms * 1e-3 + n / fps, 4), frames_per_s=round(n / (inversion_ms * 1e-3 + n / fps), 2),
-                           note='inversion (replicated on every rank) + the whole drive sequence at the measured rate')
+                           note='inversion (N > 1: source renders sharded by frame, UNet chains on ranks 0 / 1) + the whole drive sequence at the measured rate')
     return out
 
 

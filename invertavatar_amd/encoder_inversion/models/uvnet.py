@@ -127,9 +127,13 @@ class inversionNet(nn.Module):
         return out
 
     @torch.no_grad()
-    def AR_eval_forward(self, x, vid_c, vid_v, ws, r_list, e4e_results=None, return_fake=False):
+    def AR_eval_forward(self, x, vid_c, vid_v, ws, r_list, e4e_results=None, return_fake=False, y0_image=None, parts=('texture', 'triplane')):
         """Incremental update from one group of T source frames (uvnet.py:160-203).
-        x['image'] [T,3,512,512], x['uv'] [T,6,256,256]; r_list = [texture GRU states, tri-plane GRU states]."""
+        x['image'] [T,3,512,512], x['uv'] [T,6,256,256]; r_list = [texture GRU states, tri-plane GRU states].
+        `y0_image`: the group's render from the e4e features, when the caller already has it (inversion_parallel renders the source
+        frames of all groups sharded over the ranks before the UNet chains run).  `parts`: which of the two independent UNet chains
+        to run -- 'texture' (texture UNet -> texture feature offsets) and / or 'triplane' (tri-plane UNet -> conditioned static
+        backbone); the features of a chain that is left out come back as the e4e features, its ConvGRU states untouched."""
         g = self.generator
         T = vid_c.shape[0]
         if ws is None:
@@ -143,16 +147,19 @@ class inversionNet(nn.Module):
         def over_frames(feats):
             return [f.expand(T, -1, -1, -1) for f in feats]
 
-        y0 = g.synthesis_withTexture(vid_ws, over_frames(texture_feats), vid_c, vid_v, static_feats=over_frames(static_feats),
-                                     noise_mode='const')
+        y0 = {'image': y0_image} if y0_image is not None else g.synthesis_withTexture(
+            vid_ws, over_frames(texture_feats), vid_c, vid_v, static_feats=over_frames(static_feats), noise_mode='const')
         delta_x = y0['image'] - x['image'][:, :3]
-        uv_input = self.get_unet_uvinput(x['uv'], delta_x)
-        tri_input = torch.cat([x['image'][:, :3], delta_x], dim=-3)
-        offsets, r_list[0] = self.unet_encoder.texture_unet(uv_input.unsqueeze(0), r_list=r_list[0], return_list=True)
-        texture_feats = _add_offsets(texture_feats, offsets)
-        sft, r_list[1] = self.unet_encoder.triplane_unet(tri_input.unsqueeze(0), r_list=r_list[1])
-        static_feats = g.backbone.synthesis(ws, cond_list=None, return_list=True, feat_conditions=sft, update_emas=False,
-                                            noise_mode='const')
+        uv_input = None
+        if 'texture' in parts:
+            uv_input = self.get_unet_uvinput(x['uv'], delta_x)
+            offsets, r_list[0] = self.unet_encoder.texture_unet(uv_input.unsqueeze(0), r_list=r_list[0], return_list=True)
+            texture_feats = _add_offsets(texture_feats, offsets)
+        if 'triplane' in parts:
+            tri_input = torch.cat([x['image'][:, :3], delta_x], dim=-3)
+            sft, r_list[1] = self.unet_encoder.triplane_unet(tri_input.unsqueeze(0), r_list=r_list[1])
+            static_feats = g.backbone.synthesis(ws, cond_list=None, return_list=True, feat_conditions=sft, update_emas=False,
+                                                noise_mode='const')
         updated = {'w': ws, 'texture': texture_feats, 'static': static_feats}
         if not return_fake:
             return updated, r_list

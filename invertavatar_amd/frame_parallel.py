@@ -34,6 +34,22 @@ def per_frame_ray_dist(c):
     return torch.norm(cam2world[:, :3, 3].float(), dim=-1).contiguous()
 
 
+def all_gather_blocks(block, counts, group=None):
+    """Blocks of `counts[r]` leading entries per rank -> the concatenation on every rank, with ONE all_gather_into_tensor.
+    Unequal blocks are padded to the largest (neither gloo nor RCCL gathers tensors of different sizes)."""
+    world, most = len(counts), max(counts)
+    if block.shape[0] < most:
+        block = torch.cat([block, block.new_zeros((most - block.shape[0],) + tuple(block.shape[1:]))], 0)
+    full = torch.empty((world * most,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    if torch.distributed.get_backend(group) == 'gloo':      # (rehearsal backend: no _allgather_base for every device; list form, same bytes)
+        torch.distributed.all_gather(list(full.chunk(world)), block.contiguous(), group=group)
+    else:
+        torch.distributed.all_gather_into_tensor(full, block.contiguous(), group=group)
+    if all(c == most for c in counts):
+        return full
+    return torch.cat([full[r * most:r * most + counts[r]] for r in range(world)], 0)
+
+
 def render_sharded(generator, ws, c, mesh_condition, rank=0, world_size=1, jitter=None, gather=True, **synthesis_kwargs):
     """Render frames [lo, hi) of the batch on this rank and all-gather the images.
 
@@ -50,11 +66,4 @@ def render_sharded(generator, ws, c, mesh_condition, rank=0, world_size=1, jitte
     img = out['image'].contiguous()
     if not gather or world_size == 1:
         return img
-    sizes = [shard_range(n, r, world_size) for r in range(world_size)]
-    if len({b - a for a, b in sizes}) == 1:      # equal blocks: one all_gather into a preallocated batch
-        full = torch.empty((n,) + tuple(img.shape[1:]), dtype=img.dtype, device=img.device)
-        torch.distributed.all_gather_into_tensor(full, img)
-        return full
-    parts = [torch.empty((b - a,) + tuple(img.shape[1:]), dtype=img.dtype, device=img.device) for a, b in sizes]
-    torch.distributed.all_gather(parts, img)
-    return torch.cat(parts, 0)
+    return all_gather_blocks(img, [b_ - a_ for a_, b_ in (shard_range(n, r, world_size) for r in range(world_size))])

@@ -311,11 +311,11 @@ class TriPlaneGenerator(torch.nn.Module):
             torch.cuda.current_stream(ws.device).wait_stream(pending[1])
         return self._blend_planes(stitch, full_alpha, static_plane)
 
-    def _render(self, ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist=None):
+    def _render(self, ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist=None, u_importance=None):
         if evaluation:
             assert synthesis_kwargs.get('noise_mode') == 'const', ('noise_mode' in synthesis_kwargs, synthesis_kwargs.get('noise_mode'))
         feats, depth, _ = self.renderer(planes, self.decoder, origins, dirs, self.rendering_kwargs, evaluation=evaluation, jitter=jitter,
-                                        dist=ray_dist)
+                                        dist=ray_dist, **({} if u_importance is None else {'u_importance': u_importance}))
         n = ws.shape[0]
         feature_image = feats.permute(0, 2, 1).reshape(n, feats.shape[-1], nrr, nrr).contiguous()
         depth_image = depth.permute(0, 2, 1).reshape(n, 1, nrr, nrr)
@@ -351,8 +351,9 @@ class TriPlaneGenerator(torch.nn.Module):
 
     def synthesis_withTexture(self, ws, texture_feats, c, mesh_condition, static_feats=None, neural_rendering_resolution=None,
                               update_emas=False, cache_backbone=False, use_cached_backbone=False, evaluation=False, jitter=None,
-                              ray_dist=None, **synthesis_kwargs):
+                              ray_dist=None, u_importance=None, **synthesis_kwargs):
         # same orchestration as synthesis(): mouth fill + rays on the side stream, face-backbone head on its own stream
+        # (`jitter`, `u_importance`: the renderer's two random draws handed in, see ImportanceRenderer_bsMotion.forward)
         # (`ray_dist`: see ImportanceRenderer_bsMotion.forward -- 1 value for the batch or one per frame)
         mouth = self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, ray_dist))
         face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
@@ -365,7 +366,7 @@ class TriPlaneGenerator(torch.nn.Module):
             static_feats = self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **synthesis_kwargs)
         planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, mouth=mouth,
                               face_head=face_head)
-        image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist)
+        image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist, u_importance)
         return {'image': image, 'image_raw': rgb, 'image_depth': depth, 'feature_image': feature_image, 'triplane': planes}
 
     def synthesis_withCondition(self, ws, c, mesh_condition, gt_texture_feats=None, gt_static_feats=None, texture_feats_conditions=None,

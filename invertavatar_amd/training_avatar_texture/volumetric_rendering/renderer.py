@@ -90,7 +90,7 @@ class _RendererBase(nn.Module):
         d = torch.linspace(ray_start, ray_end, depth_resolution, device=dev).reshape(1, 1, depth_resolution, 1).repeat(n, m, 1, 1)
         return d + noise(d) * ((ray_end - ray_start) / (depth_resolution - 1))
 
-    def sample_importance(self, z_vals, weights, N_importance, det=False):
+    def sample_importance(self, z_vals, weights, N_importance, det=False, u=None):
         """Smoothed inverse-CDF resampling (renderer.py:410-428); note 47 bins but 45 weights are used."""
         with torch.no_grad():
             b, r, s, _ = z_vals.shape
@@ -99,9 +99,9 @@ class _RendererBase(nn.Module):
             w = torch.nn.functional.max_pool1d(w.unsqueeze(1).float(), 2, 1, padding=1)
             w = torch.nn.functional.avg_pool1d(w, 2, 1).squeeze(1) + 0.01
             z_mid = 0.5 * (z[:, :-1] + z[:, 1:])
-            return self.sample_pdf(z_mid, w[:, 1:-1], N_importance, det).detach().reshape(b, r, N_importance, 1)
+            return self.sample_pdf(z_mid, w[:, 1:-1], N_importance, det, u=u).detach().reshape(b, r, N_importance, 1)
 
-    def sample_pdf(self, bins, weights, N_importance, det=False, eps=1e-5):
+    def sample_pdf(self, bins, weights, N_importance, det=False, eps=1e-5, u=None):
         """renderer.py:430-469."""
         n_rays, n_w = weights.shape
         weights = weights + eps
@@ -109,8 +109,10 @@ class _RendererBase(nn.Module):
         cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
         if det:
             u = torch.linspace(0, 1, N_importance, device=bins.device).expand(n_rays, N_importance)
-        else:
+        elif u is None:
             u = torch.rand(n_rays, N_importance, device=bins.device)
+        else:
+            u = u.to(device=bins.device, dtype=bins.dtype).reshape(n_rays, N_importance)      # (the caller's draws in place of :453's)
         u = u.contiguous()
         inds = torch.searchsorted(cdf, u, right=True)
         below, above = torch.clamp_min(inds - 1, 0), torch.clamp_max(inds, n_w)
@@ -120,7 +122,7 @@ class _RendererBase(nn.Module):
         denom = torch.where(denom < eps, torch.ones_like(denom), denom)
         return bin_b + (u - cdf_b) / denom * (bin_a - bin_b)
 
-    def _two_pass(self, planes, decoder, ray_origins, ray_directions, depths_coarse, options, det):
+    def _two_pass(self, planes, decoder, ray_origins, ray_directions, depths_coarse, options, det, u_importance=None):
         b, r, s, _ = depths_coarse.shape
         xyz = (ray_origins.unsqueeze(-2) + depths_coarse * ray_directions.unsqueeze(-2)).reshape(b, -1, 3)
         dirs = ray_directions.unsqueeze(-2).expand(-1, -1, s, -1).reshape(b, -1, 3)
@@ -132,7 +134,7 @@ class _RendererBase(nn.Module):
             rgb, depth, weights = self.ray_marcher(col_c, den_c, depths_coarse, options)
             return rgb, depth, weights.sum(2)
         _, _, weights = self.ray_marcher(col_c, den_c, depths_coarse, options)
-        depths_fine = self.sample_importance(depths_coarse, weights, n_imp, det=det)
+        depths_fine = self.sample_importance(depths_coarse, weights, n_imp, det=det, u=None if det else u_importance)
         xyz = (ray_origins.unsqueeze(-2) + depths_fine * ray_directions.unsqueeze(-2)).reshape(b, -1, 3)
         dirs = ray_directions.unsqueeze(-2).expand(-1, -1, n_imp, -1).reshape(b, -1, 3)
         out = self.run_model(planes, decoder, xyz, dirs, options)
@@ -184,8 +186,11 @@ class ImportanceRenderer_bsMotion(_RendererBase):
                 and not options['disparity_space_sampling'] and options.get('clamp_mode') == 'softplus'
                 and options.get('density_noise', 0) == 0 and _is_osg_decoder(decoder) and not torch.is_grad_enabled())
 
-    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, evaluation=False, jitter=None, dist=None):
-        """`dist` overrides the batch mean of |ray origin| (:311).  One element: a sharded batch passes the value of the whole batch
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, evaluation=False, jitter=None, dist=None,
+                u_importance=None):
+        """`u_importance` ([B*R, 48] uniform draws, any order) replaces the importance pass's own torch.rand (:453) when the call is
+        not `evaluation`: callers that shard a stochastic render over ranks hand every frame the draws it gets in the one-process call.
+        `dist` overrides the batch mean of |ray origin| (:311).  One element: a sharded batch passes the value of the whole batch
         so that the depth range does not depend on the sharding.  B elements: frame b uses dist[b] -- a batch of frames that the
         caller's script renders one call each (eval_seq.py:206-212) keeps the per-call results."""
         if jitter is None:
@@ -205,8 +210,9 @@ class ImportanceRenderer_bsMotion(_RendererBase):
             jitter = jitter.to(device=planes.device, dtype=torch.float32).reshape(b, r, n_coarse).contiguous()
             u_imp = None
             if not evaluation:      # (drawn after the jitter, as the reference's generator sees the two calls)
-                u_imp = torch.rand(b * r, rendering_options['depth_resolution_importance'], device=planes.device).sort(dim=-1).values
-                u_imp = u_imp.to(torch.float32).contiguous()
+                n_imp = rendering_options['depth_resolution_importance']
+                u_imp = torch.rand(b * r, n_imp, device=planes.device) if u_importance is None else u_importance.to(planes.device).reshape(b * r, n_imp)
+                u_imp = u_imp.sort(dim=-1).values.to(torch.float32).contiguous()
             if dist is None:
                 dist = torch.norm(ray_origins, dim=-1).mean().reshape(1)  # stays on the device: no host sync
             dist = dist.to(device=planes.device, dtype=torch.float32).reshape(-1).contiguous()
@@ -223,13 +229,14 @@ class ImportanceRenderer_bsMotion(_RendererBase):
         # torch definition (CPU tensors, training, non-standard options)
         if per_frame:      # one reference-shaped call per frame (the depth clamp bounds are then per frame too, as in those calls)
             parts = [self.forward(planes[k:k + 1], decoder, ray_origins[k:k + 1], ray_directions[k:k + 1], rendering_options, evaluation,
-                                  None if jitter is None else jitter[k:k + 1], dist.reshape(-1)[k:k + 1]) for k in range(b)]
+                                  None if jitter is None else jitter[k:k + 1], dist.reshape(-1)[k:k + 1],
+                                  None if u_importance is None else u_importance.reshape(b, r, -1)[k]) for k in range(b)]
             return tuple(torch.cat(t, 0) for t in zip(*parts))
         self.plane_axes = self.plane_axes.to(ray_origins.device)
         dist = torch.norm(ray_origins, dim=-1).mean().item() if dist is None else float(dist.reshape(-1)[0].item())
         depths = self.sample_stratified(ray_origins, dist - 0.45, dist + 0.6, n_coarse, rendering_options['disparity_space_sampling'],
                                         jitter=jitter)
-        return self._two_pass(planes, decoder, ray_origins, ray_directions, depths, rendering_options, det=evaluation)
+        return self._two_pass(planes, decoder, ray_origins, ray_directions, depths, rendering_options, det=evaluation, u_importance=u_importance)
 
 
 def fill_mouth(images, blur_mouth_edge=True):

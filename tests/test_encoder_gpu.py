@@ -132,3 +132,73 @@ def test_se_gate_kernel_matches_the_module(in_c, depth, stride):
     with torch.no_grad():
         got = trunk_hip.se_tail(unit, full.cuda()[:, :, ::stride, ::stride], x.cuda()).cpu()
     assert got.shape == want.shape and (got - want).abs().max().item() <= 2e-6 * max(want.abs().max().item(), 1.0)
+
+
+def _fixture_draws(device='cpu'):
+    """draws(group) of inversion_parallel from the fixture's pinned randomness (encoder_common.fixed_randomness): the group's jitter
+    and RandomState(99) uniforms of the importance pass."""
+    import numpy as np
+    from encoder_common import source_batch
+    jit = source_batch(device)['jitter']
+    n_it = jit.shape[0] // 4
+
+    def draws(idx):
+        j = jit[idx::n_it]
+        u = torch.from_numpy(np.random.RandomState(99).rand(j.shape[0] * j.shape[1], 48).astype(np.float32))
+        return j.reshape(j.shape[0], j.shape[1], 48), u
+    return draws
+
+
+def _sharded_worker(rank, world, port, tmp):
+    import os
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    torch.distributed.init_process_group('gloo', rank=rank, world_size=world)        # both ranks on cuda:0, collectives over gloo
+    from encoder_common import build_inversion_net, source_batch
+    from invertavatar_amd import inversion_parallel
+    net = build_inversion_net('full').cuda()
+    net.generator.neural_rendering_resolution = 32
+    src = source_batch('cuda')
+    ws, res, r_list = inversion_parallel.few_shot_inversion_sharded(net, src['image'], src['uv'], src['c'], src['uvcoords'], rank=rank,
+                                                                    world_size=world, draws=_fixture_draws())
+    torch.save(dict(ws=ws.cpu(), texture=[t.cpu() for t in res['texture']], static=[t.cpu() for t in res['static']],
+                    gru=[[h.cpu() for h in states] for states in r_list]), f'{tmp}.{rank}')
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+def test_sharded_few_shot_inversion_equals_the_one_process_flow(tmp_path, golden):
+    """the inversion of BASELINE configs[4] over two ranks (source renders sharded by frame with their group's depth
+    range and draws; texture chain on rank 0, tri-plane chain on rank 1; one broadcast per owner) reproduces the one-process features
+    and ConvGRU states -- train-mode BatchNorm groups stay whole -- and, through them, the reference fixture."""
+    import torch.multiprocessing as mp
+    from encoder_common import build_inversion_net, fixed_randomness, source_batch
+    from invertavatar_amd import eval_seq
+    tmp = str(tmp_path / 'sharded')
+    mp.spawn(_sharded_worker, args=(2, 29661, tmp), nprocs=2, join=True)
+    got = [torch.load(f'{tmp}.{r}') for r in range(2)]
+    net = build_inversion_net('full').cuda()
+    net.generator.neural_rendering_resolution = 32
+    src = source_batch('cuda')
+    n_it = src['image'].shape[0] // 4
+    ws, res, r_list = eval_seq.few_shot_inversion(net, src['image'], src['uv'], src['c'], src['uvcoords'],
+                                                  hook=lambda idx: fixed_randomness(src['jitter'][idx::n_it]))
+    ref = dict(ws=ws.cpu(), texture=[t.cpu() for t in res['texture']], static=[t.cpu() for t in res['static']],
+               gru=[[h.cpu() for h in states] for states in r_list])
+
+    def deviation(a, b):
+        worst = {}
+        worst['ws'] = (a['ws'] - b['ws']).abs().max().item()
+        for key in ('texture', 'static'):
+            for i, (x, y) in enumerate(zip(a[key], b[key])):
+                worst[f'{key}{i}'] = (x - y).abs().max().item() / max(1.0, y.abs().max().item())
+        for u, (sa, sb) in enumerate(zip(a['gru'], b['gru'])):
+            assert len(sa) == len(sb)
+            for k, (x, y) in enumerate(zip(sa, sb)):
+                worst[f'gru{u}_{k}'] = (x - y).abs().max().item() / max(1.0, y.abs().max().item())
+        return worst
+    for rank in range(2):
+        dev = deviation(got[rank], ref)
+        print(f'sharded inversion, rank {rank}: worst deviation from the one-process flow {max(dev.values()):.2e}')
+        assert max(dev.values()) <= TOL_FEATURES, {k: v for k, v in dev.items() if v > TOL_FEATURES}
+    assert deviation(got[0], got[1]) == {k: 0.0 for k in deviation(got[0], got[1])}        # both ranks hold the same bits
