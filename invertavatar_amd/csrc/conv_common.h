@@ -38,8 +38,6 @@ struct Geo {
     int TO, T;             // out-channel tiles, tiles in total (point tiles x out-channel tiles)
     int T_dp;              // tiles [0, T_dp) run one per workgroup, tiles [T_dp, T) are stream-K
     int patch_cap;         // floats per channel reserved for the patch in LDS
-    int stages = 2;        // conv_split.hip: LDS stages of the DMA ring
-    int spread = 0;        // conv_split.hip: 1 = a chunk's DMA pieces are issued between the k-steps instead of in one burst
     int xcd_bands = 0;     // conv_split.hip: 1 = whole-tile launches give each XCD a contiguous band of tiles
     float acc_scale;       // fp16-pair form: 2^-wk_exp, takes the accumulators back from the scale of the packed weights
 };

@@ -31,6 +31,9 @@
 #ifndef IA_PAIR_TAPS
 #define IA_PAIR_TAPS 1
 #endif
+#ifndef IA_ANTIPHASE
+#define IA_ANTIPHASE 1      // 0: every tile on the in-step K loop (A/B builds in tools/)
+#endif
 #define IA_AB_NODMA (IA_ABLATE == 1 || IA_ABLATE >= 5)
 #define IA_AB_NOREAD (IA_ABLATE == 3 || IA_ABLATE >= 5)
 #define IA_AB_NOSTORE (IA_ABLATE == 4 || IA_ABLATE >= 5)
@@ -290,7 +293,7 @@ __device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], f
 // NP = operand planes: 2 = hi / lo pairs, three products per k-step (fp32-equivalent, the arithmetic of ia_conv2d_mfma_s);
 // 1 = one fp16 plane, one product (fp16 operands / fp32 accumulation, the arithmetic of ia_conv2d_mfma_h: the reference's fp16
 // blocks) -- the fp16-STORAGE form of the SR head: activations travel between its convolutions as 2 bytes per element.
-template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP, bool SK, bool RGB = false>
+template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP, bool SK, bool RGB = false, bool APH = false>
 __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void conv_split_kernel(const h16x8* __restrict__ xs, const h16x8* __restrict__ wk,
                                                                                       float* __restrict__ y, float* __restrict__ slabs, Geo g, Epi e) {
     constexpr int KS = 3, NT = 9, NTP = NT + 1;
@@ -339,7 +342,13 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     const unsigned lds_base = (unsigned)(unsigned long long)(lds_char*)lds;
 
     // the all-zero tap of every plane, in every stage of the ring (the DMA never writes there)
-    const int NS = g.stages;                           // LDS stages of the DMA ring (>= 2): chunks ch+1 .. ch+NS-1 are in flight under chunk ch
+    constexpr int NS = 2;                              // LDS stages of the DMA ring: chunk ch + 1 is in flight under chunk ch (deeper rings measured no gain, r03)
+    // The 128-channel x 256-point stride-1 tile (12 MFMAs per k-step and wave): the two wave groups of the workgroup run in antiphase (see
+    // the K loop).  The narrow whole-tile families (3 or 6 MFMAs per k-step) take it on request (APH: the host asks for layers of
+    // >= 128^2 points; same-box 256 -> 256 @128^2 88 -> 72 us with it, but 512 -> 512 @64^2 79 -> 94 us); the transposed tiles never
+    // (8-wave transposed tile 121 -> 601 us).
+    constexpr bool PP = IA_ANTIPHASE && NWAVES == 8 && !TR && ((FO == 2 && FP == 2) || APH);
+    const int grp = wave >> 2;
     for (int i = tid; i < NS * NP * BO; i += NTHREADS) {
         const int stg = i / (NP * BO), r = i - stg * NP * BO, pl = r / BO, o = r - pl * BO;
         *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + stg * stage_bytes + ((NP * NT + pl) * BO + o) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -440,9 +449,6 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     // re-use in the K loop would be waited for with vmcnt(0) there -- draining the ring on every chunk.
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();                         // the previous segment's readers (and the zero-tap stores) are done
-    int issued = c_lo;                       // next chunk to issue; chunk c lives in stage (c - c_lo) % NS
-    for (int k = 0; k < NS - 1 && issued < c_hi; ++k, ++issued) IA_ISSUE_DMA(issued, k);
-    int cur = 0;
     // PAIR (whole-tile launches): the odd tap out of a chunk's nine (tap 8; tap 4 in the transposed form) does not meet an all-zero tap
     // in its k-step -- 10 % of the MFMAs multiplying zeros -- but the same tap of the NEXT chunk: lanes 0-31 read their operands at the
     // even chunk of a pair and keep them, lanes 32-63 read theirs at the odd chunk into the same registers (exec-masked LDS reads),
@@ -452,17 +458,127 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     for (int q = 0; q < NP * FO; ++q) a_hold[q] = h16x8{};
 #pragma unroll
     for (int q = 0; q < NP * FP; ++q) b_hold[q] = h16x8{};
+    if constexpr (PP) {
+        // ---- K loop of the 8-wave tiles: two wave groups in antiphase (r04; the structure of up_rows_kernel, csrc/conv_up.hip, where the
+        // segment trace and the ablations are).  Waves w and w + 4 share a SIMD; group 1 (waves 4-7) runs ONE barrier interval behind
+        // group 0, so in every interval one wave of a SIMD is in a LOAD segment (a k-step's operand reads + its share of the refill DMA)
+        // while the other is in the COMPUTE segment of its k-step (12 MFMAs): the matrix pipe always has a wave feeding it.  With all
+        // eight waves in step (r02 / r03) both waves of a SIMD issued DMA and waited for their reads together, then queued for the pipe
+        // together -- the MFMAs' time was added to everything else, not overlapped.
+        //   * two LDS stages: chunk ch + 1 is DMA'd into the other stage during the first two LOAD segments of chunk ch (every wave
+        //     waits for its operand reads -- lgkmcnt(0) -- in front of the barrier that ends a LOAD segment, so the lagging group's reads
+        //     of chunk ch - 1 have returned before the leading group's first refill piece is issued), and waited for (vmcnt(0): nothing
+        //     younger is in flight) in the chunk's last LOAD segment, in front of the barrier after which the leading group reads it;
+        //   * every wave executes the same number of barriers (group 0 one more at the end).
+        auto pp_barrier = []() { asm volatile("s_barrier" ::: "memory"); };
+        auto mma_step = [&](const h16x8 (&a_use)[NP * FO], const h16x8 (&b_use)[NP * FP], int ph_) {
+#if IA_ABLATE == 2
+#pragma unroll
+            for (int q = 0; q < NP * FO; ++q) asm volatile("" ::"v"(a_use[q]));
+#pragma unroll
+            for (int q = 0; q < NP * FP; ++q) asm volatile("" ::"v"(b_use[q]));
+            return;
+#endif
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp)      // lo * hi
+                        acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_use[(NP - 1) * FO + fo], b_use[fp], acc[ph_][fo][fp], 0, 0, 0);
+                h16x8 a_sc[FO];                        // weight high parts at 2^-11: they meet the activation's low parts (scaled by 2^11)
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo) a_sc[fo] = a_use[fo] * (_Float16)(1.0f / kLoScale);
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp)      // (hi * 2^-11) * (lo * 2^11)
+                        acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[fo], b_use[(NP - 1) * FP + fp], acc[ph_][fo][fp], 0, 0, 0);
+            }
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int fp = 0; fp < FP; ++fp)          // hi * hi
+                    acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_use[fo], b_use[fp], acc[ph_][fo][fp], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        if (c_lo < c_hi) IA_ISSUE_DMA(c_lo, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pp_barrier();
+        if (grp) pp_barrier();
+        int cur = 0;
+        for (int ch = c_lo; ch < c_hi; ++ch) {
+            const bool fill = !IA_AB_NODMA && ch + 1 < c_hi;
+            const h16x8* wh = reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(lds) + cur * stage_bytes);
+            const h16x8* ph = wh + WSLOTS;
+            const int par = (ch - c_lo) & 1;                       // position of this chunk in its pair
+            const bool run_odd_tap = !PAIR || par == 1 || ch == c_hi - 1;
+            const int last_s = (PAIR && !run_odd_tap) ? kPairs - 2 : kPairs - 1;
+#pragma unroll
+            for (int s = 0; s < kPairs; ++s) {
+                const bool hold_step = PAIR && s == kPairs - 1;      // the odd tap of a pair of chunks: operands kept in a_hold / b_hold
+                if (hold_step && !run_odd_tap) break;
+                // LOAD segment
+                h16x8 a_use[NP * FO], b_use[NP * FP];
+                if (!hold_step) {
+                    const int tap = half ? pair_t1(TR, s) : pair_t0(TR, s);
+                    const int tof = pair_t1(TR, s) == kZeroTap ? (half ? 0 : toff[pair_t0(TR, s)]) : (half ? toff[pair_t1(TR, s)] : toff[pair_t0(TR, s)]);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                        for (int fo = 0; fo < FO; ++fo) a_use[pl * FO + fo] = wh[wrow(pl, tap) * BO + (wo * FO + fo) * 32 + l31];
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                        for (int fp = 0; fp < FP; ++fp) b_use[pl * FP + fp] = ph[pl * cap + bpos[fp] + tof];
+                }
+                if (PAIR && s == kPairs - 2) {                       // this chunk's odd tap, into this chunk's half of the lanes
+                    constexpr int tap8 = pair_t0(TR, kPairs - 1);
+                    if (half == par) {
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                            for (int fo = 0; fo < FO; ++fo) a_hold[pl * FO + fo] = wh[wrow(pl, tap8) * BO + (wo * FO + fo) * 32 + l31];
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                            for (int fp = 0; fp < FP; ++fp) b_hold[pl * FP + fp] = ph[pl * cap + bpos[fp] + toff[tap8]];
+                    } else if (par == 0 && ch == c_hi - 1) {         // a last chunk without a partner: its upper lanes multiply zeros
+#pragma unroll
+                        for (int q = 0; q < NP * FO; ++q) a_hold[q] = h16x8{};
+#pragma unroll
+                        for (int q = 0; q < NP * FP; ++q) b_hold[q] = h16x8{};
+                    }
+                }
+                if (fill && s < 2) IA_ISSUE_DMA_SLICE(ch + 1, cur ^ 1, s, 2);
+                if (fill && s == last_s) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk ch + 1 has landed (this wave's pieces)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have RETURNED before the barrier (the other group may refill their stage behind it)
+                __builtin_amdgcn_sched_barrier(0);
+                pp_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // COMPUTE segment
+                if (hold_step) mma_step(a_hold, b_hold, pair_phase(TR, s));
+                else mma_step(a_use, b_use, pair_phase(TR, s));
+                __builtin_amdgcn_sched_barrier(0);
+                pp_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cur ^= 1;
+        }
+        if (!grp) pp_barrier();
+    } else {
+    int issued = c_lo;                       // next chunk to issue; chunk c lives in stage (c - c_lo) % NS
+    for (int k = 0; k < NS - 1 && issued < c_hi; ++k, ++issued) IA_ISSUE_DMA(issued, k);
+    int cur = 0;
     for (int ch = c_lo; ch < c_hi; ++ch) {
         wait_vmcnt((issued - ch - 1) * n_dma);                // this wave's DMAs of chunk `ch` have landed (younger chunks stay in flight) ...
         __builtin_amdgcn_s_barrier();                         // ... and everybody's; the stage of chunk ch - 1 has no readers left
         asm volatile("" ::: "memory");                        // (s_barrier alone is no compiler fence: keep the operand reads below it)
-        // The chunk that goes into the stage just freed.  Issued either here in one burst, or (g.spread) a slice after each k-step's
-        // MFMAs: a piece costs its wave 60-185 issue cycles, and right after the barrier every wave of the SIMD would pay them at the
-        // same time with the matrix pipe idle; spread out, one wave's pieces run under the other wave's MFMAs.
+        // The chunk that goes into the stage just freed (4-wave tiles: two workgroups per CU overlap each other's phases).
         const bool fill = !IA_AB_NODMA && issued < c_hi;
         const int fill_chunk = issued, fill_stage = cur == 0 ? NS - 1 : cur - 1;
         if (fill) {
-            if (!g.spread) IA_ISSUE_DMA(fill_chunk, fill_stage);
+            IA_ISSUE_DMA(fill_chunk, fill_stage);
             ++issued;
         }
         const h16x8* wh = reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(lds) + cur * stage_bytes);
@@ -514,7 +630,6 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
             } else if ((!IA_AB_NOREAD || ch == c_lo) && s + 1 < kPairs) load_ops(s + 1, a_buf[(s + 1) & 1], b_buf[(s + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
             if (PAIR && s == kPairs - 1 && !run_odd_tap) {        // the even chunk of a pair: its odd tap waits for the partner's
-                if (fill && g.spread) IA_ISSUE_DMA_SLICE(fill_chunk, fill_stage, s, kPairs);
                 continue;
             }
             const h16x8 (&a_use)[NP * FO] = (PAIR && s == kPairs - 1) ? a_hold : a_buf[c_];
@@ -549,14 +664,11 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
                 for (int fp = 0; fp < FP; ++fp)          // hi * hi
                     acc[ph_][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_use[fo], b_use[fp], acc[ph_][fo][fp], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (fill && g.spread) {
-                IA_ISSUE_DMA_SLICE(fill_chunk, fill_stage, s, kPairs);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
         // (the kept operands were read from the stage that is refilled after the next barrier: they are in registers before it)
         if constexpr (PAIR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         cur = cur + 1 == NS ? 0 : cur + 1;
+    }
     }
 
 #pragma unroll
@@ -597,27 +709,17 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
 #undef IA_ISSUE_DMA_SLICE
 }
 
-template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP, bool WHOLE = false>
+template <int NP, bool TR, int FO, int FP, int WO, int WP, int JP, bool WHOLE = false, bool APH = false>
 int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const Geo& g_in, const Epi& e, hipStream_t s) {
     constexpr int BO = 32 * FO * WO, NWAVES = WO * WP;
     const size_t stage = (size_t)(NP * 10 * BO + NP * g_in.patch_cap) * 16;
     if (2 * stage > kLdsBytes) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", 2 * stage);
-    // Ring depth.  Measured on MI355X (tools/bench_conv_layers.py, r03): with the ring really running ahead (no compiler-inserted
-    // drain, see dma_piece) 3 .. 6 stages change no layer by more than the run-to-run noise -- the DMA's latency was never the
-    // exposed part -- while the 4-wave tiles lose 35-55 % when a deep ring takes the LDS of the second workgroup of their CU.
-    // So: two stages; more only on request (IA_RING_STAGES), bounded by the LDS and by the 6-bit vmcnt counter ((stages - 1)
-    // chunks of DMA instructions are outstanding per wave).
+    // Two LDS stages.  (r03: with the ring really running ahead -- no compiler-inserted drain, see dma_piece -- 3 .. 6 stages changed no
+    // layer by more than the run-to-run noise, while the 4-wave tiles lose 35-55 % when a deeper ring takes the LDS of the second workgroup
+    // of their CU; the experiment switches IA_RING_STAGES / IA_DMA_SPREAD were removed in r04.)
     Geo g = g_in;
-    const int per_wave = (NP * 9 * BO / 64 + NWAVES - 1) / NWAVES + JP;
-    int ns = 2;
-    if (const char* ev = getenv("IA_RING_STAGES")) {      // experiment switch (tools/): force the ring depth where it fits
-        const int want = atoi(ev);
-        if (want >= 2 && (size_t)want * stage <= kLdsBytes && (want - 1) * per_wave <= 63) ns = want;
-    }
-    g.stages = ns;
-    if (const char* ev = getenv("IA_DMA_SPREAD")) g.spread = atoi(ev);
+    constexpr int ns = 2;
     g.xcd_bands = (g.B == 1 || g.T_dp % ia::kNumXCD == 0) ? 1 : 0;      // (the linear workgroup id of batch element b starts at b * T_dp)
-    if (const char* ev = getenv("IA_XCD_BANDS")) g.xcd_bands = g.xcd_bands && atoi(ev);
     const size_t lds = stage * ns;
     int st = IA_OK;
     if (g.T_dp > 0) {
@@ -629,7 +731,7 @@ int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
                 return ia::check_launch("ia_conv2d_mfma_sx_rgb");
             }
         }
-        auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, false>;
+        auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, false, false, APH>;
         if (const int rs = ia::reserve_lds((const void*)k, (size_t)(lds), "conv_split")) return rs;
         hipLaunchKernelGGL(k, dim3(g.T_dp, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma_sx");
@@ -653,7 +755,7 @@ int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     return st;
 }
 
-template <int NP, bool TR, int FO, int FP, int WO, int WP, bool WHOLE = false>
+template <int NP, bool TR, int FO, int FP, int WO, int WP, bool WHOLE = false, bool APH = false>
 int launch_sx(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const Geo& g_in, const Epi& e, hipStream_t s) {
     constexpr int BP = 32 * FP * WP, NWAVES = WO * WP;
     Geo g = g_in;
@@ -667,9 +769,9 @@ int launch_sx(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d positions exceeds the LDS budget", worst);
     g.patch_cap = (worst + 63) & ~63;
     const int per_wave = (NP * g.patch_cap / 64 + NWAVES - 1) / NWAVES;
-    if (per_wave <= 2) return launch_jp<NP, TR, FO, FP, WO, WP, 2, WHOLE>(xs, wk, y, scratch, g, e, s);
-    if (per_wave <= 4) return launch_jp<NP, TR, FO, FP, WO, WP, 4, WHOLE>(xs, wk, y, scratch, g, e, s);
-    return launch_jp<NP, TR, FO, FP, WO, WP, 8, WHOLE>(xs, wk, y, scratch, g, e, s);
+    if (per_wave <= 2) return launch_jp<NP, TR, FO, FP, WO, WP, 2, WHOLE, APH>(xs, wk, y, scratch, g, e, s);
+    if (per_wave <= 4) return launch_jp<NP, TR, FO, FP, WO, WP, 4, WHOLE, APH>(xs, wk, y, scratch, g, e, s);
+    return launch_jp<NP, TR, FO, FP, WO, WP, 8, WHOLE, APH>(xs, wk, y, scratch, g, e, s);
 }
 
 }  // namespace
@@ -773,7 +875,10 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
         return launch_sx<1, false, 2, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
     }
     if (narrow && bo == 32 && transposed) return launch_sx<2, true, 1, 1, 1, 8, true>(x8, w8, y, scratch, g, e, s);
+    const bool aph = (int64_t)H * W >= 128 * 128;      // narrow tiles: antiphase wave groups from 128^2 points (see conv_split_kernel)
+    if (narrow && bo == 32 && aph) return launch_sx<2, false, 1, 1, 1, 8, true, true>(x8, w8, y, scratch, g, e, s);
     if (narrow && bo == 32) return launch_sx<2, false, 1, 1, 1, 8, true>(x8, w8, y, scratch, g, e, s);
+    if (narrow && aph) return launch_sx<2, false, 1, 2, 2, 4, true, true>(x8, w8, y, scratch, g, e, s);
     if (narrow) return launch_sx<2, false, 1, 2, 2, 4, true>(x8, w8, y, scratch, g, e, s);
     if (transposed && bp == 256) return launch_sx<2, true, 1, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
     if (transposed && bp == 128) return launch_sx<2, true, 1, 2, 2, 2>(x8, w8, y, scratch, g, e, s);

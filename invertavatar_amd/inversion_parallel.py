@@ -74,6 +74,9 @@ def few_shot_inversion_sharded(net, images, uvs, cams, uvcoords, rank=0, world_s
         draws = seeded_draws(0, nrr * nrr)
     # ---- A: identity (replicated: one frame, deterministic kernels)
     ws = net.encode(images[:1])
+    if world_size > 1:      # (the e4e trunk runs library convolutions whose algorithm choice may differ between processes: 1e-6 on ws;
+        ws = ws.contiguous()      #  everything downstream is this package's deterministic kernels, so one 28 KB broadcast makes the ranks bit-equal)
+        torch.distributed.broadcast(ws, src=0, group=group)
     tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
     sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
     e4e = {'w': ws, 'texture': tex, 'static': sta}
