@@ -629,6 +629,8 @@ def main():
                 n += 50
             el = time.perf_counter() - t_s
             result['sustained'] = dict(value=round(n / el, 3), unit='frames/s', steps=n, seconds=round(el, 2))
+            result['split_range_watch'] = dict(clamped=bool(hipops.split_saturation_poll(DEV)),
+                                               note='always-on device flag of the fp16 hi / lo split (ia_split_saturation_poll), over every frame so far')
             if not args.no_extra:
                 extra_legs(result, gen, wl, args)
             if not args.no_roofline:

@@ -179,20 +179,6 @@ int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed,
  */
 int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B, int I, int O, void* stream);
 
-/*
- * The same fused convolution for the SMALL 3x3 layers of a synthesis network (4^2 .. 16^2 blocks and the 16^2 -> 32^2
- * up-sampling layer: H * W <= 256, I % 32 == 0, O % 16 == 0) in ONE launch without scratch: 16 channel x 16 point tiles on
- * v_mfma_f32_16x16x4_f32, the K loop of a tile split over the 8 waves of its workgroup and added through LDS in wave order
- * (deterministic); operands straight from global memory.  Arguments, arithmetic (fp32 operands, fp32 accumulation) and the
- * transposed form's contract are those of ia_conv2d_mfma with ksize 3 and no residual; replaces the same reference chain
- * (training/networks_stylegan2.py:34-91, torch_utils/ops/conv2d_resample.py:114-136) and, against ia_conv2d_mfma on these shapes,
- * the stream-K slabs and the fix-up launch.  ia_conv2d_small_supported returns 1 for shapes it takes.
- */
-int ia_conv2d_small_supported(int I, int O, int H, int W, int transposed);
-int ia_conv2d_small(const float* x, const float* wk, const float* styles, const float* demod, const float* noise,
-                    const float* noise_strength, const float* bias, float* y, int B, int I, int O, int H, int W,
-                    int transposed, int act, float alpha, float gain, float clamp, void* stream);
-
 #define IA_RENDER_WHITE_BACK 1
 #define IA_RENDER_RGB_CHANNEL_MAJOR 2
 #define IA_RENDER_DIST_PER_FRAME 4
@@ -341,6 +327,9 @@ int ia_ray_sampler(const float* cam, int cam_stride, float* rays_o, float* rays_
  * the normalised tensor, as in the reference).
  */
 int ia_act_split(const float* x, const float* styles, const float* shift, void* xs, int planes, int B, int C, int H, int W, void* stream);
+
+/* 1 for the layer shapes ia_conv2d_mfma_sx covers (3x3, I % 8 == 0, O % 8 == 0, from 8^2; stride-1 layers need O >= 128, W <= 512). */
+int ia_conv2d_sx_supported(int I, int O, int H, int W, int ksize, int transposed);
 
 /*
  * ia_conv2d_mfma_s on split-format activations: same layer semantics, tiles, ksplit / scratch (ia_conv2d_plan with form = 3) and
@@ -563,6 +552,15 @@ int ia_layout_grid_u8(const float* img, uint8_t* out, int B, int C, int H, int W
  * assert a zero count over a full-width frame, and hipops.CHECK_SPLIT_RANGE makes every producer check itself.
  */
 int ia_split_saturation_count(const void* xs, int planes, int B, int C, int H, int W, unsigned int* count, void* stream);
+
+/*
+ * Always-on range watch of the hi / lo split.  Every producer of split-format activations (ia_act_split, the FIR tails, the
+ * convolution epilogues, ia_cond_blend_split) sets a device flag when a value it splits lies outside +-65504 or is not finite
+ * (it is clamped, as before).  This call reads the flags of the current device into *h_flagged (0: every split since the last
+ * reset was in range), optionally clearing them; it synchronises `stream` (a host read: call it once per frame / clip, outside
+ * captured graphs).  Real checkpoints cannot clamp silently.
+ */
+int ia_split_saturation_poll(unsigned int* h_flagged, int reset, void* stream);
 
 /*
  * Input side of a captured frame: n <= 8 device-to-device segment copies in ONE launch (src[k] -> dst[k], nbytes[k] bytes).

@@ -33,8 +33,6 @@ _SIGNATURES = {
     'ia_conv2d_mfma': [c_void_p] * 10 + [ctypes.c_size_t] + [c_int] * 8 + [c_float, c_float, c_float, c_int, c_void_p],
     'ia_conv2d_mfma_h': [c_void_p] * 10 + [ctypes.c_size_t] + [c_int] * 8 + [c_float, c_float, c_float, c_int, c_void_p],
     'ia_conv2d_mfma_s': [c_void_p] * 2 + [c_int] + [c_void_p] * 8 + [ctypes.c_size_t] + [c_int] * 8 + [c_float, c_float, c_float, c_int, c_void_p],
-    'ia_conv2d_small_supported': [c_int] * 5,
-    'ia_conv2d_small': [c_void_p] * 8 + [c_int] * 7 + [c_float, c_float, c_float, c_void_p],
     'ia_conv2d_plan': [c_int] * 8 + [ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_size_t)],
     'ia_modconv_demod': [c_void_p] * 3 + [c_int] * 3 + [c_void_p],
     'ia_render_rays': [c_void_p] * 10 + [c_float, c_float, c_int] + [c_int] * 6 + [c_void_p] * 9 + [c_void_p],
@@ -50,8 +48,10 @@ _SIGNATURES = {
     'ia_blend_planes': [c_void_p] * 3 + [c_int64, c_void_p] + [c_int] * 5 + [c_void_p],
     'ia_channels_last': [c_void_p] * 2 + [c_int] * 4 + [c_void_p],
     'ia_cond_blend': [c_void_p] * 3 + [c_int] * 4 + [c_void_p],
+    'ia_split_saturation_poll': [ctypes.POINTER(ctypes.c_uint), c_int, c_void_p],
     'ia_split_saturation_count': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'ia_act_split': [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
+    'ia_conv2d_sx_supported': [c_int] * 6,
     'ia_conv2d_mfma_sx': [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 7 + [c_int] + [c_void_p] * 2 + [ctypes.c_size_t] + [c_int] * 7 + [c_float, c_void_p, c_float, c_float] + [c_int, c_void_p],
     'ia_upconv2d_rows_plan': [c_int] * 5 + [ctypes.POINTER(ctypes.c_size_t)],
     'ia_upconv2d_rows_sx': [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t] + [c_int] * 5 + [c_void_p],

@@ -481,8 +481,7 @@ void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo
     // (form 3, r03: the 8^2 / 16^2 stride-1 layers and the 8^2 -> 16^2 / 16^2 -> 32^2 transposed ones run on the fp16-pair tiles too --
     //  a quarter of the matrix-pipe time of the fp32 tile's 36 MFMAs per chunk, although an 8^2 image fills a quarter of the 256-point
     //  tile; same-box frame A/B: 32^2 limit 340.4, 16^2 346.0 frames/s; on another box 16^2 327.0, 8^2 330.3, 4^2 332.2 (noise): 8^2)
-    static const int min_pts = getenv("IA_SX_MIN_POINTS") ? atoi(getenv("IA_SX_MIN_POINTS")) : kSplitMinPoints;      // (experiment switch)
-    const bool sx_small = form == 3 && ksize == 3 && npts >= min_pts;
+    const bool sx_small = form == 3 && ksize == 3 && npts >= kSplitMinPoints;
     if (npts <= kSmallPoints && O > 32 && !sx_small) { *bo = 128; *bp = 32; }
     else if (transposed) {
         // fp16-pair form on large images: two point fragments per wave (64ch x 128pt x 4 phases) -- one accumulator set leaves
@@ -513,24 +512,16 @@ static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transpos
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
     tile_dims(O, H, W, ksize, transposed, form, &p.bo, &p.bp, &p.cc, &p.waves);
     bool force_whole = false;
-    if (const char* ev = form == 3 ? getenv("IA_SX_TILE") : nullptr) {      // experiment switch (tools/): "bo,bp" = whole tiles of that family
-        int bo = 0, bp = 0;
-        if (sscanf(ev, "%d,%d", &bo, &bp) == 2 && bp == 256 && (bo == 32 || bo == 64 || bo == 128) && !(transposed && bo == 128) &&
-            worst_patch(npts, transposed ? W + 1 : W, 256, 3, transposed) <= kPatchFloats) {
-            p.bo = bo; p.bp = bp; p.waves = 8; force_whole = true;
-        }
-    }
     // Stride-1 3x3 layers of the split-DMA form that are smaller than the machine (512 -> 512 @64^2, 256 -> 256 @128^2 at one frame per
     // call): 32-channel x 256-point tiles, every tile whole, instead of 128 x 256 tiles cut between stream-K workers -- as soon as those
     // tiles give every CU one.  No slabs, no fix-up launch; a tile's weight rows (9 KB per chunk) are a quarter of the wide tile's.
     // Measured r03 (tools/bench_conv_layers.py, B = 1): 102.8 -> 76.2 us @64^2, 74.1 -> 67.3 us @128^2; 1024-point layers
     // (64 narrow tiles) stay on stream-K: 39 vs 64 us.
-    if (form == 3 && !force_whole && !transposed && ksize == 3 && p.waves == 8 && O % 32 == 0 && !getenv("IA_NO_NARROW_TILES")) {
+    if (form == 3 && !force_whole && !transposed && ksize == 3 && p.waves == 8 && O % 32 == 0) {
         const int64_t t_wide = (int64_t)B * ((npts + 255) / 256) * ((O + 127) / 128), t_narrow = (int64_t)B * ((npts + 255) / 256) * (O / 32);
-        static const int min_tiles = getenv("IA_NARROW_MIN_TILES") ? atoi(getenv("IA_NARROW_MIN_TILES")) : ia::kNumCU;      // (experiment switch)
+        constexpr int min_tiles = ia::kNumCU;
         if (t_wide < ia::kNumCU && t_narrow >= min_tiles) { p.bo = 32; p.bp = 256; force_whole = true; }
     }
-    if (const char* ev = form == 3 ? getenv("IA_SX_WHOLE") : nullptr) force_whole = force_whole || atoi(ev) != 0;      // experiment switch
     p.TO = (O + p.bo - 1) / p.bo;
     p.T = ((npts + p.bp - 1) / p.bp) * p.TO;
     p.C = (I + p.cc - 1) / p.cc;
@@ -553,7 +544,7 @@ static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transpos
         // measured 272 -> 280-284 frames/s at batch 1 for 0.241 -> 0.222 single-stream MFMA utilisation of the fp16-pair family;
         // capping the 128^2 layers too gives 283-285 and 0.213.  At batch >= 4 the per-element share Gb is below the cap anyway.
         if (rounds == 0 && npts <= kSmallLayerPoints) {
-            static const int cap = getenv("IA_SMALL_LAYER_WORKERS") ? atoi(getenv("IA_SMALL_LAYER_WORKERS")) : kSmallLayerWorkers;      // (experiment switch)
+            constexpr int cap = kSmallLayerWorkers;
             const int64_t lim = p.T > cap ? p.T : cap;
             if (G > lim) G = lim;
         }
@@ -571,6 +562,16 @@ int ia_conv2d_plan_tiles(int B, int I, int O, int H, int W, int ksize, int trans
     const Plan p = make_plan(B, I, O, H, W, ksize, transposed, form);
     *bo = p.bo; *bp = p.bp; *waves = p.waves; *T = p.T; *TO = p.TO; *C = p.C; *T_dp = p.T_dp; *slab_floats = p.slab_floats;
     return IA_OK;
+}
+
+// Shapes ia_conv2d_mfma_sx takes (the single source of the rule: hipops.conv_sx_supported asks here).
+extern "C" int ia_conv2d_sx_supported(int I, int O, int H, int W, int ksize, int transposed) {
+    if (ksize != 3 || I % 8 || O % 8 || H < 1 || W < 1) return 0;
+    const int npts = transposed ? (H + 1) * (W + 1) : H * W;
+    const int side = 8;                                      // smallest image: kSplitMinPoints = 8^2 (9^2 points transposed)
+    if ((H < W ? H : W) < side) return 0;
+    if (transposed) return npts >= (side + 1) * (side + 1) ? 1 : 0;
+    return (O >= 128 && npts >= kSplitMinPoints && W <= 512) ? 1 : 0;
 }
 
 static size_t scratch_bytes_for(int B, int G, int slab_floats) { return (size_t)B * G * 2 * slab_floats * sizeof(float); }

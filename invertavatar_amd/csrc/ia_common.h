@@ -13,7 +13,16 @@
 
 namespace ia {
 
-// Thread-local last-error text; the only mutable state in the library.
+// Range watch of the fp16 hi / lo split (the split clamps at +-65504 silently).  Every translation unit that splits owns
+// one device word, set by split_f16 when a value is outside the fp16 range (or not finite) -- a compare per element in kernels that
+// are memory-bound, an atomic only when it fires -- and registers a reader; ia_split_saturation_poll sums the words.
+struct SatProbe {
+    hipError_t (*read)(unsigned int* h_word, int reset, hipStream_t s);
+    SatProbe* next;
+};
+void register_sat_probe(SatProbe* p);
+
+// Thread-local last-error text; besides the range-watch words the only mutable state in the library.
 char* error_buffer();
 int fail(int code, const char* fmt, ...);
 
@@ -69,7 +78,21 @@ template <> struct Num<double> {
 // hi = fp16(v), lo = fp16((v - hi) * 2^11).  v saturates at the fp16 range; a high part that would be a denormal (flushed by
 // the MFMA) is dropped so that the value rides entirely in the scaled low part.  hi + lo * 2^-11 carries 22 mantissa bits.
 constexpr float kSplitLoScale = 2048.f;
+}  // namespace ia
+namespace {
+__device__ unsigned int ia_tu_saturated;         // this translation unit's range-watch word
+hipError_t ia_tu_read_saturated(unsigned int* h_word, int reset, hipStream_t s) {
+    hipError_t e = hipMemcpyFromSymbolAsync(h_word, HIP_SYMBOL(ia_tu_saturated), sizeof(unsigned int), 0, hipMemcpyDeviceToHost, s);
+    static const unsigned int zero = 0;
+    if (e == hipSuccess && reset) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(ia_tu_saturated), &zero, sizeof(unsigned int), 0, hipMemcpyHostToDevice, s);
+    return e;
+}
+ia::SatProbe ia_tu_probe{ia_tu_read_saturated, nullptr};
+struct IaTuProbeRegistration { IaTuProbeRegistration() { ia::register_sat_probe(&ia_tu_probe); } } ia_tu_probe_registration;
+}  // namespace
+namespace ia {
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    if (!(fabsf(v) <= 65504.f)) atomicOr(&ia_tu_saturated, 1u);      // outside the fp16 range (or NaN): clamped below, and reported
     v = fminf(fmaxf(v, -65504.f), 65504.f);
     hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.f : (_Float16)v;
     lo = (_Float16)((v - (float)hi) * kSplitLoScale);
@@ -83,7 +106,10 @@ __device__ __forceinline__ void split_f16_unscaled_lo(float v, _Float16& hi, _Fl
 }
 
 // One-plane form of the same format (fp16 operands, the arithmetic of the reference's fp16 blocks): the saturated value rounded once.
-__device__ __forceinline__ _Float16 round_f16(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
+__device__ __forceinline__ _Float16 round_f16(float v) {
+    if (!(fabsf(v) <= 65504.f)) atomicOr(&ia_tu_saturated, 1u);
+    return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+}
 
 }  // namespace ia
 

@@ -16,7 +16,28 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+static SatProbe* g_sat_probes = nullptr;      // filled by static initialisers of the translation units (before any call)
+void register_sat_probe(SatProbe* p) { p->next = g_sat_probes; g_sat_probes = p; }
+
 }  // namespace ia
+
+extern "C" int ia_split_saturation_poll(unsigned int* h_flagged, int reset, void* stream) {
+    IA_REQUIRE(h_flagged, "null output pointer");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int words[64];
+    int n = 0;
+    for (ia::SatProbe* p = ia::g_sat_probes; p && n < 64; p = p->next, ++n) {
+        words[n] = 0;
+        const hipError_t e = p->read(&words[n], reset, s);
+        if (e != hipSuccess) return ia::fail(IA_ERR_LAUNCH, "ia_split_saturation_poll: %s", hipGetErrorString(e));
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return ia::fail(IA_ERR_LAUNCH, "ia_split_saturation_poll: %s", hipGetErrorString(e));
+    unsigned int any = 0;
+    for (int i = 0; i < n; ++i) any |= words[i];
+    *h_flagged = any;
+    return IA_OK;
+}
 
 extern "C" int ia_version(void) { return IA_HIP_ABI_VERSION; }
 

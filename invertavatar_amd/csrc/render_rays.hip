@@ -41,6 +41,18 @@
 #define IA_RENDER_F16_RGB 0
 #endif
 
+// IA_RENDER_TRACE (tools/trace_render.py): workgroup 0 stamps s_memtime at the phase boundaries of its first rays into the
+// dbg_sigma_coarse buffer (a profiling build: that debug output is not written).
+#ifndef IA_RENDER_TRACE
+#define IA_RENDER_TRACE 0
+#endif
+#if IA_RENDER_TRACE
+#define IA_RSTAMP(slot) do { if (blockIdx.x == 0 && lane == 0 && tr_ray < 8 && p.dbg_sigma_coarse) \
+    reinterpret_cast<unsigned long long*>(p.dbg_sigma_coarse)[(wave * 8 + tr_ray) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define IA_RSTAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -510,9 +522,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
 
     const int nrays = p.B * p.R;
     const int PHs = SQ ? p.PW : p.PH;
+#if IA_RENDER_TRACE
+    int tr_ray = -1;
+#endif
     for (int ray0 = blockIdx.x * WAVES; ray0 < nrays; ray0 += gridDim.x * WAVES) {
         const int ray = __builtin_amdgcn_readfirstlane(ray0 + wave);      // wave-uniform: ray constants and the plane base are scalars
         if (ray >= nrays) continue;
+#if IA_RENDER_TRACE
+        ++tr_ray;
+#endif
+        IA_RSTAMP(0);
         const int b = ray / p.R;
         // depth range: renderer.py:311-313,404-406 (python doubles, fp32 tensors); one value for the batch, or one per frame when the
         // caller renders several single-frame calls of the script as one batch (wave-uniform scalar work either way)
@@ -542,18 +561,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             }
             gather_reduce(raw, wgt, f);
             features_to_operand(scr + COL_OFF + (16 * g) * CS, gj, gc, s, q, f);
+            IA_RSTAMP(1 + 4 * g);
             if (g + 1 < NS / 16) {      // next group's loads fly under this group's decoder
                 const float t = tc[16 * (g + 1) + gj];
                 gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
             }
             decoder_hidden(lds, lane, q, f, h);
+            IA_RSTAMP(2 + 4 * g);
             const float sg = decoder_sigma(lds, q, h);
             if (q == 0) sc[16 * g + s] = sg;
+            IA_RSTAMP(3 + 4 * g);
             f32x4 col[2];
             decoder_rgb(lds, lane, q, h, col);
             float4* dst = reinterpret_cast<float4*>(scr + COL_OFF + (16 * g + s) * CS + 8 * q);
             dst[0] = make_float4(col[0][0], col[0][1], col[0][2], col[0][3]);
             dst[1] = make_float4(col[1][0], col[1][1], col[1][2], col[1][3]);
+            IA_RSTAMP(4 + 4 * g);
         }
         wave_sync();
         // ---- coarse ray march: weights only (ray_marcher.py:26-42)
@@ -575,13 +598,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
                 wc[lane] = alpha * trans;
                 if (p.dbg_w_coarse) p.dbg_w_coarse[(int64_t)ray * (NS - 1) + lane] = alpha * trans;
             }
-            if (p.dbg_sigma_coarse && lane < NS) p.dbg_sigma_coarse[(int64_t)ray * NS + lane] = sc[lane];
+            if (!IA_RENDER_TRACE && p.dbg_sigma_coarse && lane < NS) p.dbg_sigma_coarse[(int64_t)ray * NS + lane] = sc[lane];
         }
         wave_sync();
+        IA_RSTAMP(13);
         // ---- importance resampling + merge
         const int ind = importance_resample(scr, lane, p.u_imp ? p.u_imp + (int64_t)ray * NS : nullptr);
+        IA_RSTAMP(14);
         int pos_c, pos_f;
         merge_sorted(scr, lane, pos_c, pos_f);
+        IA_RSTAMP(15);
         if (lane < NS) {
             if (p.dbg_z_fine) p.dbg_z_fine[(int64_t)ray * NS + lane] = scr[7 * NS + lane];
             if (p.dbg_inds) p.dbg_inds[(int64_t)ray * NS + lane] = ind;
@@ -607,20 +633,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
                 gather_issue<kEarlyPlanes, 3>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
                 gather_reduce(raw, wgt, f);
                 features_to_operand(scr + COL_OFF + (NS + 16 * g) * CS, gj, gc, s, q, f);
+                IA_RSTAMP(16 + 4 * g);
                 if (g + 1 < NS / 16) {
                     const float tn = tf[16 * (g + 1) + gj];
                     gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * p.box_scale, raw, wgt);
                 }
                 decoder_hidden(lds, lane, q, f, h);
+                IA_RSTAMP(17 + 4 * g);
                 const float sg = decoder_sigma(lds, q, h);
                 if (q == 0) scr[SGF_OFF + 16 * g + s] = sg;
+                IA_RSTAMP(18 + 4 * g);
                 decoder_rgb(lds, lane, q, h, col);
                 float4* dst = reinterpret_cast<float4*>(scr + COL_OFF + (NS + 16 * g + s) * CS + 8 * q);
                 dst[0] = make_float4(col[0][0], col[0][1], col[0][2], col[0][3]);
                 dst[1] = make_float4(col[1][0], col[1][1], col[1][2], col[1][3]);
+                IA_RSTAMP(19 + 4 * g);
             }
         }
         wave_sync();
+        IA_RSTAMP(28);
 
         // ---- compositing over the 96 merged samples, 16 at a time; lane s composites the interval that ENDS at its sample.
         // Same arithmetic in the same order as when the colours came straight from the decoder: only their source changed.
@@ -687,6 +718,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             acc_w += row_ror<N>(acc_w);                                               \
             acc_z += row_ror<N>(acc_z);                                               \
         }
+        IA_RSTAMP(29);
         IA_ROW_SUM_STEP(8) IA_ROW_SUM_STEP(4) IA_ROW_SUM_STEP(2) IA_ROW_SUM_STEP(1)
 #undef IA_ROW_SUM_STEP
         if (s == 0) {
@@ -706,6 +738,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             }
         }
         wave_sync();
+        IA_RSTAMP(30);
     }
     // per-workgroup depth range for the batch-global clamp (ray_marcher.py:50)
     __syncthreads();

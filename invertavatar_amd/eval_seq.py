@@ -179,4 +179,6 @@ def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=No
         if gt is not None:
             for k in range(b):
                 mosaics.append(layout_grid(torch.cat([gt[lo + k:lo + k + 1, :3], out['image'][k:k + 1]], dim=0), grid_w=2, grid_h=1))
+    from .reenact_avatar_next3d import _check_split_range
+    _check_split_range(cams.device)      # (one device -> host read per drive sequence: see hipops.split_saturation_poll)
     return torch.cat(imgs, 0), mosaics

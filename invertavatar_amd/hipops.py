@@ -87,21 +87,10 @@ def conv_h_supported(i, o, h, w, ksize, transposed):
     return o >= 128 and h * w >= 1024 and w <= 512
 
 
-# Smallest images the split-DMA form (ia_conv2d_mfma_sx) takes: 8^2 / 16^2 stride-1 layers (one 128 x 256 tile per 128 channels, cut
-# between stream-K workers) and 8^2 -> 16^2 / 16^2 -> 32^2 transposed layers (9^2 / 17^2 points on the 64 x 64 tile); the 4^2 layers
-# stay on the fp32 tiles (no gain measured).  IA_SX_MIN_RES=32 restores the r02 limits (the library follows with IA_SX_MIN_POINTS).
-SX_MIN_RES = int(os.environ.get('IA_SX_MIN_RES', '8'))
-
-
 def conv_sx_supported(i, o, h, w, ksize, transposed):
-    """Shapes the split-DMA form covers: those of conv_h_supported, plus (r03) the SX_MIN_RES^2 layers."""
-    if conv_h_supported(i, o, h, w, ksize, transposed):
-        return True
-    if ksize != 3 or i % 8 or o % 8 or min(h, w) < SX_MIN_RES:
-        return False
-    if transposed:
-        return (h + 1) * (w + 1) >= (SX_MIN_RES + 1) ** 2
-    return o >= 128 and h * w >= SX_MIN_RES ** 2 and w <= 512
+    """Shapes the split-DMA form (ia_conv2d_mfma_sx) covers: the library's own rule (ia_conv2d_sx_supported) -- 3x3 layers from 8^2 up
+    (the 4^2 layers stay on the fp32 tiles: no gain measured)."""
+    return bool(_lib.load().ia_conv2d_sx_supported(int(i), int(o), int(h), int(w), int(ksize), int(bool(transposed))))
 
 
 def weight_sq_sum(w):
@@ -149,51 +138,13 @@ def _scratch_buffer(device, nbytes):
     return buf
 
 
-import os as _os
-
-# ia_conv2d_small (3x3 layers up to 16^2 and 16^2 -> 32^2 in one launch, no fix-up) is OFF by default: alone it matches or beats the
-# stream-K kernel + fix-up per layer (15 vs 20 us at 4^2, 34 vs 41 at 16^2), but inside a frame its hundreds of 16 x 16 tiles re-read
-# operands from L2 next to the other networks' large layers: same-box A/B 296 vs 303 frames/s (r03, tools/ab_frame.py).
-# IA_SMALL_CONV=1 enables it (kept for batch-1 callers that run one network at a time).
-SMALL_CONV = _os.environ.get('IA_SMALL_CONV', '0') == '1'
-SMALL_CONV_MAX_RES = int(_os.environ.get('IA_SMALL_CONV_MAX_RES', '16'))       # (input resolution; 8 keeps the 16^2 layers, its heaviest launches, on the tiled route)
-SMALL_CONV_MAX_BATCH = int(_os.environ.get('IA_SMALL_CONV_MAX_BATCH', '2'))      # (a batch-8 call: 352 vs 375 frames/s with it)
-
-
-def conv2d_small(x, wk, styles=None, demod=None, noise=None, noise_strength=None, bias=None, transposed=False, act='linear', alpha=0.2,
-                 gain=1.0, clamp=None):
-    """ia_conv2d_small: the fused 3x3 convolution for the small layers (same contract as conv2d_mfma with ksize 3, no residual)."""
-    _f32c(x, 'x')
-    _f32c(wk, 'wk')
-    b, i, h, w = x.shape
-    taps, wi, o = wk.shape
-    if taps != 9 or wi != i:
-        raise RuntimeError(f'packed weight {tuple(wk.shape)} does not match 3x3, in-channels {i}')
-    for name, t in (('styles', styles), ('demod', demod), ('noise', noise), ('bias', bias)):
-        if t is not None:
-            _f32c(t, name)
-    oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (h, w)
-    y = torch.empty(b, o, oh, ow, device=x.device, dtype=torch.float32)
-    flops = 2.0 * b * h * w * i * o * 9
-    traffic = 4.0 * (x.numel() + wk.numel() + y.numel())
-    with torch.cuda.device(x.device), _Timed('conv2d_small_t' if transposed else 'conv2d_small', flops, traffic, f'B{b} I{i} O{o} {h}x{w}'):
-        st = _lib.load().ia_conv2d_small(_p(x), _p(wk), _p(styles), _p(demod), _p(noise), _p(noise_strength), _p(bias), _p(y), b, i, o, h, w,
-                                         int(transposed), ACT_ID[act], float(alpha), float(gain), float(-1 if clamp is None else clamp),
-                                         _lib.stream_ptr(x.device))
-    _lib.check(st, 'ia_conv2d_small')
-    return y
-
-
 def conv2d_mfma(x, wk, styles=None, demod=None, noise=None, noise_strength=None, bias=None, residual=None,
                 ksize=3, transposed=False, act='linear', alpha=0.2, gain=1.0, clamp=None, ksplit=None):
     """One fused StyleGAN2 convolution (see ia_conv2d_mfma in include/ia_hip.h).  A float16 `wk` (pack_conv_weight_h)
-    selects the fp16-operand form ia_conv2d_mfma_h.  Small fp32 3x3 layers go to ia_conv2d_small (SMALL_CONV)."""
+    selects the fp16-operand form ia_conv2d_mfma_h."""
     _f32c(x, 'x')
     b, i, h, w = x.shape
     half_ops = wk.dtype == torch.float16
-    if (SMALL_CONV and b <= SMALL_CONV_MAX_BATCH and h <= SMALL_CONV_MAX_RES and not half_ops and ksize == 3 and residual is None and ksplit is None and wk.dim() == 3
-            and _lib.load().ia_conv2d_small_supported(i, wk.shape[2], h, w, int(transposed))):
-        return conv2d_small(x, wk, styles, demod, noise, noise_strength, bias, transposed, act, alpha, gain, clamp)
     split = half_ops and wk.dim() == 5
     if half_ops:
         if not (wk.is_cuda and wk.is_contiguous() and wk.dim() in (4, 5) and wk.shape[-1] == 8 and (not split or wk.shape[0] == 2)):
@@ -298,6 +249,17 @@ def torgb(x, wk, styles=None, bias=None, residual=None, skip=None, skip_filter=N
 # Debug switch: every producer of a SplitAct counts the elements its hi / lo split clamped at +-65504 (ia_split_saturation_count) and
 # raises when there are any -- the range contract of the fp16-pair convolutions, otherwise silent (one sync per producer: tests only).
 CHECK_SPLIT_RANGE = False
+
+
+def split_saturation_poll(device=None, reset=True):
+    """True when any hi / lo split on `device` since the last reset met a value outside +-65504 (it was clamped): the always-on
+    range watch of the fp16-pair convolutions (ia_split_saturation_poll; a device -> host read, not for captured regions)."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    flag = ctypes.c_uint(0)
+    with torch.cuda.device(device):
+        st = _lib.load().ia_split_saturation_poll(ctypes.byref(flag), int(bool(reset)), _lib.stream_ptr(device))
+    _lib.check(st, 'ia_split_saturation_poll')
+    return flag.value != 0
 
 
 def split_saturation_count(sa):

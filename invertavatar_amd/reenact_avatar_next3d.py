@@ -151,7 +151,19 @@ def run_video_animation(G, drive, seeds, grid_dims=(None, 1), truncation_psi=1.0
         if outdir is not None:
             np.save(os.path.join(outdir, f'{fname}_{k:04d}.npy'), mosaic if to_numpy else mosaic.cpu().numpy())
         frames.append(mosaic)
+    _check_split_range(device)
     return frames
+
+
+def _check_split_range(device):
+    """The fp16 hi / lo split of the large convolutions clamps at +-65504: the library's always-on range watch says whether any
+    activation of the clip hit the clamp (random-init weights stay 5 orders of magnitude below it; a real checkpoint is checked here)."""
+    if torch.device(device).type != 'cuda':
+        return
+    from . import hipops
+    if hipops.split_saturation_poll(device):
+        raise OverflowError('activations outside the fp16 range (+-65504) were clamped by the hi / lo split of the fp16-pair convolutions: '
+                            'set training.networks_stylegan2.SPLIT_FP16_PRODUCTS = False (fp32 MFMA path) for this checkpoint')
 
 
 def main(argv=None):

@@ -41,16 +41,16 @@ STREAMING_TORGB = True           # ToRGB layers through ia_conv1x1 (one streamin
 # ia_torgb re-reads the activations once per block of 32 output channels with 8-wave workgroups: past this many pixels x channel blocks
 # (the 96-channel ToRGB of the static backbone at 256^2) the 64-thread workgroups of ia_conv1x1 (+ ia_upfirdn2d) share the machine better
 # with the convolutions of the other streams.  Same-box frame A/B, final r03 tree: 16384 / 49152 / 65536 = 345.7 / 344.2 / 346.7 frames/s.
-TORGB_MAX_WORK = int(os.environ.get('IA_TORGB_MAX_WORK', 65536))
+TORGB_MAX_WORK = 65536
 # Up-sampling layers with at most this many input channels run as one stride-1 launch on the weight composed with the resample filter
 # (ia_upconv2d_fir_sx: 4x the products, no (2H+1)^2 fp32 image, no FIR launch): the 32 -> 256 @128^2 layer of the SR head
-COMPOSED_UPFIR = os.environ.get('IA_COMPOSED_UPFIR', '1') == '1'
-COMPOSED_UPFIR_MAX_IN = int(os.environ.get('IA_COMPOSED_UPFIR_MAX_IN', 32))
+COMPOSED_UPFIR = True
+COMPOSED_UPFIR_MAX_IN = 32
 # Up-sampling layers from UPCONV_ROWS_MIN_RES^2 inputs: the transposed convolution per output row phase on the stride-1 tile
 # (ia_upconv2d_rows_sx, csrc/conv_up.hip) instead of the four-phase tile of ia_conv2d_mfma_sx.
 UPCONV_ROWS = True
 UPCONV_ROWS_MIN_RES = 64
-FUSED_TORGB_SKIP = os.environ.get('IA_FUSED_TORGB_SKIP', '1') == '1'          # ... and, where ia_torgb covers the shape, with the skip image's up-sampling + add in the same launch
+FUSED_TORGB_SKIP = True          # ... and, where ia_torgb covers the shape, with the skip image's up-sampling + add in the same launch
 SPLIT_FP16_PRODUCTS = True
 
 # ... and where the INPUT can be had as fp16 hi/lo planes (hipops.SplitAct: written by the producing layer's epilogue, or by

@@ -24,8 +24,7 @@ def _fit(x, rgb, size, antialias):
     return x, rgb
 
 
-import os as _os
-SKIP_IMAGE_STREAM = _os.environ.get('IA_SKIP_IMAGE_STREAM', '1') != '0'     # block0's skip image on a side stream (see _TwoBlockHead.forward)
+SKIP_IMAGE_STREAM = True     # block0's skip image on a side stream (see _TwoBlockHead.forward)
 
 
 class _TwoBlockHead(torch.nn.Module):

@@ -30,9 +30,9 @@ from .volumetric_rendering.ray_sampler import RaySampler, RaySampler_zxc  # noqa
 
 BBOX_256 = [57, 185, 64, 192]   # face region of the frontal plane, in 256^2 pixels (triplane_v20.py:114)
 N_COND_LEVELS_USED = 4          # cond_list entries the face backbone consumes
-CL_COPIES_ON_TEXTURE_STREAM = __import__('os').environ.get('IA_CL_ON_TEX', '1') == '1'   # False: the rasteriser's stream makes them (ia_rasterize_level's own copy)
-FACE_HEAD_AFTER_BACKBONES = __import__('os').environ.get('IA_FACE_HEAD_LATE', '0') == '1'   # launch order experiment (tools/ab_frame.py)
-LAUNCH_ORDER = __import__('os').environ.get('IA_LAUNCH_ORDER', 'default')                    # 'face_first', 'static_first'
+CL_COPIES_ON_TEXTURE_STREAM = True   # False: the rasteriser's stream makes them (ia_rasterize_level's own copy)
+FACE_HEAD_AFTER_BACKBONES = False   # launch order experiment (tools/ab_frame.py)
+LAUNCH_ORDER = 'default'                    # 'face_first', 'static_first'
 
 SINGLE_STREAM = False           # True: no side streams (every launch of a frame in program order on the caller's stream); used by
                                 # bench.py to time kernels without neighbours from other streams

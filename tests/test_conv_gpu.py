@@ -510,48 +510,6 @@ def test_conv_sx_with_fused_torgb(res, planes):
         hipops.conv2d_mfma_sx_rgb(small, wk, rgb_w, rgb_styles, rgb_bias, None, 1.5, demod)
 
 
-# ---- ia_conv2d_small: the 4^2 .. 16^2 layers (and 16^2 -> 32^2) in one launch, K split inside the workgroup
-SMALL_CASES = [  # B, I, O, res, up
-    (1, 512, 512, 4, 1), (1, 512, 512, 8, 1), (1, 512, 512, 16, 1), (2, 64, 96, 16, 1), (1, 32, 16, 5, 1),
-    (1, 512, 512, 4, 2), (1, 512, 512, 8, 2), (1, 512, 512, 16, 2), (2, 96, 48, 11, 2), (3, 32, 32, 1, 2),
-]
-
-
-@pytest.mark.parametrize('b,i,o,res,up', SMALL_CASES)
-def test_small_layer_kernel_vs_oracle_and_vs_the_tiled_kernel(b, i, o, res, up):
-    """The layer through ia_conv2d_small (hipops.SMALL_CONV) against the oracle's modulated
-    convolution, and against the stream-K + fix-up route it replaces (same fp32 arithmetic, another summation order)."""
-    assert hipops._lib.load().ia_conv2d_small_supported(i, o, res, res, int(up == 2)) == 1
-    x, w = rnd(1, b, i, res, res), rnd(2, o, i, 3, 3)
-    styles = rnd(3, b, i) * 0.3 + 1
-    out = res * up
-    noise, bias = rnd(4, out, out), rnd(5, o) * 0.2
-    ref = _layer_ref(x, w, styles, noise, 0.1, bias, up, clamp=2.0)
-    saved, saved_b = hipops.SMALL_CONV, hipops.SMALL_CONV_MAX_BATCH
-    hipops.SMALL_CONV, hipops.SMALL_CONV_MAX_BATCH = False, 8
-    try:
-        tiled = _layer_hip(x, w, styles, noise, 0.1, bias, up, clamp=2.0).cpu()
-        hipops.SMALL_CONV = True
-        got = _layer_hip(x, w, styles, noise, 0.1, bias, up, clamp=2.0).cpu()
-        again = _layer_hip(x, w, styles, noise, 0.1, bias, up, clamp=2.0).cpu()
-    finally:
-        hipops.SMALL_CONV, hipops.SMALL_CONV_MAX_BATCH = saved, saved_b
-    scale = max(ref.abs().max().item(), 1.0)
-    assert got.shape == ref.shape
-    assert max_abs(got, ref) <= 3e-5 * scale, (max_abs(got, ref), scale)
-    assert max_abs(got, tiled) <= 3e-5 * scale
-    assert torch.equal(again, got)                        # fixed summation order: run-to-run identical
-
-
-def test_small_layer_kernel_refuses_what_it_does_not_cover():
-    lib = hipops._lib.load()
-    assert lib.ia_conv2d_small_supported(512, 512, 32, 32, 0) == 0 and lib.ia_conv2d_small_supported(24, 16, 8, 8, 0) == 0
-    x = torch.zeros(1, 24, 8, 8, device='cuda')
-    wk = torch.zeros(9, 24, 16, device='cuda')
-    with pytest.raises(RuntimeError, match='ia_conv2d_small covers'):
-        hipops.conv2d_small(x, wk)
-
-
 @pytest.mark.parametrize('b,i,o,h,w', [(1, 32, 128, 64, 64), (2, 48, 256, 24, 40), (1, 16, 128, 16, 256), (1, 64, 128, 130, 128),
                                        (1, 512, 256, 64, 64), (1, 256, 128, 128, 128), (3, 32, 128, 33, 17)])
 def test_row_phase_upconv_equals_the_four_phase_form_and_fp64(b, i, o, h, w):

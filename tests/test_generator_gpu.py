@@ -311,6 +311,35 @@ def test_split_format_range_contract_holds_over_a_full_width_frame_and_trips_whe
         hipops.CHECK_SPLIT_RANGE = False
 
 
+def test_split_range_watch_is_always_on():
+    """no switch -- every split producer flags values outside the fp16 range on the device
+    (ia_split_saturation_poll): clean over a full-width frame (all producers: act_split, FIR tails, convolution epilogues, condition
+    blend), set by one out-of-range activation in any of them, cleared by the poll."""
+    hipops.split_saturation_poll()                       # clear whatever earlier tests left
+    g = _build('full')
+    frames, nrr = [3], 128
+    ws = g.mapping(synthetic.latent(0, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14)
+    with torch.no_grad():
+        g.synthesis(ws, synthetic.camera_labels(frames).cuda(), {'uvcoords_image': synthetic.uv_conditions(frames).cuda()},
+                    neural_rendering_resolution=nrr, noise_mode='const', evaluation=True, jitter=synthetic.jitter(frames, nrr * nrr).cuda())
+    assert hipops.split_saturation_poll() is False
+    x = torch.randn(1, 64, 32, 32, device='cuda')
+    hipops.act_split(x)
+    assert hipops.split_saturation_poll() is False
+    x[0, 5, 7, 9] = 7.0e4
+    hipops.act_split(x)                                  # clamps (as before) -- and says so
+    assert hipops.split_saturation_poll(reset=False) is True and hipops.split_saturation_poll() is True
+    assert hipops.split_saturation_poll() is False       # the poll cleared it
+    # a convolution epilogue that writes the split format: huge consumer styles push its output out of range
+    wk = hipops.pack_conv_weight_split(torch.randn(128, 64, 3, 3, device='cuda'))
+    xs = hipops.act_split(torch.randn(1, 64, 32, 32, device='cuda'))
+    hipops.conv2d_mfma_sx(xs, wk, styles_next=torch.full((1, 128), 1e4, device='cuda'), want_f32=False)
+    assert hipops.split_saturation_poll() is True
+    x[0, 5, 7, 9] = float('nan')
+    hipops.act_split(x)
+    assert hipops.split_saturation_poll() is True        # not-a-number counts as out of range
+
+
 def test_fill_mouth_default_blur_on_device_equals_the_cpu_route():
     """fill_mouth(images) with blur_mouth_edge=True (the default, renderer.py:732-736): ia_mouth_edge_blur == the torch-CPU restatement of
     cv2.erode x3 + cv2.blur 5x5 bit for bit (which tests/test_generator_cpu.py pins against a pixel-by-pixel evaluation)."""
