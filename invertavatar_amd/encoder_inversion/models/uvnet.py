@@ -4,6 +4,8 @@
 + tri-plane UNet (CS-SFT conditions for the static backbone), wrapped around a frozen ``TriPlaneGenerator``.
 ``AR_eval_forward`` is the incremental few-shot step of eval_seq.py:173-190: render the current estimate for the T
 source frames, feed the residual to both UNets, whose ConvGRU states ``r_list`` carry over to the next group."""
+import contextlib
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -22,6 +24,9 @@ class unet_encoder(nn.Module):
 
     def forward(self, x):
         raise NotImplementedError
+
+
+UNET_CHAINS_CONCURRENT = True      # device path of AR_eval_forward: texture chain on a side stream beside the tri-plane chain
 
 
 def _add_offsets(feats, offsets):
@@ -151,15 +156,31 @@ class inversionNet(nn.Module):
             vid_ws, over_frames(texture_feats), vid_c, vid_v, static_feats=over_frames(static_feats), noise_mode='const')
         delta_x = y0['image'] - x['image'][:, :3]
         uv_input = None
+        # The two chains read delta_x and nothing of each other, and each is a long sequence of small launches (IR-SE50 trunk on four
+        # frames + ConvGRU decoder: ~7.5 ms that leave most of the chip idle): on the device the texture chain runs on a side stream
+        # beside the tri-plane chain (r04: the same split inversion_parallel makes between two ranks).
+        fork = (UNET_CHAINS_CONCURRENT and len(parts) == 2 and delta_x.is_cuda and not torch.is_grad_enabled())
+        if fork:
+            from ... import _runtime
+            st = _runtime.state(self)
+            if getattr(st, 'chain_stream', None) is None or st.chain_stream.device != delta_x.device:
+                st.chain_stream = torch.cuda.Stream(device=delta_x.device)
+            main, side = torch.cuda.current_stream(delta_x.device), st.chain_stream
+            side.wait_stream(main)
         if 'texture' in parts:
-            uv_input = self.get_unet_uvinput(x['uv'], delta_x)
-            offsets, r_list[0] = self.unet_encoder.texture_unet(uv_input.unsqueeze(0), r_list=r_list[0], return_list=True)
-            texture_feats = _add_offsets(texture_feats, offsets)
+            with (torch.cuda.stream(side) if fork else contextlib.nullcontext()):
+                uv_input = self.get_unet_uvinput(x['uv'], delta_x)
+                offsets, r_list[0] = self.unet_encoder.texture_unet(uv_input.unsqueeze(0), r_list=r_list[0], return_list=True)
+                texture_feats = _add_offsets(texture_feats, offsets)
         if 'triplane' in parts:
             tri_input = torch.cat([x['image'][:, :3], delta_x], dim=-3)
             sft, r_list[1] = self.unet_encoder.triplane_unet(tri_input.unsqueeze(0), r_list=r_list[1])
             static_feats = g.backbone.synthesis(ws, cond_list=None, return_list=True, feat_conditions=sft, update_emas=False,
                                                 noise_mode='const')
+        if fork:
+            main.wait_stream(side)
+            for t in list(texture_feats) + list(r_list[0]) + [uv_input]:
+                t.record_stream(main)
         updated = {'w': ws, 'texture': texture_feats, 'static': static_feats}
         if not return_fake:
             return updated, r_list
