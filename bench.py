@@ -49,7 +49,7 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense fp16 MFMA
 PEAK_HBM_GBS = 8000.0
 NRR = 128
 FRAMES_PER_RANK_SHARDED = 8     # configs[3]: B = 64 over 8 GPUs
-PMC_FILE = os.path.join(REPO, 'profiles', 'r03_pmc_frame_hbm_traffic.json')
+PMC_FILE = os.path.join(REPO, 'profiles', 'r04_pmc_frame_hbm_traffic.json')
 DEV = torch.device('cuda')      # set by setup_distributed
 
 
@@ -215,7 +215,7 @@ def pmc_traffic(family):
             return None, f'{os.path.basename(PMC_FILE)} was measured on other kernel sources (digest {summ.get("csrc_digest")}): not used'
         fam = summ['fp16_pair_family']
         return int(fam['traffic_bytes_per_logical_launch']), (
-            f'{os.path.basename(PMC_FILE)}: (2 x FETCH_SIZE + WRITE_SIZE) of conv_split_kernel + its fix-ups / {fam["logical_launches_per_frame"]} '
+            f'{os.path.basename(PMC_FILE)}: (2 x FETCH_SIZE + WRITE_SIZE) of conv_split_kernel / up_rows_kernel + their fix-ups / {fam["logical_launches_per_frame"]} '
             f'launches per frame; uncorrected {fam["traffic_bytes_per_logical_launch_uncorrected"]}')
     except (KeyError, ValueError, OSError) as exc:
         return None, f'unreadable PMC summary: {exc}'

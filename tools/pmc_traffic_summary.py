@@ -22,7 +22,7 @@ def fetch_factor(kernel):
     """MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports half of the bytes of a 16-byte-per-lane coalesced read (`global_load_dwordx4`
     and `buffer_load_dwordx4 ... lds` alike).  conv_split_kernel fetches everything that way (LDS-DMA); conv_fixup_kernel reads its slabs
     as float4.  The register-staged kernels read dwords (uncalibrated: factor 1, flagged)."""
-    if 'conv_split_kernel' in kernel or 'conv_fixup_kernel' in kernel:
+    if any(n in kernel for n in ('conv_split_kernel', 'conv_fixup_kernel', 'up_rows_kernel', 'up_edge_fixup_kernel')):
         return 2.0
     return 1.0
 
@@ -31,13 +31,15 @@ def in_pair_family(kernel):
     # conv_split_kernel with two operand planes (template argument NP = 2), and the fix-ups of its tile families (2 x 2 / 2 x 4 waves)
     if 'conv_split_kernel' in kernel:
         return 'conv_split_kernelILi2E' in kernel or 'conv_split_kernel<2,' in kernel
+    if 'up_rows_kernel' in kernel or 'up_edge_fixup_kernel' in kernel:      # r04: the row-phase form of the large transposed layers
+        return True
     if 'conv_fixup_kernel' in kernel:
         t = kernel.split('<')[-1].split('>')[0].replace(' ', '').split(',')
         return len(t) >= 5 and t[3] == '2'
     return False
 
 
-conv = {k: e for k, e in d.items() if any(s in k for s in ('conv_split_kernel', 'conv_mfma_kernel', 'conv_fixup_kernel', 'conv_small_kernel', 'conv1x1_kernel'))}
+conv = {k: e for k, e in d.items() if any(s in k for s in ('conv_split_kernel', 'conv_mfma_kernel', 'conv_fixup_kernel', 'up_rows_kernel', 'up_edge_fixup_kernel', 'conv1x1_kernel'))}
 per_kernel, fam = {}, dict(fetch_raw=0.0, fetch_corrected=0.0, write=0.0, dispatches=0)
 for k, e in conv.items():
     f_raw, w = e.get('FETCH_SIZE', 0.0) * 1e3 / frames, e.get('WRITE_SIZE', 0.0) * 1e3 / frames
@@ -51,12 +53,12 @@ for k, e in conv.items():
 out = dict(_summary=dict(
     how='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--kernel-trace only) over `bench.py --steps 2 --warmup 1 --eager '
         '--no-cpu-baseline --no-roofline --no-extra` (tools/profile_round.sh); counters are KB summed over dispatches',
-    correction='FETCH_SIZE x 2 for the kernels whose reads are 16 bytes per lane (conv_split_kernel: buffer_load_dwordx4 ... lds; '
+    correction='FETCH_SIZE x 2 for the kernels whose reads are 16 bytes per lane (conv_split_kernel / up_rows_kernel: buffer_load_dwordx4 ... lds; '
                'conv_fixup_kernel: float4 slab reads), as MI355X_MICROARCH.md (HBM) prescribes for gfx950; WRITE_SIZE and dword reads are '
                'uncalibrated there and taken as reported; Infinity-Cache hits are counted by these counters, so this is fabric-side traffic',
     frames=frames, csrc_digest=build.source_digest(),
     fp16_pair_family=dict(
-        kernels='conv_split_kernel<NP = 2, ...> + conv_fixup_kernel of its tile families: the launches roofline.algorithmic_bytes_per_launch averages over',
+        kernels='conv_split_kernel<NP = 2, ...> + conv_fixup_kernel of its tile families + up_rows_kernel / up_edge_fixup_kernel: the launches roofline.algorithmic_bytes_per_launch averages over',
         logical_launches_per_frame=logical, kernel_dispatches_per_frame=round(fam['dispatches'], 1),
         fetch_raw_gb_per_frame=round(fam['fetch_raw'] / 1e9, 3), fetch_corrected_gb_per_frame=round(fam['fetch_corrected'] / 1e9, 3),
         write_gb_per_frame=round(fam['write'] / 1e9, 3),
