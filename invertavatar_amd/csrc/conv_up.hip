@@ -54,7 +54,8 @@ struct UpSub {
     int tp;                  // points per point tile (the tile's capacity BP, or fewer for the one-column grids: their window is 2 wide)
     int reps;                // whole-tile grids: consecutive tiles per workgroup
     int gpe;                 // edge grids: workers per tile (0 = whole tiles)
-    int edge_first;          // edge grids: index of the grid's first tile among all edge tiles
+    int edge_first;          // K-split grids: index of the grid's first tile among all K-split tiles (the fix-up's grid)
+    int slab_first;          // K-split grids: index of the grid's first slab (tile lt, part j -> slab_first + lt * gpe + j)
     int GH, GW;              // points
     int r_off, c_off;        // point (r, c) of the grid is point (r_off + r, c_off + c) of the layer
     int py;                  // output row phase
@@ -64,8 +65,8 @@ struct UpGeo {
     int B, I, O, H, W, OH, OW, TO;
     int nsub;
     UpSub sub[kMaxSub];
-    int E;                   // edge tiles in total
-    int gpe;                 // workers per edge tile (slab stride)
+    int E;                   // K-split tiles in total (edge grids, and the long interior tiles of K-deep small layers)
+    int n_slabs;             // slabs per batch element
     int cap;                 // patch positions per plane in LDS (all channel groups), multiple of 128
     int stages;              // LDS stages of the DMA ring (chunks ch+1 .. ch+stages-1 are in flight under chunk ch)
     int pair;                // 1: a workgroup of grid 0 (py 0) goes on to the tile of the same index of grid 1 (py 1)
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void up_rows_kernel(const h16x8* __restrict
     } else if (!sb.gpe) {
         up_store_tile<FP>(acc, y, demod, g, sb, b, o0, p0, p_last, tid);
     } else if (!IA_UP_TRACE) {
-        float4* slab = reinterpret_cast<float4*>(slabs + (((int64_t)b * g.E + sb.edge_first + lt) * g.gpe + part) * ((int64_t)NACC * NTHREADS)) + tid;
+        float4* slab = reinterpret_cast<float4*>(slabs + ((int64_t)b * g.n_slabs + sb.slab_first + lt * sb.gpe + part) * ((int64_t)NACC * NTHREADS)) + tid;
 #pragma unroll
         for (int q = 0; q < NACC / 4; ++q) {
             const int fr = q >> 2, r0 = (q & 3) * 4;
@@ -443,19 +444,19 @@ __global__ __launch_bounds__(512) void up_edge_fixup_kernel(const float* __restr
     for (int k = 0; k < kMaxSub; ++k)
         if (k < g.nsub && g.sub[k].gpe && e >= g.sub[k].edge_first) sb = g.sub[k];
     const int lt = e - sb.edge_first;
-    const float4* base = reinterpret_cast<const float4*>(slabs + (((int64_t)b * g.E + e) * g.gpe) * ((int64_t)NACC * NTHREADS)) + tid;
+    const float4* base = reinterpret_cast<const float4*>(slabs + ((int64_t)b * g.n_slabs + sb.slab_first + lt * sb.gpe) * ((int64_t)NACC * NTHREADS)) + tid;
     float4 sum[2];
 #pragma unroll
     for (int px = 0; px < 2; ++px) {
         const int q = (((px * FO + fo) * FP + fp) << 2) + rq;
         float4 a = base[(int64_t)q * NTHREADS];
-        for (int w0 = 1; w0 < g.gpe; w0 += 8) {             // eight partials in flight per round (one dependent load per partial took 15 - 21 us)
+        for (int w0 = 1; w0 < sb.gpe; w0 += 8) {             // eight partials in flight per round (one dependent load per partial took 15 - 21 us)
             float4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = base[(int64_t)min(w0 + j, g.gpe - 1) * (NACC * NTHREADS / 4) + (int64_t)q * NTHREADS];
+            for (int j = 0; j < 8; ++j) v[j] = base[(int64_t)min(w0 + j, sb.gpe - 1) * (NACC * NTHREADS / 4) + (int64_t)q * NTHREADS];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (w0 + j < g.gpe) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }      // (worker order: deterministic)
+                if (w0 + j < sb.gpe) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }      // (worker order: deterministic)
         }
         sum[px] = a;
     }
@@ -492,27 +493,31 @@ int plan_up(int B, int I, int O, int H, int W, UpPlan* out) {
     p.fp = W >= 256 ? 2 : 1;
     const int BP = 128 * p.fp;
     const int npt = (int)ia::ceil_div((int64_t)H * W, BP);
-    g.gpe = I / 16 < 16 ? I / 16 : 16;
+    const int gpe = I / 16 < 16 ? I / 16 : 16;                 // workers per edge tile
     // whole-tile grids (interior of either row phase), then the edge grids
     const bool one_round = (int64_t)B * 2 * npt * g.TO <= ia::kNumCU;
+    // K-deep layers whose tiles leave most of the machine idle (512 input channels at 64^2: 64 long tiles of 192 k-steps): the long
+    // (py 0) interior tiles are cut in two along K -- partial sums to slabs, finished by the fix-up launch that the edge grids need
+    // anyway -- and the py 1 tiles run one per workgroup: every workgroup then has 96 k-steps (same-box 93 -> see DESIGN 4.7)
+    const bool split_long = one_round && I >= 512 && (int64_t)B * 3 * npt * g.TO <= ia::kNumCU;
     constexpr int kColPts = 64;      // points per tile of the one-column grids
     const UpSub subs[kMaxSub] = {
-        // first_wg n_wg n_pt tp reps gpe edge_first GH GW r_off c_off py
-        {0, 0, npt, BP, 1, 0, 0, H, W, 0, 0, 0},
-        {0, 0, npt, BP, one_round ? 2 : 1, 0, 0, H, W, 0, 0, 1},      // (not one_round: served by the workgroups of grid 0, g.pair)
-        {0, 0, (int)ia::ceil_div(W, BP), BP, 1, g.gpe, 0, 1, W, H, 0, 0},
-        {0, 0, (int)ia::ceil_div(H + 1, kColPts), kColPts, 1, g.gpe, 0, H + 1, 1, 0, W, 0},
-        {0, 0, (int)ia::ceil_div(H, kColPts), kColPts, 1, g.gpe, 0, H, 1, 0, W, 1},
+        // first_wg n_wg n_pt tp reps gpe edge_first slab_first GH GW r_off c_off py
+        {0, 0, npt, BP, 1, split_long ? 2 : 0, 0, 0, H, W, 0, 0, 0},
+        {0, 0, npt, BP, (one_round && !split_long) ? 2 : 1, 0, 0, 0, H, W, 0, 0, 1},      // (not one_round: served by the workgroups of grid 0, g.pair)
+        {0, 0, (int)ia::ceil_div(W, BP), BP, 1, gpe, 0, 0, 1, W, H, 0, 0},
+        {0, 0, (int)ia::ceil_div(H + 1, kColPts), kColPts, 1, gpe, 0, 0, H + 1, 1, 0, W, 0},
+        {0, 0, (int)ia::ceil_div(H, kColPts), kColPts, 1, gpe, 0, 0, H, 1, 0, W, 1},
     };
     g.nsub = kMaxSub;
     g.pair = one_round ? 0 : 1;
-    int wg = 0, edge = 0, worst0 = 0, worst1 = 0;
+    int wg = 0, edge = 0, slabs = 0, worst0 = 0, worst1 = 0;
     for (int k = 0; k < kMaxSub; ++k) {
         UpSub s = subs[k];
         const int tiles = s.n_pt * g.TO;
         s.first_wg = wg;
         s.n_wg = s.gpe ? tiles * s.gpe : (k == 1 && !one_round) ? 0 : (int)ia::ceil_div(tiles, s.reps);
-        if (s.gpe) { s.edge_first = edge; edge += tiles; }
+        if (s.gpe) { s.edge_first = edge; edge += tiles; s.slab_first = slabs; slabs += tiles * s.gpe; }
         wg += s.n_wg;
         g.sub[k] = s;
         const int npts = s.GH * s.GW;
@@ -523,6 +528,7 @@ int plan_up(int B, int I, int O, int H, int W, UpPlan* out) {
         }
     }
     g.E = edge;
+    g.n_slabs = slabs;
     p.n_wg = wg;
     const int need = worst0 > 2 * worst1 ? worst0 : 2 * worst1;
     g.cap = (need + 127) & ~127;
@@ -535,7 +541,7 @@ int plan_up(int B, int I, int O, int H, int W, UpPlan* out) {
     if (g.stages > kUpMaxStages) g.stages = kUpMaxStages;
 
     p.lds = stage * g.stages + 1024;       // (+ the dummy target of all-outside DMA pieces)
-    p.scratch = (size_t)B * g.E * g.gpe * (2 * 2 * p.fp * 16) * 512 * sizeof(float);
+    p.scratch = (size_t)B * g.n_slabs * (2 * 2 * p.fp * 16) * 512 * sizeof(float);
     *out = p;
     return IA_OK;
 }
