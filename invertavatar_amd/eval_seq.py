@@ -101,6 +101,15 @@ class GraphedEncode:
 
 @torch.no_grad()
 def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=False, hook=None, graphed=None):
+    """See _few_shot_inversion; on the device the always-on range watch of the fp16 hi / lo split brackets the call."""
+    from .reenact_avatar_next3d import _check_split_range
+    _check_split_range(images.device, start=True)
+    out = _few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling, hook, graphed)
+    _check_split_range(images.device)
+    return out
+
+
+def _few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=False, hook=None, graphed=None):
     """images [S,3,512,512] in [-1,1], uvs [S,6,256,256] (x['uv']), cams [S,25], uvcoords [S,256,256,3].  S in {1, 2, 4} or a
     multiple of 4.  `hook(group_index)` may return a context manager entered around each AR_eval_forward (tests pin the
     renderer's random draws with it).  `graphed`: a dict the caller keeps as a cache of captured graphs (device tensors, no hook):
@@ -157,9 +166,11 @@ def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=No
     batch > 1 every frame keeps the depth range of its own call: per-frame `ray_dist`, frame_parallel.per_frame_ray_dist).
     Returns (images [F,3,H,W], mosaics or None): mosaics are the uint8 [gt | rendered] pictures when `gt` [F,3,H,W] is given."""
     from .frame_parallel import per_frame_ray_dist
+    from .reenact_avatar_next3d import _check_split_range
     g = net.generator
     n = cams.shape[0]
     imgs, mosaics = [], ([] if gt is not None else None)
+    _check_split_range(cams.device, start=True)
     for lo in range(0, n, batch):
         hi = min(lo + batch, n)
         b = hi - lo
@@ -179,6 +190,5 @@ def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=No
         if gt is not None:
             for k in range(b):
                 mosaics.append(layout_grid(torch.cat([gt[lo + k:lo + k + 1, :3], out['image'][k:k + 1]], dim=0), grid_w=2, grid_h=1))
-    from .reenact_avatar_next3d import _check_split_range
     _check_split_range(cams.device)      # (one device -> host read per drive sequence: see hipops.split_saturation_poll)
     return torch.cat(imgs, 0), mosaics

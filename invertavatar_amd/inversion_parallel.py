@@ -64,11 +64,13 @@ def few_shot_inversion_sharded(net, images, uvs, cams, uvcoords, rank=0, world_s
     Every rank passes the same inputs and gets (ws, {'w', 'texture', 'static'} of the last group, r_list).
     `draws`: see the module docstring (None: seeded_draws(0, R)); with world_size == 1 this is the one-process flow with the same
     draws, which is what the tests compare the sharded result with."""
+    from .reenact_avatar_next3d import _check_split_range
     s = images.shape[0]
     assert s in (1, 2, 4) or s % 4 == 0, f'{s} source frames: the script pads to a multiple of 4 first (:135-136)'
     images, uvs, cams, uvcoords = (fill_group(t, s) for t in (images, uvs, cams, uvcoords))
     n = images.shape[0]
     g = net.generator
+    _check_split_range(images.device, start=True)      # (range watch of the fp16 hi / lo split: see eval_seq.few_shot_inversion)
     nrr = neural_rendering_resolution or g.neural_rendering_resolution
     if draws is None:
         draws = seeded_draws(0, nrr * nrr)
@@ -125,6 +127,7 @@ def few_shot_inversion_sharded(net, images, uvs, cams, uvcoords, rank=0, world_s
         static = _broadcast_list([t.clone() for t in (updated['static'] if rank == tri_owner else sta)], tri_owner, group)
         updated = {'w': ws, 'texture': texture, 'static': static}
         r_list = [_broadcast_states(r_list[0], tex_owner, rank, dev, group), _broadcast_states(r_list[1], tri_owner, rank, dev, group)]
+    _check_split_range(images.device)
     return ws, updated, r_list
 
 

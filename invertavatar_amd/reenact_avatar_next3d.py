@@ -134,6 +134,7 @@ def run_video_animation(G, drive, seeds, grid_dims=(None, 1), truncation_psi=1.0
     frames = []
     if outdir is not None:
         os.makedirs(outdir, exist_ok=True)
+    _check_split_range(device, start=True)
     for k in range(min(len(drive), max_frames)):
         item = drive[k]
         target = item['image'].to(device).float()
@@ -155,13 +156,15 @@ def run_video_animation(G, drive, seeds, grid_dims=(None, 1), truncation_psi=1.0
     return frames
 
 
-def _check_split_range(device):
+def _check_split_range(device, start=False):
     """The fp16 hi / lo split of the large convolutions clamps at +-65504: the library's always-on range watch says whether any
-    activation of the clip hit the clamp (random-init weights stay 5 orders of magnitude below it; a real checkpoint is checked here)."""
+    activation of the clip hit the clamp (random-init weights stay 5 orders of magnitude below it; a real checkpoint is checked here).
+    `start`: clear the flag at the top of a clip (it is sticky: whatever ran before in this process must not be blamed on this clip)."""
     if torch.device(device).type != 'cuda':
         return
     from . import hipops
-    if hipops.split_saturation_poll(device):
+    flagged = hipops.split_saturation_poll(device)
+    if flagged and not start:
         raise OverflowError('activations outside the fp16 range (+-65504) were clamped by the hi / lo split of the fp16-pair convolutions: '
                             'set training.networks_stylegan2.SPLIT_FP16_PRODUCTS = False (fp32 MFMA path) for this checkpoint')
 
