@@ -179,7 +179,14 @@ __global__ __launch_bounds__(512, 2) void up_rows_kernel(const h16x8* __restrict
 #pragma unroll
     for (int k = 1; k < kMaxSub; ++k)
         if (k < g.nsub && wg >= g.sub[k].first_wg) sb = g.sub[k];
-    const int wl = wg - sb.first_wg;
+    int wl = wg - sb.first_wg;
+    if (!sb.gpe && g.B == 1 && (sb.first_wg & 7) == 0) {
+        // whole-tile grids: workgroups go to the 8 XCDs round-robin; give XCD x a contiguous band of the grid's tiles instead of every
+        // eighth one, so that the input rows two neighbouring tiles share (py 0 reads rows r - 1 and r) are fetched into ONE L2
+        const int per = sb.n_wg / ia::kNumXCD, rem = sb.n_wg - per * ia::kNumXCD;
+        const int x = wl % ia::kNumXCD, j = wl / ia::kNumXCD;
+        wl = x * per + (x < rem ? x : rem) + j;
+    }
     const int grp = wave >> 2;                                    // wave group: 1 runs one barrier interval behind 0 (see the K loop)
     const int cap = g.cap, NS = g.stages;
     const int HW = g.H * g.W;
@@ -493,7 +500,11 @@ int plan_up(int B, int I, int O, int H, int W, UpPlan* out) {
     p.fp = W >= 256 ? 2 : 1;
     const int BP = 128 * p.fp;
     const int npt = (int)ia::ceil_div((int64_t)H * W, BP);
-    const int gpe = I / 16 < 16 ? I / 16 : 16;                 // workers per edge tile
+    // workers per edge tile: the edge tiles only have to finish inside the time of an interior tile (they run beside them), so their K
+    // range is cut just enough for that -- ~16 chunks per worker.  (The first version cut 16-way: 16 slabs of 128 ch x 128 / 256 pt per
+    // edge tile were 205 MB of slab writes + reads per frame, PMC r04: more than the images these layers write.)
+    const int c0 = I / 8;
+    const int gpe = c0 / 16 < 2 ? 2 : (c0 / 16 > 4 ? 4 : c0 / 16);
     // whole-tile grids (interior of either row phase), then the edge grids
     const bool one_round = (int64_t)B * 2 * npt * g.TO <= ia::kNumCU;
     // K-deep layers whose tiles leave most of the machine idle (512 input channels at 64^2: 64 long tiles of 192 k-steps): the long
