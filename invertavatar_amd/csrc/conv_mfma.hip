@@ -506,7 +506,10 @@ void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo
 struct Plan { int bo, bp, cc, waves, T, TO, C, T_dp, G, slab_floats; };
 // (r03, with the 8^2 / 16^2 layers on the fp16-pair tiles and the shorter ToRGB launches: cap 128 / 64 / 48 / 32 workers = 321.8 / 326.4 /
 //  326.2 / 320.0 frames/s same-box, 96 / 192 / 256 = 329.6 / 326.7 / 321.5 against 330.3 and 333.3 for 128 and 64 on another box: 64)
-constexpr int kSmallLayerWorkers = ia::kNumCU / 4, kSmallLayerPoints = 65 * 65;
+#ifndef IA_SMALL_LAYER_WORKERS
+#define IA_SMALL_LAYER_WORKERS (ia::kNumCU / 4)      // (build-time sweeps: tools/_variants)
+#endif
+constexpr int kSmallLayerWorkers = IA_SMALL_LAYER_WORKERS, kSmallLayerPoints = 65 * 65;
 static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int form) {
     Plan p;
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
