@@ -17,7 +17,7 @@ _lib = None
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _i64p = ctypes.POINTER(ctypes.c_int64)
 
-ABI_VERSION = 3      # IA_HIP_ABI_VERSION of include/ia_hip.h
+ABI_VERSION = 4      # IA_HIP_ABI_VERSION of include/ia_hip.h
 
 DTYPE_ID = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
 
