@@ -485,7 +485,8 @@ class SynthesisLayer(torch.nn.Module):
         return hipops.upfirdn2d_bias_act(t, self.resample_filter, nz, ns, bias, up=1, pad0=(1, 1), out_hw=(res, res),
                                          fir_gain=4.0, act=self.activation, act_gain=act_gain, clamp=act_clamp)
 
-    def forward_with_torgb(self, x, w, torgb, w_rgb, skip, resample_filter, noise_mode='random', gain=1, half_ops=False, **_unused):
+    def forward_with_torgb(self, x, w, torgb, w_rgb, skip, resample_filter, noise_mode='random', gain=1, half_ops=False,
+                           skip_upsampled=None, **_unused):
         """This layer AND the ToRGB layer that is the only reader of its result, in one launch (ia_conv2d_mfma_sx_rgb): returns the
         image `upsample2d(skip) + torgb(conv(x))`, or None when the pair is not eligible (the caller then runs the two layers)."""
         res = self.resolution
@@ -508,7 +509,10 @@ class SynthesisLayer(torch.nn.Module):
         nz = self.noise_const.reshape(-1) if const_noise else None
         ns = self.noise_strength.detach().float().reshape(1) if const_noise else None
         rgb_wk, _ = torgb._packed.get(torgb.weight, scale=torgb.weight_gain)
-        residual = None if skip is None else upfirdn2d.upsample2d(skip, resample_filter).float().contiguous()
+        if skip is not None and skip_upsampled is not None:      # (made by the caller beside the previous layers, see _TwoBlockHead)
+            residual = skip_upsampled
+        else:
+            residual = None if skip is None else upfirdn2d.upsample2d(skip, resample_filter).float().contiguous()
         _, _, img = hipops.conv2d_mfma_sx_rgb(xs, wk, rgb_wk, rgb_styles, torgb.bias.detach().float(), residual, torgb.conv_clamp, demod, nz, ns,
                                               self.bias.detach().float(), act=self.activation, gain=self.act_gain * gain,
                                               clamp=self.conv_clamp * gain if self.conv_clamp is not None else None)
@@ -648,7 +652,7 @@ class SynthesisBlock(torch.nn.Module):
         return bool(self.use_fp16 and not force_fp32 and device.type == 'cuda' and not FP16_BLOCKS_COMPUTE_FP32)
 
     def forward(self, x, img, ws, condition=None, force_fp32=False, fused_modconv=None, update_emas=False, _next_conv=None, _next_half=None,
-                _x_unused=False, _img_stream=None, _img_wait=None, **layer_kwargs):
+                _x_unused=False, _img_stream=None, _img_wait=None, _skip_upsampled=None, **layer_kwargs):
         """`_next_conv`: the layer that consumes this block's x (the next block's conv0), given by the owning network on the device
         inference path so that conv1 can emit its result in the format that layer reads (hipops.SplitAct).
         `_x_unused`: the caller drops the returned x (last block of a head): conv1 may then evaluate ToRGB in its epilogue and x comes
@@ -695,7 +699,8 @@ class SynthesisBlock(torch.nn.Module):
                 torch.cuda.current_stream(x.device if torch.is_tensor(x) else ws.device).wait_stream(_img_wait)
             if _x_unused and condition is None and (self.is_last or self.architecture == 'skip'):
                 w_conv1, w_rgb = next(w_iter), next(w_iter)
-                fused_img = self.conv1.forward_with_torgb(x, w_conv1, self.torgb, w_rgb, img, self.resample_filter, **layer_kwargs)
+                fused_img = self.conv1.forward_with_torgb(x, w_conv1, self.torgb, w_rgb, img, self.resample_filter,
+                                                          skip_upsampled=_skip_upsampled, **layer_kwargs)
                 if fused_img is not None:
                     return None, fused_img.to(dtype=torch.float32, memory_format=torch.contiguous_format)
                 w_iter = iter((w_conv1, w_rgb))

@@ -25,6 +25,13 @@ def _fit(x, rgb, size, antialias):
 
 
 SKIP_IMAGE_STREAM = True     # block0's skip image on a side stream (see _TwoBlockHead.forward)
+SKIP_UPSAMPLE_ON_SIDE = True     # ... and its up-sampled copy for block1's fused ToRGB epilogue
+
+
+def _single_stream():
+    """The generator's one-stream mode (bench.py's per-launch timing): no side stream here either."""
+    from . import triplane_v20
+    return triplane_v20.SINGLE_STREAM
 
 
 class _TwoBlockHead(torch.nn.Module):
@@ -64,7 +71,7 @@ class _TwoBlockHead(torch.nn.Module):
             next_half = bool(getattr(self.block1, 'use_fp16', False)) and ws.is_cuda and not sg2.FP16_BLOCKS_COMPUTE_FP32
             chain = dict(_next_conv=getattr(self.block1, 'conv0', None), _next_half=next_half)
         side = None
-        if SKIP_IMAGE_STREAM and x.is_cuda and isinstance(self.block0, SynthesisBlock) and isinstance(self.block1, SynthesisBlock) \
+        if SKIP_IMAGE_STREAM and not _single_stream() and x.is_cuda and isinstance(self.block0, SynthesisBlock) and isinstance(self.block1, SynthesisBlock) \
                 and not torch.is_grad_enabled():
             # block0's ToRGB (+ the up-sampling of the incoming image) feeds only the final image: on a side stream it runs beside
             # block1.conv0 instead of between the two largest convolutions of the frame (nothing else occupies the GPU here)
@@ -77,6 +84,12 @@ class _TwoBlockHead(torch.nn.Module):
         last = dict(_x_unused=True) if isinstance(self.block1, SynthesisBlock) else {}      # block1's x has no reader: ToRGB in conv1's epilogue
         if side is not None:
             last['_img_wait'] = side
+            if SKIP_UPSAMPLE_ON_SIDE and rgb is not None and getattr(self.block1, 'architecture', None) == 'skip':
+                # block1's conv1 adds upsample2d(this image) in its fused ToRGB epilogue: up-sample it on the side stream as well
+                # (one launch off the chain between the head's two largest convolutions)
+                with torch.cuda.stream(side):
+                    last['_skip_upsampled'] = upfirdn2d.upsample2d(rgb, self.block1.resample_filter).float().contiguous()
+                last['_skip_upsampled'].record_stream(torch.cuda.current_stream(x0.device if torch.is_tensor(x0) else ws.device))
         x, rgb = self.block1(x0, rgb, ws, **last, **block_kwargs)
         del x0, rgb_in                   # (block0's features and input image stayed alive until block1 had joined the side stream)
         return rgb

@@ -31,8 +31,8 @@ from .volumetric_rendering.ray_sampler import RaySampler, RaySampler_zxc  # noqa
 BBOX_256 = [57, 185, 64, 192]   # face region of the frontal plane, in 256^2 pixels (triplane_v20.py:114)
 N_COND_LEVELS_USED = 4          # cond_list entries the face backbone consumes
 CL_COPIES_ON_TEXTURE_STREAM = True   # False: the rasteriser's stream makes them (ia_rasterize_level's own copy)
-FACE_HEAD_AFTER_BACKBONES = False   # launch order experiment (tools/ab_frame.py)
-LAUNCH_ORDER = 'default'                    # 'face_first', 'static_first'
+LAUNCH_ORDER = 'tmfs'           # capture order of the frame's four independent branches: m mouth fill + rays, f face-backbone head,
+                                # t texture backbone, s static backbone (profiles/r04_ab_launch_order_sweep.txt: two clusters 9 % apart)
 
 SINGLE_STREAM = False           # True: no side streams (every launch of a frame in program order on the caller's stream); used by
                                 # bench.py to time kernels without neighbours from other streams
@@ -125,7 +125,7 @@ class TriPlaneGenerator(torch.nn.Module):
         origins, dirs = self.ray_sampler(cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3), neural_rendering_resolution)
         return origins, dirs, neural_rendering_resolution
 
-    def _two_backbones(self, ws, update_emas, synthesis_kwargs, partial=False):
+    def _two_backbones(self, ws, update_emas, synthesis_kwargs, partial=False, order='ts', side_work=None):
         """The texture and the static backbone are independent: on the device they run on two streams of their own so that their
         latency-bound low-resolution layers (a handful of workgroups each at batch 1) overlap.
 
@@ -141,6 +141,8 @@ class TriPlaneGenerator(torch.nn.Module):
         def sta(**kw):
             return self.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=update_emas, **kw, **synthesis_kwargs)
         if not (ws.is_cuda and not torch.is_grad_enabled()) or SINGLE_STREAM:
+            for work in (side_work or {}).values():
+                work()
             return tex(), sta(), None
         st = _state(self)
         main, t_stream, s_stream = torch.cuda.current_stream(ws.device), st.stream('texture', ws.device), st.stream('static', ws.device)
@@ -157,28 +159,31 @@ class TriPlaneGenerator(torch.nn.Module):
             if CL_COPIES_ON_TEXTURE_STREAM:
                 make_cl(feats)
             ev_tex[len(feats)].record(t_stream)
-        static_feats = None
-        if partial and LAUNCH_ORDER == 'static_first':      # (launch-order experiment: the static backbone queued ahead of the texture one)
-            s_stream.wait_stream(main)
-            with torch.cuda.stream(s_stream):
-                static_feats = sta(_tap=(counts, lambda feats: ev_sta[len(feats)].record(s_stream)))
-        t_stream.wait_stream(main)
-        with torch.cuda.stream(t_stream):
-            if partial:
-                texture_feats = tex(_tap=(counts, tap_tex))
-            else:
+        if not partial:
+            t_stream.wait_stream(main)
+            with torch.cuda.stream(t_stream):
                 texture_feats = tex()
                 make_cl(texture_feats)
-        if partial:
-            if static_feats is None:
-                s_stream.wait_stream(main)
-                with torch.cuda.stream(s_stream):
-                    static_feats = sta(_tap=(counts, lambda feats: ev_sta[len(feats)].record(s_stream)))
-            pending = (t_stream, s_stream, ev_tex, ev_sta)
-        else:
             static_feats = sta()
             main.wait_stream(t_stream)
             pending = None
+        else:
+            # a graph replay queues its nodes branch by branch in capture order, a few microseconds each, so the order the
+            # branches are captured in decides when each starts: `order` names it (t texture, s static, others: side_work)
+            made = {}
+            for ch in order:
+                if ch == 't':
+                    t_stream.wait_stream(main)
+                    with torch.cuda.stream(t_stream):
+                        made['t'] = tex(_tap=(counts, tap_tex))
+                elif ch == 's':
+                    s_stream.wait_stream(main)
+                    with torch.cuda.stream(s_stream):
+                        made['s'] = sta(_tap=(counts, lambda feats: ev_sta[len(feats)].record(s_stream)))
+                else:
+                    side_work[ch]()
+            texture_feats, static_feats = made['t'], made['s']
+            pending = (t_stream, s_stream, ev_tex, ev_sta)
         for t in list(texture_feats) + [t for t in tex_cl if t is not None] + (list(static_feats) if partial else []):
             t.record_stream(main)
         st.tex_cl = (texture_feats, tex_cl)
@@ -327,18 +332,17 @@ class TriPlaneGenerator(torch.nn.Module):
     # ------------------------------------------------------------------ public synthesis entry points
     def synthesis(self, ws, c, mesh_condition, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
                   use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, ray_dist=None, **synthesis_kwargs):
-        face_head = self._start_face_head(ws, update_emas, synthesis_kwargs) if LAUNCH_ORDER == 'face_first' else None
-        mouth = self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, ray_dist))
-        if face_head is None and not FACE_HEAD_AFTER_BACKBONES:
-            face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
+        side = {}
+        side_work = {'m': lambda: side.__setitem__('m', self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, ray_dist))),
+                     'f': lambda: side.__setitem__('f', self._start_face_head(ws, update_emas, synthesis_kwargs))}
+        texture_feats, static_feats, pending = self._two_backbones(ws, update_emas, synthesis_kwargs, partial=True,
+                                                                   order=LAUNCH_ORDER, side_work=side_work)
+        mouth, face_head = side['m'], side['f']
         side_rays = _state(self).side_rays
         if side_rays is not None:            # made on the side stream; joined with the mouth fill inside rasterize()
             origins, dirs, nrr, ray_dist = side_rays
         else:
             origins, dirs, nrr = self._rays(c, neural_rendering_resolution)
-        texture_feats, static_feats, pending = self._two_backbones(ws, update_emas, synthesis_kwargs, partial=True)
-        if FACE_HEAD_AFTER_BACKBONES:        # (queued behind the two backbones whose taps the rasteriser waits for)
-            face_head = self._start_face_head(ws, update_emas, synthesis_kwargs)
         planes = self._planes(ws, texture_feats, static_feats, mesh_condition, update_emas, synthesis_kwargs, mouth=mouth,
                               face_head=face_head, pending=pending)
         image, rgb, depth, feature_image = self._render(ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist)
