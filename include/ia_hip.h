@@ -205,8 +205,10 @@ int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B,
  *          (IA_RENDER_DIST_PER_FRAME) = `dist` holds B values, frame b uses dist[b]: a batch of frames that the script renders one
  *          call each (eval_seq.py:206-212, where `dist` is every frame's own |ray origin|) keeps those results when batched
  *   rgb  : [B, R, 32] (or [B, 32, R], see flags) composited features scaled to (-1, 1);  depth : [B, R] clamped to the
- *          batch-global sample range;  wsum : [B, R] sum of compositing weights
- *   minmax_scratch : 2 * ia_render_rays_grid(B, R) floats of caller scratch
+ *          batch-global sample range (ray_marcher.py:50), with IA_RENDER_DIST_PER_FRAME to every frame's own sample range (what the
+ *          one-call-per-frame script computes);  wsum : [B, R] sum of compositing weights
+ *   minmax_scratch : 2 * ia_render_rays_grid(B, R) floats of caller scratch; with IA_RENDER_DIST_PER_FRAME 8 * B times that
+ *          (one range per wave and frame)
  *   dbg_* : optional stage outputs for parity tests (NULL in production): fine depths [B,R,48], searchsorted
  *          indices [B,R,48] (int32), merge order [B,R,96] (int32, < 48 = coarse sample, >= 48 = fine sample),
  *          coarse weights [B,R,47], coarse densities [B,R,48]

@@ -78,7 +78,7 @@ struct Params {
     float* rgb;                   // [B][R][32], or [B][32][R] when channel_major
     float* depth;                 // [B][R]   un-clamped (may be +inf), see ia_render_finalize
     float* wsum;                  // [B][R]
-    float* minmax;                // [gridDim.x][2] per-workgroup min / max of all sample depths
+    float* minmax;                // [gridDim.x][2] per-workgroup min / max of all sample depths; dist_per_frame: [gridDim.x * WAVES][B][2]
     // optional stage outputs for parity tests (null in production)
     float* dbg_z_fine;            // [B][R][48]
     int* dbg_inds;                // [B][R][48]
@@ -519,6 +519,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
     float* tc = scr; float* sc = scr + NS; float* wc = scr + 2 * NS; float* tm = scr + 8 * NS;
 
     float blk_min = INFINITY, blk_max = 0.f;
+    // dist_per_frame: the depth clamp is every frame's own sample range (the script renders those frames one call each), kept per wave
+    // and frame in minmax[((workgroup * WAVES + wave) * B + b) * 2]: a wave meets its frames in ascending order and writes a frame's
+    // range when it leaves it (lane 0 wrote the empty range to all its slots first: same lane, program order)
+    int cur_b = -1;
+    float* mm_wave = p.minmax + (int64_t)(blockIdx.x * WAVES + wave) * p.B * 2;
+    if (p.dist_per_frame && lane == 0)
+        for (int i = 0; i < p.B; ++i) { mm_wave[2 * i] = INFINITY; mm_wave[2 * i + 1] = 0.f; }
 
     const int nrays = p.B * p.R;
     const int PHs = SQ ? p.PW : p.PH;
@@ -533,6 +540,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
 #endif
         IA_RSTAMP(0);
         const int b = ray / p.R;
+        if (p.dist_per_frame && b != cur_b) {
+            if (cur_b >= 0 && lane == 0) { mm_wave[2 * cur_b] = blk_min; mm_wave[2 * cur_b + 1] = blk_max; }
+            blk_min = INFINITY; blk_max = 0.f; cur_b = b;
+        }
         // depth range: renderer.py:311-313,404-406 (python doubles, fp32 tensors); one value for the batch, or one per frame when the
         // caller renders several single-frame calls of the script as one batch (wave-uniform scalar work either way)
         const double dist = (double)p.dist[p.dist_per_frame ? b : 0];
@@ -740,6 +751,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         wave_sync();
         IA_RSTAMP(30);
     }
+    if (p.dist_per_frame) {      // (kernel-uniform)
+        if (cur_b >= 0 && lane == 0) { mm_wave[2 * cur_b] = blk_min; mm_wave[2 * cur_b + 1] = blk_max; }
+        return;
+    }
     // per-workgroup depth range for the batch-global clamp (ray_marcher.py:50)
     __syncthreads();
     float* red = lds + SCR_OFF;
@@ -765,6 +780,23 @@ __global__ __launch_bounds__(256) void render_finalize_kernel(float* depth, cons
     }
     mn = s_mn[0]; mx = s_mx[0];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) depth[i] = fminf(fmaxf(depth[i], mn), mx);
+}
+
+// ... per frame (IA_RENDER_DIST_PER_FRAME): blockIdx.y = frame, its range from the per-wave slots the render kernel filled
+__global__ __launch_bounds__(256) void render_finalize_frames_kernel(float* depth, const float* minmax, int nslots, int R, int B) {
+    __shared__ float s_mn[256], s_mx[256];
+    const int b = blockIdx.y;
+    float mn = INFINITY, mx = 0.f;
+    for (int i = threadIdx.x; i < nslots; i += 256) { mn = fminf(mn, minmax[((int64_t)i * B + b) * 2]); mx = fmaxf(mx, minmax[((int64_t)i * B + b) * 2 + 1]); }
+    s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { s_mn[threadIdx.x] = fminf(s_mn[threadIdx.x], s_mn[threadIdx.x + off]); s_mx[threadIdx.x] = fmaxf(s_mx[threadIdx.x], s_mx[threadIdx.x + off]); }
+        __syncthreads();
+    }
+    mn = s_mn[0]; mx = s_mx[0];
+    float* d = depth + (int64_t)b * R;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += gridDim.x * 256) d[i] = fminf(fmaxf(d[i], mn), mx);
 }
 
 // Stage kernel for parity tests: importance resampling + merge order from GIVEN coarse depths/weights.
@@ -832,7 +864,11 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), LDS_FLOATS * sizeof(float), s, p);
     int st = ia::check_launch("ia_render_rays");
     if (st != IA_OK) return st;
-    hipLaunchKernelGGL(render_finalize_kernel, dim3(ia::streaming_grid((int64_t)B * R, 256)), dim3(256), 0, s, depth, minmax_scratch, grid, B * R);
+    if (p.dist_per_frame)
+        hipLaunchKernelGGL(render_finalize_frames_kernel, dim3(ia::streaming_grid((int64_t)R, 256), B), dim3(256), 0, s, depth, minmax_scratch,
+                           grid * WAVES, R, B);
+    else
+        hipLaunchKernelGGL(render_finalize_kernel, dim3(ia::streaming_grid((int64_t)B * R, 256)), dim3(256), 0, s, depth, minmax_scratch, grid, B * R);
     return ia::check_launch("ia_render_rays(finalize)");
 }
 

@@ -585,7 +585,7 @@ def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_mult
     rgb = torch.empty(b, 32, r, device=dev).permute(0, 2, 1) if channel_major else torch.empty(b, r, 32, device=dev)
     depth = torch.empty(b, r, 1, device=dev)
     wsum = torch.empty(b, r, 1, device=dev)
-    scratch = torch.empty(2 * lib.ia_render_rays_grid(b, r), device=dev)
+    scratch = torch.empty(2 * lib.ia_render_rays_grid(b, r) * (8 * b if dist_per_frame else 1), device=dev)      # (8 waves per workgroup: include/ia_hip.h)
     aux = {}
     if debug:
         aux = dict(z_fine=torch.empty(b, r, 48, device=dev), inds=torch.empty(b, r, 48, device=dev, dtype=torch.int32),

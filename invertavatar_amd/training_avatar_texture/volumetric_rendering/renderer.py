@@ -192,7 +192,8 @@ class ImportanceRenderer_bsMotion(_RendererBase):
         not `evaluation`: callers that shard a stochastic render over ranks hand every frame the draws it gets in the one-process call.
         `dist` overrides the batch mean of |ray origin| (:311).  One element: a sharded batch passes the value of the whole batch
         so that the depth range does not depend on the sharding.  B elements: frame b uses dist[b] -- a batch of frames that the
-        caller's script renders one call each (eval_seq.py:206-212) keeps the per-call results."""
+        caller's script renders one call each (eval_seq.py:206-212) keeps the per-call results, the depth image included (its clamp
+        range, ray_marcher.py:50, is then every frame's own sample range: tests/test_renderer_gpu.py)."""
         if jitter is None:
             jitter, self._jitter = self._jitter, None
         b, r, _ = ray_origins.shape

@@ -158,3 +158,29 @@ def test_fused_renderer_with_random_importance_draws_vs_oracle():
                                        jit.to(dev).reshape(b, nrr * nrr, 48).contiguous(), dist, dec['net.0.weight'].to(dev),
                                        dec['net.0.bias'].to(dev), dec['net.2.weight'].to(dev), dec['net.2.bias'].to(dev))
     assert max_abs(det_rgb.cpu(), rgb.cpu()) > 1e-4            # the draws are really used
+
+
+def test_per_frame_dist_batch_equals_one_call_per_frame():
+    """IA_RENDER_DIST_PER_FRAME: a batch of frames with every frame's own |ray origin| returns what the script's one call per frame
+    returns -- colours, weights AND the depth image, whose clamp range (ray_marcher.py:50) is then each frame's own sample range."""
+    frames, nrr, res = [0, 3, 6], 16, 64
+    planes = rnd(31, len(frames), 3, 32, res, res)
+    planes[1] *= 0.02            # a nearly empty frame: many of its rays clamp to the range limits
+    cams = synthetic.camera_labels(frames)
+    cams[:, 3] *= torch.tensor([1.0, 1.03, 0.97])          # different distances, so the frames' sample ranges differ
+    cams[:, 7] *= torch.tensor([1.0, 1.03, 0.97])
+    cams[:, 11] *= torch.tensor([1.0, 1.03, 0.97])
+    ro, rd = OR.ray_sampler_zxc(cams[:, :16].view(-1, 4, 4), cams[:, 16:25].view(-1, 3, 3), nrr)
+    jit = synthetic.jitter(frames, nrr * nrr).reshape(len(frames), nrr * nrr, 48)
+    dec = {k: v.cuda() for k, v in _decoder().items()}
+    pl = hipops.planes_channels_last(planes.cuda())
+    run = lambda sl, dist: hipops.render_rays(pl[sl].contiguous(), ro[sl].cuda().contiguous(), rd[sl].cuda().contiguous(), jit[sl].cuda().contiguous(),
+                                              dist, dec['net.0.weight'], dec['net.0.bias'], dec['net.2.weight'], dec['net.2.bias'])
+    dists = torch.norm(ro, dim=-1).mean(dim=1).cuda()
+    assert float(dists.max() - dists.min()) > 0.05
+    rgb, depth, wsum = run(slice(0, 3), dists.contiguous())
+    for k in range(3):
+        rgb1, depth1, wsum1 = run(slice(k, k + 1), dists[k:k + 1].contiguous())
+        assert torch.equal(rgb[k:k + 1], rgb1) and torch.equal(wsum[k:k + 1], wsum1)
+        assert torch.equal(depth[k:k + 1], depth1), f'frame {k}: depth clamp range differs from the one-frame call'
+    assert not torch.equal(depth[1].clamp(depth[0].min(), depth[0].max()), depth[1])       # (the frames' ranges really differ)
