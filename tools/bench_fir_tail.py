@@ -5,7 +5,7 @@ import torch
 from invertavatar_amd import hipops
 from invertavatar_amd.torch_utils.ops import upfirdn2d
 
-SHAPES = [(512, 32), (512, 64), (256, 128), (128, 256), (256, 256), (128, 512)]      # (channels, output resolution)
+SHAPES = [(512, 8), (512, 16), (512, 32), (512, 64), (256, 128), (128, 256), (256, 256), (128, 512)]      # (channels, output resolution)
 
 
 def bench(fn, n=30):
