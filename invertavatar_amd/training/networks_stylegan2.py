@@ -49,7 +49,7 @@ COMPOSED_UPFIR_MAX_IN = 32
 # Up-sampling layers from UPCONV_ROWS_MIN_RES^2 inputs: the transposed convolution per output row phase on the stride-1 tile
 # (ia_upconv2d_rows_sx, csrc/conv_up.hip) instead of the four-phase tile of ia_conv2d_mfma_sx.
 UPCONV_ROWS = True
-UPCONV_ROWS_MIN_RES = 64
+UPCONV_ROWS_MIN_RES = 32      # (same-box frame A/B, 5 rounds: from 64^2 364.5, from 32^2 367.6 frames/s; at 16^2 the four-phase tile is twice as fast alone)
 FUSED_TORGB_SKIP = True          # ... and, where ia_torgb covers the shape, with the skip image's up-sampling + add in the same launch
 SPLIT_FP16_PRODUCTS = True
 
