@@ -359,3 +359,29 @@ def test_fill_mouth_default_blur_on_device_equals_the_cpu_route():
         dev_full, dev_soft = fill_mouth(masks.cuda())
         assert torch.equal(dev_full.cpu(), cpu_full) and torch.equal(dev_soft.cpu(), cpu_soft)
         assert 0 < (cpu_soft > 0).float().mean() < 1 and ((cpu_soft > 0) & (cpu_soft < 1)).any()
+
+
+def test_capture_order_of_the_branches_does_not_change_the_frame(small):
+    """triplane_v20.LAUNCH_ORDER only decides in which order the frame's four independent branches are queued (and therefore which
+    side streams exist first): every order, and the one-stream mode, returns the same frame to the bit."""
+    from invertavatar_amd.training_avatar_texture import triplane_v20
+    g = small
+    ws = g.mapping(synthetic.latent(5, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14)
+    c, uv, jit = synthetic.camera_labels([2]).cuda(), synthetic.uv_conditions([2]).cuda(), synthetic.jitter([2], 64 * 64).cuda()
+    run = lambda: g.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=64, noise_mode='const', evaluation=True, jitter=jit)
+    saved = triplane_v20.LAUNCH_ORDER, triplane_v20.SINGLE_STREAM
+    try:
+        with torch.no_grad():
+            ref = run()
+            torch.cuda.synchronize()
+            for order in ('mfts', 'stfm', 'fsmt'):
+                triplane_v20.LAUNCH_ORDER = order
+                out = run()
+                torch.cuda.synchronize()
+                assert torch.equal(out['image'], ref['image']) and torch.equal(out['image_depth'], ref['image_depth']), order
+            triplane_v20.LAUNCH_ORDER, triplane_v20.SINGLE_STREAM = saved[0], True
+            out = run()
+            torch.cuda.synchronize()
+            assert torch.equal(out['image'], ref['image']) and torch.equal(out['image_depth'], ref['image_depth'])
+    finally:
+        triplane_v20.LAUNCH_ORDER, triplane_v20.SINGLE_STREAM = saved
