@@ -57,6 +57,8 @@ class _RendererBase(nn.Module):
     """Shared torch definition of the coarse / importance / composite pipeline."""
 
     def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
+        if getattr(self, 'flip_z', False):       # ImportanceRenderer only (renderer.py:196-197); in place, as the reference does it
+            sample_coordinates[..., -1] *= -1
         feats = sample_from_planes(self.plane_axes.clone(), planes, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
         out = decoder(feats, sample_directions)
         if options.get('density_noise', 0) > 0:

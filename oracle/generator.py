@@ -253,3 +253,37 @@ def synthesis(sd, ws, c, uvcoords_image, jitter, nrr=128, texture_feats=None, st
         out.update(feature_image=feature_image, triplane=planes, texture=texture_feats, static=static_feats,
                    cond=cond, full_alpha=full_alpha, stitch=stitch)
     return out
+
+
+def blended_planes(sd, ws, uvcoords_image, texture_feats=None, static_feats=None, static_feat_conditions=None, fused=True):
+    """The tri-planes every entry point of TriPlaneGenerator builds before rendering (triplane_v20.py:262-290 = :356-380)."""
+    if texture_feats is None:
+        texture_feats = synthesis_network(sub(sd, 'texture_backbone.synthesis'), ws, return_list=True, fused=fused)
+    if static_feats is None:
+        static_feats = synthesis_network(sub(sd, 'backbone.synthesis'), ws, return_list=True, feat_conditions=static_feat_conditions,
+                                         fused=fused)
+    static_for_raster, static_plane = split_static(static_feats)
+    cond, full_alpha, _ = rasterize(texture_feats, uvcoords_image, static_for_raster)
+    stitch = synthesis_network(sub(sd, 'face_backbone.synthesis'), ws, cond_list=cond, fused=fused)
+    return blend_planes(stitch, full_alpha, static_plane), texture_feats, static_feats
+
+
+def synthesis_with_condition(sd, ws, c, uvcoords_image, jitter, nrr, static_feat_conditions=None):
+    """TriPlaneGenerator.synthesis_withCondition with noise_mode='const' (=> evaluation, :293).  Reference: triplane_v20.py:246-315."""
+    cam = c[:, -25:]
+    rays_o, rays_d = renderer.ray_sampler_zxc(cam[:, :16].reshape(-1, 4, 4), cam[:, 16:25].reshape(-1, 3, 3), nrr)
+    planes, texture_feats, static_feats = blended_planes(sd, ws, uvcoords_image, static_feat_conditions=static_feat_conditions)
+    feat, depth, _ = renderer.render(planes, sub(sd, 'decoder'), rays_o, rays_d, jitter)
+    b = ws.shape[0]
+    feature_image = feat.permute(0, 2, 1).reshape(b, feat.shape[-1], nrr, nrr).contiguous()
+    image = superresolution_8xdc(sub(sd, 'superresolution'), feature_image[:, :3], feature_image, ws)
+    return dict(image=image, image_raw=feature_image[:, :3], image_depth=depth.permute(0, 2, 1).reshape(b, 1, nrr, nrr),
+                feature_image=feature_image, triplane=planes, static=static_feats, texture=texture_feats)
+
+
+def query_points(sd, ws, coordinates, uvcoords_image, box_warp=1.0):
+    """TriPlaneGenerator.sample_mixed (and sample, after the mapping network): density + colour features at arbitrary points.
+    Reference: triplane_v20.py:341-402 -> renderer.py:353-363."""
+    planes, _, _ = blended_planes(sd, ws, uvcoords_image)
+    rgb, sigma = renderer.osg_decoder(sub(sd, 'decoder'), renderer.sample_from_planes(planes, coordinates, box_warp))
+    return dict(rgb=rgb, sigma=sigma)

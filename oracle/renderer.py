@@ -192,6 +192,76 @@ def render(planes, dec, rays_o, rays_d, jitter, n_coarse=48, n_fine=48, box_warp
     return rgb, depth, w.sum(2)
 
 
+def ray_limits_box(rays_o, rays_d, box_side_length):
+    """Slab test of every ray against the cube [-s/2, s/2]^3; (-1, -2) marks a miss.
+    Reference: volumetric_rendering/math_utils.py:46-98 (the sign-indexed bounds are restated per axis:
+    near = bound on the side the ray comes from, far = the other one)."""
+    shape = rays_o.shape
+    o, d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    half = box_side_length / 2
+    inv = 1 / d
+    neg = inv < 0
+    lo = torch.full_like(o, -half)
+    hi = torch.full_like(o, half)
+    near = (torch.where(neg, hi, lo) - o) * inv
+    far = (torch.where(neg, lo, hi) - o) * inv
+    tmin, tmax = near[:, 0], far[:, 0]
+    valid = torch.ones_like(tmin, dtype=torch.bool)
+    for ax in (1, 2):
+        valid &= ~((tmin > far[:, ax]) | (near[:, ax] > tmax))
+        tmin = torch.max(tmin, near[:, ax])
+        tmax = torch.min(tmax, far[:, ax])
+    tmin = torch.where(valid, tmin, torch.full_like(tmin, -1))
+    tmax = torch.where(valid, tmax, torch.full_like(tmax, -2))
+    return tmin.reshape(*shape[:-1], 1), tmax.reshape(*shape[:-1], 1)
+
+
+def coarse_depths_eg3d(rays_o, rays_d, ray_start, ray_end, n_coarse, jitter, box_warp):
+    """Coarse depths of ImportanceRenderer.  Reference: renderer.py:131-140,220-240.  'auto' limits: per-ray box entry / exit, rays
+    that miss get (min, max) of the hitting rays' ENTRY depths (:135-136 -- both from ray_start, as written there); tensor limits
+    use math_utils.linspace (:101-118: start + k/(n-1) * (stop - start), NOT torch.linspace's bit rule)."""
+    b, r, _ = rays_o.shape
+    if ray_start == ray_end == 'auto':
+        t0, t1 = ray_limits_box(rays_o, rays_d, box_warp)
+        ok = t1 > t0
+        if ok.any():
+            lo, hi = t0[ok].min(), t0[ok].max()
+            t0 = torch.where(ok, t0, lo)
+            t1 = torch.where(ok, t1, hi)
+        steps = (torch.arange(n_coarse, dtype=torch.float32) / (n_coarse - 1)).reshape(1, 1, n_coarse, 1)
+        lin = t0.unsqueeze(-2) + steps * (t1 - t0).unsqueeze(-2)
+        return lin + jitter * ((t1 - t0) / (n_coarse - 1)).unsqueeze(-1)
+    lin = torch.linspace(ray_start, ray_end, n_coarse).reshape(1, 1, n_coarse, 1).repeat(b, r, 1, 1)
+    return lin + jitter * ((ray_end - ray_start) / (n_coarse - 1))
+
+
+def render_eg3d(planes, dec, rays_o, rays_d, jitter, u, ray_start='auto', ray_end='auto', flip_z=False, n_coarse=48, n_fine=48,
+                box_warp=1.0, return_aux=False):
+    """ImportanceRenderer.forward.  Reference: renderer.py:122-293.  `jitter` [B,R,S,1] and `u` [B*R, n_fine] are
+    the two random draws (:234/:238 torch.rand_like, :453 torch.rand); flip_z negates the z coordinate of every query (:196-197)."""
+    b, r, _ = rays_o.shape
+    sign = torch.tensor([1.0, 1.0, -1.0 if flip_z else 1.0])
+
+    def decode(z):
+        xyz = (rays_o.unsqueeze(-2) + z * rays_d.unsqueeze(-2)).reshape(b, -1, 3) * sign
+        col, den = osg_decoder(dec, sample_from_planes(planes, xyz, box_warp))
+        return col.reshape(b, r, z.shape[2], -1), den.reshape(b, r, z.shape[2], 1)
+    z_c = coarse_depths_eg3d(rays_o, rays_d, ray_start, ray_end, n_coarse, jitter, box_warp)
+    col_c, den_c = decode(z_c)
+    _, _, w_c = ray_march(col_c, den_c, z_c)
+    z_f, ibuf = sample_importance(z_c, w_c, n_fine, u=u)
+    col_f, den_f = decode(z_f)
+    z_all = torch.cat([z_c, z_f], -2)
+    _, order = torch.sort(z_all, dim=-2)
+    z_all = torch.gather(z_all, -2, order)
+    col_all = torch.gather(torch.cat([col_c, col_f], -2), -2, order.expand(-1, -1, -1, col_c.shape[-1]))
+    den_all = torch.gather(torch.cat([den_c, den_f], -2), -2, order)
+    rgb, depth, w = ray_march(col_all, den_all, z_all)
+    if return_aux:
+        return rgb, depth, w.sum(2), dict(z_coarse=z_c, w_coarse=w_c, order=order, **ibuf)
+    return rgb, depth, w.sum(2)
+
+
 def flood_fill_outside(alpha255):
     """4-connected fixed-range flood fill from pixel (0,0): lo 0, up 254, new value 255.
 

@@ -1,3 +1,4 @@
+import contextlib
 import os
 import sys
 
@@ -57,3 +58,24 @@ def rnd(seed, *shape):
 
 def max_abs(a, b):
     return (a.double() - b.double()).abs().max().item()
+
+
+@contextlib.contextmanager
+def fixed_randomness(jit, u_seed=99):
+    """The two random draws of the renderer pinned exactly as tests/golden/make_golden.py:fixed_randomness pins them for the
+    reference: torch.rand_like -> `jit` (stratified jitter), torch.rand(shape) -> RandomState(u_seed).rand(shape) (importance draws)."""
+    orig_like, orig_rand = torch.rand_like, torch.rand
+
+    def fake_like(t, *a, **k):
+        assert tuple(t.shape) == tuple(jit.shape), (t.shape, jit.shape)
+        return jit.to(device=t.device, dtype=t.dtype)
+
+    def fake_rand(*size, **k):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        t = torch.from_numpy(np.random.RandomState(u_seed).rand(*shape).astype(np.float32))
+        return t.to(k['device']) if k.get('device') is not None else t
+    torch.rand_like, torch.rand = fake_like, fake_rand
+    try:
+        yield
+    finally:
+        torch.rand_like, torch.rand = orig_like, orig_rand

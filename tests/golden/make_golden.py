@@ -8,7 +8,7 @@ reference imports but the container lacks are stubbed: ``
 ``torchvision`` (unused on the path) and ``cv2`` (only ``floodFill`` is reached; stubbed with
 scipy.ndimage connected-component labelling, 4-connectivity).
 
-Usage:  python tests/golden/make_golden.py [--only ops,camera,renderer,small,full,names,encoder]
+Usage:  python tests/golden/make_golden.py [--only ops,camera,renderer,eg3d,small,extra,full,names,encoder]
 """
 import argparse
 import contextlib
@@ -178,6 +178,107 @@ def gen_renderer():
         fill_masks=masks, fill_full=full, fill_mouth=mouth)
 
 
+EG3D_CASES = {   # name: (flip_z, ray_start, ray_end)   -- 'auto' = per-ray box limits (renderer.py:131-137)
+    'auto': (False, 'auto', 'auto'),
+    'auto_flip': (True, 'auto', 'auto'),
+    'fixed': (False, 2.25, 3.3),
+    'fixed_flip': (True, 2.25, 3.3),
+}
+
+
+def eg3d_inputs():
+    """Inputs of the R9 fixture: two orbit cameras whose focal length is shortened (x 0.45) so that the corner rays MISS the
+    tri-plane box (the `is_ray_valid` repair of renderer.py:133-136 is exercised), 12^2 rays, 48^2 planes."""
+    frames, nrr = [3, 77], 12
+    cams = synthetic.camera_labels(frames).clone()
+    cams[:, 16] *= 0.45
+    cams[:, 20] *= 0.45
+    return frames, nrr, cams, rnd(21, 2, 3, 32, 48, 48)
+
+
+def gen_renderer_eg3d():
+    """R9: the reference's ImportanceRenderer (renderer.py:122-293) with flip_z in {False, True}, 'auto' and fixed ray limits.  Both
+    random draws are pinned (fixed_randomness: stratified jitter :234/:238, uniform importance draws :453)."""
+    from training_avatar_texture.triplane_v20 import OSGDecoder
+    from training_avatar_texture.volumetric_rendering import math_utils
+    from training_avatar_texture.volumetric_rendering.renderer import ImportanceRenderer
+    from training_avatar_texture.volumetric_rendering.ray_sampler import RaySampler_zxc
+    frames, nrr, cams, planes = eg3d_inputs()
+    dec = OSGDecoder(32, {'decoder_lr_mul': 1, 'decoder_output_dim': 32})
+    synthetic.fill_parameters(dec, salt=5)
+    ro, rd = RaySampler_zxc()(cams[:, :16].view(-1, 4, 4), cams[:, 16:25].view(-1, 3, 3), nrr)
+    jit = synthetic.jitter(frames, nrr * nrr)
+    arrays = dict(frames=np.array(frames), nrr=nrr, cams=cams, rays_o=ro, rays_d=rd)
+    t0, t1 = math_utils.get_ray_limits_box(ro, rd, box_side_length=1)
+    arrays['box_near'], arrays['box_far'] = t0, t1
+    assert (t1 > t0).any() and not (t1 > t0).all(), 'fixture needs both hitting and missing rays'
+    for name, (flip, start, end) in EG3D_CASES.items():
+        ren = ImportanceRenderer(flip_z=flip)
+        rec = {'march': [], 'search': [], 'sort': []}
+        ren.ray_marcher.register_forward_hook(lambda m, i, o: rec['march'].append((i[2], o[2])))
+        orig_search, orig_sort = torch.searchsorted, torch.sort
+
+        def search(cdf, u, **k):
+            r = orig_search(cdf, u, **k)
+            rec['search'].append((cdf, u, r))
+            return r
+
+        def sort(t, **k):
+            r = orig_sort(t, **k)
+            rec['sort'].append(r[1])
+            return r
+        torch.searchsorted, torch.sort = search, sort
+        try:
+            with fixed_randomness(jit):
+                rgb, depth, wsum = ren(planes, dec, ro.clone(), rd.clone(), synthetic.rendering_kwargs(ray_start=start, ray_end=end))
+        finally:
+            torch.searchsorted, torch.sort = orig_search, orig_sort
+        (zc, wc), _ = rec['march']
+        cdf, u, inds = rec['search'][0]
+        arrays.update({f'{name}/rgb': rgb, f'{name}/depth': depth, f'{name}/wsum': wsum, f'{name}/z_coarse': zc, f'{name}/w_coarse': wc,
+                       f'{name}/u': u, f'{name}/inds': inds, f'{name}/order': rec['sort'][0]})
+    npz('renderer_eg3d.npz', **arrays)
+
+
+def g2_extra_inputs():
+    """Inputs of the G2 fixture (synthesis_withCondition / sample / sample_mixed on the reduced-width generator)."""
+    frames, nrr = [9, 130], 32
+    cond = torch.stack([1 + 0.1 * rnd(31, 2, 16, 64, 64), 0.2 * rnd(32, 2, 16, 64, 64)])      # CS-SFT (scale, shift) at 64^2: C/2 = 16
+    pts = torch.from_numpy(np.random.RandomState(33).uniform(-0.55, 0.55, (2, 700, 3)).astype(np.float32))
+    dirs = torch.nn.functional.normalize(rnd(34, 2, 700, 3), dim=-1)
+    return frames, nrr, cond, pts, dirs
+
+
+def gen_generator_extra():
+    """G2: the entry points of TriPlaneGenerator that no BASELINE config calls (triplane_v20.py:246-315, 341-402)."""
+    g = build_reference_generator('small')
+    frames, nrr, cond, pts, dirs = g2_extra_inputs()
+    z = synthetic.latent(0, 2)
+    c = synthetic.camera_labels(frames)
+    uv = synthetic.uv_conditions(frames)
+    ws = g.mapping(z, c, truncation_psi=0.7, truncation_cutoff=14)
+    jit = synthetic.jitter(frames, nrr * nrr)
+    arrays = dict(frames=np.array(frames), nrr=nrr, ws=ws)
+    with injected_jitter(jit):
+        out = g.synthesis_withCondition(ws, c, {'uvcoords_image': uv}, static_feats_conditions={64: cond}, neural_rendering_resolution=nrr,
+                                        noise_mode='const', return_feats=True)
+    arrays.update({'cond/image_sub4': sub4(out['image']), 'cond/image_raw': out['image_raw'], 'cond/image_depth': out['image_depth'],
+                   'cond/feature_image': out['feature_image'], 'cond/triplane_s8': out['triplane'][..., ::8, ::8]})
+    for kind in ('static', 'texture'):
+        for i, t in enumerate(out[kind]):
+            thin_into(arrays, f'cond/{kind}{i}', t, limit=20000)
+    with injected_jitter(jit):
+        only = g.synthesis_withCondition(ws, c, {'uvcoords_image': uv}, gt_texture_feats=None, neural_rendering_resolution=nrr,
+                                         noise_mode='const', only_image=True)
+    assert list(only.keys()) == ['image']
+    arrays['cond_plain/image_sub4'] = sub4(only['image'])
+    q = g.sample(pts.clone(), dirs, z, c, {'uvcoords_image': uv}, truncation_psi=0.7, truncation_cutoff=14, noise_mode='const')
+    arrays['sample/rgb'], arrays['sample/sigma'] = q['rgb'], q['sigma']
+    q = g.sample_mixed(pts.clone(), dirs, ws.flip(0).contiguous(), {'uvcoords_image': uv}, noise_mode='const')
+    arrays['sample_mixed/rgb'], arrays['sample_mixed/sigma'] = q['rgb'], q['sigma']
+    npz('generator_small_extra.npz', **arrays)
+
+
 def build_reference_generator(width):
     from training_avatar_texture.triplane_v20 import TriPlaneGenerator
     g = TriPlaneGenerator(**synthetic.generator_kwargs(width)).eval().requires_grad_(False)
@@ -187,6 +288,14 @@ def build_reference_generator(width):
 
 def sub4(t):
     return t[..., ::4, ::4]
+
+
+def thin_into(arrays, name, t, limit=50000):
+    """Spatial sub-sampling with the stride recorded in the key: <name>_s<stride>."""
+    stride = 1
+    while t[..., ::stride, ::stride].numel() > limit:
+        stride *= 2
+    arrays[f'{name}_s{stride}'] = t[..., ::stride, ::stride]
 
 
 def gen_generator(width):
@@ -524,7 +633,7 @@ def gen_names():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='ops,flr,camera,renderer,small,full,bench,harness,names,encoder,encoder_new')
+    ap.add_argument('--only', default='ops,flr,camera,renderer,eg3d,small,extra,full,bench,harness,names,encoder,encoder_new')
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -535,7 +644,9 @@ def main():
         if 'flr' in todo: gen_filtered_lrelu()
         if 'camera' in todo: gen_camera()
         if 'renderer' in todo: gen_renderer()
+        if 'eg3d' in todo: gen_renderer_eg3d()
         if 'small' in todo: gen_generator('small')
+        if 'extra' in todo: gen_generator_extra()
         if 'full' in todo: gen_generator('full')
         if 'bench' in todo: gen_generator_bench()
         if 'harness' in todo: gen_harness()
