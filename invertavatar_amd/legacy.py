@@ -15,6 +15,7 @@ latter stay shells."""
 import collections
 import copy
 import importlib
+import io
 import pickle
 
 import torch
@@ -131,6 +132,11 @@ def _materialize(obj):
     return obj
 
 
+def _load_storage_from_bytes(b):
+    """Stand-in for torch.storage._load_from_bytes inside network pickles: same bytes, restricted (weights-only) unpickler."""
+    return torch.load(io.BytesIO(b), weights_only=True)
+
+
 class _Unpickler(pickle.Unpickler):
     """Resolves only (a) classes DEFINED in this package's mirror of the reference's module paths, (b) torch.nn layer classes,
     (c) the reconstruction helpers of _SAFE_GLOBALS.  Names are never walked: protocol >= 4 lets a pickle name
@@ -171,6 +177,11 @@ class _Unpickler(pickle.Unpickler):
                 return cls
         # Everything else must be on the allow-list of reconstruction helpers a network pickle legitimately needs: a pickle that
         # names any other global (os.system, builtins.eval, subprocess ...) is refused instead of resolved.
+        if (module, name) == ('torch.storage', '_load_from_bytes'):
+            # Tensor.__reduce_ex__ of legacy-format tensors.  torch's helper is torch.load(BytesIO(b), weights_only=False), i.e. the
+            # STOCK unpickler on a nested payload -- an allow-list bypass.  The nested payload is a storage: the
+            # weights-only loader reads exactly that and nothing else.
+            return _load_storage_from_bytes
         if (module, name) in _SAFE_GLOBALS or (module in ('torch', 'torch.storage') and name.endswith('Storage')):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f'global {module}.{name} is not on the allow-list of the network-pickle loader')
@@ -181,7 +192,7 @@ _SAFE_GLOBALS = {
     ('builtins', 'bytearray'), ('builtins', 'range'),
     ('torch._utils', '_rebuild_tensor'), ('torch._utils', '_rebuild_tensor_v2'), ('torch._utils', '_rebuild_parameter'),
     ('torch._utils', '_rebuild_parameter_with_state'), ('torch._utils', '_rebuild_device_tensor_from_numpy'),
-    ('torch.storage', '_load_from_bytes'), ('torch', 'Size'), ('torch', 'device'), ('torch', 'dtype'), ('torch', 'Tensor'),
+    ('torch', 'Size'), ('torch', 'device'), ('torch', 'dtype'), ('torch', 'Tensor'),
     ('torch.nn.parameter', 'Parameter'), ('torch._tensor', '_rebuild_from_type_v2'),
     ('torch', 'float32'), ('torch', 'float16'), ('torch', 'float64'), ('torch', 'bfloat16'), ('torch', 'int64'), ('torch', 'int32'),
     ('torch', 'int16'), ('torch', 'int8'), ('torch', 'uint8'), ('torch', 'bool'),

@@ -170,3 +170,43 @@ def test_pickle_walking_dotted_names_through_an_allowed_module_is_refused(tmp_pa
     import torch
     assert u.find_class('torch.nn.modules.conv', 'Conv2d') is torch.nn.Conv2d
     assert u.find_class('dnnlib.util', 'EasyDict') is legacy.dnnlib.util.EasyDict
+
+
+def test_nested_payload_through_load_from_bytes_is_refused(tmp_path):
+    """torch.storage._load_from_bytes is torch.load(..., weights_only=False) -- the stock unpickler on a nested payload.
+    A pickle that hands it a nested pickle of os.system(...) must not run it; a pickle that hands it a real storage must still load."""
+    import io
+    import os
+    import pickle
+    import pytest
+    import torch
+    from invertavatar_amd import legacy
+
+    marker = tmp_path / 'pwned'
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f'touch {marker}',))
+
+    class Carrier:
+        def __init__(self, payload):
+            self.payload = payload
+
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (self.payload,))
+    for nested in (pickle.dumps(Evil(), protocol=4), pickle.dumps(Evil(), protocol=2)):
+        blob = pickle.dumps({'G_ema': Carrier(nested)}, protocol=4)
+        with pytest.raises(Exception):
+            legacy._Unpickler(io.BytesIO(blob)).load()
+        assert not marker.exists()
+    # a nested torch.save in the legacy format whose pickle stream names a foreign global
+    buf = io.BytesIO()
+    torch.save({'x': Evil()}, buf, _use_new_zipfile_serialization=False)
+    blob = pickle.dumps({'G_ema': Carrier(buf.getvalue())}, protocol=4)
+    with pytest.raises(Exception):
+        legacy._Unpickler(io.BytesIO(blob)).load()
+    assert not marker.exists()
+    # the legitimate use: tensors pickled with the plain pickle module reduce to _load_from_bytes(storage bytes)
+    t = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    back = legacy._Unpickler(io.BytesIO(pickle.dumps({'t': t, 'h': t.half()[1:]}))).load()
+    assert torch.equal(back['t'], t) and torch.equal(back['h'], t.half()[1:])
