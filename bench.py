@@ -3,7 +3,7 @@
 max |dRGB| of those frames against the CPU oracle.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank
-per GPU, RCCL over xGMI).  A step = one pass of the generator hot path over one batch of synthetic frames:
+per GPU, RCCL over xGMI; run WITHOUT a launcher -- WORLD_SIZE unset -- it starts the N ranks itself the same way).  A step = one pass of the generator hot path over one batch of synthetic frames:
 
   N = 1  BASELINE configs[1]: reenact_avatar_next3d single-seed 512^2 render, nrr = 128, ONE frame per synthesis call.
   N > 1  BASELINE configs[3]: batched reenactment, 8 frames per rank per step (B = 8 N; B = 64 at N = 8), sharded by
@@ -577,9 +577,29 @@ def drive_main(args, rank, world):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves through torch.distributed.run,
+    one per GPU, rendezvous on 127.0.0.1 at a free port, and pass the command line through unchanged.  The ranks' stdout is ours, so
+    rank 0's ONE JSON line is this command's JSON line; `n_gpus` in it is the world size the ranks saw."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
     rank, world, _ = setup_distributed(args)
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started {world} rank(s)')
     torch.backends.cudnn.benchmark = False
     if args.workload == 'drive':
         result = drive_main(args, rank, world)

@@ -11,9 +11,12 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 
 
 def run_bench(port, *flags, nproc=2, timeout=900):
-    env = dict(os.environ, OMP_NUM_THREADS='2')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', str(nproc), *flags]
+    """port = None: plain `python bench.py --gpus N ...` (no launcher, WORLD_SIZE unset): bench.py starts its ranks itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '2'
+    launcher = [] if port is None else ['-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+                                        '--master-port', str(port)]
+    cmd = [sys.executable, *launcher, os.path.join(REPO, 'bench.py'), '--gpus', str(nproc), *flags]
     r = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -35,3 +38,9 @@ def test_bench_two_ranks_drive_workload_over_gloo():
     out = run_bench(29633, *CPU, '--frames-per-rank', '2', '--workload', 'drive', '--drive-frames', '8')
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['value'] > 0
     assert 'configs[4]' in out['config']['workload'] and out['config']['identity_features'] == 'backbone'
+
+
+def test_bench_without_a_launcher_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` (the shape of the driver's N = 1 command) must run two ranks, not one."""
+    out = run_bench(None, *CPU, '--frames-per-rank', '1')
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 2 and out['config']['parallelism'] == 'frame-sharded dp2'

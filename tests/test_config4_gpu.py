@@ -98,7 +98,8 @@ def test_bench_n_gt_1_path_two_ranks_on_one_gpu(workload, extra):
     """bench.py --gpus 2 with both ranks on cuda:0 and the collectives over gloo: device tensors, captured graphs with the
     batch-global / per-frame ray_dist input, the all-gather and the max-over-ranks timing all execute (RCCL itself is the driver's)."""
     from test_bench_cpu import run_bench
-    out = run_bench(29641 if workload == 'reenact' else 29643, '--dist-backend', 'gloo', '--width', 'full', '--steps', '2', '--warmup', '1',
+    # reenact: plain `python bench.py --gpus 2` (bench.py starts its own ranks); drive: under torch.distributed.run, as the driver's N > 1 command
+    out = run_bench(None if workload == 'reenact' else 29643, '--dist-backend', 'gloo', '--width', 'full', '--steps', '2', '--warmup', '1',
                     '--frames-per-rank', '2', '--workload', workload, *extra, timeout=1500)
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['value'] > 0
     assert out['config']['launch'].startswith('hipGraph replay'), out['config']['launch']
