@@ -49,7 +49,8 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense fp16 MFMA
 PEAK_HBM_GBS = 8000.0
 NRR = 128
 FRAMES_PER_RANK_SHARDED = 8     # configs[3]: B = 64 over 8 GPUs
-PMC_FILE = os.path.join(REPO, 'profiles', 'r04_pmc_frame_hbm_traffic.json')
+PMC_FILE = next((p for p in (os.path.join(REPO, 'profiles', f'r{r:02d}_pmc_frame_hbm_traffic.json') for r in (5, 4)) if os.path.exists(p)),
+                os.path.join(REPO, 'profiles', 'r05_pmc_frame_hbm_traffic.json'))      # newest committed PMC collection
 DEV = torch.device('cuda')      # set by setup_distributed
 
 
@@ -265,10 +266,15 @@ def roofline_leg(gen, wl, frames=3):
     achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
     if dom == 'conv2d_mfma' and split['ms'] > 0.5 * d['ms']:
         alg = split['flops'] / (split['ms'] * 1e-3) / 1e12
+        traffic, traffic_note = pmc_traffic(dom)
+        alg_all = round(split_all['bytes'] / split_all['launches'])      # the launch set `traffic` is counted over
         out = dict(bound='mfma', kernel='conv2d_mfma (3x3 layers >= 32^2: fp32 products from fp16 hi/lo pairs, 3 x v_mfma_f32_32x32x16_f16)',
                    achieved=round(3 * alg, 2), peak=PEAK_FP16_MFMA_TFLOPS, unit='TFLOP/s', frac=round(3 * alg / PEAK_FP16_MFMA_TFLOPS, 4),
                    frac_algorithmic=round(alg / PEAK_FP16_MFMA_TFLOPS, 4), mfma_util=round(3 * alg / PEAK_FP16_MFMA_TFLOPS, 4),
-                   algorithmic_f32_tflops=round(alg, 2), traffic=pmc_traffic(dom)[0], traffic_source=pmc_traffic(dom)[1],
+                   algorithmic_f32_tflops=round(alg, 2), traffic=traffic, traffic_source=traffic_note,
+                   traffic_launch_set='all_fp16_pair_launches (PMC kernel names do not separate layers)',
+                   traffic_algorithmic_bytes_per_launch=alg_all,
+                   traffic_over_algorithmic=None if traffic is None else round(traffic / alg_all, 3),
                    algorithmic_bytes_per_launch=round(split['bytes'] / split['launches']),
                    launches_per_frame=split['launches'] // frames, avg_launch_us=round(split['ms'] * 1e3 / split['launches'], 2),
                    algorithmic_gflop_per_frame=round(split['flops'] / frames / 1e9, 1),
@@ -354,13 +360,15 @@ def cpu_baseline_leg(gen, wl, frames):
             by_threads[str(n_thr)] = round(r_n, 4)
             refs = refs if refs is not None else refs_n
     torch.set_num_threads(cores)
+    if refs is None:       # every point's warm-up frame was over the bound: the rate is the warm-up's; parity still gets ONE reference frame
+        refs = [oracle(sets[0])]
     err_rgb = err_raw = 0.0
     for s, ref in zip(sets, refs):
         out = wl.eager(gen, s)
         err_rgb = max(err_rgb, (out['image'].cpu() - ref['image']).abs().max().item())
         err_raw = max(err_raw, (out['image_raw'].cpu() - ref['image_raw']).abs().max().item())
     base = dict(value=round(rate, 4), unit='frames/s', cores=cores, kind='port',
-                sample=f'{frames} frames of the same workload (B=1, nrr={NRR}, 512^2 out, fp32) after 1 warm-up frame',
+                sample=f'{len(refs)} frames of the same workload (B=1, nrr={NRR}, 512^2 out, fp32) after 1 warm-up frame',
                 frames_per_s_by_threads=by_threads, logical_cores_of_this_box=os.cpu_count(),
                 note='cores = physical cores this process may run on; oracle/ restates the reference op by op for checking, not for '
                      'speed; see product_cpu_route for the reference\'s own CPU route')
@@ -373,18 +381,22 @@ def cpu_baseline_leg(gen, wl, frames):
         for n_thr in sorted({8, 32, cores}):     # n = 8 is the survey container's core count (0.34 frames/s there)
             if n_thr > cores:
                 continue
+            warm, n_timed = (3, 10) if n_thr == cores else (1, 2)      # 3 warm + 10 timed at all physical cores
             torch.set_num_threads(n_thr)
-            call(sets[0])
+            for k in range(warm):
+                call(sets[k % len(sets)])
             t0 = time.perf_counter()
-            call(sets[-1])
-            by_threads[str(n_thr)] = round(1 / (time.perf_counter() - t0), 4)
+            for k in range(n_timed):
+                call(sets[k % len(sets)])
+            by_threads[str(n_thr)] = round(n_timed / (time.perf_counter() - t0), 4)
         torch.set_num_threads(cores)
-        base['product_cpu_route'] = dict(value=by_threads[str(cores)], unit='frames/s', cores=cores, sample='1 frame after 1 warm-up frame',
+        base['product_cpu_route'] = dict(value=by_threads[str(cores)], unit='frames/s', cores=cores,
+                                         sample='10 frames after 3 warm-up frames at `cores` threads (SURVEY 8d); 2 after 1 at the other points',
                                          survey_container_8_cores=0.34, frames_per_s_by_threads=by_threads)
     except Exception as exc:   # noqa: BLE001
         base['product_cpu_route'] = f'failed: {exc}'
     return base, dict(max_abs_rgb_vs_oracle=float(f'{err_rgb:.3e}'), max_abs_raw_rgb_vs_oracle=float(f'{err_raw:.3e}'),
-                      frames_compared=frames, tolerance=1e-3)
+                      frames_compared=len(refs), tolerance=1e-3)
 
 
 def variant_leg(gen, wl, args, batch=1, **flags):
@@ -656,8 +668,11 @@ def main():
             if not args.no_roofline:
                 result['roofline'], result['kernels'] = roofline_leg(gen, wl)
             if not args.no_cpu_baseline:
-                result['cpu_baseline'], parity = cpu_baseline_leg(gen, wl, args.cpu_frames)
-                result.update(parity)
+                try:
+                    result['cpu_baseline'], parity = cpu_baseline_leg(gen, wl, args.cpu_frames)
+                    result.update(parity)
+                except Exception as exc:   # noqa: BLE001  a failure of the reported baseline must not lose the measured line
+                    result['cpu_baseline'] = dict(value=None, unit='frames/s', cores=host_physical_cores(), kind='port', sample=f'failed: {exc!r}')
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
