@@ -3,6 +3,7 @@
 Device tensors run the HIP kernel ``ia_bias_act``; CPU tensors (and impl='ref') run the
 plain-torch definition, exactly as the reference dispatches (bias_act.py:86-88).  A device
 tensor never falls back to torch ops: if libia_hip.so is missing the call raises."""
+import dataclasses
 import math
 
 import torch
@@ -50,7 +51,8 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, 
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
     if impl == 'cuda' and x.device.type == 'cuda' and _init():
-        return _bias_act_cuda(dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp).apply(x, b)
+        _, a, g, c = _resolve(act, alpha, gain, clamp)
+        return _BiasAct.apply(x, b, _ActConfig(act, dim, a, g, c))
     return _bias_act_ref(x=x, b=b, dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp)
 
 
@@ -71,64 +73,80 @@ def _bias_act_ref(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=N
     return x
 
 
-_cache = {}
+@dataclasses.dataclass(frozen=True)
+class _ActConfig:
+    """Everything but the tensors: resolved once per call, handed to the autograd Functions as one non-tensor argument."""
+    name: str
+    dim: int
+    alpha: float
+    gain: float
+    clamp: float
+
+    @property
+    def spec(self):
+        return activation_funcs[self.name]
+
+    @property
+    def is_identity(self):            # y = x: nothing to launch when there is no bias either
+        return self.name == 'linear' and self.gain == 1 and self.clamp < 0
+
+    def kernel(self, order, t, b, x, y, dy):
+        """ia_bias_act: order 0 = forward on t; 1 = d/dx applied to the incoming gradient t; 2 = second-order term (needs dy)."""
+        return _plugin.bias_act(t, b, x, y, dy, order, self.dim, self.spec.cuda_idx, self.alpha, self.gain, self.clamp)
+
+    def bias_grad(self, g):
+        return g.sum([i for i in range(g.ndim) if i != self.dim])
 
 
-def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
-    """autograd.Function bound to one (dim, act, alpha, gain, clamp); cached like the reference (:128-209)."""
-    spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
-    key = (dim, act, alpha, gain, clamp)
-    if key in _cache:
-        return _cache[key]
-    keep_x = 'x' in spec.ref or spec.has_2nd_grad
-    trivial = act == 'linear' and gain == 1 and clamp < 0
+def _layout_of(t):
+    return torch.channels_last if t.ndim > 2 and t.stride(1) == 1 else torch.contiguous_format
 
-    def layout(t):
-        return torch.channels_last if t.ndim > 2 and t.stride(1) == 1 else torch.contiguous_format
 
-    class BiasActCuda(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x, b):
-            ctx.memory_format = layout(x)
-            x = x.contiguous(memory_format=ctx.memory_format)
-            b = b.contiguous() if b is not None else _null
-            y = x
-            if not trivial or b is not _null:
-                y = _plugin.bias_act(x, b, _null, _null, _null, 0, dim, spec.cuda_idx, alpha, gain, clamp)
-            ctx.save_for_backward(x if keep_x else _null, b if keep_x else _null, y if 'y' in spec.ref else _null)
-            return y
+class _BiasAct(torch.autograd.Function):
+    """y = act(x + b) * gain, clamped.  Saves what the activation's derivative is written in (`ref`: 'x', 'y' or nothing)."""
 
-        @staticmethod
-        def backward(ctx, dy):
-            dy = dy.contiguous(memory_format=ctx.memory_format)
-            x, b, y = ctx.saved_tensors
-            dx = db = None
-            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-                dx = dy if trivial else BiasActCudaGrad.apply(dy, x, b, y)
-            if ctx.needs_input_grad[1]:
-                db = dx.sum([i for i in range(dx.ndim) if i != dim])
-            return dx, db
+    @staticmethod
+    def forward(ctx, x, b, cfg):
+        ctx.cfg, ctx.layout = cfg, _layout_of(x)
+        x = x.contiguous(memory_format=ctx.layout)
+        b = _null if b is None else b.contiguous()
+        y = x if (cfg.is_identity and b is _null) else cfg.kernel(0, x, b, _null, _null, _null)
+        needs_x = 'x' in cfg.spec.ref or cfg.spec.has_2nd_grad
+        ctx.save_for_backward(x if needs_x else _null, b if needs_x else _null, y if 'y' in cfg.spec.ref else _null)
+        return y
 
-    class BiasActCudaGrad(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, dy, x, b, y):
-            ctx.memory_format = layout(dy)
-            dx = _plugin.bias_act(dy, b, x, y, _null, 1, dim, spec.cuda_idx, alpha, gain, clamp)
-            ctx.save_for_backward(dy if spec.has_2nd_grad else _null, x, b, y)
-            return dx
+    @staticmethod
+    def backward(ctx, grad_y):
+        cfg = ctx.cfg
+        want_x, want_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (want_x or want_b):
+            return None, None, None
+        x, b, y = ctx.saved_tensors
+        grad_y = grad_y.contiguous(memory_format=ctx.layout)
+        grad_x = grad_y if cfg.is_identity else _BiasActGrad.apply(grad_y, x, b, y, cfg)
+        return grad_x, (cfg.bias_grad(grad_x) if want_b else None), None
 
-        @staticmethod
-        def backward(ctx, d_dx):
-            d_dx = d_dx.contiguous(memory_format=ctx.memory_format)
-            dy, x, b, y = ctx.saved_tensors
-            d_dy = d_x = d_b = None
-            if ctx.needs_input_grad[0]:
-                d_dy = BiasActCudaGrad.apply(d_dx, x, b, y)
-            if spec.has_2nd_grad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
-                d_x = _plugin.bias_act(d_dx, b, x, y, dy, 2, dim, spec.cuda_idx, alpha, gain, clamp)
-            if spec.has_2nd_grad and ctx.needs_input_grad[2]:
-                d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
-            return d_dy, d_x, d_b, None
 
-    _cache[key] = BiasActCuda
-    return BiasActCuda
+class _BiasActGrad(torch.autograd.Function):
+    """g -> g * act'(x + b) * gain (zero where the clamp is active): linear in g, so its own gradient w.r.t. g is itself; the
+    derivative w.r.t. x / b exists for the activations with a second derivative (order-2 kernel)."""
+
+    @staticmethod
+    def forward(ctx, g, x, b, y, cfg):
+        ctx.cfg, ctx.layout = cfg, _layout_of(g)
+        out = cfg.kernel(1, g, b, x, y, _null)
+        ctx.save_for_backward(g if cfg.spec.has_2nd_grad else _null, x, b, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        cfg = ctx.cfg
+        g, x, b, y = ctx.saved_tensors
+        gg = gg.contiguous(memory_format=ctx.layout)
+        d_g = _BiasActGrad.apply(gg, x, b, y, cfg) if ctx.needs_input_grad[0] else None
+        d_x = d_b = None
+        if cfg.spec.has_2nd_grad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            d_x = cfg.kernel(2, gg, b, x, y, g)
+            if ctx.needs_input_grad[2]:
+                d_b = cfg.bias_grad(d_x)
+        return d_g, d_x, d_b, None, None

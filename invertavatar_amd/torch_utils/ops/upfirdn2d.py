@@ -2,6 +2,8 @@
 
 Public names and argument meaning follow the reference (setup_filter :72, upfirdn2d :120,
 filter2d :279, upsample2d :315, downsample2d :354).  Device tensors run ``ia_upfirdn2d``."""
+import dataclasses
+
 import numpy as np
 import torch
 
@@ -69,7 +71,7 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cu
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
     if impl == 'cuda' and x.device.type == 'cuda' and _init():
-        return _upfirdn2d_cuda(up=up, down=down, padding=padding, flip_filter=flip_filter, gain=gain).apply(x, f)
+        return _UpFirDn.apply(x, f, _FirPlan.parse(up, down, padding, flip_filter, gain))
     return _upfirdn2d_ref(x, f, up=up, down=down, padding=padding, flip_filter=flip_filter, gain=gain)
 
 
@@ -100,50 +102,62 @@ def _upfirdn2d_ref(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
     return z[:, :, ::dny, ::dnx]
 
 
-_cache = {}
+@dataclasses.dataclass(frozen=True)
+class _FirPlan:
+    """One resampling step: zero-insert by `up`, pad by `pad` (x0, x1, y0, y1; negative crops), correlate with the (flipped unless
+    `flip`) filter times `gain`, keep every `down`-th sample.  Hashable plain data: travels through autograd as a non-tensor argument."""
+    up: tuple
+    down: tuple
+    pad: tuple
+    flip: bool
+    gain: float
+
+    @staticmethod
+    def parse(up, down, padding, flip_filter, gain):
+        return _FirPlan(_parse_scaling(up), _parse_scaling(down), _parse_padding(padding), bool(flip_filter), gain)
+
+    def adjoint(self, filter_wh, in_hw, out_hw):
+        """Plan of the transposed operator (the input gradient): rates swapped, filter flipped the other way, and the padding that
+        maps an `out_hw` gradient back onto `in_hw` samples."""
+        (fw, fh), (ih, iw), (oh, ow) = filter_wh, in_hw, out_hw
+        (ux, uy), (dx, dy), (px0, _, py0, _) = self.up, self.down, self.pad
+        pad = (fw - px0 - 1, iw * ux - ow * dx + px0 - ux + 1, fh - py0 - 1, ih * uy - oh * dy + py0 - uy + 1)
+        return _FirPlan(self.down, self.up, pad, not self.flip, self.gain)
 
 
-def _upfirdn2d_cuda(up=1, down=1, padding=0, flip_filter=False, gain=1):
-    upx, upy = _parse_scaling(up)
-    dnx, dny = _parse_scaling(down)
-    px0, px1, py0, py1 = _parse_padding(padding)
-    key = (upx, upy, dnx, dny, px0, px1, py0, py1, flip_filter, gain)
-    if key in _cache:
-        return _cache[key]
+def _launch(x, f, plan):
+    """ia_upfirdn2d through the plugin-shaped entry; a 1-D filter is two launches (rows with unit gain, then columns)."""
+    (ux, uy), (dx, dy), (px0, px1, py0, py1) = plan.up, plan.down, plan.pad
+    if f.ndim == 2:
+        return _plugin.upfirdn2d(x, f, ux, uy, dx, dy, px0, px1, py0, py1, plan.flip, plan.gain)
+    y = _plugin.upfirdn2d(x, f.unsqueeze(0), ux, 1, dx, 1, px0, px1, 0, 0, plan.flip, 1.0)
+    return _plugin.upfirdn2d(y, f.unsqueeze(1), 1, uy, 1, dy, 0, 0, py0, py1, plan.flip, plan.gain)
 
-    class Upfirdn2dCuda(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x, f):
-            assert isinstance(x, torch.Tensor) and x.ndim == 4
-            if f is None:
-                f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
-            if f.ndim == 1 and f.shape[0] == 1:
-                f = f.square().unsqueeze(0)
-            assert f.ndim in [1, 2]
-            if f.ndim == 2:
-                y = _plugin.upfirdn2d(x, f, upx, upy, dnx, dny, px0, px1, py0, py1, flip_filter, gain)
-            else:  # separable: horizontal pass with unit gain, then vertical pass
-                y = _plugin.upfirdn2d(x, f.unsqueeze(0), upx, 1, dnx, 1, px0, px1, 0, 0, flip_filter, 1.0)
-                y = _plugin.upfirdn2d(y, f.unsqueeze(1), 1, upy, 1, dny, 0, 0, py0, py1, flip_filter, gain)
-            ctx.save_for_backward(f)
-            ctx.x_shape = x.shape
-            return y
 
-        @staticmethod
-        def backward(ctx, dy):
-            f, = ctx.saved_tensors
-            _, _, ih, iw = ctx.x_shape
-            _, _, oh, ow = dy.shape
-            fw, fh = _get_filter_size(f)
-            p = [fw - px0 - 1, iw * upx - ow * dnx + px0 - upx + 1, fh - py0 - 1, ih * upy - oh * dny + py0 - upy + 1]
-            dx = None
-            if ctx.needs_input_grad[0]:
-                dx = _upfirdn2d_cuda(up=down, down=up, padding=p, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
-            assert not ctx.needs_input_grad[1]
-            return dx, None
+class _UpFirDn(torch.autograd.Function):
+    """Device path of upfirdn2d().  The operator is linear in x, so its gradient is the same Function under the adjoint plan
+    (and so on for higher orders); the filter gets no gradient (reference: upfirdn2d.py:250-273)."""
 
-    _cache[key] = Upfirdn2dCuda
-    return Upfirdn2dCuda
+    @staticmethod
+    def forward(ctx, x, f, plan):
+        assert isinstance(x, torch.Tensor) and x.ndim == 4
+        if f is None:
+            f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+        elif f.ndim == 1 and f.shape[0] == 1:
+            f = f.square().unsqueeze(0)          # one separable tap = one 2-D tap
+        assert f.ndim in [1, 2]
+        ctx.plan, ctx.in_hw = plan, tuple(x.shape[2:])
+        ctx.save_for_backward(f)
+        return _launch(x, f, plan)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        assert not ctx.needs_input_grad[1], 'the FIR filter is a constant'
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        f, = ctx.saved_tensors
+        back = ctx.plan.adjoint(_get_filter_size(f), ctx.in_hw, tuple(grad_out.shape[2:]))
+        return _UpFirDn.apply(grad_out, f, back), None, None
 
 
 def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='cuda'):
