@@ -560,7 +560,8 @@ int ia_split_saturation_count(const void* xs, int planes, int B, int C, int H, i
  * convolution epilogues, ia_cond_blend_split) sets a device flag when a value it splits lies outside +-65504 or is not finite
  * (it is clamped, as before).  This call reads the flags of the current device into *h_flagged (0: every split since the last
  * reset was in range), optionally clearing them; it synchronises `stream` (a host read: call it once per frame / clip, outside
- * captured graphs).  Real checkpoints cannot clamp silently.
+ * captured graphs).  h_flagged == NULL with reset != 0 clears the flags in stream order WITHOUT a host synchronisation (the top of
+ * a clip).  Real checkpoints cannot clamp silently.
  */
 int ia_split_saturation_poll(unsigned int* h_flagged, int reset, void* stream);
 

@@ -497,6 +497,9 @@ int plan_up(int B, int I, int O, int H, int W, UpPlan* out) {
     UpGeo& g = p.g;
     g.B = B; g.I = I; g.O = O; g.H = H; g.W = W; g.OH = 2 * H + 1; g.OW = 2 * W + 1; g.TO = O / 128;
     if ((int64_t)B * O * g.OH * g.OW > INT32_MAX || (int64_t)B * I * H * W > INT32_MAX) return IA_ERR_UNSUPPORTED;
+    // the DMA plan does 32-bit BYTE arithmetic: a frame's two split planes (4 bytes per element) and the packed weights (2 planes x 9
+    // taps x I x O fp16) are each one buffer resource whose size must stay below the "outside" offset (0x7ffffff0) that yields zeros
+    if (4 * (int64_t)I * H * W >= 0x7ffffff0LL || 36 * (int64_t)I * O >= 0x7ffffff0LL) return IA_ERR_UNSUPPORTED;
     p.fp = W >= 256 ? 2 : 1;
     const int BP = 128 * p.fp;
     const int npt = (int)ia::ceil_div((int64_t)H * W, BP);

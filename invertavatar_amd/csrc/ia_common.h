@@ -82,7 +82,8 @@ constexpr float kSplitLoScale = 2048.f;
 namespace {
 __device__ unsigned int ia_tu_saturated;         // this translation unit's range-watch word
 hipError_t ia_tu_read_saturated(unsigned int* h_word, int reset, hipStream_t s) {
-    hipError_t e = hipMemcpyFromSymbolAsync(h_word, HIP_SYMBOL(ia_tu_saturated), sizeof(unsigned int), 0, hipMemcpyDeviceToHost, s);
+    hipError_t e = h_word ? hipMemcpyFromSymbolAsync(h_word, HIP_SYMBOL(ia_tu_saturated), sizeof(unsigned int), 0, hipMemcpyDeviceToHost, s)
+                          : hipSuccess;          // (no destination: clear only, nothing for the host to wait for)
     static const unsigned int zero = 0;
     if (e == hipSuccess && reset) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(ia_tu_saturated), &zero, sizeof(unsigned int), 0, hipMemcpyHostToDevice, s);
     return e;

@@ -22,15 +22,16 @@ void register_sat_probe(SatProbe* p) { p->next = g_sat_probes; g_sat_probes = p;
 }  // namespace ia
 
 extern "C" int ia_split_saturation_poll(unsigned int* h_flagged, int reset, void* stream) {
-    IA_REQUIRE(h_flagged, "null output pointer");
+    IA_REQUIRE(h_flagged || reset, "nothing to do: no output pointer and no reset");
     hipStream_t s = (hipStream_t)stream;
     unsigned int words[64];
     int n = 0;
     for (ia::SatProbe* p = ia::g_sat_probes; p && n < 64; p = p->next, ++n) {
         words[n] = 0;
-        const hipError_t e = p->read(&words[n], reset, s);
+        const hipError_t e = p->read(h_flagged ? &words[n] : nullptr, reset, s);
         if (e != hipSuccess) return ia::fail(IA_ERR_LAUNCH, "ia_split_saturation_poll: %s", hipGetErrorString(e));
     }
+    if (!h_flagged) return IA_OK;          // clear only: stream-ordered, the host does not wait
     const hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) return ia::fail(IA_ERR_LAUNCH, "ia_split_saturation_poll: %s", hipGetErrorString(e));
     unsigned int any = 0;

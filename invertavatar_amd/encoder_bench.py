@@ -26,25 +26,32 @@ def encoder_leg(gen, n_sources=8, n_drive=32):
         drive = list(range(40, 40 + n_drive))
         d_c, d_uv = synthetic.camera_labels(drive).cuda(), synthetic.uv_conditions(drive).cuda()
 
+        cache = {}        # captured e4e encode (eval_seq.GraphedEncode) kept across the runs, as a clip-processing service keeps it
+
         def run():
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
-            ws, res, _ = eval_seq.few_shot_inversion(net, images, uvs, cams, uvc)
+            ws, res, _ = eval_seq.few_shot_inversion(net, images, uvs, cams, uvcoords=uvc, graphed=cache)
             ev[1].record()
             imgs, _ = eval_seq.drive_sequence(net, ws, res, d_c, d_uv, neural_rendering_resolution=NRR)
             ev[2].record()
             torch.cuda.synchronize()
             return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), imgs
-        run()                                         # warm-up (allocations, MIOpen kernel selection)
-        t0 = time.perf_counter()
-        inv_ms, drive_ms, imgs = run()
-        wall = time.perf_counter() - t0
+        for _ in range(2):                            # warm-ups (allocations, graph capture of the encode, library kernel selection)
+            run()
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            inv_ms, drive_ms, imgs = run()
+            runs.append((inv_ms, drive_ms, time.perf_counter() - t0))
+        inv_ms, drive_ms, wall = (min(r[k] for r in runs) for k in range(3))
         ok = bool(torch.isfinite(imgs).all().item())
     finally:
         gen.train(was_training)
     return dict(workload=f'BASELINE configs[2]: encode + {n_sources // 4} AR_eval_forward groups of 4 sources (ConvGRU) + {n_drive} drive frames '
-                         '(synthesis_withTexture, B=1 per call), eager launches, generator in train() mode as eval_seq.py leaves it',
-                inversion_ms=round(inv_ms, 2), drive_ms=round(drive_ms, 2), drive_frames_per_s=round(n_drive / (drive_ms * 1e-3), 2),
+                         '(synthesis_withTexture, B=1 per call), e4e encode replayed as a hipGraph, everything else eager launches (UNet chains '
+                         'on two streams), generator in train() mode as eval_seq.py leaves it; min of 3 runs after 2 warm-ups',
+                inversion_ms=round(inv_ms, 2), inversion_ms_runs=[round(r[0], 2) for r in runs], drive_ms=round(drive_ms, 2), drive_frames_per_s=round(n_drive / (drive_ms * 1e-3), 2),
                 clip_frames_per_s=round(n_drive / wall, 2), finite=ok)
 
 
@@ -64,12 +71,15 @@ def oneshot_leg(gen, n_drive=8):
         cam, uvc = synthetic.camera_labels(src).cuda(), synthetic.uv_conditions(src).cuda()
         drive = list(range(40, 40 + n_drive))
         d_c, d_uv = synthetic.camera_labels(drive).cuda(), synthetic.uv_conditions(drive).cuda()
-        for _ in range(3):      # (first runs: allocations, library kernel selection)
+        times = []
+        for k in range(5):      # 2 warm-ups (allocations, library kernel selection), then min of 3
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             ws, res = eval_updated_os.one_shot_inversion(net, image, uv, cam, uvc)
             torch.cuda.synchronize()
-            inv_ms = (time.perf_counter() - t0) * 1e3
+            if k >= 2:
+                times.append((time.perf_counter() - t0) * 1e3)
+        inv_ms = min(times)
         t0 = time.perf_counter()
         imgs, _ = eval_seq.drive_sequence(net, ws, res, d_c, d_uv, neural_rendering_resolution=NRR)
         torch.cuda.synchronize()
@@ -79,4 +89,4 @@ def oneshot_leg(gen, n_drive=8):
         gen.train(was_training)
     return dict(workload='SURVEY 8(f)4: eval_updated_os.py one-shot inversion (uvnet_new: e4e + 2 IR-SE50 UNets with 13 + 12 transformer '
                          f'blocks, attention through ia_attention) of 1 source frame + {n_drive} drive frames, eager launches',
-                inversion_ms=round(inv_ms, 2), drive_frames_per_s=round(n_drive / (drive_ms * 1e-3), 2), finite=ok)
+                inversion_ms=round(inv_ms, 2), inversion_ms_runs=[round(t, 2) for t in times], drive_frames_per_s=round(n_drive / (drive_ms * 1e-3), 2), finite=ok)

@@ -103,9 +103,9 @@ class GraphedEncode:
 def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=False, hook=None, graphed=None):
     """See _few_shot_inversion; on the device the always-on range watch of the fp16 hi / lo split brackets the call."""
     from .reenact_avatar_next3d import _check_split_range
-    _check_split_range(images.device, start=True)
+    _check_split_range(net, start=True)
     out = _few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling, hook, graphed)
-    _check_split_range(images.device)
+    _check_split_range(net)
     return out
 
 
@@ -170,7 +170,7 @@ def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=No
     g = net.generator
     n = cams.shape[0]
     imgs, mosaics = [], ([] if gt is not None else None)
-    _check_split_range(cams.device, start=True)
+    _check_split_range(net, start=True)
     for lo in range(0, n, batch):
         hi = min(lo + batch, n)
         b = hi - lo
@@ -190,5 +190,5 @@ def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=No
         if gt is not None:
             for k in range(b):
                 mosaics.append(layout_grid(torch.cat([gt[lo + k:lo + k + 1, :3], out['image'][k:k + 1]], dim=0), grid_w=2, grid_h=1))
-    _check_split_range(cams.device)      # (one device -> host read per drive sequence: see hipops.split_saturation_poll)
+    _check_split_range(net)      # (one device -> host read per drive sequence: see hipops.split_saturation_poll)
     return torch.cat(imgs, 0), mosaics

@@ -262,6 +262,14 @@ def split_saturation_poll(device=None, reset=True):
     return flag.value != 0
 
 
+def split_saturation_clear(device=None):
+    """Clear the range-watch flags of `device` in stream order; no host synchronisation (the top of a clip / an inversion)."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(device):
+        st = _lib.load().ia_split_saturation_poll(None, 1, _lib.stream_ptr(device))
+    _lib.check(st, 'ia_split_saturation_poll')
+
+
 def split_saturation_count(sa):
     """Elements of the SplitAct's hi plane that sit on the fp16 maximum (a device -> host sync)."""
     b, c, h, w = sa.shape

@@ -38,8 +38,14 @@ def seeded_draws(seed, n_rays, n_frames=4, n_samples=48):
     return draws
 
 
-def _flat(tensors):
-    return torch.cat([t.reshape(-1) for t in tensors]) if tensors else torch.zeros(0)
+def _flat(tensors, device=None):
+    """One buffer on the tensors' own device in their own dtype (torch.cat would silently promote a mixed list: refused instead)."""
+    if not tensors:
+        return torch.zeros(0, device=device)
+    dtypes = {t.dtype for t in tensors}
+    if len(dtypes) != 1:
+        raise TypeError(f'one flat broadcast carries one dtype, got {sorted(str(d) for d in dtypes)}')
+    return torch.cat([t.reshape(-1) for t in tensors])
 
 
 def _unflat(flat, like):
@@ -50,10 +56,11 @@ def _unflat(flat, like):
     return out
 
 
-def _broadcast_list(tensors, src, group=None):
+def _broadcast_list(tensors, src, group=None, device=None):
     """One broadcast of a list of same-dtype tensors whose shapes every rank knows (flat buffer: one collective per owner)."""
-    flat = _flat(tensors).contiguous()
-    torch.distributed.broadcast(flat, src=src, group=group)
+    flat = _flat(tensors, device).contiguous()
+    if flat.numel():
+        torch.distributed.broadcast(flat, src=src, group=group)
     return _unflat(flat, tensors)
 
 
@@ -70,7 +77,7 @@ def few_shot_inversion_sharded(net, images, uvs, cams, uvcoords, rank=0, world_s
     images, uvs, cams, uvcoords = (fill_group(t, s) for t in (images, uvs, cams, uvcoords))
     n = images.shape[0]
     g = net.generator
-    _check_split_range(images.device, start=True)      # (range watch of the fp16 hi / lo split: see eval_seq.few_shot_inversion)
+    _check_split_range(net, start=True)      # (range watch of the fp16 hi / lo split: see eval_seq.few_shot_inversion)
     nrr = neural_rendering_resolution or g.neural_rendering_resolution
     if draws is None:
         draws = seeded_draws(0, nrr * nrr)
@@ -127,7 +134,7 @@ def few_shot_inversion_sharded(net, images, uvs, cams, uvcoords, rank=0, world_s
         static = _broadcast_list([t.clone() for t in (updated['static'] if rank == tri_owner else sta)], tri_owner, group)
         updated = {'w': ws, 'texture': texture, 'static': static}
         r_list = [_broadcast_states(r_list[0], tex_owner, rank, dev, group), _broadcast_states(r_list[1], tri_owner, rank, dev, group)]
-    _check_split_range(images.device)
+    _check_split_range(net)
     return ws, updated, r_list
 
 
@@ -135,7 +142,8 @@ def _broadcast_states(states, src, rank, device, group=None):
     """ConvGRU states of one UNet (a list of tensors known on `src` only): shapes first (int64 header), then one flat buffer."""
     if rank == src:
         shapes = [list(h.shape) for h in states]
-        header = torch.tensor([len(shapes)] + [v for sh in shapes for v in [len(sh)] + sh], dtype=torch.int64, device=device)
+        dtype_code = _STATE_DTYPES.index(states[0].dtype) if states else 0
+        header = torch.tensor([len(shapes), dtype_code] + [v for sh in shapes for v in [len(sh)] + sh], dtype=torch.int64, device=device)
         count = torch.tensor([header.numel()], dtype=torch.int64, device=device)
     else:
         count = torch.zeros(1, dtype=torch.int64, device=device)
@@ -144,10 +152,13 @@ def _broadcast_states(states, src, rank, device, group=None):
         header = torch.zeros(int(count.item()), dtype=torch.int64, device=device)
     torch.distributed.broadcast(header, src=src, group=group)
     if rank != src:
-        vals, shapes, at = header.tolist(), [], 1
+        vals, shapes, at = header.tolist(), [], 2
         for _ in range(vals[0]):
             nd = vals[at]
             shapes.append(vals[at + 1:at + 1 + nd])
             at += 1 + nd
-        states = [torch.empty(sh, dtype=torch.float32, device=device) for sh in shapes]
-    return _broadcast_list([h.contiguous() for h in states], src, group)
+        states = [torch.empty(sh, dtype=_STATE_DTYPES[vals[1]], device=device) for sh in shapes]
+    return _broadcast_list([h.contiguous() for h in states], src, group, device)
+
+
+_STATE_DTYPES = (torch.float32, torch.float16, torch.bfloat16, torch.float64)      # header code of the ConvGRU states' dtype

@@ -159,12 +159,21 @@ def run_video_animation(G, drive, seeds, grid_dims=(None, 1), truncation_psi=1.0
 def _check_split_range(device, start=False):
     """The fp16 hi / lo split of the large convolutions clamps at +-65504: the library's always-on range watch says whether any
     activation of the clip hit the clamp (random-init weights stay 5 orders of magnitude below it; a real checkpoint is checked here).
-    `start`: clear the flag at the top of a clip (it is sticky: whatever ran before in this process must not be blamed on this clip)."""
+    `device`: where the NETWORK lives (a module, a parameter device or a tensor's device).  `start`: clear the flag at the top of a
+    clip -- stream-ordered, no host synchronisation (it is sticky: whatever ran before in this process must not be blamed on this
+    clip).  The check at the end is the clip's one device -> host read."""
+    if isinstance(device, torch.nn.Module):
+        first = next(device.parameters(), None)
+        if first is None:
+            return
+        device = first.device
     if torch.device(device).type != 'cuda':
         return
     from . import hipops
-    flagged = hipops.split_saturation_poll(device)
-    if flagged and not start:
+    if start:
+        hipops.split_saturation_clear(device)
+        return
+    if hipops.split_saturation_poll(device):
         raise OverflowError('activations outside the fp16 range (+-65504) were clamped by the hi / lo split of the fp16-pair convolutions: '
                             'set training.networks_stylegan2.SPLIT_FP16_PRODUCTS = False (fp32 MFMA path) for this checkpoint')
 
