@@ -33,14 +33,10 @@
 // the 47-bin / 45-weight quirk of sample_importance are preserved.
 #include "ia_common.h"
 
-// IA_RENDER_F16_RGB = 1: the colour rows of layer 2 (half of the decoder's matrix work, no influence on the index buffers) form their
-// fp32 products from fp16 hi / lo pairs on v_mfma_f32_16x16x32_f16 (12 instructions of 16 pipe cycles instead of 32 of 32), issued as
-// inline assembly with their own wait states (the compiler's hazard handling around this instruction next to the fp32 MFMAs and
-// their VALU consumers produced run-to-run differences in r02).  Experimental: see DESIGN.md 4.2.
-#ifndef IA_RENDER_F16_RGB
-#define IA_RENDER_F16_RGB 0
-#endif
-
+// Activation constants are folded into the staged weights (r05): layer 1 weights and bias carry log2(e), so softplus is
+// log2(1 + exp2(acc)) in units of ln 2, which the density row of layer 2 carries; the colour rows of layer 2 are staged NEGATED with
+// bias -log2(e) b, so sigmoid is rcp(1 + exp2(acc)); both accumulators start from the bias instead of zero (10 -> 5 and 6 -> 4 vector
+// instructions per activation).  Cross-row sums and broadcasts are lane swaps / DPP (v_permlane16/32_swap, row_share), no ds_bpermute.
 // IA_RENDER_TRACE (tools/trace_render.py): workgroup 0 stamps s_memtime at the phase boundaries of its first rays into the
 // dbg_sigma_coarse buffer (a profiling build: that debug output is not written).
 #ifndef IA_RENDER_TRACE
@@ -56,7 +52,6 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x8r __attribute__((ext_vector_type(8)));
 
 constexpr int NS = 48;            // coarse samples == importance samples (depth_resolution[_importance])
 constexpr int NM = 2 * NS;        // merged
@@ -89,11 +84,12 @@ struct Params {
 
 // LDS image (floats)
 constexpr int A1_OFF = 0;                       // [4 tiles][8 ksteps][64 lanes]
-constexpr int A2_OFF = A1_OFF + 4 * 8 * 64;     // [2 tiles][16 ksteps][64 lanes]; IA_RENDER_F16_RGB: [3 variants][2 tiles][2 k-halves][64 lanes] x 8 halves
-constexpr int WS_OFF = A2_OFF + (IA_RENDER_F16_RGB ? 12 * 64 * 4 : 2 * 16 * 64);    // [16 ksteps][4 quarters]   density row of layer 2
+constexpr int A2_OFF = A1_OFF + 4 * 8 * 64;     // [2 tiles][16 ksteps][64 lanes]
+constexpr int WS_OFF = A2_OFF + 2 * 16 * 64;    // [16 ksteps][4 quarters]   density row of layer 2
 constexpr int B0_OFF = WS_OFF + 64;             // [64]
 constexpr int B1_OFF = B0_OFF + 64;             // [33] (+pad)
-constexpr int SCR_OFF = B1_OFF + 40;            // per-wave scratch
+constexpr int B1C_OFF = B1_OFF + 40;            // [32] colour biases of layer 2 as the accumulators start from them, 16-byte aligned
+constexpr int SCR_OFF = B1C_OFF + 32;           // per-wave scratch
 constexpr int COL_OFF = 10 * NS;                // colours of the 96 samples, [sample][quarter][8] (coarse 0..47, fine 48..95)
 constexpr int CS = 36;                          // floats per colour slot: 32 + 4 of padding (slots 128 bytes apart put the 16 samples of a group on two banks)
 constexpr int SGF_OFF = COL_OFF + NM * CS;      // densities of the fine samples [48]
@@ -118,6 +114,24 @@ __device__ __forceinline__ float softplus_fast(float x) {
     const float l = log_of_normal(1.f + exp_raw(x));
     const unsigned big = x > 20.f ? 0xffffffffu : 0u;
     return __uint_as_float((__float_as_uint(x) & big) | (__float_as_uint(l) & ~big));
+}
+
+// The same function in base 2: x2 = x * log2(e) in, softplus(x) / ln 2 out.  log2(1 + 2^x2) >= x2 always, and equals x2 to fp32
+// precision from x2 = 25 up, so max(., x2) is the large-argument branch (torch's threshold 20 = 28.9 here: both sides agree to an
+// ulp long before); the min keeps 2^x2 finite.  Five instructions, no constants.
+__device__ __forceinline__ float softplus2_fast(float x2) {
+    const float l = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(fminf(x2, 126.f)));
+    return fmaxf(l, x2);
+}
+
+// x + (value of the lane 16 / 32 rows away): the xor-16 / xor-32 butterfly steps on the VALU (gfx950 lane swaps)
+__device__ __forceinline__ float add_across_rows(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);       // {rows 0,0,2,2 ; rows 1,1,3,3}
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned v = __float_as_uint(s);
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);       // {lower half twice ; upper half twice}
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // CPU torch.linspace bit rule.
@@ -233,7 +247,7 @@ __device__ __forceinline__ void features_to_operand(float* group_slots, int gj, 
 // Out: h[T][r] = hidden unit 16T + 4q + r of this lane's sample.
 __device__ __forceinline__ void decoder_hidden(const float* __restrict__ lds, int lane, int q, const float (&f)[8], f32x4 (&h)[4]) {
 #pragma unroll
-    for (int T = 0; T < 4; ++T) h[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int T = 0; T < 4; ++T) h[T] = *reinterpret_cast<const f32x4*>(lds + B0_OFF + 16 * T + 4 * q);      // accumulate onto the bias
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -242,7 +256,8 @@ __device__ __forceinline__ void decoder_hidden(const float* __restrict__ lds, in
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[T][r] = softplus_fast(h[T][r] + lds[B0_OFF + 16 * T + 4 * q + r]);
+        for (int r = 0; r < 4; ++r)
+            h[T][r] = softplus2_fast(h[T][r]);
 }
 
 // Density: output row 0 of layer 2.  Each lane owns 16 of the 64 hidden units; butterfly over the 4 quarters.
@@ -252,85 +267,14 @@ __device__ __forceinline__ float decoder_sigma(const float* __restrict__ lds, in
     for (int T = 0; T < 4; ++T)
 #pragma unroll
         for (int r = 0; r < 4; ++r) part = fmaf(h[T][r], lds[WS_OFF + (T * 4 + r) * 4 + q], part);
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
-    return part + lds[B1_OFF];
+    return add_across_rows(part) + lds[B1_OFF];
 }
 
-#if IA_RENDER_F16_RGB
-// One product term of the pair form for both colour tiles and both k-halves: acc[U][j] += A_v[U][j] * B[j].  Four independent
-// accumulators, so no MFMA of a block depends on another; wait states around the block by hand (VALU-written operands before,
-// VALU readers of the accumulators after).
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-#ifndef IA_RENDER_F16_NOPS
-#define IA_RENDER_F16_NOPS 1      // 1: two s_nop 15 after every block; 0: one s_nop 15 after the last block only
-#endif
-template <bool LAST>
-__device__ __forceinline__ void rgb_pair_block(const h16x8r* __restrict__ A, int v, int lane, const h16x8r (&b)[2], f32x4 (&acc)[2][2]) {
-    const h16x8r a00 = A[((v * 2 + 0) * 2 + 0) * 64 + lane], a01 = A[((v * 2 + 0) * 2 + 1) * 64 + lane];
-    const h16x8r a10 = A[((v * 2 + 1) * 2 + 0) * 64 + lane], a11 = A[((v * 2 + 1) * 2 + 1) * 64 + lane];
-    if (IA_RENDER_F16_NOPS)
-        asm volatile("s_nop 4\n\t"
-                     "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
-                     "v_mfma_f32_16x16x32_f16 %1, %5, %9, %1\n\t"
-                     "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"
-                     "v_mfma_f32_16x16x32_f16 %3, %7, %9, %3\n\t"
-                     "s_nop 15\n\t"
-                     "s_nop 15"
-                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
-                     : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b[0]), "v"(b[1]));
-    else if (LAST)
-        asm volatile("s_nop 1\n\t"
-                     "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
-                     "v_mfma_f32_16x16x32_f16 %1, %5, %9, %1\n\t"
-                     "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"
-                     "v_mfma_f32_16x16x32_f16 %3, %7, %9, %3\n\t"
-                     "s_nop 15"
-                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
-                     : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b[0]), "v"(b[1]));
-    else
-        asm volatile("s_nop 1\n\t"
-                     "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
-                     "v_mfma_f32_16x16x32_f16 %1, %5, %9, %1\n\t"
-                     "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"
-                     "v_mfma_f32_16x16x32_f16 %3, %7, %9, %3"
-                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
-                     : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b[0]), "v"(b[1]));
-}
-#pragma clang diagnostic pop
-#endif
 
 // Colours: output rows 1..32 of layer 2 on MFMA.  c[U][r] = channel 16U + 4q + r of this lane's sample.
 __device__ __forceinline__ void decoder_rgb(const float* __restrict__ lds, int lane, int q, const f32x4 (&h)[4], f32x4 (&c)[2]) {
-    c[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    c[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#if IA_RENDER_F16_RGB
-    // B operands: k-half j of this lane = hidden units 16T + 4q + r for T = 2j, 2j + 1 (8 values), as hi and lo * 2^11 halves
-    h16x8r bh[2], bl[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            _Float16 hi, lo;
-            ia::split_f16(h[2 * j + (e >> 2)][e & 3], hi, lo);
-            bh[j][e] = hi; bl[j][e] = lo;
-        }
-    const h16x8r* A = reinterpret_cast<const h16x8r*>(lds + A2_OFF);     // variants: 0 = hi, 1 = lo, 2 = hi * 2^-11 of w * 2^e
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int U = 0; U < 2; ++U)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[U][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    rgb_pair_block<false>(A, 1, lane, bh, acc);      // lo * hi
-    rgb_pair_block<false>(A, 2, lane, bl, acc);      // (hi * 2^-11) * (lo * 2^11)
-    rgb_pair_block<true>(A, 0, lane, bh, acc);       // hi * hi
-    const float back = lds[B1_OFF + 36];      // 2^-e
-#pragma unroll
-    for (int U = 0; U < 2; ++U)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c[U][r] = (acc[U][0][r] + acc[U][1][r]) * back;
-#else
+    c[0] = *reinterpret_cast<const f32x4*>(lds + B1C_OFF + 4 * q);
+    c[1] = *reinterpret_cast<const f32x4*>(lds + B1C_OFF + 16 + 4 * q);
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -338,13 +282,11 @@ __device__ __forceinline__ void decoder_rgb(const float* __restrict__ lds, int l
 #pragma unroll
             for (int U = 0; U < 2; ++U)
                 c[U] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[A2_OFF + (U * 16 + T * 4 + r) * 64 + lane], h[T][r], c[U], 0, 0, 0);
-#endif
 #pragma unroll
     for (int U = 0; U < 2; ++U)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = c[U][r] + lds[B1_OFF + 1 + 16 * U + 4 * q + r];
-            c[U][r] = __builtin_amdgcn_rcpf(1.f + exp_raw(-v)) * 1.002f - 0.001f;   // sigmoid * (1 + 2e-3) - 1e-3 (v_rcp_f32: 1 ulp)
+            c[U][r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(c[U][r])) * 1.002f - 0.001f;      // c = -log2(e) * logit
         }
 }
 
@@ -362,6 +304,12 @@ __device__ __forceinline__ double row_shr(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x110 + N, 0xf, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x110 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double row_last(double x) {      // lane 15 of the caller's row of 16, in every lane of that row (DPP row_share:15)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x15f, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x15f, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
@@ -472,47 +420,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
     const int s = lane & 15, q = lane >> 4;       // decoder (MFMA operand) role of the lane: sample s of the group, k-slot q
     const int gj = lane >> 2, gc = lane & 3;      // gather role: sample gj of the group, 16-byte chunks gc and 4 + gc of its texels
 
+    // layer 1 produces log2(e) * (W0 f + b0); the hidden value is softplus / ln 2, so the density row carries ln 2;
+    // the colour rows need -log2(e) * ln 2 = -1: an exact negation
+    constexpr float kIn = 1.44269504088896340736f, kHid = 0.693147180559945309417f, kRgb = -1.f;
     // ---- stage decoder weights in MFMA-fragment order
     for (int e = tid; e < 4 * 8 * 64; e += WAVES * 64) {
         const int l = e & 63, t = (e >> 6) & 7, T = e >> 9;
-        lds[A1_OFF + e] = p.w0[(16 * T + (l & 15)) * 32 + 8 * (l >> 4) + t] * p.w0_gain;
+        lds[A1_OFF + e] = p.w0[(16 * T + (l & 15)) * 32 + 8 * (l >> 4) + t] * p.w0_gain * kIn;
     }
-#if IA_RENDER_F16_RGB
-    {
-        // power of two that takes the largest colour weight to <= 32768 (fp16 range, denormal-free low parts; conv_split.hip's scheme)
-        float mx = 0.f;
-        for (int i = lane; i < 32 * 64; i += 64) mx = fmaxf(mx, fabsf(p.w1[64 + i] * p.w1_gain));
-        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        int ew = (mx > 0.f && mx < INFINITY) ? (int)floorf(log2f(32768.f / mx)) : 0;
-        ew = min(max(ew, -14), 30);
-        const float up = ldexpf(1.f, ew);
-        if (tid == 0) lds[B1_OFF + 36] = ldexpf(1.f, -ew);
-        h16x8r* A = reinterpret_cast<h16x8r*>(lds + A2_OFF);
-        for (int e = tid; e < 12 * 64; e += WAVES * 64) {
-            const int l = e & 63, frag = e >> 6, j = frag & 1, U = (frag >> 1) & 1, v = frag >> 2;
-            h16x8r out;
-#pragma unroll
-            for (int ee = 0; ee < 8; ++ee) {
-                const int unit = 16 * (2 * j + (ee >> 2)) + 4 * (l >> 4) + (ee & 3);
-                _Float16 hi, lo;
-                ia::split_f16_unscaled_lo(p.w1[(1 + 16 * U + (l & 15)) * 64 + unit] * p.w1_gain * up, hi, lo);
-                out[ee] = v == 0 ? hi : v == 1 ? lo : (_Float16)(hi * (_Float16)(1.f / 2048.f));
-            }
-            A[e] = out;
-        }
-    }
-#else
     for (int e = tid; e < 2 * 16 * 64; e += WAVES * 64) {
         const int l = e & 63, k = (e >> 6) & 15, U = e >> 10;     // k = T*4 + r
-        lds[A2_OFF + e] = p.w1[(1 + 16 * U + (l & 15)) * 64 + 16 * (k >> 2) + 4 * (l >> 4) + (k & 3)] * p.w1_gain;
+        lds[A2_OFF + e] = p.w1[(1 + 16 * U + (l & 15)) * 64 + 16 * (k >> 2) + 4 * (l >> 4) + (k & 3)] * p.w1_gain * kRgb;
     }
-#endif
     if (tid < 64) {
         const int k = tid >> 2, qq = tid & 3;
-        lds[WS_OFF + tid] = p.w1[16 * (k >> 2) + 4 * qq + (k & 3)] * p.w1_gain;
-        lds[B0_OFF + tid] = p.b0[tid] * p.b_gain;
+        lds[WS_OFF + tid] = p.w1[16 * (k >> 2) + 4 * qq + (k & 3)] * p.w1_gain * kHid;
+        lds[B0_OFF + tid] = p.b0[tid] * p.b_gain * kIn;
     }
     if (tid < 33) lds[B1_OFF + tid] = p.b1[tid] * p.b_gain;
+    if (tid < 32) lds[B1C_OFF + tid] = p.b1[1 + tid] * p.b_gain * -1.44269504088896340736f;
     __syncthreads();
 
     float* scr = lds + SCR_OFF + wave * SCR;
@@ -601,10 +527,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
                 fac = (double)(1.f - alpha + 1e-10f);
             }
             double incl = fac;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const double u = __shfl_up(incl, off); if (lane >= off) incl *= u; }
-            const double excl_up = __shfl_up(incl, 1);
-            const float trans = lane == 0 ? 1.f : (float)excl_up;
+            // transmittance = exclusive fp64 prefix product: scan inside the rows of 16 lanes (DPP), then the totals of the rows before
+            { const double u = row_shr<1>(incl); if ((lane & 15) >= 1) incl *= u; }
+            { const double u = row_shr<2>(incl); if ((lane & 15) >= 2) incl *= u; }
+            { const double u = row_shr<4>(incl); if ((lane & 15) >= 4) incl *= u; }
+            { const double u = row_shr<8>(incl); if ((lane & 15) >= 8) incl *= u; }
+            const double r0 = lane_value(incl, 15), r1 = lane_value(incl, 31);
+            const double up1 = row_shr<1>(incl);
+            const int row = lane >> 4;
+            const double before = row == 0 ? 1.0 : (row == 1 ? r0 : r0 * r1);
+            const float trans = (float)((lane & 15) == 0 ? before : before * up1);
             if (lane < NS - 1) {
                 wc[lane] = alpha * trans;
                 if (p.dbg_w_coarse) p.dbg_w_coarse[(int64_t)ray * (NS - 1) + lane] = alpha * trans;
@@ -711,7 +643,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             const double up1 = row_shr<1>(incl);
             const double excl = (s == 0) ? 1.0 : up1;
             const float trans = (float)(carry_T * excl);
-            carry_T *= __shfl(incl, 15, 16);
+            carry_T *= row_last(incl);
             const float wgt_ = alpha * trans;
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc_c[c] = fmaf(wgt_, (nb_c[c] + cur_c[c]) * 0.5f, acc_c[c]);
