@@ -80,13 +80,13 @@ typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
 
 // Channels o .. o+3 (o % 4 == 0) of output pixel `pix` into the split tensor: 8 bytes per plane; the lane that holds channels
 // o+4 .. o+7 (or o-4 .. o-1) of the same pixel writes the other half of the 16-byte unit.
-__device__ __forceinline__ void split_store4(void* ys, const float* sn, int planes, int b, int O, int64_t ohw, int o, int64_t pix, const float (&v)[4]) {
+__device__ __forceinline__ void split_store4(void* ys, const float* sn, int planes, int b, int O, int64_t ohw, int o, int64_t pix, const float (&v)[4], ia::SatWatch& watch) {
     h16x4_t hi, lo;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float t = sn ? v[k] * sn[b * O + o + k] : v[k];
-        if (planes == 2) { _Float16 h, l; ia::split_f16(t, h, l); hi[k] = h; lo[k] = l; }
-        else hi[k] = ia::round_f16(t);
+        if (planes == 2) { _Float16 h, l; ia::split_f16(t, h, l, watch); hi[k] = h; lo[k] = l; }
+        else hi[k] = ia::round_f16(t, watch);
     }
     char* base = static_cast<char*>(ys);
     const int64_t slot = ((int64_t)(b * planes) * (O / 8) + (o >> 3)) * ohw + pix;
@@ -305,7 +305,11 @@ __global__ __launch_bounds__(WO * WP * 64) void conv_fixup_kernel(const float* _
     }
     if constexpr (!TR) {
         const int o_first = o0 + (wo * FO + fo) * 32 + 8 * rq + 4 * half;      // channels (rq*4 + k): k + 8*rq + 4*half
-        if (e.ys && o_first + 3 < g.O) split_store4(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, pix, outv);
+        if (e.ys && o_first + 3 < g.O) {
+            ia::SatWatch watch;
+            split_store4(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, pix, outv, watch);
+            watch.report();
+        }
     }
 }
 

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
                                                        h16x8* __restrict__ out, int B, int C, int64_t HW, int planes) {
     const int C8 = C / 8;
     const int64_t total = (int64_t)B * C8 * HW, stride = (int64_t)gridDim.x * blockDim.x;
+    ia::SatWatch watch;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t pix = i % HW;
         const int c8 = (int)((i / HW) % C8), b = (int)(i / (HW * C8));
@@ -57,12 +58,13 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
             float v = x[((int64_t)b * C + c) * HW + pix];
             if (styles) v *= styles[b * C + c];
             if (shift) v += shift[b * C + c];
-            if (planes == 2) { _Float16 h, l; ia::split_f16(v, h, l); hi[cc] = h; lo[cc] = l; }
-            else hi[cc] = ia::round_f16(v);
+            if (planes == 2) { _Float16 h, l; ia::split_f16(v, h, l, watch); hi[cc] = h; lo[cc] = l; }
+            else hi[cc] = ia::round_f16(v, watch);
         }
         out[((int64_t)(b * planes) * C8 + c8) * HW + pix] = hi;
         if (planes == 2) out[((int64_t)(b * 2 + 1) * C8 + c8) * HW + pix] = lo;
     }
+    watch.report();
 }
 
 // The same, four consecutive pixels per thread (H*W % 4 == 0): 16-byte loads, a quarter of the load instructions.
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(256) void act_split4_kernel(const float* __restrict
                                                         h16x8* __restrict__ out, int B, int C, int64_t HW, int planes) {
     const int C8 = C / 8;
     const int64_t HW4 = HW / 4, total = (int64_t)B * C8 * HW4, stride = (int64_t)gridDim.x * blockDim.x;
+    ia::SatWatch watch;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t p4 = i % HW4;
         const int c8 = (int)((i / HW4) % C8), b = (int)(i / (HW4 * C8));
@@ -87,8 +90,8 @@ __global__ __launch_bounds__(256) void act_split4_kernel(const float* __restrict
                 float v = v4[k];
                 if (styles) v *= st;
                 if (shift) v += sh;
-                if (planes == 2) { _Float16 h, l; ia::split_f16(v, h, l); hi[k][cc] = h; lo[k][cc] = l; }
-                else hi[k][cc] = ia::round_f16(v);
+                if (planes == 2) { _Float16 h, l; ia::split_f16(v, h, l, watch); hi[k][cc] = h; lo[k][cc] = l; }
+                else hi[k][cc] = ia::round_f16(v, watch);
             }
         }
         h16x8* dh = out + ((int64_t)(b * planes) * C8 + c8) * HW + 4 * p4;
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(256) void act_split4_kernel(const float* __restrict
             for (int k = 0; k < 4; ++k) dl[k] = lo[k];
         }
     }
+    watch.report();
 }
 
 // Elements of the hi plane that sit on the fp16 maximum: values the split clamped (see ia_split_saturation_count).
@@ -134,6 +138,7 @@ __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], 
     float* c_dm = lds_f;                                         // [BO] demodulation (1 if none)
     float* c_bs = lds_f + BO;                                    // [BO] bias (0 if none)
     float* c_sn = lds_f + 2 * BO;                                // [BO] styles of the consumer (1 if none)
+    ia::SatWatch watch;
     __syncthreads();                                             // the K loop's last operand reads are done
     for (int t = tid; t < BO; t += NTHREADS) {
         // real channel of tile row t (depth-to-space: rows are groups of 32 = (row phase, block of 32 real channels, column phase))
@@ -181,10 +186,11 @@ __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], 
                     t[k] = v[k] * sn[k];
                     if (yb && o < OR) yb[(int64_t)o * ohw_out + pix] = v[k];
                 }
-                if (e.ys && o_first + 3 < OR) split_store4(e.ys, nullptr, e.ys_planes, b, OR, ohw_out, o_first, pix, t);
+                if (e.ys && o_first + 3 < OR) split_store4(e.ys, nullptr, e.ys_planes, b, OR, ohw_out, o_first, pix, t, watch);
             }
         }
     }
+    watch.report();
 }
 
 // store_tile_dual + the ToRGB layer that consumes the tile (Epi::rgb_*): the tile holds every output channel of its pixels, so the
@@ -204,6 +210,7 @@ __device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], f
     float* red = lds_f + kMaxRgb * BO;              // [WO][WP][FP][kMaxRgb][32]
     float* c_dm = red + WO * WP * FP * kMaxRgb * 32; // [BO] per-channel epilogue terms, staged once per tile (see store_tile_dual)
     float* c_bs = c_dm + BO;
+    ia::SatWatch watch;
     __syncthreads();                                // the K loop's last operand reads are done
     for (int i = tid; i < kMaxRgb * BO; i += NTHREADS) {
         const int c = i / BO, o = o0 + i - c * BO;
@@ -259,7 +266,7 @@ __device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], f
             }
 #pragma unroll
             for (int fp = 0; fp < FP; ++fp)
-                if (e.ys && valid[fp] && o_first + 3 < g.O) split_store4(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, pp[fp], v[fp]);
+                if (e.ys && valid[fp] && o_first + 3 < g.O) split_store4(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, pp[fp], v[fp], watch);
             __builtin_amdgcn_sched_barrier(0);      // keep the next quad's weight / noise / bias loads from being hoisted over this one
         }
 #pragma unroll
@@ -269,6 +276,7 @@ __device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], f
             part[fp][c] += __shfl_xor(part[fp][c], 32);
             if (half == 0) red[((((wo * WP + wp) * FP + fp) * kMaxRgb) + c) * 32 + l31] = part[fp][c];
         }
+    watch.report();
     __syncthreads();
     if (wo != 0 || half != 0) return;
 #pragma unroll

@@ -92,8 +92,17 @@ ia::SatProbe ia_tu_probe{ia_tu_read_saturated, nullptr};
 struct IaTuProbeRegistration { IaTuProbeRegistration() { ia::register_sat_probe(&ia_tu_probe); } } ia_tu_probe_registration;
 }  // namespace
 namespace ia {
-__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
-    if (!(fabsf(v) <= 65504.f)) atomicOr(&ia_tu_saturated, 1u);      // outside the fp16 range (or NaN): clamped below, and reported
+// Range watch of one thread: `see` is a compare and an OR per value (no control flow: a branch with an atomic behind every split
+// value broke the producers' loops into ~5 basic blocks per element and made the HBM-bound ones issue-bound, r05 ISA), `report`
+// is the thread's one conditional atomic, called once when the thread has split its last value.
+struct SatWatch {
+    unsigned bad = 0u;
+    __device__ __forceinline__ void see(float v) { bad |= (fabsf(v) <= 65504.f) ? 0u : 1u; }      // outside the fp16 range, or NaN
+    __device__ __forceinline__ void report() const { if (bad) atomicOr(&ia_tu_saturated, 1u); }
+};
+
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo, SatWatch& watch) {
+    watch.see(v);                                                     // clamped below, and reported by the caller's watch
     v = fminf(fmaxf(v, -65504.f), 65504.f);
     hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.f : (_Float16)v;
     lo = (_Float16)((v - (float)hi) * kSplitLoScale);
@@ -107,8 +116,8 @@ __device__ __forceinline__ void split_f16_unscaled_lo(float v, _Float16& hi, _Fl
 }
 
 // One-plane form of the same format (fp16 operands, the arithmetic of the reference's fp16 blocks): the saturated value rounded once.
-__device__ __forceinline__ _Float16 round_f16(float v) {
-    if (!(fabsf(v) <= 65504.f)) atomicOr(&ia_tu_saturated, 1u);
+__device__ __forceinline__ _Float16 round_f16(float v, SatWatch& watch) {
+    watch.see(v);
     return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
 }
 

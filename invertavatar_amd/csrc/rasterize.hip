@@ -501,6 +501,7 @@ __global__ __launch_bounds__(256) void cond_blend_split_kernel(const float* __re
                                                                const float* __restrict__ styles_next, h16x8_cb* __restrict__ ys, int B, int C, int64_t hw) {
     const int C8 = C / 8;
     const int64_t total = (int64_t)B * C8 * hw, stride = (int64_t)gridDim.x * blockDim.x;
+    ia::SatWatch watch;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t pix = i % hw;
         const int c8 = (int)((i / hw) % C8), b = (int)(i / (hw * C8));
@@ -513,12 +514,13 @@ __global__ __launch_bounds__(256) void cond_blend_split_kernel(const float* __re
             float v = cv * a + xv * (1.f - a);
             if (styles_next) v *= styles_next[b * C + c];
             _Float16 h, l;
-            ia::split_f16(v, h, l);
+            ia::split_f16(v, h, l, watch);
             hi[cc] = h; lo[cc] = l;
         }
         ys[((int64_t)(b * 2) * C8 + c8) * hw + pix] = hi;
         ys[((int64_t)(b * 2 + 1) * C8 + c8) * hw + pix] = lo;
     }
+    watch.report();
 }
 
 // The same, four consecutive pixels per thread (H*W % 4 == 0): 16-byte loads of both inputs -- a quarter of the load instructions of
@@ -527,6 +529,7 @@ __global__ __launch_bounds__(256) void cond_blend_split4_kernel(const float* __r
                                                                 const float* __restrict__ styles_next, h16x8_cb* __restrict__ ys, int B, int C, int64_t hw) {
     const int C8 = C / 8;
     const int64_t hw4 = hw / 4, total = (int64_t)B * C8 * hw4, stride = (int64_t)gridDim.x * blockDim.x;
+    ia::SatWatch watch;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t p4 = i % hw4;
         const int c8 = (int)((i / hw4) % C8), b = (int)(i / (hw4 * C8));
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(256) void cond_blend_split4_kernel(const float* __r
                 float v = c4[k] * a[k] + x4[k] * (1.f - a[k]);
                 if (styles_next) v *= sn;
                 _Float16 h, l;
-                ia::split_f16(v, h, l);
+                ia::split_f16(v, h, l, watch);
                 hi[k][cc] = h; lo[k][cc] = l;
             }
         }
@@ -558,6 +561,7 @@ __global__ __launch_bounds__(256) void cond_blend_split4_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) { dh[k] = hi[k]; dl[k] = lo[k]; }
     }
+    watch.report();
 }
 
 extern "C" int ia_cond_blend_split(const float* cond, const float* x, const float* styles_next, void* ys, int B, int C, int H, int W, void* stream) {

@@ -14,6 +14,7 @@
 //   * generic: any strides (channels_last), any up/down, filter <= 32x32.
 // HBM-bound: algorithmic traffic = (in_h*in_w + out_h*out_w) * sizeof(T) bytes per channel.
 #include "ia_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -251,6 +252,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled_pipe(const T* __restrict_
 // registers, and after the eighth channel every thread holds the 8 channels of its 4 pixels: 1 KB contiguous per wave, plane
 // and row.  Optionally the fp32 NCHW result is written as well (callers that still need it, e.g. the CS-SFT modulation).
 typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+#ifndef IA_FIR_DMA_MIN_PIXELS
+#define IA_FIR_DMA_MIN_PIXELS 0      // (tools/: 1 << 30 = the register-staged kernel everywhere)
+#endif
 #ifndef IA_FIR_ABLATE
 #define IA_FIR_ABLATE 0      // tools/: bit 0 = one tap instead of 16 (LDS reads + FMAs), bit 1 = no global loads
 #endif
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(256, IA_FIR_WAVES) void fir_tail_split_kernel(const
         nz[r] = (tail.noise && ox < g.out_w && oy < g.out_h) ? tail.noise[(int64_t)oy * g.out_w + ox] : 0.f;
     }
     h16x8_t hi[RPT], lo[RPT];
+    ia::SatWatch watch;
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
         const int buf = ch & 1, c = c8 * 8 + ch;
@@ -340,13 +345,148 @@ __global__ __launch_bounds__(256, IA_FIR_WAVES) void fir_tail_split_kernel(const
             const int oy = oy0 + ty + r;
             if (y && ox < g.out_w && oy < g.out_h) y[((int64_t)b * g.c + c) * ohw + (int64_t)oy * g.out_w + ox] = acc;
             const float t = styles_next ? acc * sn : acc;
-            if (planes == 2) { _Float16 h, l; ia::split_f16(t, h, l); hi[r][ch] = h; lo[r][ch] = l; }
-            else hi[r][ch] = ia::round_f16(t);
+            if (planes == 2) { _Float16 h, l; ia::split_f16(t, h, l, watch); hi[r][ch] = h; lo[r][ch] = l; }
+            else hi[r][ch] = ia::round_f16(t, watch);
         }
         if (ch + 1 < 8) commit(buf ^ 1, (ch + 1) % kFirSets);     // (its last readers passed the barrier of the previous channel)
         if (ch + 1 + kFirSets < 8) fetch(ch + 1 + kFirSets, (ch + 1) % kFirSets);
         __syncthreads();
     }
+    watch.report();
+    if (ox >= g.out_w) return;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int oy = oy0 + ty + r;
+        if (oy >= g.out_h) break;
+        const int64_t pix = (int64_t)oy * g.out_w + ox;
+        ys[((int64_t)(b * planes) * C8 + c8) * ohw + pix] = hi[r];
+        if (planes == 2) ys[((int64_t)(b * 2 + 1) * C8 + c8) * ohw + pix] = lo[r];
+    }
+}
+
+// The same kernel with the input images DMA'd straight into LDS (r05).  The register-staged form above keeps two channels (11 KB per
+// workgroup, 43 KB per CU) in flight and spends part of every channel period with nothing in flight at all (commit -> barrier ->
+// filter): latency x occupancy, not HBM, bounds it at 3.1 TB/s.  Here a workgroup issues the loads of ALL EIGHT channel images of its
+// tile up front as `buffer_load_dword ... lds` pieces (64 lanes x 4 bytes, lane-linear in LDS; the rows of the (2H+1)-wide
+// transposed-convolution output are only 4-byte aligned, so wider pieces do not apply) -- 43.5 KB per workgroup, three workgroups
+// per CU -- and filters channel c as soon as its 22 pieces have landed (loads return in order: s_waitcnt vmcnt(6 * (7 - c)) per wave,
+// then the barrier).  No staging registers, no ds_write.  Zero padding comes from the buffer bounds check (out-of-range lanes carry
+// an offset beyond the resource and write zeros).  Every wave issues the same number of pieces per channel (22 real ones padded to
+// 4 x 6 with all-outside pieces that land behind the image), so the wait counts are compile-time constants.  Same sums in the same
+// order as fir_tail_split_kernel: bit-identical results.
+typedef unsigned int u32x4_f __attribute__((ext_vector_type(4)));
+constexpr unsigned kFirOutside = 0x7ffffff0u;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void fir_dma_dword(u32x4_f rsrc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <int N> __device__ __forceinline__ void fir_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+__global__ __launch_bounds__(256) void fir_tail_split_dma_kernel(const float* __restrict__ x, const float* __restrict__ f, h16x8_t* __restrict__ ys,
+                                                                 const float* __restrict__ styles_next, Geo g, int flip, Tail tail, int planes) {
+    constexpr int FS = 4;
+    constexpr int IH = TH + FS, IW = TW + FS, NPIX = IH * IW;             // 20 x 68 input pixels per channel image
+    constexpr int NPIECE = (NPIX + 63) / 64, PPW = (NPIECE + 3) / 4;      // 22 pieces of 64 pixels, 6 per wave (2 of the 24 are padding)
+    constexpr int IMG = 4 * PPW * 64;                                      // floats reserved per channel image in LDS
+    static_assert(8 * PPW <= 63, "all pieces of a wave must fit the vmcnt counter");
+    __shared__ float k_lds[FS * FS];
+    __shared__ __attribute__((aligned(16))) float in_lds[8][IMG];
+    const int tiles_x = (g.out_w + TW - 1) / TW;
+    const int ox0 = (blockIdx.x % tiles_x) * TW, oy0 = (blockIdx.x / tiles_x) * TH;
+    const int C8 = g.c / 8, c8 = blockIdx.y % C8, b = blockIdx.y / C8;
+    const int iy0 = oy0 - g.pady0, ix0 = ox0 - g.padx0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    stage_filter(k_lds, f, FS, FS, FS, 1, flip, g.gain);
+    const int64_t in_plane = (int64_t)g.in_h * g.in_w, ohw = (int64_t)g.out_h * g.out_w;
+    const float* xb = x + ((int64_t)b * g.c + c8 * 8) * in_plane;
+    // everything the channel loop reads besides the images is fetched first: a vector load issued between the pieces and their
+    // waits would shift the counts
+    const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * RPT;
+    const int ox = ox0 + tx;
+    const float t_ns = tail.noise ? (tail.noise_strength ? *tail.noise_strength : 1.f) : 0.f;
+    float nz[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int oy = oy0 + ty + r;
+        nz[r] = (tail.noise && ox < g.out_w && oy < g.out_h) ? tail.noise[(int64_t)oy * g.out_w + ox] : 0.f;
+    }
+    float t_bias[8], sn[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        t_bias[ch] = tail.bias ? ((const float*)tail.bias)[c8 * 8 + ch] : 0.f;
+        sn[ch] = styles_next ? styles_next[b * g.c + c8 * 8 + ch] : 1.f;
+    }
+    // this wave's pieces: piece j = wave + 4 s covers image pixels 64 j .. 64 j + 63 (row-major over IH x IW)
+    unsigned voff[PPW];
+#pragma unroll
+    for (int s_ = 0; s_ < PPW; ++s_) {
+        const int i = 64 * (wave + 4 * s_) + lane, r = i / IW, c = i - r * IW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        const bool ok = i < NPIX && iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w;
+        voff[s_] = ok ? (unsigned)(iy * g.in_w + ix) * 4u : kFirOutside;
+    }
+    u32x4_f rsrc;
+    {
+        const unsigned long long a = (unsigned long long)xb;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+        rsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+        rsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)(8 * in_plane * 4));
+        rsrc[3] = 0x00020000u;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&in_lds[0][0];
+    // noise / bias / styles must have LANDED before the first piece is issued: from there on only pieces are counted.  The empty asm
+    // statements are uses the compiler has to satisfy here (its own s_waitcnt vmcnt(0) for these loads would otherwise appear at
+    // their first real use, inside channel 0, and drain all eight images)
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) asm volatile("" : "+v"(nz[r]));
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) asm volatile("" : "+v"(t_bias[ch]), "+v"(sn[ch]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch)
+#pragma unroll
+        for (int s_ = 0; s_ < PPW; ++s_)
+            fir_dma_dword(rsrc, lds0 + (unsigned)(ch * IMG + 64 * (wave + 4 * s_)) * 4u, voff[s_], (unsigned)(ch * in_plane * 4));
+    __syncthreads();                                        // (k_lds)
+    float kf[FS * FS];
+#pragma unroll
+    for (int i = 0; i < FS * FS; ++i) kf[i] = k_lds[i];
+    h16x8_t hi[RPT], lo[RPT];
+    ia::SatWatch watch;
+    // the tail's options as values instead of branches: every element of the loop below is straight-line code (selects), so the
+    // LDS reads and FMAs of its four rows interleave; identical results (x * 1, fma(0, 0, x), clamp at infinity are exact)
+    const float slope = tail.act == IA_ACT_LRELU ? tail.alpha : 1.f, clamp = tail.clamp >= 0.f ? tail.clamp : INFINITY;
+    const bool two_planes = planes == 2;
+    // one channel: wait for its pieces (this wave's, then everybody's), filter, tail, split.  A macro with a literal channel index on
+    // purpose: hi / lo must stay registers (through a lambda, next to the asm statements' memory clobbers, they went to the stack)
+#define IA_FIR_CH(ch)                                                                                                          \
+    {                                                                                                                          \
+        fir_wait_vmcnt<PPW * (7 - ch)>();                                                                                      \
+        __syncthreads();                                                                                                       \
+        _Pragma("unroll") for (int r = 0; r < RPT; ++r) {                                                                      \
+            float acc = 0.f;                                                                                                   \
+            _Pragma("unroll") for (int a = 0; a < FS; ++a)                                                                     \
+                _Pragma("unroll") for (int bb = 0; bb < FS; ++bb)                                                              \
+                    acc = fmaf(in_lds[ch][(ty + r + a) * IW + tx + bb], kf[a * FS + bb], acc);                                 \
+            acc = fmaf(nz[r], t_ns, acc);                      /* (no noise: 0 * 0) */                                         \
+            acc += t_bias[ch];                                                                                                 \
+            acc = acc > 0.f ? acc : acc * slope;               /* (linear: slope 1) */                                         \
+            acc *= tail.gain;                                                                                                  \
+            acc = fminf(fmaxf(acc, -clamp), clamp);            /* (no clamp: +-inf) */                                         \
+            const float t = acc * sn[ch];                      /* (no styles: 1) */                                            \
+            _Float16 h, l;                                                                                                     \
+            ia::split_f16(t, h, l, watch);                                                                                     \
+            const _Float16 h1 = (_Float16)fminf(fmaxf(t, -65504.f), 65504.f);      /* round_f16 without a second watch */      \
+            hi[r][ch] = two_planes ? h : h1;                                                                                   \
+            lo[r][ch] = l;                                                                                                     \
+        }                                                                                                                      \
+    }
+    IA_FIR_CH(0) IA_FIR_CH(1) IA_FIR_CH(2) IA_FIR_CH(3) IA_FIR_CH(4) IA_FIR_CH(5) IA_FIR_CH(6) IA_FIR_CH(7)
+#undef IA_FIR_CH
+    watch.report();
     if (ox >= g.out_w) return;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -456,6 +596,12 @@ extern "C" int ia_fir_tail_split(const float* x, const float* f, const float* no
     g.f_h = g.f_w = 4; g.upx = g.upy = 1; g.downx = g.downy = 1; g.padx0 = padx0; g.pady0 = pady0; g.gain = fir_gain;
     Tail tail{noise, noise_strength, bias, act, alpha, act_gain, clamp};
     const dim3 grid(((out_w + TW - 1) / TW) * ((out_h + TH - 1) / TH), n * (c / 8));
+    // LDS-DMA form: split output only (a fp32 copy's stores would share the wave's vmcnt with the pieces), 8 channel planes inside one
+    // buffer resource, and enough tiles that the deeper prefetch matters (below 64^2 outputs a launch is latency either way)
+    if (!y && 8 * (int64_t)in_h * in_w * 4 < (int64_t)kFirOutside && (int64_t)out_h * out_w >= IA_FIR_DMA_MIN_PIXELS) {
+        hipLaunchKernelGGL(fir_tail_split_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, f, static_cast<h16x8_t*>(ys), styles_next, g, flip, tail, ys_planes);
+        return ia::check_launch("ia_fir_tail_split");
+    }
     hipLaunchKernelGGL(fir_tail_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, f, y, static_cast<h16x8_t*>(ys), styles_next, g, flip, tail, ys_planes);
     return ia::check_launch("ia_fir_tail_split");
 }
