@@ -80,13 +80,27 @@ typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
 
 // Channels o .. o+3 (o % 4 == 0) of output pixel `pix` into the split tensor: 8 bytes per plane; the lane that holds channels
 // o+4 .. o+7 (or o-4 .. o-1) of the same pixel writes the other half of the 16-byte unit.
-__device__ __forceinline__ void split_store4(void* ys, const float* sn, int planes, int b, int O, int64_t ohw, int o, int64_t pix, const float (&v)[4], ia::SatWatch& watch) {
+template <bool STRAIGHT = true, class Watch = ia::SatWatch>
+__device__ __forceinline__ void split_store4(void* ys, const float* sn, int planes, int b, int O, int64_t ohw, int o, int64_t pix, const float (&v)[4], Watch& watch) {
     h16x4_t hi, lo;
+    if constexpr (STRAIGHT) {
+        h16x4_t h1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float t = sn ? v[k] * sn[b * O + o + k] : v[k];
-        if (planes == 2) { _Float16 h, l; ia::split_f16(t, h, l, watch); hi[k] = h; lo[k] = l; }
-        else hi[k] = ia::round_f16(t, watch);
+        for (int k = 0; k < 4; ++k) {   // straight-line: both forms of the high part are computed, the plane count selects (one branch below, not four)
+            const float t = sn ? v[k] * sn[b * O + o + k] : v[k];
+            _Float16 h, l;
+            ia::split_f16(t, h, l, watch);
+            hi[k] = h; lo[k] = l;
+            h1[k] = (_Float16)fminf(fmaxf(t, -65504.f), 65504.f);      // (round_f16's value; the watch has seen t)
+        }
+        if (planes != 2) hi = h1;
+    } else {                            // (the fused-ToRGB epilogue sits at the register limit: the plane test per value keeps its live ranges short)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = sn ? v[k] * sn[b * O + o + k] : v[k];
+            if (planes == 2) { _Float16 h, l; ia::split_f16(t, h, l, watch); hi[k] = h; lo[k] = l; }
+            else hi[k] = ia::round_f16(t, watch);
+        }
     }
     char* base = static_cast<char*>(ys);
     const int64_t slot = ((int64_t)(b * planes) * (O / 8) + (o >> 3)) * ohw + pix;
@@ -185,6 +199,37 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
                 if (oy >= g.OH) continue;
                 const int64_t pix = (int64_t)oy * g.OW + ox;
                 const bool pair = ox + 1 < g.OW;
+                if (simple) {
+                    // the frame's case, straight-line: the option tests (`simple`, last column, channel range) sit around the
+                    // element loops, not inside them (r05 ISA: ~1400 branches in this store)
+                    float* dst0 = yb + pix;
+                    if (pair) {
+#pragma unroll
+                        for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int o_first = o0 + (wo * FO + fo) * 32 + 8 * q + 4 * half;
+                                if (o_first + 3 >= g.O) continue;         // (channel counts are multiples of 8)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const int r = 4 * q + k;
+                                    const float2 v = make_float2(acc[2 * py][fo][fp][r] * dmv[fo][r], acc[2 * py + 1][fo][fp][r] * dmv[fo][r]);
+                                    __builtin_memcpy(dst0 + (int64_t)(o_first + k) * ohw, &v, 8);     // (rows of odd width: 4-byte aligned only)
+                                }
+                            }
+                    } else {
+#pragma unroll
+                        for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int o_first = o0 + (wo * FO + fo) * 32 + 8 * q + 4 * half;
+                                if (o_first + 3 >= g.O) continue;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) dst0[(int64_t)(o_first + k) * ohw] = acc[2 * py][fo][fp][4 * q + k] * dmv[fo][4 * q + k];
+                            }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
@@ -192,10 +237,10 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
                         const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                         if (o >= g.O) continue;
                         float* dst = yb + (int64_t)o * ohw + pix;
-                        const float v0 = simple ? acc[2 * py][fo][fp][r] * dmv[fo][r] : epilogue(acc[2 * py][fo][fp][r], b, o, pix, ohw, g, e, ns);
+                        const float v0 = epilogue(acc[2 * py][fo][fp][r], b, o, pix, ohw, g, e, ns);
                         if (pair) {
-                            const float v1 = simple ? acc[2 * py + 1][fo][fp][r] * dmv[fo][r] : epilogue(acc[2 * py + 1][fo][fp][r], b, o, pix + 1, ohw, g, e, ns);
-                            __builtin_memcpy(dst, &(const float2&)make_float2(v0, v1), 8);     // (rows of odd width: 4-byte aligned only)
+                            const float v1 = epilogue(acc[2 * py + 1][fo][fp][r], b, o, pix + 1, ohw, g, e, ns);
+                            __builtin_memcpy(dst, &(const float2&)make_float2(v0, v1), 8);
                         } else dst[0] = v0;
                     }
             }

@@ -138,7 +138,9 @@ __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], 
     float* c_dm = lds_f;                                         // [BO] demodulation (1 if none)
     float* c_bs = lds_f + BO;                                    // [BO] bias (0 if none)
     float* c_sn = lds_f + 2 * BO;                                // [BO] styles of the consumer (1 if none)
+    float* c_sl = lds_f + 3 * BO;                                // [BO] negative slope of the activation (1 = linear)
     ia::SatWatch watch;
+    const bool lrelu = e.act == IA_ACT_LRELU;
     __syncthreads();                                             // the K loop's last operand reads are done
     for (int t = tid; t < BO; t += NTHREADS) {
         // real channel of tile row t (depth-to-space: rows are groups of 32 = (row phase, block of 32 real channels, column phase))
@@ -147,12 +149,17 @@ __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], 
         c_dm[t] = (e.demod && ok) ? e.demod[b * OR + o] : 1.f;
         c_bs[t] = (e.bias && ok) ? e.bias[o] : 0.f;
         c_sn[t] = (e.styles_next && ok) ? e.styles_next[b * OR + o] : 1.f;
+        c_sl[t] = !lrelu ? 1.f : (e.alpha_vec && ok) ? e.alpha_vec[o] : e.alpha;
     }
     __syncthreads();
-    const bool lrelu = e.act == IA_ACT_LRELU;
+    // The options of the epilogue as VALUES, not branches: a lane finishes 64 values here, and with a handful of uniform branches per
+    // value (noise? activation? clamp? second output? channel in range?) the loop was ~57 vector instructions and 7 branches per value
+    // (r05 ISA) -- a quarter of a 128-channel layer's time.  x * 1, fma(0, 0, x) and a clamp at infinity are exact.
+    const float clamp = e.clamp >= 0.f ? e.clamp : INFINITY, gain = e.gain;
     const int OW2 = 2 * g.GW;
     const int64_t ohw_out = e.d2s ? 4 * ohw : ohw;
     float* yb = y ? y + ((int64_t)b * OR) * ohw_out : nullptr;
+    const float* rb = e.residual ? e.residual + ((int64_t)b * OR) * ohw_out : nullptr;
 #pragma unroll
     for (int fp = 0; fp < FP; ++fp) {
         const int p = p0 + (wp * FP + fp) * 32 + l31;
@@ -169,24 +176,34 @@ __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], 
             for (int q = 0; q < 4; ++q) {                      // register quad q: channels 8q + 4*half + (0..3) of the fragment
                 const int trow = (wo * FO + fo) * 32 + 8 * q + 4 * half, o_first = o_frag + 8 * q + 4 * half;
                 const float4 dm4 = *reinterpret_cast<const float4*>(c_dm + trow), bs4 = *reinterpret_cast<const float4*>(c_bs + trow);
-                const float4 sn4 = *reinterpret_cast<const float4*>(c_sn + trow);
+                const float4 sn4 = *reinterpret_cast<const float4*>(c_sn + trow), sl4 = *reinterpret_cast<const float4*>(c_sl + trow);
                 const float dm[4] = {dm4.x, dm4.y, dm4.z, dm4.w}, bs[4] = {bs4.x, bs4.y, bs4.z, bs4.w}, sn[4] = {sn4.x, sn4.y, sn4.z, sn4.w};
+                const float sl[4] = {sl4.x, sl4.y, sl4.z, sl4.w};
+                const bool inside = o_first + 3 < OR;            // (channel counts are multiples of 8: a quad is inside or outside as a whole)
+                const int64_t at = (int64_t)o_first * ohw_out + pix;
+                float res[4] = {0.f, 0.f, 0.f, 0.f};
+                if (rb && inside) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) res[k] = rb[at + k * ohw_out];
+                }
                 float v[4], t[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int o = o_first + k;
                     float a = acc[0][fo][fp][4 * q + k] * dm[k];                       // (the order of epilogue(): demod, noise, bias, ...)
-                    if (e.noise) a = fmaf(nz, ns, a);
+                    a = fmaf(nz, ns, a);
                     a += bs[k];
-                    if (lrelu) a = a > 0.f ? a : a * (e.alpha_vec ? e.alpha_vec[min(o, OR - 1)] : e.alpha);
-                    a *= e.gain;
-                    if (e.clamp >= 0.f) a = fminf(fmaxf(a, -e.clamp), e.clamp);
-                    if (e.residual && o < OR) a += e.residual[((int64_t)b * OR + o) * ohw_out + pix];
-                    v[k] = o < OR ? a : 0.f;
+                    a = a > 0.f ? a : a * sl[k];
+                    a *= gain;
+                    a = fminf(fmaxf(a, -clamp), clamp);
+                    a += res[k];
+                    v[k] = inside ? a : 0.f;
                     t[k] = v[k] * sn[k];
-                    if (yb && o < OR) yb[(int64_t)o * ohw_out + pix] = v[k];
                 }
-                if (e.ys && o_first + 3 < OR) split_store4(e.ys, nullptr, e.ys_planes, b, OR, ohw_out, o_first, pix, t, watch);
+                if (yb && inside) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) yb[at + k * ohw_out] = v[k];
+                }
+                if (e.ys && inside) split_store4(e.ys, nullptr, e.ys_planes, b, OR, ohw_out, o_first, pix, t, watch);
             }
         }
     }
@@ -210,7 +227,7 @@ __device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], f
     float* red = lds_f + kMaxRgb * BO;              // [WO][WP][FP][kMaxRgb][32]
     float* c_dm = red + WO * WP * FP * kMaxRgb * 32; // [BO] per-channel epilogue terms, staged once per tile (see store_tile_dual)
     float* c_bs = c_dm + BO;
-    ia::SatWatch watch;
+    ia::SatWatchNow watch;                          // (no register for a flag here: 256 VGPRs)
     __syncthreads();                                // the K loop's last operand reads are done
     for (int i = tid; i < kMaxRgb * BO; i += NTHREADS) {
         const int c = i / BO, o = o0 + i - c * BO;
@@ -252,6 +269,8 @@ __device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], f
                 for (int c = 0; c < kMaxRgb; ++c) wc[c] = ws[c * BO + ol + k];
 #pragma unroll
                 for (int fp = 0; fp < FP; ++fp) {
+                    // (this epilogue sits at the 256-register limit: the option tests stay branches here -- as values, store_tile_dual's
+                    //  form, the longer straight-line regions spilled 7 - 19 registers)
                     float a = acc[0][fo][fp][4 * q + k] * c_dm[ol + k];              // (the order of epilogue(): demod, noise, bias, ...)
                     if (e.noise) a = fmaf(nz[fp], ns, a);
                     a += c_bs[ol + k];
@@ -266,7 +285,7 @@ __device__ __forceinline__ void store_tile_rgb(const f32x16 (&acc)[1][FO][FP], f
             }
 #pragma unroll
             for (int fp = 0; fp < FP; ++fp)
-                if (e.ys && valid[fp] && o_first + 3 < g.O) split_store4(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, pp[fp], v[fp], watch);
+                if (e.ys && valid[fp] && o_first + 3 < g.O) split_store4<false>(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, pp[fp], v[fp], watch);
             __builtin_amdgcn_sched_barrier(0);      // keep the next quad's weight / noise / bias loads from being hoisted over this one
         }
 #pragma unroll

@@ -101,7 +101,15 @@ struct SatWatch {
     __device__ __forceinline__ void report() const { if (bad) atomicOr(&ia_tu_saturated, 1u); }
 };
 
-__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo, SatWatch& watch) {
+// The same interface without a register: every out-of-range value goes to the device word at once (a branch and an atomic per value).
+// For the one producer that has no register to spare (the fused-ToRGB convolution epilogue, 256 VGPRs).
+struct SatWatchNow {
+    __device__ __forceinline__ void see(float v) const { if (!(fabsf(v) <= 65504.f)) atomicOr(&ia_tu_saturated, 1u); }
+    __device__ __forceinline__ void report() const {}
+};
+
+template <class Watch>
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo, Watch& watch) {
     watch.see(v);                                                     // clamped below, and reported by the caller's watch
     v = fminf(fmaxf(v, -65504.f), 65504.f);
     hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.f : (_Float16)v;
@@ -116,7 +124,8 @@ __device__ __forceinline__ void split_f16_unscaled_lo(float v, _Float16& hi, _Fl
 }
 
 // One-plane form of the same format (fp16 operands, the arithmetic of the reference's fp16 blocks): the saturated value rounded once.
-__device__ __forceinline__ _Float16 round_f16(float v, SatWatch& watch) {
+template <class Watch>
+__device__ __forceinline__ _Float16 round_f16(float v, Watch& watch) {
     watch.see(v);
     return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
 }
