@@ -370,7 +370,7 @@ int ia_fir_tail_split(const float* x, const float* f, const float* noise, const 
  * 128 x 512^2 activation only through ToRGB, so neither that tensor nor its re-read has to exist.
  *   rgb_out[b,c] = clamp( sum_o (rgb_wk[o,c] * rgb_styles[b,o]) * v[b,o] + rgb_bias[c], rgb_clamp ) + rgb_residual[b,c]
  * with v the layer's own result (after noise / bias / activation / clamp).  rgb_wk [O, rgb_channels] is ia_conv2d_mfma's ksize-1
- * packing of the ToRGB weight (weight_gain folded in), rgb_channels <= 4.  y and ys may both be NULL.  The layer must run in whole
+ * packing of the ToRGB weight (weight_gain folded in), rgb_channels <= 3.  y and ys may both be NULL.  The layer must run in whole
  * rounds of tiles that hold every output channel (O <= 128 at the sizes the planner gives the 128 x 256 tile), else
  * IA_ERR_UNSUPPORTED (callers use ia_conv2d_mfma_sx + ia_conv1x1).  Other arguments as ia_conv2d_mfma_sx.
  */

@@ -74,7 +74,7 @@ struct Epi {
     // styles_next are indexed by the real channel and the output pixel
     int d2s = 0;
 };
-constexpr int kMaxRgb = 4;
+constexpr int kMaxRgb = 3;      // (ToRGB proper: three colours; a fourth accumulator per point fragment spilled in the 256-register epilogue)
 
 typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
 

@@ -122,40 +122,44 @@ __host__ __device__ inline int unit_cg(int py, int u) { return py ? u / 3 : 0; }
 // pixels of output row 2r + py, stored as one 8-byte pair; the demodulation coefficients of a lane's 32 channels are read once.
 template <int FP>
 __device__ __forceinline__ void up_store_tile(const f32x16 (&acc)[2][2][FP], float* __restrict__ y, const float* __restrict__ demod, const UpGeo& g,
-                                              const UpSub& sb, int b, int o0, int p0, int p_last, int tid) {
+                                              const UpSub& sb, int b, int o0, int p0, int p_last, int tid, float acc_scale) {
     constexpr int FO = 2, WP = 4;
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int wo = wave / WP, wp = wave % WP;
     const int64_t ohw = (int64_t)g.OH * g.OW;
+    // demodulation x the power of two that takes the accumulators back from the scale of the packed weights (exact: one multiply per
+    // value instead of two)
     float dmv[FO][16];
 #pragma unroll
     for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            dmv[fo][r] = demod ? demod[b * g.O + o] : 1.f;
+            dmv[fo][r] = (demod ? demod[b * g.O + o] : 1.f) * acc_scale;
         }
-    float* yb = y + ((int64_t)b * g.O) * ohw;
+    float* yb = y + ((int64_t)b * g.O + o0 + wo * FO * 32 + 4 * half) * ohw;
 #pragma unroll
     for (int fp = 0; fp < FP; ++fp) {
         const int p = p0 + (wp * FP + fp) * 32 + l31;
         if (p > p_last) continue;
         const int pr = p / sb.GW, pc = p - pr * sb.GW;
         const int oy = 2 * (sb.r_off + pr) + sb.py, ox = 2 * (sb.c_off + pc);
-        const int64_t pix = (int64_t)oy * g.OW + ox;
-        const bool pair = ox + 1 < g.OW;
+        float* dst0 = yb + (int64_t)oy * g.OW + ox;
+        // the last column has no right neighbour: that test sits around the element loop, not inside it (a divergent branch per value)
+        if (ox + 1 < g.OW) {
 #pragma unroll
-        for (int fo = 0; fo < FO; ++fo)
+            for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = o0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float* dst = yb + (int64_t)o * ohw + pix;
-                const float v0 = acc[0][fo][fp][r] * dmv[fo][r];
-                if (pair) {
-                    const float v1 = acc[1][fo][fp][r] * dmv[fo][r];
-                    __builtin_memcpy(dst, &(const float2&)make_float2(v0, v1), 8);     // (rows of odd width: 4-byte aligned only)
-                } else dst[0] = v0;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float2 v = make_float2(acc[0][fo][fp][r] * dmv[fo][r], acc[1][fo][fp][r] * dmv[fo][r]);
+                    __builtin_memcpy(dst0 + (int64_t)(fo * 32 + (r & 3) + 8 * (r >> 2)) * ohw, &v, 8);     // (rows of odd width: 4-byte aligned only)
+                }
+        } else {
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst0[(int64_t)(fo * 32 + (r & 3) + 8 * (r >> 2)) * ohw] = acc[0][fo][fp][r] * dmv[fo][r];
+        }
     }
 }
 
@@ -405,14 +409,16 @@ __global__ __launch_bounds__(512, 2) void up_rows_kernel(const h16x8* __restrict
     if (!grp) ia_barrier();
 #undef IA_UP_ISSUE
 
+    if (sb.gpe || IA_UP_ABLATE == 3) {      // (whole tiles fold the scale into their demodulation coefficients, see up_store_tile)
 #pragma unroll
-    for (int px = 0; px < 2; ++px)
+        for (int px = 0; px < 2; ++px)
 #pragma unroll
-        for (int fo = 0; fo < FO; ++fo)
+            for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
-            for (int fp = 0; fp < FP; ++fp)
+                for (int fp = 0; fp < FP; ++fp)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[px][fo][fp][r] *= g.acc_scale;      // back from the scale of the packed weights (exact)
+                    for (int r = 0; r < 16; ++r) acc[px][fo][fp][r] *= g.acc_scale;      // back from the scale of the packed weights (exact)
+    }
     if (IA_UP_ABLATE == 3) {
         float sink = 0.f;
 #pragma unroll
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void up_rows_kernel(const h16x8* __restrict
                     for (int r = 0; r < 16; ++r) sink += acc[px][fo][fp][r];
         if (sink == 123.456f) y[0] = sink;
     } else if (!sb.gpe) {
-        up_store_tile<FP>(acc, y, demod, g, sb, b, o0, p0, p_last, tid);
+        up_store_tile<FP>(acc, y, demod, g, sb, b, o0, p0, p_last, tid, g.acc_scale);
     } else if (!IA_UP_TRACE) {
         float4* slab = reinterpret_cast<float4*>(slabs + ((int64_t)b * g.n_slabs + sb.slab_first + lt * sb.gpe + part) * ((int64_t)NACC * NTHREADS)) + tid;
 #pragma unroll

@@ -491,7 +491,7 @@ class SynthesisLayer(torch.nn.Module):
         image `upsample2d(skip) + torgb(conv(x))`, or None when the pair is not eligible (the caller then runs the two layers)."""
         res = self.resolution
         if not (FUSED_TORGB and self.up == 1 and _on_device(x) and self.activation in hipops.ACT_ID and self.weight.shape[2] == 3
-                and torgb.weight.shape[2] == 1 and torgb.out_channels <= 4 and torgb.in_channels == self.out_channels
+                and torgb.weight.shape[2] == 1 and torgb.out_channels <= 3 and torgb.in_channels == self.out_channels
                 and noise_mode != 'random' and not _needs_autograd(x, w, w_rgb, self.weight, self.bias, torgb.weight, torgb.bias, skip)
                 and self._takes_split_input(res, noise_mode, half_ops)
                 and hipops.conv_sx_rgb_supported(x.shape[0], self.in_channels, self.out_channels, res, res)):
