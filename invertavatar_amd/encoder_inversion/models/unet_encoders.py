@@ -236,6 +236,22 @@ class TriPlaneSFTfeat_Encoder(_UNetBase):
             return torch.stack([trunk_hip.conv_lrelu_conv_forward(scale, ts), trunk_hip.conv_lrelu_conv_forward(shift, ts)])
         return torch.stack([scale(t), shift(t)])
 
+    def forward_onlyEncoder(self, x):
+        """The IR-SE50 trunk alone (eval-mode BatchNorm: every frame on its own), as TriPlanefeat_Encoder.forward_onlyEncoder: the
+        half of this UNet that inversion_parallel shards by frame."""
+        assert x.dim() == 5
+        return list(self._encode(x.flatten(0, 1)))
+
+    def forward_onlyDecoder(self, T, feats, r_list=None):
+        """The recurrent decoder + CS-SFT heads on trunk features of T frames (see forward)."""
+        if self.use_gru and r_list is None:
+            r_list = [None] * 4
+        out, t = {}, None
+        for res, t in zip((16, 32, 64, 128), self._decode(feats, T, r_list)):
+            out[res] = self._sft(res, t)
+        out[256] = self._sft(256, self.final_head(self.head(t)))
+        return (out, r_list) if self.use_gru else out
+
     def forward(self, x, r_list=None):
         T = 1
         if x.dim() == 5:

@@ -132,13 +132,42 @@ class inversionNet(nn.Module):
         return out
 
     @torch.no_grad()
-    def AR_eval_forward(self, x, vid_c, vid_v, ws, r_list, e4e_results=None, return_fake=False, y0_image=None, parts=('texture', 'triplane')):
+    def trunk_features(self, image, uv, y0_image):
+        """IR-SE50 trunk features of both UNets for source frames [T, ...] given their renders from the e4e features: the per-frame
+        half of AR_eval_forward (eval-mode BatchNorm: no coupling between frames).  Returns {'texture': [5 tensors], 'triplane': [5]}."""
+        delta_x = y0_image - image[:, :3]
+        tri_input = torch.cat([image[:, :3], delta_x], dim=-3)
+        # two latency-bound launch chains (3.3 ms each on one frame, 3.6 ms on four: r05 stage profile) that read delta_x and nothing
+        # of each other: on the device the texture trunk runs on the side stream AR_eval_forward uses for the texture chain
+        fork = UNET_CHAINS_CONCURRENT and delta_x.is_cuda and not torch.is_grad_enabled()
+        if fork:
+            from ... import _runtime
+            st = _runtime.state(self)
+            if getattr(st, 'chain_stream', None) is None or st.chain_stream.device != delta_x.device:
+                st.chain_stream = torch.cuda.Stream(device=delta_x.device)
+            main, side = torch.cuda.current_stream(delta_x.device), st.chain_stream
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if fork else contextlib.nullcontext()):
+            uv_input = self.get_unet_uvinput(uv, delta_x)
+            tex = self.unet_encoder.texture_unet.forward_onlyEncoder(uv_input.unsqueeze(0))
+        tri = self.unet_encoder.triplane_unet.forward_onlyEncoder(tri_input.unsqueeze(0))
+        if fork:
+            main.wait_stream(side)
+            for t in tex:
+                t.record_stream(main)
+        return {'texture': tex, 'triplane': tri}
+
+    @torch.no_grad()
+    def AR_eval_forward(self, x, vid_c, vid_v, ws, r_list, e4e_results=None, return_fake=False, y0_image=None, parts=('texture', 'triplane'),
+                        trunk_feats=None):
         """Incremental update from one group of T source frames (uvnet.py:160-203).
         x['image'] [T,3,512,512], x['uv'] [T,6,256,256]; r_list = [texture GRU states, tri-plane GRU states].
         `y0_image`: the group's render from the e4e features, when the caller already has it (inversion_parallel renders the source
         frames of all groups sharded over the ranks before the UNet chains run).  `parts`: which of the two independent UNet chains
         to run -- 'texture' (texture UNet -> texture feature offsets) and / or 'triplane' (tri-plane UNet -> conditioned static
-        backbone); the features of a chain that is left out come back as the e4e features, its ConvGRU states untouched."""
+        backbone); the features of a chain that is left out come back as the e4e features, its ConvGRU states untouched.
+        `trunk_feats`: {'texture': [...], 'triplane': [...]}, the IR-SE50 trunk features of the group's T frames when the caller has
+        them already (`trunk_features`; inversion_parallel computes them sharded by frame): the chains then run their decoders only."""
         g = self.generator
         T = vid_c.shape[0]
         if ws is None:
@@ -169,17 +198,23 @@ class inversionNet(nn.Module):
             side.wait_stream(main)
         if 'texture' in parts:
             with (torch.cuda.stream(side) if fork else contextlib.nullcontext()):
-                uv_input = self.get_unet_uvinput(x['uv'], delta_x)
-                offsets, r_list[0] = self.unet_encoder.texture_unet(uv_input.unsqueeze(0), r_list=r_list[0], return_list=True)
+                if trunk_feats is not None:
+                    offsets, r_list[0] = self.unet_encoder.texture_unet.forward_onlyDecoder(T, trunk_feats['texture'], r_list[0])
+                else:
+                    uv_input = self.get_unet_uvinput(x['uv'], delta_x)
+                    offsets, r_list[0] = self.unet_encoder.texture_unet(uv_input.unsqueeze(0), r_list=r_list[0], return_list=True)
                 texture_feats = _add_offsets(texture_feats, offsets)
         if 'triplane' in parts:
-            tri_input = torch.cat([x['image'][:, :3], delta_x], dim=-3)
-            sft, r_list[1] = self.unet_encoder.triplane_unet(tri_input.unsqueeze(0), r_list=r_list[1])
+            if trunk_feats is not None:
+                sft, r_list[1] = self.unet_encoder.triplane_unet.forward_onlyDecoder(T, trunk_feats['triplane'], r_list[1])
+            else:
+                tri_input = torch.cat([x['image'][:, :3], delta_x], dim=-3)
+                sft, r_list[1] = self.unet_encoder.triplane_unet(tri_input.unsqueeze(0), r_list=r_list[1])
             static_feats = g.backbone.synthesis(ws, cond_list=None, return_list=True, feat_conditions=sft, update_emas=False,
                                                 noise_mode='const')
         if fork:
             main.wait_stream(side)
-            for t in list(texture_feats) + list(r_list[0]) + [uv_input]:
+            for t in list(texture_feats) + list(r_list[0]) + ([uv_input] if uv_input is not None else []):
                 t.record_stream(main)
         updated = {'w': ws, 'texture': texture_feats, 'static': static_feats}
         if not return_fake:

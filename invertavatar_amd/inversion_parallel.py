@@ -10,7 +10,8 @@ What `eval_seq.few_shot_inversion` does on one GPU, in dependency order:
        tri-plane chain: image residual -> tri-plane UNet -> CS-SFT conditions -> conditioned static backbone
      the two chains never read each other.
 
-Sharding.  B is frame-parallel: the S source frames are dealt to the ranks in contiguous blocks, each frame rendered with the depth
+Sharding (r05: C split into C1 trunks / C2 decoders -- the IR-SE50 trunks of both UNets run in eval mode, so they are frame-parallel too;
+they go to the ranks with the renders, and the owners of the chains run the recurrent decoders only).  B is frame-parallel: the S source frames are dealt to the ranks in contiguous blocks, each frame rendered with the depth
 range (`ray_dist`) and the random draws of ITS group's four-frame call, and the renders meet in one all-gather.  C is two-way model
 parallel: rank 0 runs the texture chain of all groups, rank 1 (when there is one) the tri-plane chain; each owner then broadcasts its
 six feature maps and its ConvGRU states (one flat buffer per owner).  Groups stay whole on their owner (BatchNorm statistics), the
@@ -66,7 +67,7 @@ def _broadcast_list(tensors, src, group=None, device=None):
 
 @torch.no_grad()
 def few_shot_inversion_sharded(net, images, uvs, cams, uvcoords, rank=0, world_size=1, draws=None, sequential_sampling=False,
-                               neural_rendering_resolution=None, group=None):
+                               neural_rendering_resolution=None, group=None, shard_trunks=True):
     """`eval_seq.few_shot_inversion` with the source renders sharded by frame and the two UNet chains on ranks 0 and 1.
     Every rank passes the same inputs and gets (ws, {'w', 'texture', 'static'} of the last group, r_list).
     `draws`: see the module docstring (None: seeded_draws(0, R)); with world_size == 1 this is the one-process flow with the same
@@ -110,12 +111,37 @@ def few_shot_inversion_sharded(net, images, uvs, cams, uvcoords, rank=0, world_s
         mine.append(y0['image'])
     shape = (3, g.img_resolution, g.img_resolution)
     block = torch.cat(mine, 0) if mine else torch.zeros((0,) + shape, device=dev)
-    if world_size > 1:
-        counts = [b_ - a_ for a_, b_ in (frame_parallel.shard_range(len(items), r_, world_size) for r_ in range(world_size))]
-        y0_all = frame_parallel.all_gather_blocks(block, counts, group)
-    else:
-        y0_all = block
-    # ---- C: the two chains, groups in order, on their owners
+    counts = [b_ - a_ for a_, b_ in (frame_parallel.shard_range(len(items), r_, world_size) for r_ in range(world_size))]
+    y0_all = frame_parallel.all_gather_blocks(block, counts, group) if world_size > 1 else block
+    # ---- C1: the IR-SE50 trunks of both UNets, frame-parallel like B (eval-mode BatchNorm: a frame's trunk features depend on that
+    # frame's render only, SURVEY 8e iii names train-mode BatchNorm in the DECODERS).  Each rank runs the two trunks on its frames of the
+    # group-major list; one all-gather of the flattened features (7.9 MB per frame and UNet at 256^2 inputs) hands them to the owners.
+    trunk_all = None
+    if shard_trunks and world_size > 1:
+        mine_feats, like = [], None
+        for j, (gi, t) in enumerate(items[lo:hi]):
+            f = frames_of[gi][t]
+            tf = net.trunk_features(images[f:f + 1], uvs[f:f + 1], block[j:j + 1])
+            like = like or tf
+            mine_feats.append(torch.cat([v.reshape(-1) for key in ('texture', 'triplane') for v in tf[key]]))
+        if like is None:         # (a rank without frames: shapes from one trunk pass on a zero frame -- every rank must know the row length)
+            like = net.trunk_features(torch.zeros_like(images[:1]), uvs[:1], torch.zeros((1,) + shape, device=dev))
+        row = sum(v.numel() for key in ('texture', 'triplane') for v in like[key])
+        rows = torch.stack(mine_feats) if mine_feats else torch.zeros((0, row), device=dev)
+        trunk_all = (frame_parallel.all_gather_blocks(rows, counts, group), like)
+
+    def group_trunk_feats(at, k):
+        """{'texture': [...], 'triplane': [...]} of frames at .. at + k - 1 of the group-major list, from the gathered rows."""
+        rows, like = trunk_all
+        out, col = {}, 0
+        for key in ('texture', 'triplane'):
+            out[key] = []
+            for v in like[key]:
+                n = v.numel()
+                out[key].append(rows[at:at + k, col:col + n].reshape((k,) + tuple(v.shape[1:])))
+                col += n
+        return out
+    # ---- C2: the two chains (recurrent decoders; with C1 off: trunks + decoders), groups in order, on their owners
     tex_owner, tri_owner = 0, (1 if world_size > 1 else 0)
     parts = tuple(p for p, owner in (('texture', tex_owner), ('triplane', tri_owner)) if owner == rank)
     r_list = [None, None]
@@ -125,7 +151,8 @@ def few_shot_inversion_sharded(net, images, uvs, cams, uvcoords, rank=0, world_s
         sel, k = sels[gi], len(frames_of[gi])
         if parts:
             updated, r_list = net.AR_eval_forward({'image': images[sel], 'uv': uvs[sel]}, cams[sel], {'uvcoords_image': uvcoords[sel]}, ws, r_list,
-                                                  e4e_results=e4e, return_fake=False, y0_image=y0_all[at:at + k], parts=parts)
+                                                  e4e_results=e4e, return_fake=False, y0_image=y0_all[at:at + k], parts=parts,
+                                                  trunk_feats=None if trunk_all is None else group_trunk_feats(at, k))
         at += k
     if world_size > 1:
         # shapes of the results are those of the e4e features (offsets are added in place of them); the GRU states' shapes are

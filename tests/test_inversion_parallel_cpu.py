@@ -56,8 +56,9 @@ class _Generator(torch.nn.Module):
 
 
 class _UNet(torch.nn.Module):
-    """Stand-in for a ConvGRU UNet: per-level outputs mix ALL frames of the group (like its train-mode BatchNorm) with a recurrent
-    state that the next group continues from."""
+    """Stand-in for a ConvGRU UNet.  Like the real ones it is a per-frame trunk (`forward_onlyEncoder`: nothing couples the frames,
+    the IR-SE50 trunks run eval-mode BatchNorm) followed by a decoder whose per-level outputs mix ALL frames of the group (like its
+    train-mode BatchNorm) with a recurrent state that the next group continues from (`forward_onlyDecoder`)."""
 
     def __init__(self, in_ch, levels, seed):
         super().__init__()
@@ -65,23 +66,30 @@ class _UNet(torch.nn.Module):
         self.w = [torch.randn(ch, in_ch, generator=g) * 0.2 for ch, _ in levels]
         self.levels = levels
 
-    def forward(self, x, r_list=None, return_list=True):
-        t = x[0]                                            # [T, C, H, W]
+    def forward_onlyEncoder(self, x):
+        t = x.flatten(0, 1)                                 # [T, C, H, W]
+        return [torch.einsum('oc,tchw->tohw', w, torch.tanh(torch.nn.functional.adaptive_avg_pool2d(t, res))) for w, (ch, res) in zip(self.w, self.levels)]
+
+    def forward_onlyDecoder(self, T, feats, r_list=None):
         if r_list is None:
             r_list = [torch.zeros(1, ch, res, res) for ch, res in self.levels]
         outs, states = [], []
-        for w, (ch, res), h in zip(self.w, self.levels, r_list):
-            pooled = torch.nn.functional.adaptive_avg_pool2d(t, res)                                   # [T, C, res, res]
-            mixed = torch.einsum('oc,tchw->tohw', w, pooled) * torch.arange(1, t.shape[0] + 1).reshape(-1, 1, 1, 1)
+        for f, h in zip(feats, r_list):
+            assert f.shape[0] == T
+            mixed = f * torch.arange(1, T + 1).reshape(-1, 1, 1, 1)
             new_h = torch.tanh(0.5 * h + mixed.mean(0, keepdim=True) - mixed.std(0, keepdim=True))
             outs.append(new_h * 0.3)
             states.append(new_h)
         return outs, states
 
+    def forward(self, x, r_list=None, return_list=True):
+        return self.forward_onlyDecoder(x.shape[1], self.forward_onlyEncoder(x), r_list)
+
 
 class _Toy(torch.nn.Module):
     AR_eval_forward = inversionNet.AR_eval_forward          # the product's own group update and UV-space residual
     get_unet_uvinput = inversionNet.get_unet_uvinput
+    trunk_features = inversionNet.trunk_features           # ... and the per-frame half the sharded flow deals to the ranks
 
     def __init__(self):
         super().__init__()
@@ -108,12 +116,12 @@ def _inputs(s=8):
     return images, uvs, cams, uvcoords
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, shard_trunks):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(1)
     out = inversion_parallel.few_shot_inversion_sharded(_Toy(), *_inputs(), rank=rank, world_size=world,
-                                                       draws=inversion_parallel.seeded_draws(7, NRR * NRR))
+                                                       draws=inversion_parallel.seeded_draws(7, NRR * NRR), shard_trunks=shard_trunks)
     torch.save(out, f'{tmp}.{rank}')
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -129,10 +137,12 @@ def _same(a, b, tol=0.0):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('world', [2, 3])
-def test_sharded_inversion_reproduces_the_one_process_flow(tmp_path, world):
+@pytest.mark.parametrize('world,shard_trunks', [(2, True), (3, True), (2, False), (5, True)])
+def test_sharded_inversion_reproduces_the_one_process_flow(tmp_path, world, shard_trunks):
+    """shard_trunks: the UNet trunks dealt to the ranks by frame with the renders (r05) or run whole on the chains' owners (r04).
+    5 ranks on 8 frames: uneven blocks, and the frames of one group spread over three ranks."""
     tmp = str(tmp_path / 'out')
-    mp.spawn(_worker, args=(world, 29651 + world, tmp), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, 29651 + world + (10 if not shard_trunks else 0), tmp, shard_trunks), nprocs=world, join=True)
     draws = inversion_parallel.seeded_draws(7, NRR * NRR)
     one = inversion_parallel.few_shot_inversion_sharded(_Toy(), *_inputs(), rank=0, world_size=1, draws=draws)
     for rank in range(world):                              # every rank ends with the same features and states
