@@ -585,7 +585,7 @@ def drive_main(args, rank, world):
         n = args.drive_frames
         out['inversion_ms'] = round(inversion_ms, 2)
         out['clip'] = dict(frames=n, seconds=round(inversion_ms * 1e-3 + n / fps, 4), frames_per_s=round(n / (inversion_ms * 1e-3 + n / fps), 2),
-                           note='inversion (N > 1: source renders sharded by frame, UNet chains on ranks 0 / 1) + the whole drive sequence at the measured rate')
+                           note='inversion (N > 1: source renders and UNet trunks sharded by frame, the recurrent decoder chains on ranks 0 / 1) + the whole drive sequence at the measured rate')
     return out
 
 
