@@ -776,6 +776,7 @@ class StylePlan:
             st = _lib.load().ia_styles_demod(_p(ws), b, num_ws, w_dim, _p(self.table), _p(self.gains), _p(self.srl), self.srows,
                                              _p(self.drl), self.drows, _p(styles), _p(demod), _lib.stream_ptr(ws.device))
         _lib.check(st, 'ia_styles_demod')
+        self.last_buffers = (styles, demod)      # alive until the next run: the per-layer views may be consumed on other streams than this one
         out = []
         for e in self.entries:
             s = styles[b * e['soff']:b * (e['soff'] + e['I'])].view(b, e['I'])

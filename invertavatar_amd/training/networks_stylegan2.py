@@ -751,20 +751,23 @@ class _StyleBatcher(_runtime.DeviceCache):
         self.plan = None
         self.layers = None
 
-    def prepare(self, blocks, ws_offsets, ws, enabled=True):
+    def prepare(self, blocks, ws_offsets, ws, enabled=True, fixed_w=None):
+        """`fixed_w`: per block None or an index into ws that ALL of the block's layers read (the SR head: every layer sees the last w)."""
         if not (enabled and ws.is_cuda and not _needs_autograd(ws) and not torch.is_grad_enabled()):
-            return
+            return False
         if self.plan is None or self.plan.device != ws.device:
             entries, self.layers = [], []
-            for block, off in zip(blocks, ws_offsets):
+            for n, (block, off) in enumerate(zip(blocks, ws_offsets)):
                 if block.architecture == 'resnet':
-                    return
+                    return False
                 for layer, k, demod in _modulated_layers(block):
-                    entries.append(dict(affine=layer.affine, weight=layer.weight, widx=off + k, demod=demod))
+                    widx = off + k if fixed_w is None or fixed_w[n] is None else fixed_w[n]
+                    entries.append(dict(affine=layer.affine, weight=layer.weight, widx=widx, demod=demod))
                     self.layers.append(layer)
             self.plan = hipops.StylePlan(entries, ws.device)
         for layer, pre in zip(self.layers, self.plan.run(ws)):
             layer._pre = pre
+        return True
 
 
 def _block_plan(img_resolution, channel_base, channel_max, num_fp16_res):
@@ -799,14 +802,23 @@ class SynthesisNetwork(torch.nn.Module):
             setattr(self, f'b{res}', block)
         self._style_batcher = _StyleBatcher()
 
-    def _prepare_styles(self, ws):
-        """Batch every affine + demodulation of this network (device inference path only)."""
+    def _style_blocks(self):
+        """(blocks, index of each block's first w): what a style batcher needs to know about this network."""
         blocks = [getattr(self, f'b{res}') for res in self.block_resolutions]
         offs, idx = [], 0
         for blk in blocks:
             offs.append(idx)
             idx += blk.num_conv
-        self._style_batcher.prepare(blocks, offs, ws.to(torch.float32))
+        return blocks, offs
+
+    def _prepare_styles(self, ws):
+        """Batch every affine + demodulation of this network (device inference path only).  A caller that has batched SEVERAL
+        networks' styles for this `ws` object already (triplane_v20: one launch pair per frame) marks them with `_styles_for`."""
+        rt = _runtime.state(self)          # (runtime state lives outside the module: deepcopy / pickle see parameters only)
+        marked, rt.styles_for = getattr(rt, 'styles_for', None), None
+        if marked is not None and marked is ws:
+            return
+        self._style_batcher.prepare(*self._style_blocks(), ws.to(torch.float32))
 
     def _split_ws(self, ws):
         out, idx = [], 0

@@ -49,12 +49,21 @@ class _TwoBlockHead(torch.nn.Module):
         if isinstance(self.block0, SynthesisBlock) and isinstance(self.block1, SynthesisBlock):
             rt.style_batcher.prepare([self.block0, self.block1], [0, 0], ws3.to(torch.float32))
 
-    def hoist_styles(self, ws):
+    def hoist_styles(self, ws, prepared=False):
         """The head's styles depend only on ws: a caller that knows ws long before the rendered features exist (triplane_v20:
-        at the top of the frame, on a side stream) can have them computed then; forward() with the same ws object uses them."""
+        at the top of the frame, on a side stream) can have them computed then; forward() with the same ws object uses them.
+        `prepared`: the caller's frame-level style batch has parked this head's styles already (`style_blocks`)."""
         w3 = _last_w(ws)
-        self._prepare_styles(w3)
+        if not prepared:
+            self._prepare_styles(w3)
         _runtime.state(self).hoisted = (ws, w3)
+
+    def style_blocks(self):
+        """The head's blocks for a frame-level style batch: every layer reads the LAST w (`_last_w`), or None when the head is not
+        made of SynthesisBlocks."""
+        if isinstance(self.block0, SynthesisBlock) and isinstance(self.block1, SynthesisBlock):
+            return [self.block0, self.block1]
+        return None
 
     def forward(self, rgb, x, ws, **block_kwargs):
         rt = _runtime.state(self)

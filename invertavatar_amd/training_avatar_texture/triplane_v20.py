@@ -34,6 +34,8 @@ CL_COPIES_ON_TEXTURE_STREAM = True   # False: the rasteriser's stream makes them
 LAUNCH_ORDER = 'tmfs'           # capture order of the frame's four independent branches: m mouth fill + rays, f face-backbone head,
                                 # t texture backbone, s static backbone (profiles/r04_ab_launch_order_sweep.txt: two clusters 9 % apart)
 
+FRAME_STYLE_BATCH = True        # synthesis(): the styles of all three backbones + the SR head in one launch pair at the top of the frame
+
 SINGLE_STREAM = False           # True: no side streams (every launch of a frame in program order on the caller's stream); used by
                                 # bench.py to time kernels without neighbours from other streams
 
@@ -189,7 +191,34 @@ class TriPlaneGenerator(torch.nn.Module):
         st.tex_cl = (texture_feats, tex_cl)
         return texture_feats, static_feats, pending
 
-    def _start_face_head(self, ws, update_emas, synthesis_kwargs):
+    def _frame_styles(self, ws):
+        """Every affine style vector and demodulation coefficient of the frame -- three backbones and the SR head, ~190 layers -- in
+        ONE `ia_styles_demod` launch pair on the caller's stream before the branches fork (they were 2 launches at the head of each
+        network's chain: 8 per frame, ~25 us in front of each backbone's first convolution).  Marks the networks so that their own
+        batchers skip this `ws`; returns True when the SR head's styles were part of the batch."""
+        if not (FRAME_STYLE_BATCH and ws.is_cuda and not torch.is_grad_enabled()):
+            return False
+        from ..training.networks_stylegan2 import _StyleBatcher
+        st = _state(self)
+        nets = [self.texture_backbone.synthesis, self.backbone.synthesis, self.face_backbone.synthesis]
+        if any(n.num_ws > ws.shape[1] for n in nets):
+            return False
+        if getattr(st, 'style_batcher', None) is None:
+            st.style_batcher = _StyleBatcher()
+        blocks, offs, fixed = [], [], []
+        for n in nets:
+            b, o = n._style_blocks()
+            blocks += b; offs += o; fixed += [None] * len(b)
+        sr = self.superresolution.style_blocks() if hasattr(self.superresolution, 'style_blocks') else None
+        if sr is not None:
+            blocks += sr; offs += [0] * len(sr); fixed += [ws.shape[1] - 1] * len(sr)
+        if not st.style_batcher.prepare(blocks, offs, ws.to(torch.float32), fixed_w=fixed):
+            return False
+        for n in nets:
+            _runtime.state(n).styles_for = ws
+        return sr is not None
+
+    def _start_face_head(self, ws, update_emas, synthesis_kwargs, sr_styles_ready=False):
         """The 4^2..32^2 blocks of the face backbone depend only on ws; run them on a third stream under the other backbones."""
         if not (ws.is_cuda and not torch.is_grad_enabled()) or SINGLE_STREAM:
             return None
@@ -198,7 +227,7 @@ class TriPlaneGenerator(torch.nn.Module):
         with torch.cuda.stream(side):
             x, img, first = self.face_backbone.synthesis.forward_head(ws, update_emas=update_emas, **synthesis_kwargs)
             if hasattr(self.superresolution, 'hoist_styles'):      # three small launches off the render -> SR chain
-                self.superresolution.hoist_styles(ws)
+                self.superresolution.hoist_styles(ws, prepared=sr_styles_ready)
             done = torch.cuda.Event()
             done.record(side)
         x.record_stream(main)
@@ -333,8 +362,9 @@ class TriPlaneGenerator(torch.nn.Module):
     def synthesis(self, ws, c, mesh_condition, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
                   use_cached_backbone=False, return_featmap=False, evaluation=False, jitter=None, ray_dist=None, **synthesis_kwargs):
         side = {}
+        sr_ready = self._frame_styles(ws)
         side_work = {'m': lambda: side.__setitem__('m', self._start_mouth_fill(mesh_condition, rays=(c, neural_rendering_resolution, ray_dist))),
-                     'f': lambda: side.__setitem__('f', self._start_face_head(ws, update_emas, synthesis_kwargs))}
+                     'f': lambda: side.__setitem__('f', self._start_face_head(ws, update_emas, synthesis_kwargs, sr_ready))}
         texture_feats, static_feats, pending = self._two_backbones(ws, update_emas, synthesis_kwargs, partial=True,
                                                                    order=LAUNCH_ORDER, side_work=side_work)
         mouth, face_head = side['m'], side['f']
