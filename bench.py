@@ -33,7 +33,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (what this driver supports): RCCL between the ranks of a node needs it
+
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -109,7 +111,8 @@ def setup_distributed(args):
     if args.gpus > 1 or world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        torch.distributed.init_process_group(args.dist_backend, rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        kw = {'device_id': DEV} if args.dist_backend == 'nccl' and DEV.type == 'cuda' else {}      # bind the communicator to this rank's GPU at once
+        torch.distributed.init_process_group(args.dist_backend, rank=rank, world_size=world, **kw)   # nccl == RCCL on ROCm
     return rank, world, local
 
 
