@@ -364,16 +364,15 @@ __global__ __launch_bounds__(256, IA_FIR_WAVES) void fir_tail_split_kernel(const
     }
 }
 
-// The same kernel with the input images DMA'd straight into LDS (r05).  The register-staged form above keeps two channels (11 KB per
-// workgroup, 43 KB per CU) in flight and spends part of every channel period with nothing in flight at all (commit -> barrier ->
-// filter): latency x occupancy, not HBM, bounds it at 3.1 TB/s.  Here a workgroup issues the loads of ALL EIGHT channel images of its
-// tile up front as `buffer_load_dword ... lds` pieces (64 lanes x 4 bytes, lane-linear in LDS; the rows of the (2H+1)-wide
-// transposed-convolution output are only 4-byte aligned, so wider pieces do not apply) -- 43.5 KB per workgroup, three workgroups
-// per CU -- and filters channel c as soon as its 22 pieces have landed (loads return in order: s_waitcnt vmcnt(6 * (7 - c)) per wave,
-// then the barrier).  No staging registers, no ds_write.  Zero padding comes from the buffer bounds check (out-of-range lanes carry
-// an offset beyond the resource and write zeros).  Every wave issues the same number of pieces per channel (22 real ones padded to
-// 4 x 6 with all-outside pieces that land behind the image), so the wait counts are compile-time constants.  Same sums in the same
-// order as fir_tail_split_kernel: bit-identical results.
+// The same kernel with the input images DMA'd straight into LDS (r05).  The register-staged form above was issue-bound (440
+// instructions per channel and 4 outputs, a branch + atomic per split value) and kept only two channel images in flight.  Here the
+// images arrive as `buffer_load_dword ... lds` pieces (64 lanes x 4 bytes, lane-linear in LDS; the rows of the (2H+1)-wide
+// transposed-convolution output are only 4-byte aligned, so wider pieces do not apply) through a ring of LDS slots, three channels
+// in flight, and channel c is filtered as soon as its 22 pieces have landed (loads return in order: a compile-time
+// `s_waitcnt vmcnt(...)` per wave, then the barrier).  No staging registers, no ds_write.  Zero padding comes from the buffer bounds
+// check (out-of-range lanes carry an offset beyond the resource and write zeros).  Every wave issues the same number of pieces per
+// channel (22 real ones padded to 4 x 6 with all-outside pieces that land behind the image), so the wait counts are constants.
+// Same sums in the same order as fir_tail_split_kernel: bit-identical results.
 typedef unsigned int u32x4_f __attribute__((ext_vector_type(4)));
 constexpr unsigned kFirOutside = 0x7ffffff0u;
 #pragma clang diagnostic push
@@ -385,17 +384,24 @@ __device__ __forceinline__ void fir_dma_dword(u32x4_f rsrc, unsigned lds_addr, u
 #pragma clang diagnostic pop
 template <int N> __device__ __forceinline__ void fir_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// TH_ x 64 output tile (RPT_ = TH_ / 4 rows per thread); the images of a tile's eight channels travel through a ring of kFirRing LDS
+// slots: channels 0 .. kFirRing - 2 are issued up front, channel c + kFirRing - 1 right after the barrier in front of channel c (every
+// wave has left channel c - 1 by then, whose slot it takes).  24 KB of LDS and 128 registers: four workgroups per CU (the first form
+// of this kernel kept all eight images resident: 49 KB, three per CU -- 1024 workgroups of a 128-channel 256^2 layer on 768 slots).
+constexpr int kFirRing = 4;
+template <int TH_, int RPT_>
 __global__ __launch_bounds__(256) void fir_tail_split_dma_kernel(const float* __restrict__ x, const float* __restrict__ f, h16x8_t* __restrict__ ys,
                                                                  const float* __restrict__ styles_next, Geo g, int flip, Tail tail, int planes) {
+    static_assert(TH_ == 4 * RPT_, "256 threads: 64 columns x 4 row groups");
     constexpr int FS = 4;
-    constexpr int IH = TH + FS, IW = TW + FS, NPIX = IH * IW;             // 20 x 68 input pixels per channel image
-    constexpr int NPIECE = (NPIX + 63) / 64, PPW = (NPIECE + 3) / 4;      // 22 pieces of 64 pixels, 6 per wave (2 of the 24 are padding)
-    constexpr int IMG = 4 * PPW * 64;                                      // floats reserved per channel image in LDS
-    static_assert(8 * PPW <= 63, "all pieces of a wave must fit the vmcnt counter");
-    __shared__ float k_lds[FS * FS];
-    __shared__ __attribute__((aligned(16))) float in_lds[8][IMG];
+    constexpr int IH = TH_ + FS, IW = TW + FS, NPIX = IH * IW;            // (TH_ + 4) x 68 input pixels per channel image
+    constexpr int NPIECE = (NPIX + 63) / 64, PPW = (NPIECE + 3) / 4;      // pieces of 64 pixels; per wave (padded with all-outside pieces)
+    constexpr int IMG = 4 * PPW * 64;                                      // floats reserved per ring slot
+    static_assert((kFirRing - 1) * PPW <= 63, "the pieces in flight of a wave must fit the vmcnt counter");
+    extern __shared__ __attribute__((aligned(16))) float fir_lds[];       // [kFirRing][IMG] images, then the 16 filter taps
+    float* k_lds = fir_lds + kFirRing * IMG;
     const int tiles_x = (g.out_w + TW - 1) / TW;
-    const int ox0 = (blockIdx.x % tiles_x) * TW, oy0 = (blockIdx.x / tiles_x) * TH;
+    const int ox0 = (blockIdx.x % tiles_x) * TW, oy0 = (blockIdx.x / tiles_x) * TH_;
     const int C8 = g.c / 8, c8 = blockIdx.y % C8, b = blockIdx.y / C8;
     const int iy0 = oy0 - g.pady0, ix0 = ox0 - g.padx0;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -404,12 +410,12 @@ __global__ __launch_bounds__(256) void fir_tail_split_dma_kernel(const float* __
     const float* xb = x + ((int64_t)b * g.c + c8 * 8) * in_plane;
     // everything the channel loop reads besides the images is fetched first: a vector load issued between the pieces and their
     // waits would shift the counts
-    const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * RPT;
+    const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * RPT_;
     const int ox = ox0 + tx;
     const float t_ns = tail.noise ? (tail.noise_strength ? *tail.noise_strength : 1.f) : 0.f;
-    float nz[RPT];
+    float nz[RPT_];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
+    for (int r = 0; r < RPT_; ++r) {
         const int oy = oy0 + ty + r;
         nz[r] = (tail.noise && ox < g.out_w && oy < g.out_h) ? tail.noise[(int64_t)oy * g.out_w + ox] : 0.f;
     }
@@ -436,41 +442,45 @@ __global__ __launch_bounds__(256) void fir_tail_split_dma_kernel(const float* __
         rsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)(8 * in_plane * 4));
         rsrc[3] = 0x00020000u;
     }
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&in_lds[0][0];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)fir_lds;
     // noise / bias / styles must have LANDED before the first piece is issued: from there on only pieces are counted.  The empty asm
     // statements are uses the compiler has to satisfy here (its own s_waitcnt vmcnt(0) for these loads would otherwise appear at
-    // their first real use, inside channel 0, and drain all eight images)
+    // their first real use, inside channel 0, and drain the ring)
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) asm volatile("" : "+v"(nz[r]));
+    for (int r = 0; r < RPT_; ++r) asm volatile("" : "+v"(nz[r]));
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) asm volatile("" : "+v"(t_bias[ch]), "+v"(sn[ch]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch)
-#pragma unroll
-        for (int s_ = 0; s_ < PPW; ++s_)
-            fir_dma_dword(rsrc, lds0 + (unsigned)(ch * IMG + 64 * (wave + 4 * s_)) * 4u, voff[s_], (unsigned)(ch * in_plane * 4));
+    const unsigned plane_bytes = (unsigned)(in_plane * 4);
+#define IA_FIR_ISSUE(ch)                                                                                                       \
+    _Pragma("unroll") for (int s_ = 0; s_ < PPW; ++s_)                                                                         \
+        fir_dma_dword(rsrc, lds0 + (unsigned)(((ch) % kFirRing) * IMG + 64 * (wave + 4 * s_)) * 4u, voff[s_], (unsigned)(ch) * plane_bytes);
+    IA_FIR_ISSUE(0) IA_FIR_ISSUE(1) IA_FIR_ISSUE(2)
     __syncthreads();                                        // (k_lds)
     float kf[FS * FS];
 #pragma unroll
     for (int i = 0; i < FS * FS; ++i) kf[i] = k_lds[i];
-    h16x8_t hi[RPT], lo[RPT];
+    h16x8_t hi[RPT_], lo[RPT_];
     ia::SatWatch watch;
     // the tail's options as values instead of branches: every element of the loop below is straight-line code (selects), so the
-    // LDS reads and FMAs of its four rows interleave; identical results (x * 1, fma(0, 0, x), clamp at infinity are exact)
+    // LDS reads and FMAs of its rows interleave; identical results (x * 1, fma(0, 0, x), clamp at infinity are exact)
     const float slope = tail.act == IA_ACT_LRELU ? tail.alpha : 1.f, clamp = tail.clamp >= 0.f ? tail.clamp : INFINITY;
     const bool two_planes = planes == 2;
-    // one channel: wait for its pieces (this wave's, then everybody's), filter, tail, split.  A macro with a literal channel index on
-    // purpose: hi / lo must stay registers (through a lambda, next to the asm statements' memory clobbers, they went to the stack)
+    // one channel: wait for its pieces (this wave's, then everybody's), refill the slot the previous channel left, filter, tail,
+    // split.  Channels younger than `ch` in flight at its wait: ch + 1, ch + 2 (ch + 3 is issued behind the barrier).  A macro with a
+    // literal channel index on purpose: hi / lo must stay registers (through a lambda, next to the asm statements' memory clobbers,
+    // they went to the stack)
 #define IA_FIR_CH(ch)                                                                                                          \
     {                                                                                                                          \
-        fir_wait_vmcnt<PPW * (7 - ch)>();                                                                                      \
+        fir_wait_vmcnt<PPW * ((ch) + 2 <= 7 ? 2 : 7 - (ch))>();                                                                \
         __syncthreads();                                                                                                       \
-        _Pragma("unroll") for (int r = 0; r < RPT; ++r) {                                                                      \
+        if ((ch) + kFirRing - 1 <= 7) { IA_FIR_ISSUE((ch) + kFirRing - 1) }                                                    \
+        const float* img = fir_lds + ((ch) % kFirRing) * IMG;                                                                  \
+        _Pragma("unroll") for (int r = 0; r < RPT_; ++r) {                                                                     \
             float acc = 0.f;                                                                                                   \
             _Pragma("unroll") for (int a = 0; a < FS; ++a)                                                                     \
                 _Pragma("unroll") for (int bb = 0; bb < FS; ++bb)                                                              \
-                    acc = fmaf(in_lds[ch][(ty + r + a) * IW + tx + bb], kf[a * FS + bb], acc);                                 \
+                    acc = fmaf(img[(ty + r + a) * IW + tx + bb], kf[a * FS + bb], acc);                                        \
             acc = fmaf(nz[r], t_ns, acc);                      /* (no noise: 0 * 0) */                                         \
             acc += t_bias[ch];                                                                                                 \
             acc = acc > 0.f ? acc : acc * slope;               /* (linear: slope 1) */                                         \
@@ -486,16 +496,28 @@ __global__ __launch_bounds__(256) void fir_tail_split_dma_kernel(const float* __
     }
     IA_FIR_CH(0) IA_FIR_CH(1) IA_FIR_CH(2) IA_FIR_CH(3) IA_FIR_CH(4) IA_FIR_CH(5) IA_FIR_CH(6) IA_FIR_CH(7)
 #undef IA_FIR_CH
+#undef IA_FIR_ISSUE
     watch.report();
     if (ox >= g.out_w) return;
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
+    for (int r = 0; r < RPT_; ++r) {
         const int oy = oy0 + ty + r;
         if (oy >= g.out_h) break;
         const int64_t pix = (int64_t)oy * g.out_w + ox;
         ys[((int64_t)(b * planes) * C8 + c8) * ohw + pix] = hi[r];
         if (planes == 2) ys[((int64_t)(b * 2 + 1) * C8 + c8) * ohw + pix] = lo[r];
     }
+}
+
+template <int TH_, int RPT_>
+int launch_fir_dma(const float* x, const float* f, void* ys, const float* styles_next, const Geo& g, int flip, const Tail& tail, int planes, hipStream_t s) {
+    constexpr int IMG = 4 * ((((TH_ + 4) * (TW + 4) + 63) / 64 + 3) / 4) * 64;
+    const size_t lds = (size_t)(kFirRing * IMG + 16) * sizeof(float);
+    const auto kernel = fir_tail_split_dma_kernel<TH_, RPT_>;
+    if (const int rs = ia::reserve_lds((const void*)kernel, lds, "ia_fir_tail_split")) return rs;
+    const dim3 grid(((g.out_w + TW - 1) / TW) * ((g.out_h + TH_ - 1) / TH_), g.n * (g.c / 8));
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, x, f, static_cast<h16x8_t*>(ys), styles_next, g, flip, tail, planes);
+    return ia::check_launch("ia_fir_tail_split");
 }
 
 template <class T>
@@ -599,8 +621,9 @@ extern "C" int ia_fir_tail_split(const float* x, const float* f, const float* no
     // LDS-DMA form: split output only (a fp32 copy's stores would share the wave's vmcnt with the pieces), 8 channel planes inside one
     // buffer resource, and enough tiles that the deeper prefetch matters (below 64^2 outputs a launch is latency either way)
     if (!y && 8 * (int64_t)in_h * in_w * 4 < (int64_t)kFirOutside && (int64_t)out_h * out_w >= IA_FIR_DMA_MIN_PIXELS) {
-        hipLaunchKernelGGL(fir_tail_split_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, f, static_cast<h16x8_t*>(ys), styles_next, g, flip, tail, ys_planes);
-        return ia::check_launch("ia_fir_tail_split");
+        // (32-row tiles -- 1.20x halo instead of 1.33x, one round for 128 channels @256^2 -- measured 66.2 / 21.1 us against 57.8 / 19.1
+        //  for these on the 512^2 / 256^2 layers: 192 registers, two waves per SIMD)
+        return launch_fir_dma<16, 4>(x, f, ys, styles_next, g, flip, tail, ys_planes, (hipStream_t)stream);
     }
     hipLaunchKernelGGL(fir_tail_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, f, y, static_cast<h16x8_t*>(ys), styles_next, g, flip, tail, ys_planes);
     return ia::check_launch("ia_fir_tail_split");
