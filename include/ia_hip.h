@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 4      /* 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -353,6 +353,23 @@ int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_split, int wk_e
                       const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                       const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
                       int transposed, int act, float alpha, const float* prelu_alpha, float gain, float clamp, int ksplit, void* stream);
+
+/*
+ * 3x3 convolution with STRIDE 2 and padding 1 on split-format activations: y[b,o,r,c] = sum w[o,i,ky,kx] * x[b,i,2r+ky-1,2c+kx-1], on
+ * the stride-1 tile families of ia_conv2d_mfma_sx with the point grid laid over every second pixel of the input window (same
+ * products as torch.nn.functional.conv2d(stride 2, padding 1): a quarter of the stride-1 layer's).  Replaces the stride-2 layers of
+ * the inversion encoders (encoder_inversion/models/helpers.py:102-124, second convolution of the first residual unit of a stage;
+ * e4e.py:22-45, GradualStyleBlock), which the reference hands to cuDNN through torch.nn.Conv2d.
+ *   xs [B][planes][I/8][H][W][8], wk_split, wk_exp, demod, bias, residual, y, ys, ys_planes, styles_next, act, alpha, prelu_alpha, gain,
+ *   clamp: as ia_conv2d_mfma_sx; y / ys / residual have the output size ((H-1)/2+1) x ((W-1)/2+1).
+ *   ksplit, scratch: from ia_conv2d_down_plan (same stream-K slabs as ia_conv2d_plan).
+ * I % 8 == 0, O % 8 == 0, O >= 64, outputs from 8^2 up, input windows that fit the LDS stages (W <= ~1000); else IA_ERR_UNSUPPORTED
+ * from ia_conv2d_down_plan (callers evaluate the layer at stride 1 and sub-sample, or use the library).
+ */
+int ia_conv2d_down_plan(int B, int I, int O, int H, int W, int* h_ksplit, size_t* h_scratch_bytes);
+int ia_conv2d_down_sx(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* bias, const float* residual,
+                      float* y, void* ys, int ys_planes, const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O,
+                      int H, int W, int act, float alpha, const float* prelu_alpha, float gain, float clamp, int ksplit, void* stream);
 
 /*
  * ia_upfirdn2d_bias_act for the 4x4 filter at up = 1 (the FIR + noise + bias + activation tail of an up-sampling SynthesisLayer,

@@ -17,7 +17,7 @@ _lib = None
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _i64p = ctypes.POINTER(ctypes.c_int64)
 
-ABI_VERSION = 4      # IA_HIP_ABI_VERSION of include/ia_hip.h
+ABI_VERSION = 5      # IA_HIP_ABI_VERSION of include/ia_hip.h
 
 DTYPE_ID = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
 
@@ -53,6 +53,9 @@ _SIGNATURES = {
     'ia_act_split': [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
     'ia_conv2d_sx_supported': [c_int] * 6,
     'ia_conv2d_mfma_sx': [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 7 + [c_int] + [c_void_p] * 2 + [ctypes.c_size_t] + [c_int] * 7 + [c_float, c_void_p, c_float, c_float] + [c_int, c_void_p],
+    'ia_conv2d_down_plan': [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_size_t)],
+    'ia_conv2d_down_sx': [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, ctypes.c_size_t] + [c_int] * 6
+                         + [c_float, c_void_p, c_float, c_float, c_int, c_void_p],
     'ia_upconv2d_rows_plan': [c_int] * 5 + [ctypes.POINTER(ctypes.c_size_t)],
     'ia_upconv2d_rows_sx': [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t] + [c_int] * 5 + [c_void_p],
     'ia_upconv2d_fir_sx': [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 5 + [c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_float] * 3 + [c_void_p],

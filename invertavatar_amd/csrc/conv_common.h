@@ -39,6 +39,7 @@ struct Geo {
     int T_dp;              // tiles [0, T_dp) run one per workgroup, tiles [T_dp, T) are stream-K
     int patch_cap;         // floats per channel reserved for the patch in LDS
     int xcd_bands = 0;     // conv_split.hip: 1 = whole-tile launches give each XCD a contiguous band of tiles
+    int stride = 1;        // conv_split.hip, stride-1 tile families: 2 = the point grid is every second pixel of the padded input (3x3 stride-2 convolution)
     float acc_scale;       // fp16-pair form: 2^-wk_exp, takes the accumulators back from the scale of the packed weights
 };
 
@@ -119,7 +120,9 @@ struct Window {
     int PW, PSZ;               // shared row stride, floats per channel
 };
 
-__host__ __device__ inline Window tile_window(int p0, int p_last, int GW, int pad, bool tr) {
+__host__ __device__ inline Window tile_window(int p0, int p_last, int GW, int pad, bool tr, int stride = 1) {
+    // `stride` (stride-1 form only): grid point (r, c) reads input (stride * r + ky - pad, stride * c + kx - pad)
+    const int s = tr ? 1 : stride;
     const int up = tr ? 1 : pad, dn = tr ? 0 : pad, lf = tr ? 1 : pad, rt = tr ? 0 : pad;
     const int r_first = p0 / GW, r_last = p_last / GW;
     const int c_first = p0 - r_first * GW, c_last = p_last - r_last * GW;
@@ -127,17 +130,17 @@ __host__ __device__ inline Window tile_window(int p0, int p_last, int GW, int pa
     Window w;
     w.nr[1] = 0; w.r0[1] = 0; w.c0[1] = 0;
     if (r_first == r_last) {
-        w.r0[0] = r_first - up; w.nr[0] = nrows; w.c0[0] = c_first - lf; w.PW = (c_last + rt) - w.c0[0] + 1;
+        w.r0[0] = s * r_first - up; w.nr[0] = nrows; w.c0[0] = s * c_first - lf; w.PW = (s * c_last + rt) - w.c0[0] + 1;
     } else {
-        const int w0 = (GW - 1 + rt) - (c_first - lf) + 1, w1 = (c_last + rt) - (0 - lf) + 1;
-        const int pw_split = w0 > w1 ? w0 : w1, pw_full = GW + lf + rt;
-        const int sz_split = 2 * nrows * pw_split, sz_full = (r_last - r_first + nrows) * pw_full;
+        const int w0 = (s * (GW - 1) + rt) - (s * c_first - lf) + 1, w1 = (s * c_last + rt) - (0 - lf) + 1;
+        const int pw_split = w0 > w1 ? w0 : w1, pw_full = s * (GW - 1) + 1 + lf + rt;
+        const int sz_split = 2 * nrows * pw_split, sz_full = (s * (r_last - r_first) + nrows) * pw_full;
         if (r_last == r_first + 1 && sz_split < sz_full) {
-            w.r0[0] = r_first - up; w.nr[0] = nrows; w.c0[0] = c_first - lf;
-            w.r0[1] = r_last - up;  w.nr[1] = nrows; w.c0[1] = -lf;
+            w.r0[0] = s * r_first - up; w.nr[0] = nrows; w.c0[0] = s * c_first - lf;
+            w.r0[1] = s * r_last - up;  w.nr[1] = nrows; w.c0[1] = -lf;
             w.PW = pw_split;
         } else {
-            w.r0[0] = r_first - up; w.nr[0] = r_last - r_first + nrows; w.c0[0] = -lf; w.PW = pw_full;
+            w.r0[0] = s * r_first - up; w.nr[0] = s * (r_last - r_first) + nrows; w.c0[0] = -lf; w.PW = pw_full;
         }
     }
     w.PSZ = (w.nr[0] + w.nr[1]) * w.PW;

@@ -465,17 +465,24 @@ constexpr int kWideTransposedPoints = 32768;   // (H+1)(W+1): the 256^2 -> 512^2
 constexpr int kSplitWideTransposedPoints = 4096;   // split-DMA form: the 8-wave transposed tile for 64^2 inputs
 constexpr int kSplitMinPoints = 64;                // split-DMA form: smallest point grid (8^2; 9^2 transposed)
 
-int worst_patch(int npts, int GW, int bp, int ksize, bool tr) {
+int worst_patch(int npts, int GW, int bp, int ksize, bool tr, int stride = 1) {
     int worst = 0;
     for (int q0 = 0; q0 < npts; q0 += bp) {
         const int q1 = (q0 + bp < npts ? q0 + bp : npts) - 1;
-        const Window w = tile_window(q0, q1, GW, tr ? 0 : ksize / 2, tr);
+        const Window w = tile_window(q0, q1, GW, tr ? 0 : ksize / 2, tr, stride);
         if (w.PSZ > worst) worst = w.PSZ;
     }
     return worst;
 }
 
-void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo, int* bp, int* cc, int* waves) {
+// Patch positions per plane that the two LDS stages of the split-DMA form hold beside the weight rows of a `bo`-channel tile (two
+// operand planes), and that eight patch DMA instructions per wave of an 8-wave tile reach: the budget of the stride-2 windows.
+constexpr int down_patch_cap(int bo) {
+    const int lds = (160 * 1024 / 2 - 2 * 10 * bo * 16) / (2 * 16) / 64 * 64;
+    return lds < 2048 ? lds : 2048;
+}
+
+void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo, int* bp, int* cc, int* waves, int stride = 1) {
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
     *waves = 4; *cc = kChunkConv;
     // (form 3, r03: the 8^2 / 16^2 stride-1 layers and the 8^2 -> 16^2 / 16^2 -> 32^2 transposed ones run on the fp16-pair tiles too --
@@ -494,8 +501,12 @@ void tile_dims(int O, int H, int W, int ksize, int transposed, int form, int* bo
         if (form == 3 && npts >= kSplitWideTransposedPoints && npts < 2 * kSplitWideTransposedPoints) { *bp = 256; *waves = 8; }
     }
     else if (O <= 32) { *bo = 32; *bp = 256; }
-    else if (ksize == 3 && (O >= 128 || (O >= 64 && form == 3)) && O % 4 == 0 && (npts >= kWidePoints || sx_small) && worst_patch(npts, W, 256, 3, false) <= kPatchFloats) {
+    else if (ksize == 3 && (O >= 128 || (O >= 64 && form == 3)) && O % 4 == 0 && (npts >= kWidePoints || sx_small)
+             && worst_patch(npts, W, 256, 3, false, stride) <= (stride == 1 ? kPatchFloats : down_patch_cap(128))) {
         *bo = 128; *bp = 256; *waves = 8;
+    }
+    else if (stride == 2 && form == 3 && ksize == 3 && O % 32 == 0 && worst_patch(npts, W, 256, 3, false, stride) <= down_patch_cap(32)) {
+        *bo = 32; *bp = 256; *waves = 8;         // stride-2 windows too large beside 128 channels of weights: the narrow whole-tile family
     }
     else { *bo = 128; *bp = 128; }
 }
@@ -510,11 +521,12 @@ struct Plan { int bo, bp, cc, waves, T, TO, C, T_dp, G, slab_floats; };
 #define IA_SMALL_LAYER_WORKERS (ia::kNumCU / 4)      // (build-time sweeps: tools/_variants)
 #endif
 constexpr int kSmallLayerWorkers = IA_SMALL_LAYER_WORKERS, kSmallLayerPoints = 65 * 65;
-static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int form) {
+// `stride` = 2 (form 3, stride-1 tile families): H x W is the OUTPUT grid of a 3x3 stride-2 convolution with padding 1.
+static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int stride = 1) {
     Plan p;
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
-    tile_dims(O, H, W, ksize, transposed, form, &p.bo, &p.bp, &p.cc, &p.waves);
-    bool force_whole = false;
+    tile_dims(O, H, W, ksize, transposed, form, &p.bo, &p.bp, &p.cc, &p.waves, stride);
+    bool force_whole = stride == 2 && p.bo == 32 && O > 32;
     // Stride-1 3x3 layers of the split-DMA form that are smaller than the machine (512 -> 512 @64^2, 256 -> 256 @128^2 at one frame per
     // call): 32-channel x 256-point tiles, every tile whole, instead of 128 x 256 tiles cut between stream-K workers -- as soon as those
     // tiles give every CU one.  No slabs, no fix-up launch; a tile's weight rows (9 KB per chunk) are a quarter of the wide tile's.
@@ -560,9 +572,9 @@ static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transpos
 }
 
 // Tile plan of a layer for the sibling translation unit (conv_split.hip): same tiles, worker counts and slab sizes for both forms.
-int ia_conv2d_plan_tiles(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int* bo, int* bp, int* waves, int* T, int* TO,
-                         int* C, int* T_dp, int* slab_floats) {
-    const Plan p = make_plan(B, I, O, H, W, ksize, transposed, form);
+int ia_conv2d_plan_tiles(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int stride, int* bo, int* bp, int* waves, int* T,
+                         int* TO, int* C, int* T_dp, int* slab_floats) {
+    const Plan p = make_plan(B, I, O, H, W, ksize, transposed, form, stride);
     *bo = p.bo; *bp = p.bp; *waves = p.waves; *T = p.T; *TO = p.TO; *C = p.C; *T_dp = p.T_dp; *slab_floats = p.slab_floats;
     return IA_OK;
 }
@@ -578,6 +590,21 @@ extern "C" int ia_conv2d_sx_supported(int I, int O, int H, int W, int ksize, int
 }
 
 static size_t scratch_bytes_for(int B, int G, int slab_floats) { return (size_t)B * G * 2 * slab_floats * sizeof(float); }
+
+extern "C" int ia_conv2d_down_plan(int B, int I, int O, int H, int W, int* h_ksplit, size_t* h_scratch_bytes) {
+    IA_REQUIRE(h_ksplit && h_scratch_bytes, "null output pointer");
+    IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    if (I % 8 || O % 8 || OH * OW < kSplitMinPoints || (OH < OW ? OH : OW) < 8)
+        return ia::fail(IA_ERR_UNSUPPORTED, "the stride-2 form takes I %% 8 == 0, O %% 8 == 0 and outputs from 8^2 up (%d -> %d @%dx%d)", I, O, H, W);
+    const Plan p = make_plan(B, I, O, OH, OW, 3, 0, 3, 2);
+    const bool narrow = p.waves == 8 && p.bp == 256 && p.bo == 32;
+    if (p.waves != 8 || (narrow && p.T_dp != p.T))
+        return ia::fail(IA_ERR_UNSUPPORTED, "no stride-2 tile for %d -> %d @%dx%d (B %d)", I, O, H, W, B);
+    *h_ksplit = p.G;
+    *h_scratch_bytes = scratch_bytes_for(B, p.G, p.slab_floats);
+    return IA_OK;
+}
 
 extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int* h_ksplit,
                               size_t* h_scratch_bytes) {

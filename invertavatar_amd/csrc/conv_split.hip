@@ -390,7 +390,8 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
     const int o0 = (tile % g.TO) * BO;
     const int p0 = (tile / g.TO) * BP;
     const int p_last = min(p0 + BP, npts) - 1;
-    const Window win = tile_window(p0, p_last, g.GW, PAD, TR);
+    const int SD = TR ? 1 : g.stride;                  // stride-2 convolution: point (r, c) sits at window position (2r, 2c)
+    const Window win = tile_window(p0, p_last, g.GW, PAD, TR, SD);
     const int PW = win.PW, PSZ = win.PSZ, seg1_off = win.nr[0] * PW;
     const int r_split = (win.nr[1] > 0) ? p_last / g.GW : (1 << 30);
     const float inv_pw = 1.0f / (float)PW;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
         const int p = min(p0 + (wp * FP + fp) * 32 + l31, p_last);
         const int r = p / g.GW, c = p - r * g.GW;
         const int sg = (r == r_split) ? 1 : 0;
-        bpos[fp] = sg * seg1_off + (r - PAD - win.r0[sg]) * PW + (c - PAD - win.c0[sg]);
+        bpos[fp] = sg * seg1_off + (SD * r - PAD - win.r0[sg]) * PW + (SD * c - PAD - win.c0[sg]);
     }
     int toff[NT];
 #pragma unroll
@@ -790,10 +791,13 @@ int launch_sx(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     int worst = 0;
     for (int q0 = 0; q0 < npts; q0 += BP) {
         const int q1 = (q0 + BP < npts ? q0 + BP : npts) - 1;
-        const Window w = tile_window(q0, q1, g.GW, TR ? 0 : 1, TR);
+        const Window w = tile_window(q0, q1, g.GW, TR ? 0 : 1, TR, g.stride);
         if (w.PSZ > worst) worst = w.PSZ;
     }
-    if (worst > kPatchFloats) return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d positions exceeds the LDS budget", worst);
+    // stride 1: the planner's budget (it chose this tile family knowing that its windows fit); stride 2: whatever the two LDS stages hold
+    // beside the weight rows (launch_jp checks) and eight patch DMA instructions per wave reach
+    if (worst > (g.stride == 1 ? kPatchFloats : 8 * NWAVES * 64 / NP))
+        return ia::fail(IA_ERR_UNSUPPORTED, "conv tile patch of %d positions exceeds the LDS budget", worst);
     g.patch_cap = (worst + 63) & ~63;
     const int per_wave = (NP * g.patch_cap / 64 + NWAVES - 1) / NWAVES;
     if (per_wave <= 2) return launch_jp<NP, TR, FO, FP, WO, WP, 2, WHOLE, APH>(xs, wk, y, scratch, g, e, s);
@@ -831,8 +835,8 @@ extern "C" int ia_split_saturation_count(const void* xs, int planes, int B, int 
 }
 
 // (make_plan / tile selection live in conv_mfma.hip: both forms of a layer share tiles, worker counts and slab sizes)
-int ia_conv2d_plan_tiles(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int* bo, int* bp, int* waves, int* T, int* TO,
-                         int* C, int* T_dp, int* slab_floats);
+int ia_conv2d_plan_tiles(int B, int I, int O, int H, int W, int ksize, int transposed, int form, int stride, int* bo, int* bp, int* waves, int* T,
+                         int* TO, int* C, int* T_dp, int* slab_floats);
 
 struct RgbArgs { const float* w; const float* styles; const float* bias; const float* res; float* out; int n; float clamp; };
 
@@ -840,8 +844,9 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
                         const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                         const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
                         int transposed, int act, float alpha, float gain, float clamp, int ksplit, void* stream, const RgbArgs& rgb,
-                        const float* prelu_alpha = nullptr, int d2s = 0) {
+                        const float* prelu_alpha = nullptr, int d2s = 0, int stride = 1) {
     IA_REQUIRE(xs && wk_split && (y || ys || rgb.out), "xs, wk and at least one output must be device pointers");
+    IA_REQUIRE(stride == 1 || (stride == 2 && !transposed && !d2s && !rgb.out && noise == nullptr), "stride 2: the plain 3x3 convolution with padding 1");
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
     IA_REQUIRE(I % 8 == 0 && O % 8 == 0, "the split form needs I %% 8 == 0 and O %% 8 == 0");
     IA_REQUIRE(wk_exp >= -14 && wk_exp <= 30, "wk_exp is the power of two the weights were scaled by at pack time");
@@ -855,11 +860,14 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
     g.B = B; g.I = I; g.O = O; g.H = H; g.W = W;
     g.GH = transposed ? H + 1 : H; g.GW = transposed ? W + 1 : W;
     g.OH = transposed ? 2 * H + 1 : H; g.OW = transposed ? 2 * W + 1 : W;
+    g.stride = stride;
+    if (stride == 2) { g.GH = g.OH = (H - 1) / 2 + 1; g.GW = g.OW = (W - 1) / 2 + 1; }
     IA_REQUIRE((int64_t)B * O * g.OH * g.OW <= INT32_MAX && (int64_t)B * I * H * W <= INT32_MAX, "tensor is too large");
     IA_REQUIRE(!d2s || (!transposed && O % 32 == 0 && residual == nullptr && !rgb.out && !prelu_alpha),
                "the depth-to-space store takes a stride-1 layer of 4 x O/4 channels without residual / fused ToRGB");
     int bo, bp, waves, slab_floats;
-    const int st_plan = ia_conv2d_plan_tiles(B, I, O, H, W, 3, transposed, 3, &bo, &bp, &waves, &g.T, &g.TO, &g.C, &g.T_dp, &slab_floats);
+    const int st_plan = ia_conv2d_plan_tiles(B, I, O, stride == 2 ? g.GH : H, stride == 2 ? g.GW : W, 3, transposed, 3, stride, &bo, &bp, &waves, &g.T, &g.TO,
+                                             &g.C, &g.T_dp, &slab_floats);
     if (st_plan != IA_OK) return st_plan;
     const bool wide = waves == 8;
     IA_REQUIRE(wide || (transposed && bo == 64), "the split form covers 3x3 layers on the two-stage tiles (large stride-1 layers, stride-2 transposed)");
@@ -902,7 +910,7 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
         return launch_sx<1, false, 2, 2, 2, 4>(x8, w8, y, scratch, g, e, s);
     }
     if (narrow && bo == 32 && transposed) return launch_sx<2, true, 1, 1, 1, 8, true>(x8, w8, y, scratch, g, e, s);
-    const bool aph = (int64_t)H * W >= 128 * 128;      // narrow tiles: antiphase wave groups from 128^2 points (see conv_split_kernel)
+    const bool aph = (int64_t)g.GH * g.GW >= 128 * 128;      // narrow tiles: antiphase wave groups from 128^2 points (see conv_split_kernel)
     if (narrow && bo == 32 && aph) return launch_sx<2, false, 1, 1, 1, 8, true, true>(x8, w8, y, scratch, g, e, s);
     if (narrow && bo == 32) return launch_sx<2, false, 1, 1, 1, 8, true>(x8, w8, y, scratch, g, e, s);
     if (narrow && aph) return launch_sx<2, false, 1, 2, 2, 4, true, true>(x8, w8, y, scratch, g, e, s);
@@ -923,6 +931,16 @@ extern "C" int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_spli
     return conv_sx_impl(xs, planes, wk_split, wk_exp, demod, noise, noise_strength, bias, residual, y, ys, ys_planes, styles_next, scratch, scratch_bytes,
                         B, I, O, H, W, transposed, act, alpha, gain, clamp, ksplit, stream, RgbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1.f},
                         prelu_alpha);
+}
+
+extern "C" int ia_conv2d_down_sx(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* bias, const float* residual,
+                                 float* y, void* ys, int ys_planes, const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O,
+                                 int H, int W, int act, float alpha, const float* prelu_alpha, float gain, float clamp, int ksplit, void* stream) {
+    IA_REQUIRE(!prelu_alpha || act == IA_ACT_LRELU, "prelu_alpha are the per-channel slopes of IA_ACT_LRELU");
+    IA_REQUIRE(H >= 1 && W >= 1 && ((H - 1) / 2 + 1) >= 8 && ((W - 1) / 2 + 1) >= 8, "the stride-2 form takes outputs from 8^2 up");
+    return conv_sx_impl(xs, planes, wk_split, wk_exp, demod, nullptr, nullptr, bias, residual, y, ys, ys_planes, styles_next, scratch, scratch_bytes,
+                        B, I, O, H, W, 0, act, alpha, gain, clamp, ksplit, stream, RgbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1.f},
+                        prelu_alpha, 0, 2);
 }
 
 extern "C" int ia_conv2d_mfma_sx_rgb(const void* xs, int planes, const void* wk_split, int wk_exp, const float* demod, const float* noise,

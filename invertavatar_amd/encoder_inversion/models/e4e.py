@@ -6,10 +6,11 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
-from torch.nn import Conv2d, Module
+from torch.nn import Module
 
 from ...training.networks_stylegan2 import FullyConnectedLayer
 from .helpers import irse50_trunk, run_trunk
+from .layers import Conv2d
 
 
 class GradualStyleBlock(Module):
@@ -43,8 +44,8 @@ class Encoder4Editing(Module):
         self.middle_ind = 7
         self.styles = nn.ModuleList([GradualStyleBlock(512, 512, 16 if i < self.coarse_ind else 32 if i < self.middle_ind else 64)
                                      for i in range(n_styles)])
-        self.latlayer1 = nn.Conv2d(256, 512, kernel_size=1, stride=1, padding=0)
-        self.latlayer2 = nn.Conv2d(128, 512, kernel_size=1, stride=1, padding=0)
+        self.latlayer1 = Conv2d(256, 512, kernel_size=1, stride=1, padding=0)
+        self.latlayer2 = Conv2d(128, 512, kernel_size=1, stride=1, padding=0)
 
     def forward(self, x):
         _, (c1, c2, c3) = run_trunk(self.body, self.input_layer(x), (6, 20, 23))

@@ -3,7 +3,9 @@ Module and parameter names follow the reference so that its checkpoints load by 
 from collections import namedtuple
 
 import torch
-from torch.nn import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, MaxPool2d, Module, PReLU, ReLU, Sequential, Sigmoid
+from torch.nn import AdaptiveAvgPool2d, BatchNorm2d, MaxPool2d, Module, PReLU, ReLU, Sequential, Sigmoid
+
+from .layers import Conv2d
 
 
 class Flatten(Module):

@@ -10,6 +10,8 @@ import math
 import torch
 import torch.nn as nn
 
+from ..layers import Conv2d
+
 
 HIP_ATTENTION = True      # device inference: softmax(QK^T)V of the 1024-dim / 4-head blocks through ia_attention
 
@@ -94,7 +96,7 @@ class Attention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.sr_ratio = sr_ratio
         if sr_ratio > 1:
-            self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.sr = Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = nn.LayerNorm(dim)
         self.apply(_init_weights)
 
@@ -142,7 +144,7 @@ class OverlapPatchEmbed(nn.Module):
         self.img_size, self.patch_size = _pair(img_size), _pair(patch_size)
         self.H, self.W = self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1]
         self.num_patches = self.H * self.W
-        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=stride,
+        self.proj = Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=stride,
                               padding=(self.patch_size[0] // 2, self.patch_size[1] // 2))
         self.norm = nn.LayerNorm(embed_dim)
         self.apply(_init_weights)
@@ -229,7 +231,7 @@ class transformer_block(nn.Module):
         self.patch_embed = OverlapPatchEmbed(img_size=0, stride=2, in_chans=in_chans, embed_dim=embed_dim)
         self.ViT = nn.ModuleList([Block(dim=embed_dim, num_heads=4, mlp_ratio=2, sr_ratio=1) for _ in range(num_vit)])
         self.pixel_shuffle = nn.PixelShuffle(upscale_factor=2)
-        self.mlp = nn.Conv2d(embed_dim // 4, in_chans, kernel_size=1)
+        self.mlp = Conv2d(embed_dim // 4, in_chans, kernel_size=1)
         self.norm = nn.LayerNorm(embed_dim)
 
     def forward(self, f):

@@ -10,12 +10,19 @@ arithmetic the generator's large layers use):
     shift: the zero padding then applies to the normalised tensor, as in the reference);
   * PReLU runs in conv1's epilogue (per-channel slopes), and conv1 hands its result to conv2 in split format, never as fp32;
   * the second BatchNorm is conv2's epilogue (scale = ``demod``, shift = ``bias`` per output channel);
-  * a stride-2 conv2 is evaluated at stride 1 and sub-sampled (``y[..., ::2, ::2]`` is exactly the stride-2 result with padding 1):
-    4 of the 48 convolutions of a trunk, +22 % FLOPs, no second kernel family.
+  * a stride-2 conv2 (4 of the 48 convolutions of a trunk) runs on ``ia_conv2d_down_sx``: the same tiles with the point grid over every
+    second pixel of the input window (r05; r03 / r04 evaluated it at stride 1 and sub-sampled -- still the route of the shapes the
+    planner refuses).
 
-The squeeze-and-excitation gate, the shortcut and the residual add stay ATen element-wise / tiny GEMM launches.  Units in TRAIN
-mode (batch statistics: the e4e trunk under eval_seq.py's module modes), CPU tensors, autograd and layers below 32^2 (fewer points
-than the 8-wave tile needs) take the unit's own ``torch.nn`` forward.
+Units in TRAIN mode (batch statistics: the e4e trunk under eval_seq.py's module modes) take the same route: the first BatchNorm's
+affine map comes from the batch statistics of the unit's input (with the running-statistics update torch.nn.BatchNorm2d makes), the
+second one is applied to conv2's fp32 result by the library's batch-norm kernel.  Layers from 8^2 up are covered (the planner cuts
+the 8^2 / 16^2 layers between stream-K workers, conv_mfma.hip make_plan); CPU tensors and autograd take the unit's own ``torch.nn``
+forward.
+
+``conv_forward`` is the route of every other ``Conv2d`` of the encoders (layers.Conv2d): 1x1 layers and 3x3 layers with a handful of
+input channels on the fp32 MFMA kernel (``ia_conv2d_mfma``; a stride-s 1x1 layer reads the sub-sampled input), 3x3 stride-1 layers
+on ``ia_conv2d_mfma_sx``, 3x3 stride-2 layers on ``ia_conv2d_down_sx``.
 """
 import torch
 
@@ -23,39 +30,81 @@ from ... import _runtime, hipops
 
 
 class _UnitPack(_runtime.DeviceCache):
-    """Kernel-side parameters of one residual unit, rebuilt when a parameter / buffer changes."""
+    """Kernel-side parameters of one residual unit, rebuilt when a parameter / buffer changes: packed weights and PReLU slopes under
+    one key, the eval-mode affine maps of the two BatchNorms under another (train-mode calls move the running statistics)."""
 
     def __init__(self):
-        self.key = None
+        self.key = self.bn_key = None
 
     def get(self, unit):
-        bn1, conv1, prelu, conv2, bn2 = unit.res_layer[0], unit.res_layer[1], unit.res_layer[2], unit.res_layer[3], unit.res_layer[4]
-        tensors = (bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, conv1.weight, prelu.weight, conv2.weight, bn2.weight, bn2.bias,
-                   bn2.running_mean, bn2.running_var)
-        key = tuple((t.data_ptr(), t._version) for t in tensors) + (conv1.weight.device,)
+        conv1, prelu, conv2 = unit.res_layer[1], unit.res_layer[2], unit.res_layer[3]
+        key = tuple((t.data_ptr(), t._version) for t in (conv1.weight, prelu.weight, conv2.weight)) + (conv1.weight.device,)
         if key != self.key:
-            def affine(bn):
-                a = (bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps))
-                return a.contiguous(), (bn.bias.detach().float() - bn.running_mean.detach().float() * a).contiguous()
-            self.a1, self.c1 = affine(bn1)
-            self.a2, self.c2 = affine(bn2)
             self.w1 = hipops.pack_conv_weight_split(conv1.weight.detach().float())
             self.w2 = hipops.pack_conv_weight_split(conv2.weight.detach().float())
             self.slopes = prelu.weight.detach().float().contiguous()
             self.key = key
         return self
 
+    def eval_affines(self, unit):
+        bn1, bn2 = unit.res_layer[0], unit.res_layer[4]
+        tensors = (bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if key != self.bn_key:
+            self.a1, self.c1 = _affine(bn1, bn1.running_mean, bn1.running_var)
+            self.a2, self.c2 = _affine(bn2, bn2.running_mean, bn2.running_var)
+            self.bn_key = key
+        return self.a1, self.c1, self.a2, self.c2
+
+
+def _affine(bn, mean, var):
+    a = bn.weight.detach().float() * torch.rsqrt(var.detach().float() + bn.eps)
+    return a.contiguous(), (bn.bias.detach().float() - mean.detach().float() * a).contiguous()
+
+
+def batch_norm_affine(bn, x):
+    """(scale, shift) per channel of the map ``bn`` applies to ``x``.  Train mode (or no running statistics): batch statistics, and
+    the running-statistics update a train-mode call of torch.nn.BatchNorm2d makes; eval mode: the running statistics."""
+    if bn.training or not bn.track_running_stats:
+        var, mean = torch.var_mean(x, dim=(0, 2, 3), unbiased=False)
+        if bn.track_running_stats and bn.running_mean is not None:
+            n = x.numel() / x.shape[1]
+            bn.num_batches_tracked += 1
+            # momentum=None is the cumulative moving average: factor 1 / num_batches_tracked (torch/nn/modules/batchnorm.py)
+            factor = bn.momentum if bn.momentum is not None else 1.0 / bn.num_batches_tracked.to(mean.dtype)
+            bn.running_mean.lerp_(mean, factor)
+            bn.running_var.lerp_(var * (n / max(n - 1, 1)), factor)
+        return _affine(bn, mean, var)
+    return _affine(bn, bn.running_mean, bn.running_var)
+
+
+def _rows(v, b):
+    return v.unsqueeze(0).expand(b, -1).contiguous()
+
+
+def sx_size_ok(i, o, h, w):
+    """3x3 stride-1 shapes ia_conv2d_mfma_sx takes: the 8-wave tile from 32^2 points and 64 outputs up, and whatever the library's own
+    rule adds (ia_conv2d_sx_supported: 128 outputs and 8^2 points up -- the stream-K plans of the low-resolution layers)."""
+    if i % 8 or o % 8 or w > 320:
+        return False
+    return (o >= 64 and h * w >= 1024) or hipops.conv_sx_supported(i, o, h, w, 3, False)
+
+
+DOWN_TILES = True     # stride-2 3x3 layers on ia_conv2d_down_sx (False: at stride 1 and sub-sampled, the r03 / r04 route)
+
 
 def unit_supported(unit, x):
     """True when the unit's two 3x3 convolutions can run on ia_conv2d_mfma_sx for this input."""
-    if not (x.is_cuda and x.dtype == torch.float32 and not unit.training and not torch.is_grad_enabled()):
+    if not (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()):
+        return False
+    if unit.training and x.shape[0] * x.shape[2] * x.shape[3] <= 1:       # torch.nn.BatchNorm2d raises on one value per channel
         return False
     conv1, conv2 = unit.res_layer[1], unit.res_layer[3]
     i, o = conv1.in_channels, conv1.out_channels
     h, w = x.shape[-2:]
     plain = all(c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == 'zeros' for c in (conv1, conv2))
     return (plain and conv1.kernel_size == (3, 3) and conv2.kernel_size == (3, 3) and conv1.stride == (1, 1) and conv2.stride in ((1, 1), (2, 2))
-            and conv1.bias is None and conv2.bias is None and i % 8 == 0 and o % 8 == 0 and o >= 64 and h * w >= 1024 and w <= 320
+            and conv1.bias is None and conv2.bias is None and sx_size_ok(i, o, h, w) and sx_size_ok(o, o, h, w)
             and conv2.in_channels == o and conv2.out_channels == o)
 
 
@@ -65,15 +114,25 @@ def unit_forward(unit, x):
     if not hasattr(pack, 'trunk'):
         pack.trunk = _UnitPack()
     p = pack.trunk.get(unit)
-    b, c, h, w = x.shape
+    bn1, bn2 = unit.res_layer[0], unit.res_layer[4]
+    b = x.shape[0]
     x = x.contiguous()
     stride = unit.res_layer[3].stride[0]
-    xs = hipops.act_split(x, p.a1.unsqueeze(0).expand(b, -1).contiguous(), shift=p.c1.unsqueeze(0).expand(b, -1).contiguous())
+    batch_stats = bn1.training or bn2.training or not (bn1.track_running_stats and bn2.track_running_stats)
+    a1, c1 = batch_norm_affine(bn1, x) if batch_stats else p.eval_affines(unit)[:2]
+    xs = hipops.act_split(x, _rows(a1, b), shift=_rows(c1, b))
     us = hipops.conv2d_mfma_sx(xs, p.w1, act='lrelu', prelu=p.slopes, want_f32=False, want_split=True)
-    o = p.a2.numel()
-    v = hipops.conv2d_mfma_sx(us, p.w2, demod=p.a2.unsqueeze(0).expand(b, -1).contiguous(), bias=p.c2, act='linear')
-    if stride == 2:
-        v = v[:, :, ::2, ::2]
+    conv2, sub = hipops.conv2d_mfma_sx, stride == 2
+    if stride == 2 and DOWN_TILES and hipops.conv_down_supported(b, us.shape[1], us.shape[1], *us.shape[2:]):
+        conv2, sub = hipops.conv2d_down_sx, False
+    if batch_stats:
+        v = conv2(us, p.w2, act='linear')
+        v = bn2(v[:, :, ::2, ::2].contiguous() if sub else v)
+    else:
+        a2, c2 = p.eval_affines(unit)[2:]
+        v = conv2(us, p.w2, demod=_rows(a2, b), bias=c2, act='linear')
+        if sub:
+            v = v[:, :, ::2, ::2]
     return se_tail(unit, v, x)
 
 
@@ -98,10 +157,10 @@ def se_tail(unit, v, x):
 
 # ------------------------------------------------------------------ plain 3x3 convolutions of the UNet decoders / heads
 def conv_supported(conv, h, w):
-    """A torch.nn.Conv2d(3x3, stride 1, padding 1) whose shape ia_conv2d_mfma_sx takes (8-wave tile: >= 1024 points, >= 64 outputs)."""
+    """A torch.nn.Conv2d(3x3, stride 1, padding 1) whose shape ia_conv2d_mfma_sx takes (sx_size_ok)."""
     return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
-            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros' and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0
-            and conv.out_channels >= 64 and h * w >= 1024 and w <= 320)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
+            and sx_size_ok(conv.in_channels, conv.out_channels, h, w))
 
 
 def _device_path(x):
@@ -140,20 +199,8 @@ def double_conv_forward(dc, x):
     bn, conv1, p1, conv2, p2, p3 = dc.double_conv
     x = x.contiguous()
     b = x.shape[0]
-    if bn.training or not bn.track_running_stats:
-        var, mean = torch.var_mean(x, dim=(0, 2, 3), unbiased=False)
-        if bn.track_running_stats and bn.running_mean is not None:  # the side effect of a train-mode call (torch.nn.BatchNorm2d)
-            n = x.numel() / x.shape[1]
-            bn.num_batches_tracked += 1
-            # momentum=None is the cumulative moving average: factor 1 / num_batches_tracked (torch/nn/modules/batchnorm.py)
-            factor = bn.momentum if bn.momentum is not None else 1.0 / bn.num_batches_tracked.to(mean.dtype)
-            bn.running_mean.lerp_(mean, factor)
-            bn.running_var.lerp_(var * (n / max(n - 1, 1)), factor)
-    else:
-        var, mean = bn.running_var, bn.running_mean
-    a = bn.weight.detach().float() * torch.rsqrt(var.float() + bn.eps)
-    c = bn.bias.detach().float() - mean.float() * a
-    xs = hipops.act_split(x, a.unsqueeze(0).expand(b, -1).contiguous(), shift=c.unsqueeze(0).expand(b, -1).contiguous())
+    a, c = batch_norm_affine(bn, x)
+    xs = hipops.act_split(x, _rows(a, b), shift=_rows(c, b))
     us = conv3x3(xs, conv1, slopes=p1.weight.detach().float().contiguous(), want_split=True)
     a2, a3 = p2.weight.detach().float(), p3.weight.detach().float()
     return conv3x3(us, conv2, slopes=torch.where(a2 > 0, a2 * a3, a2).contiguous())
@@ -168,3 +215,69 @@ def conv_lrelu_conv_supported(seq, x):
 def conv_lrelu_conv_forward(seq, xs):
     """`xs`: the SplitAct of the head's input (shared by the scale and the shift head)."""
     return conv3x3(conv3x3(xs, seq[0], alpha=seq[1].negative_slope, want_split=True), seq[2])
+
+
+# ------------------------------------------------------------------ every other Conv2d of the encoders (layers.Conv2d)
+FP32_KERNEL_MAX_IN = 32     # 3x3 layers with at most this many input channels run on the fp32 MFMA kernel (image / UV input layers)
+
+
+def _conv_route(conv, x):
+    """Which kernel takes this torch.nn.Conv2d on this input: 'gemm' (1x1, any stride, no padding), 'patch' (k x k with stride k, no
+    padding: a 1x1 layer on the space-to-depth image), 'sx' (3x3 stride 1 / 2, padding 1, split-format tile), 'f32' (3x3 stride 1 / 2,
+    padding 1, few input channels) or None (library)."""
+    if not (_device_path(x) and x.dim() == 4 and conv.groups == 1 and conv.dilation == (1, 1) and conv.padding_mode == 'zeros'
+            and conv.weight.dtype == torch.float32 and conv.stride[0] == conv.stride[1]):
+        return None
+    b, i, h, w = x.shape
+    o, s = conv.out_channels, conv.stride[0]
+    if conv.kernel_size == (1, 1) and conv.padding == (0, 0):
+        oh, ow = (h - 1) // s + 1, (w - 1) // s + 1
+        return 'gemm' if oh * ow >= 16 else None       # (a 1x1 image is a matrix product: the squeeze-and-excitation gates have their own kernel)
+    if conv.kernel_size == (s, s) and conv.padding == (0, 0) and s > 1:
+        return 'patch' if (h // s) * (w // s) >= 16 else None
+    if conv.kernel_size == (3, 3) and conv.padding == (1, 1) and s in (1, 2) and (s == 1 or (h % 2 == 0 and w % 2 == 0)):
+        if sx_size_ok(i, o, h, w):
+            return 'sx'
+        if i <= FP32_KERNEL_MAX_IN and h * w >= 1024:
+            return 'f32'
+    return None
+
+
+def conv_covered(conv, x):
+    return _conv_route(conv, x) is not None
+
+
+def _packed_f32(conv, as_1x1=False):
+    st = _runtime.state(conv)
+    key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.device)
+    if getattr(st, 'wf_key', None) != key:
+        w = conv.weight.detach().float()
+        st.wf = hipops.pack_conv_weight(w.reshape(w.shape[0], -1, 1, 1) if as_1x1 else w)
+        st.wf_key = key
+    return st.wf
+
+
+def conv_forward(conv, x):
+    """torch.nn.Conv2d.forward on the HIP kernels (see _conv_route).  A stride-2 3x3 layer with padding 1 on an even image is the
+    stride-1 result at the even positions (the route of the shapes ia_conv2d_down_sx does not take)."""
+    route = _conv_route(conv, x)
+    s = conv.stride[0]
+    bias = None if conv.bias is None else conv.bias.detach().float()
+    if route == 'gemm':
+        xin = x if s == 1 else x[:, :, ::s, ::s]
+        return hipops.conv2d_mfma(xin.contiguous(), _packed_f32(conv), bias=bias, ksize=1)
+    if route == 'patch':        # channels of the space-to-depth image in the weight's own (i, ky, kx) order
+        b, i, h, w = x.shape
+        oh, ow = h // s, w // s
+        xin = x[:, :, :oh * s, :ow * s].reshape(b, i, oh, s, ow, s).permute(0, 1, 3, 5, 2, 4).reshape(b, i * s * s, oh, ow)
+        return hipops.conv2d_mfma(xin.contiguous(), _packed_f32(conv, as_1x1=True), bias=bias, ksize=1)
+    if route == 'sx':
+        xs = hipops.act_split(x.contiguous())
+        if s == 2 and DOWN_TILES and hipops.conv_down_supported(x.shape[0], conv.in_channels, conv.out_channels, *x.shape[-2:]):
+            return hipops.conv2d_down_sx(xs, packed_weight(conv), bias=bias)
+        y = hipops.conv2d_mfma_sx(xs, packed_weight(conv), bias=bias)
+    elif route == 'f32':
+        y = hipops.conv2d_mfma(x.contiguous(), _packed_f32(conv), bias=bias, ksize=3)
+    else:
+        raise RuntimeError('conv_forward: this layer is not covered (ask conv_covered first)')
+    return y if s == 1 else y[:, :, ::2, ::2].contiguous()

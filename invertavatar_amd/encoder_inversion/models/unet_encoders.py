@@ -13,9 +13,10 @@ from torch.nn import Module
 import torch.nn.functional as F
 
 from .helpers import irse50_trunk, run_trunk
+from .layers import Conv2d
 
 
-HIP_GRU_CONVS = True      # ConvGRU cells from 32^2 up: their convolutions through ia_conv2d_mfma_sx instead of the library
+HIP_GRU_CONVS = True      # ConvGRU cells, DoubleConv and CS-SFT heads: their convolutions through ia_conv2d_mfma_sx instead of the library
 
 
 class ConvGRU(torch.nn.Module):
@@ -24,8 +25,8 @@ class ConvGRU(torch.nn.Module):
     def __init__(self, channels: int, kernel_size: int = 3, padding: int = 1, out_act_prelu=False):
         super().__init__()
         self.channels = channels
-        self.ih = torch.nn.Sequential(nn.Conv2d(channels * 2, channels * 2, kernel_size, padding=padding), torch.nn.Sigmoid())
-        self.hh = torch.nn.Sequential(nn.Conv2d(channels * 2, channels, kernel_size, padding=padding),
+        self.ih = torch.nn.Sequential(Conv2d(channels * 2, channels * 2, kernel_size, padding=padding), torch.nn.Sigmoid())
+        self.hh = torch.nn.Sequential(Conv2d(channels * 2, channels, kernel_size, padding=padding),
                                       nn.PReLU(channels) if out_act_prelu else torch.nn.Tanh())
 
     def _fused(self, x):
@@ -35,13 +36,15 @@ class ConvGRU(torch.nn.Module):
 
     def _hip_convs(self, x):
         """The cell's two 3x3 convolutions on ia_conv2d_mfma_sx (fp32 products from fp16 hi / lo pairs) instead of the library:
-        from 32^2 up (the 8-wave tile needs 1024 points), channel counts in units of 8.  Packed weights are cached per cell."""
+        the sizes trunk_hip.sx_size_ok names (8^2 up for the cells of the model), channel counts in units of 8.  Packed weights are
+        cached per cell."""
         conv_ih, conv_hh = self.ih[0], self.hh[0]
         c2, h, w = conv_ih.in_channels, x.shape[-2], x.shape[-1]
         plain = all(c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride == (1, 1) and c.dilation == (1, 1) and c.groups == 1
                     and c.padding_mode == 'zeros' and c.bias is not None for c in (conv_ih, conv_hh))
-        if not (HIP_GRU_CONVS and plain and c2 % 16 == 0 and conv_hh.in_channels == c2 and self.channels >= 64
-                and h * w >= 1024 and w <= 320):
+        from . import trunk_hip
+        if not (HIP_GRU_CONVS and plain and c2 % 16 == 0 and conv_hh.in_channels == c2 and trunk_hip.sx_size_ok(c2, c2, h, w)
+                and trunk_hip.sx_size_ok(c2, self.channels, h, w)):
             return None
         from ... import _runtime, hipops
         st = _runtime.state(self)
@@ -107,8 +110,8 @@ class DoubleConv(nn.Module):
         super().__init__()
         self.double_conv = nn.Sequential(
             nn.InstanceNorm2d(in_channels) if use_instnorm else nn.BatchNorm2d(in_channels),
-            nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1), nn.PReLU(out_channels),
-            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1), nn.PReLU(out_channels), nn.PReLU(out_channels))
+            Conv2d(in_channels, out_channels, kernel_size=3, padding=1), nn.PReLU(out_channels),
+            Conv2d(out_channels, out_channels, kernel_size=3, padding=1), nn.PReLU(out_channels), nn.PReLU(out_channels))
 
     def forward(self, x):
         from . import trunk_hip
@@ -179,10 +182,10 @@ class TriPlanefeat_Encoder(_UNetBase):
         super().__init__()
         self.seq2seq = seq2seq
         self._build(inp_ch, res, use_gru)
-        self.outconv0 = nn.Conv2d(384, 32, kernel_size=1, padding=0)
-        self.outconv1 = nn.Conv2d(384, 512, kernel_size=1, padding=0)
-        self.outconv2 = nn.Conv2d(256, 512, kernel_size=1, padding=0)
-        self.outconv3 = nn.Conv2d(96, 256, kernel_size=1, padding=0)
+        self.outconv0 = Conv2d(384, 32, kernel_size=1, padding=0)
+        self.outconv1 = Conv2d(384, 512, kernel_size=1, padding=0)
+        self.outconv2 = Conv2d(256, 512, kernel_size=1, padding=0)
+        self.outconv3 = Conv2d(96, 256, kernel_size=1, padding=0)
 
     def forward_onlyEncoder(self, x):
         assert x.dim() == 5
@@ -216,16 +219,16 @@ class TriPlaneSFTfeat_Encoder(_UNetBase):
         self.sft_half = sft_half
         self._build(inp_ch, res, use_gru)
         self.head = nn.PixelShuffle(upscale_factor=2)
-        self.final_head = nn.Sequential(nn.Conv2d(24, 96, kernel_size=3, padding=1), nn.PReLU(96),
-                                        nn.Conv2d(96, 96, kernel_size=3, padding=1), nn.PReLU(96))
+        self.final_head = nn.Sequential(Conv2d(24, 96, kernel_size=3, padding=1), nn.PReLU(96),
+                                        Conv2d(96, 96, kernel_size=3, padding=1), nn.PReLU(96))
         self.block_resolutions = [2 ** i for i in range(int(np.log2(16)), int(np.log2(256)) + 1)]
         gen_channels = {res: min(32768 // res, 512) for res in self.block_resolutions}
         dec_channels = {16: 512, 32: 384, 64: 256, 128: 96, 256: 96}
         for res in self.block_resolutions:
             ch, out = dec_channels[res], gen_channels[res] // 2 if sft_half else gen_channels[res]
             for kind in ('scale', 'shift'):
-                setattr(self, f'condition_{kind}{res}', nn.Sequential(nn.Conv2d(ch, ch, 3, 1, 1), nn.LeakyReLU(0.2, True),
-                                                                     nn.Conv2d(ch, out, 3, 1, 1)))
+                setattr(self, f'condition_{kind}{res}', nn.Sequential(Conv2d(ch, ch, 3, 1, 1), nn.LeakyReLU(0.2, True),
+                                                                     Conv2d(ch, out, 3, 1, 1)))
 
     def _sft(self, res, t):
         from . import trunk_hip

@@ -373,6 +373,56 @@ def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=Non
     return y if want_f32 else out_s
 
 
+def conv_down_supported(b, i, o, h, w):
+    """Shapes ia_conv2d_down_sx covers (3x3, stride 2, padding 1 on an h x w input): asks the library's planner."""
+    ks, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)
+    return _lib.load().ia_conv2d_down_plan(int(b), int(i), int(o), int(h), int(w), ctypes.byref(ks), ctypes.byref(nbytes)) == 0
+
+
+def conv2d_down_sx(xs, wk, demod=None, bias=None, residual=None, act='linear', alpha=0.2, gain=1.0, clamp=None, want_f32=True, split_for=None,
+                   styles_next=None, split_planes=2, prelu=None, want_split=None):
+    """ia_conv2d_down_sx: 3x3 convolution with stride 2 and padding 1 of a SplitAct -> [B, O, (H-1)//2+1, (W-1)//2+1]; results as
+    conv2d_mfma_sx returns them."""
+    if not isinstance(xs, SplitAct):
+        raise RuntimeError('xs must be a SplitAct (hipops.act_split or a producing layer)')
+    if xs.planes == 2 and not (wk.dtype == torch.float16 and wk.dim() == 5 and wk.shape[0] == 2 and hasattr(wk, 'wk_exp')):
+        raise RuntimeError('wk must come from pack_conv_weight_split')
+    if xs.planes == 1 and not (wk.dtype == torch.float16 and wk.dim() == 4):
+        raise RuntimeError('a one-plane input takes the weights of pack_conv_weight_h')
+    b, i, h, w = xs.shape
+    o = wk.shape[-2]
+    if wk.shape[-4] != 9 or wk.shape[-3] * 8 != i:
+        raise RuntimeError(f'packed weight {tuple(wk.shape)} does not match 3x3, in-channels {i}')
+    if want_split is None:
+        want_split = split_for is not None or styles_next is not None
+    if prelu is not None and (_f32c(prelu, 'prelu').numel() != o or act != 'lrelu'):
+        raise RuntimeError('prelu: [O] per-channel slopes, with act="lrelu"')
+    for name, t in (('demod', demod), ('bias', bias), ('residual', residual), ('styles_next', styles_next)):
+        if t is not None:
+            _f32c(t, name)
+    lib = _lib.load()
+    plan_s, plan_bytes = ctypes.c_int(0), ctypes.c_size_t(0)
+    _lib.check(lib.ia_conv2d_down_plan(b, i, o, h, w, ctypes.byref(plan_s), ctypes.byref(plan_bytes)), 'ia_conv2d_down_plan')
+    nbytes, ksplit = plan_bytes.value, plan_s.value
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dev = xs.data.device
+    y = torch.empty(b, o, oh, ow, device=dev, dtype=torch.float32) if want_f32 else None
+    ys = torch.empty(b, split_planes, o // 8, oh, ow, 8, device=dev, dtype=torch.float16) if want_split else None
+    scratch = _scratch_buffer(dev, nbytes) if nbytes else None
+    flops = 2.0 * b * oh * ow * i * o * 9
+    traffic = (2.0 * (xs.data.numel() + wk.numel()) + 4.0 * (y.numel() if want_f32 else 0) + 2.0 * (ys.numel() if want_split else 0)
+               + 4.0 * (residual.numel() if residual is not None else 0))
+    with torch.cuda.device(dev), _Timed('conv2d_mfma_k3', flops, traffic, f'B{b} I{i} O{o} {h}x{w} s2 G{ksplit} ' + ('f16x3 dma' if xs.planes == 2 else 'f16 dma')):
+        st = lib.ia_conv2d_down_sx(_p(xs.data), int(xs.planes), _p(wk), int(getattr(wk, 'wk_exp', 0)), _p(demod), _p(bias), _p(residual), _p(y), _p(ys),
+                                   int(split_planes), _p(styles_next), _p(scratch), nbytes, b, i, o, h, w, ACT_ID[act], float(alpha), _p(prelu),
+                                   float(gain), float(-1 if clamp is None else clamp), int(ksplit), _lib.stream_ptr(dev))
+    _lib.check(st, 'ia_conv2d_down_sx')
+    out_s = SplitAct(ys, o, split_for) if want_split else None
+    if want_f32 and want_split:
+        return y, out_s
+    return y if want_f32 else out_s
+
+
 def upconv_rows_supported(b, i, o, h, w):
     """Shapes ia_upconv2d_rows_sx covers (the row-phase form of the transposed 3x3 convolution): asks the library."""
     nbytes = ctypes.c_size_t(0)

@@ -319,6 +319,51 @@ def test_split_dma_convolution_on_the_small_layers(b, i, o, res, tr):
     assert torch.equal(got_s.data[:, 1].permute(0, 1, 4, 2, 3).reshape(got.shape), lo)
 
 
+@pytest.mark.parametrize('b,i,o,h,w', [(1, 512, 512, 32, 32), (1, 512, 512, 64, 64), (1, 512, 512, 16, 16), (4, 256, 256, 64, 64), (4, 64, 64, 256, 256),
+                                       (1, 128, 128, 256, 256), (4, 128, 128, 128, 128), (2, 64, 128, 33, 47), (1, 72, 64, 100, 36)])
+def test_stride_2_convolution_on_the_stride_1_tiles(b, i, o, h, w):
+    """ia_conv2d_down_sx (r05): 3x3, stride 2, padding 1 -- the stride-1 tiles with the point grid over every second pixel of the input
+    window (wide tile whole / stream-K, narrow whole tiles where the window does not fit beside 128 channels of weights, odd sizes) --
+    against the fp64 convolution of the operands the kernel sees, with the epilogue terms the encoders use (BatchNorm scale / shift,
+    per-channel PReLU, residual) and the split second output; and against the stride-1 launch sub-sampled (the r04 route)."""
+    assert hipops.conv_down_supported(b, i, o, h, w)
+    g = torch.Generator(device='cuda').manual_seed(23 + i + h)
+    x = torch.randn(b, i, h, w, device='cuda', generator=g) * 2
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g)
+    scale = torch.rand(b, o, device='cuda', generator=g) + 0.5
+    bias = torch.randn(o, device='cuda', generator=g)
+    slopes = torch.rand(o, device='cuda', generator=g) * 0.5
+    sn = torch.rand(b, o, device='cuda', generator=g) + 0.5
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    res = torch.randn(b, o, oh, ow, device='cuda', generator=g)
+    xs = hipops.act_split(x)
+    wk = hipops.pack_conv_weight_split(wt)
+    got, got_s = hipops.conv2d_down_sx(xs, wk, demod=scale, bias=bias, residual=res, act='lrelu', prelu=slopes, gain=1.1, styles_next=sn)
+    ref = torch.nn.functional.conv2d(xs.float().double(), wt.double(), stride=2, padding=1) * scale.double()[:, :, None, None] + bias.double()[None, :, None, None]
+    ref = torch.where(ref > 0, ref, ref * slopes.double()[None, :, None, None]) * 1.1 + res.double()
+    assert got.shape == ref.shape == (b, o, oh, ow)
+    err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f'stride-2 {i}->{o} @{h}x{w} B{b}: {err:.2e} of max |ref| (vs fp64)')
+    assert err <= 3e-6
+    hi, lo = _split_reference(got, sn)
+    assert torch.equal(got_s.data[:, 0].permute(0, 1, 4, 2, 3).reshape(got.shape), hi)
+    assert torch.equal(got_s.data[:, 1].permute(0, 1, 4, 2, 3).reshape(got.shape), lo)
+    assert torch.equal(got, hipops.conv2d_down_sx(xs, wk, demod=scale, bias=bias, residual=res, act='lrelu', prelu=slopes, gain=1.1))   # deterministic
+    plain = hipops.conv2d_down_sx(xs, wk)
+    if hipops.conv_sx_supported(i, o, h, w, 3, False) or (o >= 64 and h * w >= 1024):
+        full = hipops.conv2d_mfma_sx(xs, wk)[:, :, ::2, ::2]
+        assert (plain - full).abs().max().item() <= 3e-6 * full.abs().max().item()
+
+
+def test_stride_2_convolution_refuses_what_it_does_not_cover():
+    assert not hipops.conv_down_supported(1, 64, 32, 64, 64)        # fewer than 64 output channels: no 8-wave tile
+    assert not hipops.conv_down_supported(1, 512, 512, 8, 8)        # 4^2 outputs
+    assert not hipops.conv_down_supported(1, 60, 64, 64, 64)        # channel octets
+    xs = hipops.act_split(torch.randn(1, 64, 64, 64, device='cuda'))
+    with pytest.raises(RuntimeError):
+        hipops.conv2d_down_sx(xs, hipops.pack_conv_weight_split(torch.randn(32, 64, 3, 3, device='cuda')))
+
+
 @pytest.mark.parametrize('b,i,o,res,planes', [(1, 32, 256, 128, 2), (2, 16, 256, 64, 2), (1, 8, 128, 128, 2), (1, 32, 256, 128, 1)])
 def test_composed_upfir_layer_equals_the_two_launch_route(b, i, o, res, planes):
     """ia_upconv2d_fir_sx (transposed convolution + resample FIR + noise + bias + lrelu as ONE stride-1 launch on the composed weight,

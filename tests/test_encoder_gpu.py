@@ -40,43 +40,91 @@ def test_convgru_cell_kernels_match_the_torch_cell(prelu):
     assert (one.cpu() - want[:, 0]).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize('in_c,depth,stride,res', [(64, 64, 2, 64), (64, 128, 2, 48), (128, 128, 1, 32), (256, 256, 1, 32)])
-def test_residual_unit_on_hip_convolutions_matches_torch(in_c, depth, stride, res):
-    """bottleneck_IR_SE in eval mode: BatchNorm folded into the staging / epilogue of ia_conv2d_mfma_sx, PReLU in the epilogue,
-    stride 2 by sub-sampling -- against the module's own torch.nn forward in fp64 on the CPU (helpers.py:102-124)."""
-    from invertavatar_amd.encoder_inversion.models import helpers, trunk_hip
-    torch.manual_seed(in_c + depth + stride)
-    unit = helpers.bottleneck_IR_SE(in_c, depth, stride).requires_grad_(False).eval()
+def _randomise_unit(unit):
     for m in unit.modules():                       # non-trivial BatchNorm statistics and PReLU slopes
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.normal_(0, 0.5); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3)
         if isinstance(m, torch.nn.PReLU):
             m.weight.uniform_(0.05, 0.4)
+
+
+@pytest.mark.parametrize('in_c,depth,stride,res', [(64, 64, 2, 64), (64, 128, 2, 48), (128, 128, 1, 32), (256, 256, 1, 32), (512, 512, 1, 16),
+                                                  (256, 512, 2, 32)])
+def test_residual_unit_on_hip_convolutions_matches_torch(in_c, depth, stride, res):
+    """bottleneck_IR_SE: BatchNorm folded into the staging / epilogue of ia_conv2d_mfma_sx, PReLU in the epilogue, stride 2 by
+    sub-sampling -- against the module's own torch.nn forward in fp64 on the CPU (helpers.py:102-124).  Eval mode, then TRAIN mode
+    (batch statistics, as eval_seq.py runs the e4e trunk): result and running statistics."""
+    import copy
+    from invertavatar_amd.encoder_inversion.models import helpers, layers, trunk_hip
+    torch.manual_seed(in_c + depth + stride)
+    unit = helpers.bottleneck_IR_SE(in_c, depth, stride).requires_grad_(False).eval()
+    _randomise_unit(unit)
     x = torch.randn(3, in_c, res, res)
-    want = unit.double()(x.double()).float()
-    unit = unit.float().cuda()
+    ref = copy.deepcopy(unit).double()
+    want = ref(x.double()).float()
+    unit = unit.cuda()
     with torch.no_grad():
         assert trunk_hip.unit_supported(unit, x.cuda())
         got = trunk_hip.unit_forward(unit, x.cuda()).cpu()
-        lib = unit(x.cuda()).cpu()                     # the library route, for scale
+        layers.HIP_CONVS = False
+        try:
+            lib = unit(x.cuda()).cpu()                 # the library route, for scale
+        finally:
+            layers.HIP_CONVS = True
     assert got.shape == want.shape
     err = (got - want).abs().max().item() / max(want.abs().max().item(), 1.0)
     err_lib = (lib - want).abs().max().item() / max(want.abs().max().item(), 1.0)
     print(f'unit {in_c}->{depth} s{stride} @{res}: HIP {err:.2e}, library fp32 {err_lib:.2e} (relative to max |ref|, vs fp64)')
     assert err <= 2e-5
-    unit.train()
+    unit.train(); ref.train()
+    want = ref(x.double()).float()
     with torch.no_grad():
-        assert not trunk_hip.unit_supported(unit, x.cuda())      # batch statistics: the unit's own forward
+        assert trunk_hip.unit_supported(unit, x.cuda())
+        got = trunk_hip.unit_forward(unit, x.cuda()).cpu()
+    err = (got - want).abs().max().item() / max(want.abs().max().item(), 1.0)
+    print(f'   train mode: HIP {err:.2e}')
+    assert err <= 3e-5
+    for k in (0, 4):
+        assert (unit.res_layer[k].running_mean.cpu() - ref.res_layer[k].running_mean.float()).abs().max().item() <= 2e-5
+        assert (unit.res_layer[k].running_var.cpu() - ref.res_layer[k].running_var.float()).abs().max().item() <= 2e-5
+        assert int(unit.res_layer[k].num_batches_tracked) == int(ref.res_layer[k].num_batches_tracked) == 1
 
 
-def test_convgru_cell_with_hip_convolutions_matches_the_torch_cell():
-    """From 32^2 up the cell's two convolutions run on ia_conv2d_mfma_sx (unet_encoders.ConvGRU._hip_convs): against the same
-    module on the CPU (unet_encoders.py:8-49), 4-frame series, carried state."""
+@pytest.mark.parametrize('i,o,k,s,p,b,h,w,route', [
+    (256, 512, 1, 2, 0, 4, 32, 32, 'gemm'), (64, 128, 1, 2, 0, 1, 128, 128, 'gemm'), (384, 32, 1, 1, 0, 1, 32, 32, 'gemm'), (96, 256, 1, 1, 0, 1, 128, 128, 'gemm'),
+    (7, 64, 3, 1, 1, 4, 256, 256, 'f32'), (3, 64, 3, 1, 1, 1, 256, 256, 'f32'), (24, 96, 3, 1, 1, 1, 256, 256, 'sx'), (96, 96, 3, 1, 1, 1, 256, 256, 'sx'),
+    (512, 512, 3, 2, 1, 1, 16, 16, 'sx'), (512, 512, 3, 2, 1, 1, 64, 64, 'sx'), (1024, 512, 3, 1, 1, 1, 16, 16, 'sx'), (64, 64, 2, 2, 0, 2, 64, 64, 'patch'),
+    (32, 64, 8, 8, 0, 1, 128, 128, 'patch'), (512, 512, 3, 2, 1, 1, 4, 4, None), (16, 16, 3, 1, 1, 1, 8, 8, None), (3, 64, 7, 4, 3, 1, 256, 256, None)])
+def test_conv2d_layer_routes(i, o, k, s, p, b, h, w, route):
+    """layers.Conv2d on a device tensor: every route of trunk_hip.conv_forward (and the library fall-through for the shapes it does
+    not take) against the same torch.nn.Conv2d in fp64 on the CPU."""
+    from invertavatar_amd.encoder_inversion.models import layers, trunk_hip
+    torch.manual_seed(i + o + k)
+    conv = layers.Conv2d(i, o, k, s, p, bias=(o != 64)).requires_grad_(False)
+    x = torch.randn(b, i, h, w)
+    want = torch.nn.functional.conv2d(x.double(), conv.weight.double(), None if conv.bias is None else conv.bias.double(), s, p).float()
+    conv = conv.cuda()
+    with torch.no_grad():
+        assert trunk_hip._conv_route(conv, x.cuda()) == route
+        got = conv(x.cuda()).cpu()
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item() / max(want.abs().max().item(), 1.0)
+    print(f'conv {i}->{o} k{k} s{s} @{h}x{w} B{b} [{route}]: {err:.2e} relative to max |ref| (vs fp64)')
+    assert err <= 2e-5
+    with torch.enable_grad():                         # autograd takes torch.nn.Conv2d.forward
+        xg = x.cuda().requires_grad_(True)
+        assert trunk_hip._conv_route(conv, xg) is None and conv(xg).requires_grad
+
+
+@pytest.mark.parametrize('ch,h,w', [(64, 32, 40), (512, 16, 16)])
+def test_convgru_cell_with_hip_convolutions_matches_the_torch_cell(ch, h, w):
+    """The cell's two convolutions on ia_conv2d_mfma_sx (unet_encoders.ConvGRU._hip_convs; the 16^2 cell of the decoders on the
+    stream-K plan): against the same module on the CPU (unet_encoders.py:8-49), 4-frame series, carried state."""
     from invertavatar_amd.encoder_inversion.models.unet_encoders import ConvGRU
     torch.manual_seed(5)
-    cell = ConvGRU(64).requires_grad_(False)
-    x = torch.randn(1, 4, 64, 32, 40) * 0.5
-    h0 = torch.randn(1, 64, 32, 40) * 0.5
+    cell = ConvGRU(ch).requires_grad_(False)
+    x = torch.randn(1, 4, ch, h, w) * 0.5
+    h0 = torch.randn(1, ch, h, w) * 0.5
     want, want_h = cell(x, h0.clone(), seq2seq=True)
     dev = cell.cuda()
     with torch.no_grad():
