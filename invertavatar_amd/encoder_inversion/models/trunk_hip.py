@@ -90,6 +90,7 @@ def sx_size_ok(i, o, h, w):
     return (o >= 64 and h * w >= 1024) or hipops.conv_sx_supported(i, o, h, w, 3, False)
 
 
+TRAIN_UNITS = True    # residual units in train mode (batch statistics) on the HIP convolutions too (False: the unit's torch.nn forward)
 DOWN_TILES = True     # stride-2 3x3 layers on ia_conv2d_down_sx (False: at stride 1 and sub-sampled, the r03 / r04 route)
 
 
@@ -97,7 +98,7 @@ def unit_supported(unit, x):
     """True when the unit's two 3x3 convolutions can run on ia_conv2d_mfma_sx for this input."""
     if not (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()):
         return False
-    if unit.training and x.shape[0] * x.shape[2] * x.shape[3] <= 1:       # torch.nn.BatchNorm2d raises on one value per channel
+    if unit.training and (not TRAIN_UNITS or x.shape[0] * x.shape[2] * x.shape[3] <= 1):       # (torch.nn.BatchNorm2d raises on one value per channel)
         return False
     conv1, conv2 = unit.res_layer[1], unit.res_layer[3]
     i, o = conv1.in_channels, conv1.out_channels

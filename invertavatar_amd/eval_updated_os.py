@@ -18,3 +18,34 @@ def one_shot_inversion(net, image, uv, cam, uvcoords):
     out = net({'image': image, 'uv': uv}, cam, {'uvcoords_image': uvcoords}, e4e_results={'w': ws, 'texture': tex, 'static': sta},
               return_feats=True)
     return ws, {'w': ws, 'texture': out['texture'], 'static': list(sta[:-1]) + list(out['static'][-1:])}
+
+
+class GraphedOneShot:
+    """hipGraph of ``one_shot_inversion`` for one input shape: the flow is ~2500 launches of batch-1 work that eager PyTorch issues more
+    slowly than the GPU runs them.  Captured once per network (a clip-processing service keeps it); a call copies the four inputs into
+    the graph's tensors, replays, and returns copies of the results.  The split-range watch brackets the replay as it brackets the
+    eager call."""
+
+    def __init__(self, net, image, uv, cam, uvcoords, warmup=2):
+        self.net = net
+        self.inputs = [t.clone() for t in (image, uv, cam, uvcoords)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                one_shot_inversion(net, *self.inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.ws, self.res = one_shot_inversion(net, *self.inputs)
+
+    def __call__(self, image, uv, cam, uvcoords):
+        from .reenact_avatar_next3d import _check_split_range
+        for dst, src in zip(self.inputs, (image, uv, cam, uvcoords)):
+            dst.copy_(src)
+        _check_split_range(self.net, start=True)
+        self.graph.replay()
+        _check_split_range(self.net)
+        ws = self.ws.clone()
+        return ws, {'w': ws, 'texture': [t.clone() for t in self.res['texture']], 'static': [t.clone() for t in self.res['static']]}

@@ -79,6 +79,53 @@ def test_one_shot_inversion_matches_reference(golden):
 
 
 @pytest.mark.gpu
+def test_graphed_one_shot_inversion_equals_the_eager_flow():
+    """eval_updated_os.GraphedOneShot (the whole one-shot inversion as one hipGraph, bench.py's oneshot leg) against the eager flow on
+    the source it was captured with and on another one; the renderer's random draws pinned to device tensors made before the capture."""
+    import contextlib
+    import numpy as np
+    net = _build('cuda')
+    nrr = 32
+    net.generator.neural_rendering_resolution = nrr
+    jit = synthetic.jitter([12], nrr * nrr).cuda()
+    draws = {}
+
+    @contextlib.contextmanager
+    def device_randomness():
+        orig_like, orig_rand = torch.rand_like, torch.rand
+
+        def fake_like(t, *a, **k):
+            assert tuple(t.shape) == tuple(jit.shape)
+            return jit.to(t.dtype)
+
+        def fake_rand(*size, **k):
+            shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+            if shape not in draws:
+                draws[shape] = torch.from_numpy(np.random.RandomState(99).rand(*shape).astype(np.float32)).cuda()
+            return draws[shape]
+        torch.rand_like, torch.rand = fake_like, fake_rand
+        try:
+            yield
+        finally:
+            torch.rand_like, torch.rand = orig_like, orig_rand
+
+    def inputs(seed, frame):
+        return (synthetic.source_frames(seed, 1).cuda(), synthetic.source_uv(seed + 10, [frame]).cuda(), synthetic.camera_labels([frame]).cuda(),
+                synthetic.uv_conditions([frame]).cuda())
+    first, second = inputs(9, 12), inputs(4, 27)
+    with device_randomness():
+        replay = eval_updated_os.GraphedOneShot(net, *first)
+        for inp in (first, second, first):
+            ws_e, res_e = eval_updated_os.one_shot_inversion(net, *inp)
+            ws_g, res_g = replay(*inp)
+            worst = (ws_g - ws_e).abs().max().item()
+            for a, b in zip(res_g['texture'] + res_g['static'], res_e['texture'] + res_e['static']):
+                worst = max(worst, (a - b).abs().max().item() / max(b.abs().max().item(), 1.0))
+            print(f'graph replay vs eager: worst relative deviation {worst:.2e}')
+            assert worst <= 5e-6          # (library GEMMs may pick other kernels under capture; the fixture tolerance is TOL_ONESHOT)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('b,n,m', [(1, 64, 64), (2, 256, 256), (1, 512, 256), (1, 96, 40)])
 def test_fused_attention_matches_the_torch_definition(b, n, m):
     """ia_attention (softmax(QK^T * scale) V per head, online softmax, no score matrix) against mix_transformer.Attention's own
