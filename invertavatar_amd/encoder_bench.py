@@ -11,7 +11,7 @@ from .encoder_inversion.models.uvnet import inversionNet
 NRR = 128
 
 
-def encoder_leg(gen, n_sources=8, n_drive=32, group_graph=False):
+def encoder_leg(gen, n_sources=8, n_drive=32, group_graph=False, whole_graph=False):
     net = inversionNet(generator=gen, encoding_triplane=True, encoding_texture=True).requires_grad_(False)
     synthetic.fill_encoder_parameters(net)
     net = net.cuda()
@@ -26,7 +26,7 @@ def encoder_leg(gen, n_sources=8, n_drive=32, group_graph=False):
         drive = list(range(40, 40 + n_drive))
         d_c, d_uv = synthetic.camera_labels(drive).cuda(), synthetic.uv_conditions(drive).cuda()
 
-        cache = {'group_graph': group_graph}        # captured e4e encode (eval_seq.GraphedEncode) kept across the runs, as a clip-processing service keeps it
+        cache = {'group_graph': group_graph, 'whole': whole_graph}        # captured e4e encode (eval_seq.GraphedEncode) kept across the runs, as a clip-processing service keeps it
 
         def run():
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

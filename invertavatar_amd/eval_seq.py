@@ -99,11 +99,96 @@ class GraphedEncode:
         return self.ws.clone()
 
 
+class GraphedInversion:
+    """The few-shot inversion of one clip shape (S source frames) as captured hipGraphs, one per stage, handing over through the
+    tensors they were captured with and replayed in order on the caller's stream:
+        E        e4e encode + the two backbones of the identity
+        R_k      render of group k from the e4e features (synthesis_withTexture, T = 4)
+        T_k      inversionNet.trunk_features of group k: IR-SE50 trunks of both UNets
+        D_k      AR_eval_forward(y0_image, trunk_feats) of group k: decoder chains (ConvGRU states carried) + conditioned static backbone
+    The same calls with the same arguments as the sequential loop; a replay on new inputs is the eager call on them (the train-mode
+    BatchNorms move their running statistics once per replay).  Nothing is issued from the host (~5 000 launches otherwise), and the
+    stage graphs replayed alone are the GPU times of the stages (tools/profile_inversion_graph_stages.py: the table of DESIGN.md 7).
+    Only D_k depends on the previous group (every group starts from the e4e features, eval_seq.py:187), so R_k+1 / T_k+1 could run
+    beside D_k -- but not on this runtime (r05, profiles/r05_inversion_pipeline.txt): graphs replayed on different streams run one
+    after the other (T_0 and T_1 on two streams: 9.5 ms for 4.8 + 4.8), one graph over the whole flow cannot hold the pipeline
+    because a captured stream that forks a stream which forks another one crashes hipStreamEndCapture
+    (tools/probes/nested_fork_capture.py), and issued eagerly the three-stream pipeline is host-bound (42.3 vs 41.9 ms).
+    Results are copies.  The graphs hold the packed weights of the moment of capture: capture again after changing parameters."""
+
+    def __init__(self, net, images, uvs, cams, uvcoords, sequential_sampling=False, warmup=2):
+        self.net = net
+        self.inputs = [t.clone() for t in (images, uvs, cams, uvcoords)]
+        images, uvs, cams, uvcoords = self.inputs
+        dev = images.device
+        n = max(images.shape[0] // 4, 1)
+        sels = [slice(4 * k, 4 * (k + 1)) if sequential_sampling else slice(k, None, n) for k in range(n)]
+        group_in = [tuple(t[sel].clone() for t in self.inputs) for sel in sels]        # (images, uvs, cams, uvcoords) of each group
+        self.group_in, self.sels = group_in, sels
+        g = net.generator
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                _few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+
+        def capture(fn):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = fn()
+            return graph, out
+
+        def encode():
+            ws = net.encode(images[:1])
+            tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
+            sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
+            return ws, {'w': ws, 'texture': tex, 'static': sta}
+        self.g_encode, (self.ws, self.e4e) = capture(encode)
+        ws, e4e = self.ws, self.e4e
+        self.g_render, self.g_trunks, self.g_decode = [], [], []
+        r_list = [None, None]
+        for k, (im, uv, cm, uc) in enumerate(group_in):
+            t = cm.shape[0]
+            gr, y0 = capture(lambda: g.synthesis_withTexture(ws.expand(t, -1, -1), [f.expand(t, -1, -1, -1) for f in e4e['texture']], cm, {'uvcoords_image': uc},
+                                                             static_feats=[f.expand(t, -1, -1, -1) for f in e4e['static']], noise_mode='const')['image'])
+            gt, feats = capture(lambda: net.trunk_features(im, uv, y0))
+            gd, (updated, r_list) = capture(lambda: net.AR_eval_forward({'image': im, 'uv': uv}, cm, {'uvcoords_image': uc}, ws, r_list, e4e_results=e4e,
+                                                                      return_fake=False, y0_image=y0, trunk_feats=feats))
+            self.g_render.append(gr); self.g_trunks.append(gt); self.g_decode.append(gd)
+            self._keep = getattr(self, '_keep', []) + [y0, feats]
+        self.updated, self.r_list = updated, r_list
+
+    def __call__(self, images, uvs, cams, uvcoords):
+        for dst, src in zip(self.inputs, (images, uvs, cams, uvcoords)):
+            dst.copy_(src)
+        for bufs, sel in zip(self.group_in, self.sels):
+            for dst, src in zip(bufs, self.inputs):
+                dst.copy_(src[sel])
+        self.g_encode.replay()
+        for gr, gt, gd in zip(self.g_render, self.g_trunks, self.g_decode):
+            gr.replay()
+            gt.replay()
+            gd.replay()
+        ws = self.ws.clone()
+        res = {'w': ws, 'texture': [t.clone() for t in self.updated['texture']], 'static': [t.clone() for t in self.updated['static']]}
+        return ws, res, [[h.clone() for h in states] for states in self.r_list]
+
+
 @torch.no_grad()
 def few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=False, hook=None, graphed=None):
-    """See _few_shot_inversion; on the device the always-on range watch of the fp16 hi / lo split brackets the call."""
+    """See _few_shot_inversion; on the device the always-on range watch of the fp16 hi / lo split brackets the call.
+    ``graphed['whole'] = True``: the whole inversion as one hipGraph per clip shape (GraphedInversion, kept in the cache)."""
     from .reenact_avatar_next3d import _check_split_range
     _check_split_range(net, start=True)
+    if graphed is not None and graphed.get('whole', False) and hook is None and images.is_cuda:
+        key = ('inversion', tuple(images.shape), bool(sequential_sampling))
+        if key not in graphed:
+            graphed[key] = GraphedInversion(net, images, uvs, cams, uvcoords, sequential_sampling)
+        out = graphed[key](images, uvs, cams, uvcoords)
+        _check_split_range(net)
+        return out
     out = _few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling, hook, graphed)
     _check_split_range(net)
     return out

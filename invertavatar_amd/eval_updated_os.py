@@ -24,7 +24,7 @@ class GraphedOneShot:
     """hipGraph of ``one_shot_inversion`` for one input shape: the flow is ~2500 launches of batch-1 work that eager PyTorch issues more
     slowly than the GPU runs them.  Captured once per network (a clip-processing service keeps it); a call copies the four inputs into
     the graph's tensors, replays, and returns copies of the results.  The split-range watch brackets the replay as it brackets the
-    eager call."""
+    eager call.  The graph holds the packed weights of the moment of capture: capture again after changing parameters."""
 
     def __init__(self, net, image, uv, cam, uvcoords, warmup=2):
         self.net = net

@@ -11,7 +11,7 @@ import torch
 from invertavatar_amd import encoder_bench, synthetic
 from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
 
-GROUP_GRAPH = '--group-graph' in sys.argv
+GROUP_GRAPH, WHOLE = '--group-graph' in sys.argv, '--whole-graph' in sys.argv
 for spec in [a for a in sys.argv[1:] if not a.startswith('--')]:
     target, value = spec.split('=', 1)
     mod, attr = target.rsplit('.', 1)
@@ -19,7 +19,7 @@ for spec in [a for a in sys.argv[1:] if not a.startswith('--')]:
 gen = TriPlaneGenerator(**synthetic.generator_kwargs('full')).train().requires_grad_(False).cuda()
 synthetic.fill_parameters(gen)
 with torch.no_grad():
-    few = encoder_bench.encoder_leg(gen, group_graph=GROUP_GRAPH)
+    few = encoder_bench.encoder_leg(gen, group_graph=GROUP_GRAPH, whole_graph=WHOLE)
     one = encoder_bench.oneshot_leg(gen)
 print(sys.argv[1:], 'few-shot inversion_ms', few['inversion_ms'], few['inversion_ms_runs'], 'drive f/s', few['drive_frames_per_s'],
       '| one-shot inversion_ms', one['inversion_ms'], one['inversion_ms_runs'])
