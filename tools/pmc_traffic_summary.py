@@ -39,24 +39,28 @@ def in_pair_family(kernel):
     return False
 
 
+# bench.py's sustained loop is time-based, so the passes run different numbers of frames (the 9-counter SQ pass fewer): each counter is
+# divided by the frames of ITS pass, counted on a once-per-frame kernel (profile_round.sh records dispatches per pass since r05)
+once = next((e for k, e in d.items() if 'render_rays_kernel' in k), {})
+frames_fetch, frames_write = once.get('dispatches_fetch', frames), once.get('dispatches_write', frames)
 conv = {k: e for k, e in d.items() if any(s in k for s in ('conv_split_kernel', 'conv_mfma_kernel', 'conv_fixup_kernel', 'up_rows_kernel', 'up_edge_fixup_kernel', 'conv1x1_kernel'))}
 per_kernel, fam = {}, dict(fetch_raw=0.0, fetch_corrected=0.0, write=0.0, dispatches=0)
 for k, e in conv.items():
-    f_raw, w = e.get('FETCH_SIZE', 0.0) * 1e3 / frames, e.get('WRITE_SIZE', 0.0) * 1e3 / frames
+    f_raw, w = e.get('FETCH_SIZE', 0.0) * 1e3 / frames_fetch, e.get('WRITE_SIZE', 0.0) * 1e3 / frames_write
     fac = fetch_factor(k)
     per_kernel[k.replace('_ZN12_GLOBAL__N_117', '')[:72]] = dict(
-        dispatches_per_frame=round(e['dispatches'] / frames, 1), fetch_raw_mb_per_frame=round(f_raw / 1e6, 1),
+        dispatches_per_frame=round(e.get('dispatches_fetch', e['dispatches']) / frames_fetch, 1), fetch_raw_mb_per_frame=round(f_raw / 1e6, 1),
         fetch_corrected_mb_per_frame=round(f_raw * fac / 1e6, 1), fetch_factor=fac, write_mb_per_frame=round(w / 1e6, 1),
         fp16_pair_family=in_pair_family(k))
     if in_pair_family(k):
-        fam['fetch_raw'] += f_raw; fam['fetch_corrected'] += f_raw * fac; fam['write'] += w; fam['dispatches'] += e['dispatches'] / frames
+        fam['fetch_raw'] += f_raw; fam['fetch_corrected'] += f_raw * fac; fam['write'] += w; fam['dispatches'] += e.get('dispatches_fetch', e['dispatches']) / frames_fetch
 out = dict(_summary=dict(
     how='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--kernel-trace only) over `bench.py --steps 2 --warmup 1 --eager '
         '--no-cpu-baseline --no-roofline --no-extra` (tools/profile_round.sh); counters are KB summed over dispatches',
     correction='FETCH_SIZE x 2 for the kernels whose reads are 16 bytes per lane (conv_split_kernel / up_rows_kernel: buffer_load_dwordx4 ... lds; '
                'conv_fixup_kernel: float4 slab reads), as MI355X_MICROARCH.md (HBM) prescribes for gfx950; WRITE_SIZE and dword reads are '
                'uncalibrated there and taken as reported; Infinity-Cache hits are counted by these counters, so this is fabric-side traffic',
-    frames=frames, csrc_digest=build.source_digest(),
+    frames=frames_fetch, frames_of_the_write_pass=frames_write, csrc_digest=build.source_digest(),
     fp16_pair_family=dict(
         kernels='conv_split_kernel<NP = 2, ...> + conv_fixup_kernel of its tile families + up_rows_kernel / up_edge_fixup_kernel: the launches roofline.algorithmic_bytes_per_launch averages over',
         logical_launches_per_frame=logical, kernel_dispatches_per_frame=round(fam['dispatches'], 1),

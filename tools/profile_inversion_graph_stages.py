@@ -66,3 +66,30 @@ with torch.no_grad():
         main.wait_stream(sa); main.wait_stream(sb)
     for la, ga, lb, gb in (('T0', gi.g_trunks[0], 'T1', gi.g_trunks[1]), ('R0', gi.g_render[0], 'T1', gi.g_trunks[1]), ('R0', gi.g_render[0], 'R1', gi.g_render[1])):
         print(f'{la} and {lb} on two streams: {timed(lambda: both(ga, gb)):6.2f} ms   (alone {timed(ga.replay):.2f} + {timed(gb.replay):.2f})')
+
+    # the pieces inversion_parallel shards: one frame's render and trunks (frame-parallel stages at N = 8), and the two
+    # decoder chains of a group alone (their owners run them side by side)
+    def graph_of(fn):
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn(); fn()
+        torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            out = fn()
+        return gr, out
+    ws, e4e = gi.ws, gi.e4e
+    im, uv, cm, uc = gi.group_in[0]
+    for t in (1, 2):
+        gr, y = graph_of(lambda: gen.synthesis_withTexture(ws.expand(t, -1, -1), [f.expand(t, -1, -1, -1) for f in e4e['texture']], cm[:t], {'uvcoords_image': uc[:t]},
+                                                           static_feats=[f.expand(t, -1, -1, -1) for f in e4e['static']], noise_mode='const')['image'])
+        print(f'render of {t} frame(s) from the e4e features                        {timed(gr.replay):7.2f} ms')
+        gt, _ = graph_of(lambda: net.trunk_features(im[:t], uv[:t], y))
+        print(f'IR-SE50 trunks of both UNets, {t} frame(s)                          {timed(gt.replay):7.2f} ms')
+    y4, feats = gi._keep[0], gi._keep[1]
+    for parts in (('texture',), ('triplane',)):
+        gd, _ = graph_of(lambda: net.AR_eval_forward({'image': im, 'uv': uv}, cm, {'uvcoords_image': uc}, ws, [None, None], e4e_results=e4e, return_fake=False,
+                                                     y0_image=y4, trunk_feats=feats, parts=parts))
+        print(f'decoder chain of group 0 alone: {parts[0]:10s}                          {timed(gd.replay):7.2f} ms')
+    ge, _ = graph_of(lambda: net.encode(gi.inputs[0][:1]))
+    print(f'e4e encode alone                                                   {timed(ge.replay):7.2f} ms')

@@ -12,7 +12,7 @@ rm -rf /tmp/prof_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python $repo/bench.py > $out/${tag}_bench_under_rocprof.json 2> /tmp/prof_stats.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv 2>/dev/null || tail -5 /tmp/prof_stats.err
 declare -A SETS=( [fetch]="FETCH_SIZE" [write]="WRITE_SIZE" [sq]="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE" )
-for s in fetch write sq; do
+for s in ${PMC_PASSES:-fetch write sq}; do
   rm -rf /tmp/pmc_$s
   timeout 400 rocprofv3 --pmc ${SETS[$s]} --kernel-trace --output-format csv -d /tmp/pmc_$s -o p -- \
       python $repo/bench.py --steps 2 --warmup 1 --eager --no-cpu-baseline --no-roofline --no-extra > /tmp/pmc_$s.log 2>&1
@@ -44,6 +44,7 @@ for s in ('fetch', 'write', 'sq'):
     for k, d in agg.items():
         e = summary.setdefault(k, {})
         e['dispatches'] = len(cnt[k])
+        e['dispatches_' + s] = len(cnt[k])      # (bench.py's sustained loop is time-based: the passes do not run the same number of frames)
         e.update({c: v for c, v in d.items()})
 # durations of the SAME dispatches (kernel trace of the sq pass): matrix-pipe utilisation = busy cycles / (SIMDs x kernel cycles)
 import glob
