@@ -225,7 +225,9 @@ FP32_KERNEL_MAX_IN = 32     # 3x3 layers with at most this many input channels r
 def _conv_route(conv, x):
     """Which kernel takes this torch.nn.Conv2d on this input: 'gemm' (1x1, any stride, no padding), 'patch' (k x k with stride k, no
     padding: a 1x1 layer on the space-to-depth image), 'sx' (3x3 stride 1 / 2, padding 1, split-format tile), 'f32' (3x3 stride 1 / 2,
-    padding 1, few input channels) or None (library)."""
+    padding 1, few input channels) or None (library: what remains of the few-shot flow are the 4^2 -> 2^2 -> 1^2 layers of the style heads
+    -- routed as unfold + library GEMM they came back wrong from a replayed hipGraph, r05 -- and, in the one-shot decoders, the
+    depthwise 3x3 and the 7x7 stride-4 layers of the mix-transformer blocks)."""
     if not (_device_path(x) and x.dim() == 4 and conv.groups == 1 and conv.dilation == (1, 1) and conv.padding_mode == 'zeros'
             and conv.weight.dtype == torch.float32 and conv.stride[0] == conv.stride[1]):
         return None
