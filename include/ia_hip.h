@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -353,6 +353,17 @@ int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_split, int wk_e
                       const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                       const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
                       int transposed, int act, float alpha, const float* prelu_alpha, float gain, float clamp, int ksplit, void* stream);
+
+/*
+ * 3x3 convolution with stride 2 and padding 1 on an image of 2^2, 4^2 or 8^2 pixels (outputs 1^2, 2^2, 4^2): the last layers of a
+ * GradualStyleBlock of the e4e encoder (encoder_inversion/models/e4e.py:22-45: Conv2d(512, 512, 3, 2, 1) + LeakyReLU down to 1x1), cuDNN
+ * through torch.nn.Conv2d in the reference.  A matrix-vector product that streams the weight once; fp32 FMAs, deterministic.
+ *   x [B,I,H,W], w [O,I,3,3] (the module's own layout), bias [O] or NULL, y [B,O,H/2,W/2]; act IA_ACT_LINEAR or IA_ACT_LRELU (alpha).
+ * H == W in {2, 4, 8} and I * (H*W + 1) * 4 bytes <= 160 KB (ia_conv3x3_s2_tiny_supported = 1), else IA_ERR_UNSUPPORTED.
+ */
+int ia_conv3x3_s2_tiny_supported(int I, int O, int H, int W);
+int ia_conv3x3_s2_tiny(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int H, int W, int act, float alpha,
+                       void* stream);
 
 /*
  * 3x3 convolution with STRIDE 2 and padding 1 on split-format activations: y[b,o,r,c] = sum w[o,i,ky,kx] * x[b,i,2r+ky-1,2c+kx-1], on

@@ -225,9 +225,8 @@ FP32_KERNEL_MAX_IN = 32     # 3x3 layers with at most this many input channels r
 def _conv_route(conv, x):
     """Which kernel takes this torch.nn.Conv2d on this input: 'gemm' (1x1, any stride, no padding), 'patch' (k x k with stride k, no
     padding: a 1x1 layer on the space-to-depth image), 'sx' (3x3 stride 1 / 2, padding 1, split-format tile), 'f32' (3x3 stride 1 / 2,
-    padding 1, few input channels) or None (library: what remains of the few-shot flow are the 4^2 -> 2^2 -> 1^2 layers of the style heads
-    -- routed as unfold + library GEMM they came back wrong from a replayed hipGraph, r05 -- and, in the one-shot decoders, the
-    depthwise 3x3 and the 7x7 stride-4 layers of the mix-transformer blocks)."""
+    padding 1, few input channels), 'tiny' (3x3 stride 2 on 2^2 / 4^2 / 8^2 images: ia_conv3x3_s2_tiny, the last layers of the style heads) or
+    None (library: in the one-shot decoders, the depthwise 3x3 and the 7x7 stride-4 layers of the mix-transformer blocks)."""
     if not (_device_path(x) and x.dim() == 4 and conv.groups == 1 and conv.dilation == (1, 1) and conv.padding_mode == 'zeros'
             and conv.weight.dtype == torch.float32 and conv.stride[0] == conv.stride[1]):
         return None
@@ -239,6 +238,8 @@ def _conv_route(conv, x):
     if conv.kernel_size == (s, s) and conv.padding == (0, 0) and s > 1:
         return 'patch' if (h // s) * (w // s) >= 16 else None
     if conv.kernel_size == (3, 3) and conv.padding == (1, 1) and s in (1, 2) and (s == 1 or (h % 2 == 0 and w % 2 == 0)):
+        if s == 2 and hipops.conv_tiny_supported(i, o, h, w):      # (2^2 / 4^2 / 8^2 images: below the outputs ia_conv2d_down_sx starts at)
+            return 'tiny'
         if sx_size_ok(i, o, h, w):
             return 'sx'
         if i <= FP32_KERNEL_MAX_IN and h * w >= 1024:
@@ -274,6 +275,8 @@ def conv_forward(conv, x):
         oh, ow = h // s, w // s
         xin = x[:, :, :oh * s, :ow * s].reshape(b, i, oh, s, ow, s).permute(0, 1, 3, 5, 2, 4).reshape(b, i * s * s, oh, ow)
         return hipops.conv2d_mfma(xin.contiguous(), _packed_f32(conv, as_1x1=True), bias=bias, ksize=1)
+    if route == 'tiny':
+        return hipops.conv3x3_s2_tiny(x.contiguous(), conv.weight.detach(), bias=bias)
     if route == 'sx':
         xs = hipops.act_split(x.contiguous())
         if s == 2 and DOWN_TILES and hipops.conv_down_supported(x.shape[0], conv.in_channels, conv.out_channels, *x.shape[-2:]):

@@ -373,6 +373,29 @@ def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=Non
     return y if want_f32 else out_s
 
 
+def conv_tiny_supported(i, o, h, w):
+    """Shapes ia_conv3x3_s2_tiny covers (3x3, stride 2, padding 1 on 2^2 / 4^2 / 8^2 images)."""
+    return bool(_lib.load().ia_conv3x3_s2_tiny_supported(int(i), int(o), int(h), int(w)))
+
+
+def conv3x3_s2_tiny(x, w, bias=None, act='linear', alpha=0.2):
+    """ia_conv3x3_s2_tiny: [B, I, H, W] (H = W in {2, 4, 8}) -> [B, O, H/2, W/2] with the module's own weight [O, I, 3, 3]."""
+    _f32c(x, 'x')
+    _f32c(w, 'w')
+    b, i, h, wd = x.shape
+    o = w.shape[0]
+    if tuple(w.shape) != (o, i, 3, 3):
+        raise RuntimeError(f'weight {tuple(w.shape)} does not match [O, {i}, 3, 3]')
+    if bias is not None and _f32c(bias, 'bias').numel() != o:
+        raise RuntimeError(f'bias has {bias.numel()} elements, expected {o}')
+    y = torch.empty(b, o, h // 2, wd // 2, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device), _Timed('conv3x3_tiny', 2.0 * b * (h // 2) * (wd // 2) * i * o * 9, 4.0 * (x.numel() + w.numel() + y.numel()),
+                                             f'B{b} I{i} O{o} {h}x{wd} s2'):
+        st = _lib.load().ia_conv3x3_s2_tiny(_p(x), _p(w), _p(bias), _p(y), b, i, o, h, wd, ACT_ID[act], float(alpha), _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_conv3x3_s2_tiny')
+    return y
+
+
 def conv_down_supported(b, i, o, h, w):
     """Shapes ia_conv2d_down_sx covers (3x3, stride 2, padding 1 on an h x w input): asks the library's planner."""
     ks, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)

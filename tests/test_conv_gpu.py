@@ -355,6 +355,29 @@ def test_stride_2_convolution_on_the_stride_1_tiles(b, i, o, h, w):
         assert (plain - full).abs().max().item() <= 3e-6 * full.abs().max().item()
 
 
+@pytest.mark.parametrize('b,i,o,n,act', [(1, 512, 512, 8, 'lrelu'), (1, 512, 512, 4, 'lrelu'), (1, 512, 512, 2, 'linear'), (3, 70, 10, 8, 'linear'), (2, 8, 5, 2, 'lrelu')])
+def test_tiny_stride_2_convolution(b, i, o, n, act):
+    """ia_conv3x3_s2_tiny (the 8^2 -> 4^2 -> 2^2 -> 1^2 layers of the e4e style heads: one wave per output channel, fp32 FMAs) against the
+    fp64 convolution; bias + leaky ReLU in the epilogue; deterministic; shapes it does not take are refused."""
+    g = torch.Generator(device='cuda').manual_seed(31 + i + n)
+    x = torch.randn(b, i, n, n, device='cuda', generator=g)
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g) / (3 * i ** 0.5)
+    bias = torch.randn(o, device='cuda', generator=g)
+    assert hipops.conv_tiny_supported(i, o, n, n)
+    got = hipops.conv3x3_s2_tiny(x, wt, bias=bias, act=act, alpha=0.01)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), stride=2, padding=1)
+    if act == 'lrelu':
+        ref = torch.nn.functional.leaky_relu(ref, 0.01)
+    assert got.shape == ref.shape == (b, o, n // 2, n // 2)
+    err = (got.double() - ref).abs().max().item() / max(ref.abs().max().item(), 1.0)
+    print(f'tiny stride-2 {i}->{o} @{n}x{n} B{b}: {err:.2e}')
+    assert err <= 2e-6
+    assert torch.equal(got, hipops.conv3x3_s2_tiny(x, wt, bias=bias, act=act, alpha=0.01))
+    assert not hipops.conv_tiny_supported(i, o, 16, 16) and not hipops.conv_tiny_supported(i, o, 8, 4) and not hipops.conv_tiny_supported(1024, o, 8, 8)
+    with pytest.raises(RuntimeError):
+        hipops.conv3x3_s2_tiny(torch.randn(1, i, 6, 6, device='cuda'), wt)
+
+
 def test_stride_2_convolution_refuses_what_it_does_not_cover():
     assert not hipops.conv_down_supported(1, 64, 32, 64, 64)        # fewer than 64 output channels: no 8-wave tile
     assert not hipops.conv_down_supported(1, 512, 512, 8, 8)        # 4^2 outputs

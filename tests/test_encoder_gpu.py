@@ -140,7 +140,7 @@ def test_residual_unit_on_hip_convolutions_matches_torch(in_c, depth, stride, re
     (256, 512, 1, 2, 0, 4, 32, 32, 'gemm'), (64, 128, 1, 2, 0, 1, 128, 128, 'gemm'), (384, 32, 1, 1, 0, 1, 32, 32, 'gemm'), (96, 256, 1, 1, 0, 1, 128, 128, 'gemm'),
     (7, 64, 3, 1, 1, 4, 256, 256, 'f32'), (3, 64, 3, 1, 1, 1, 256, 256, 'f32'), (24, 96, 3, 1, 1, 1, 256, 256, 'sx'), (96, 96, 3, 1, 1, 1, 256, 256, 'sx'),
     (512, 512, 3, 2, 1, 1, 16, 16, 'sx'), (512, 512, 3, 2, 1, 1, 64, 64, 'sx'), (1024, 512, 3, 1, 1, 1, 16, 16, 'sx'), (64, 64, 2, 2, 0, 2, 64, 64, 'patch'),
-    (32, 64, 8, 8, 0, 1, 128, 128, 'patch'), (512, 512, 3, 2, 1, 1, 4, 4, None), (16, 16, 3, 1, 1, 1, 8, 8, None), (3, 64, 7, 4, 3, 1, 256, 256, None)])
+    (32, 64, 8, 8, 0, 1, 128, 128, 'patch'), (512, 512, 3, 2, 1, 1, 4, 4, 'tiny'), (512, 512, 3, 2, 1, 1, 2, 2, 'tiny'), (512, 512, 3, 2, 1, 1, 8, 8, 'tiny'), (40, 24, 3, 2, 1, 3, 8, 8, 'tiny'), (16, 16, 3, 1, 1, 1, 8, 8, None), (3, 64, 7, 4, 3, 1, 256, 256, None)])
 def test_conv2d_layer_routes(i, o, k, s, p, b, h, w, route):
     """layers.Conv2d on a device tensor: every route of trunk_hip.conv_forward (and the library fall-through for the shapes it does
     not take) against the same torch.nn.Conv2d in fp64 on the CPU."""
