@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -329,6 +329,20 @@ int ia_ray_sampler(const float* cam, int cam_stride, float* rays_o, float* rays_
  * the normalised tensor, as in the reference).
  */
 int ia_act_split(const float* x, const float* styles, const float* shift, void* xs, int planes, int B, int C, int H, int W, void* stream);
+
+/*
+ * torch.nn.BatchNorm2d in TRAIN mode followed by ia_act_split, in two launches: xs = split((x - mean_c) * weight_c / sqrt(var_c + eps) +
+ * bias_c) with mean / biased variance over (B, H, W) per channel, and the running-statistics update of a train-mode call
+ * (running = running + momentum * (batch - running), unbiased variance; num_batches_tracked += 1).  The inversion encoders run the
+ * BatchNorms of the e4e trunk and of the decoders' DoubleConv on batch statistics at evaluation time (the reference's eval_seq.py:91-97
+ * leaves those modules in train()): encoder_inversion/models/helpers.py:102-124 (BatchNorm2d -> Conv2d 3x3), unet_encoders.py:52-66.
+ *   weight, bias [C] or NULL (1 / 0); running_mean, running_var [C] or both NULL; num_batches_tracked: device int64 or NULL;
+ *   partials: caller-owned scratch of C * chunks * 2 doubles; chunks = partial sums per channel (1 .. 1024: enough workgroups for
+ *   pass 1, e.g. ceil(B*H*W / 8192)); xs, planes as ia_act_split.  C % 8 == 0, B*H*W > 1.
+ */
+int ia_bn_train_split(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                      long long* num_batches_tracked, double* partials, int chunks, void* xs, int planes, int B, int C, int H, int W,
+                      float eps, float momentum, void* stream);
 
 /* 1 for the layer shapes ia_conv2d_mfma_sx covers (3x3, I % 8 == 0, O % 8 == 0, from 8^2; stride-1 layers need O >= 128, W <= 512). */
 int ia_conv2d_sx_supported(int I, int O, int H, int W, int ksize, int transposed);

@@ -106,6 +106,89 @@ __global__ __launch_bounds__(256) void act_split4_kernel(const float* __restrict
     watch.report();
 }
 
+// Train-mode BatchNorm2d folded into the split staging (ia_bn_train_split), pass 1: per (channel, chunk) sum and sum of squares of the
+// channel's B * HW values, in double (the variance is taken as E[x^2] - E[x]^2 of those sums).
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, double* __restrict__ partials, int B, int C, int64_t HW, int J) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x, j = blockIdx.y;
+    const int64_t n = (int64_t)B * HW, per = (n + J - 1) / J, e0 = j * per, e1 = e0 + per < n ? e0 + per : n;
+    double s = 0.0, q = 0.0;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int64_t b = e / HW, p = e - b * HW;
+        const double v = (double)x[((int64_t)b * C + c) * HW + p];
+        s += v; q = fma(v, v, q);
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[((int64_t)c * J + j) * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partials[((int64_t)c * J + j) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// Pass 2: one workgroup = one 8-channel group of one batch element and one pixel chunk.  Its first eight threads finish the statistics
+// of their channels (fixed order over the J partials), the workgroup of chunk 0 / batch 0 also moves the running statistics the way
+// torch.nn.BatchNorm2d does in train mode (momentum lerp, unbiased variance), then the block streams split((x - mean) * a + bias).
+template <int PX>      // pixels per thread: 4 (HW % 4 == 0, 16-byte loads) or 1
+__global__ __launch_bounds__(256) void bn_split_kernel(const float* __restrict__ x, const double* __restrict__ partials, const float* __restrict__ weight,
+                                                      const float* __restrict__ bias, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                      long long* __restrict__ num_batches, h16x8* __restrict__ out, int B, int C, int64_t HW, int J,
+                                                      float eps, float momentum, int planes) {
+    __shared__ float sc_a[8], sc_c[8];
+    const int c8 = blockIdx.x, b = blockIdx.z, C8 = C / 8;
+    if (threadIdx.x < 8) {
+        const int c = c8 * 8 + threadIdx.x;
+        double s = 0.0, q = 0.0;
+        for (int j = 0; j < J; ++j) { s += partials[((int64_t)c * J + j) * 2]; q += partials[((int64_t)c * J + j) * 2 + 1]; }
+        const double n = (double)B * (double)HW, mean = s / n;
+        double var = q / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float a = (weight ? weight[c] : 1.f) * rsqrtf((float)var + eps);
+        sc_a[threadIdx.x] = a;
+        sc_c[threadIdx.x] = (bias ? bias[c] : 0.f) - (float)mean * a;
+        if (blockIdx.y == 0 && b == 0 && running_mean) {
+            running_mean[c] += momentum * ((float)mean - running_mean[c]);
+            running_var[c] += momentum * ((float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0))) - running_var[c]);
+        }
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && b == 0 && num_batches) *num_batches += 1;
+    __syncthreads();
+    float a[8], cc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] = sc_a[k]; cc[k] = sc_c[k]; }
+    ia::SatWatch watch;
+    const int64_t items = HW / PX;
+    const float* xb = x + ((int64_t)b * C + c8 * 8) * HW;
+    h16x8* dh = out + ((int64_t)(b * planes) * C8 + c8) * HW;
+    h16x8* dl = out + ((int64_t)(b * 2 + 1) * C8 + c8) * HW;
+    for (int64_t it = (int64_t)blockIdx.y * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.y * 256) {
+        float v[8][PX];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if constexpr (PX == 4) {
+                const float4 t = reinterpret_cast<const float4*>(xb + k * HW)[it];
+                v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+            } else {
+                v[k][0] = xb[k * HW + it];
+            }
+        }
+#pragma unroll
+        for (int px = 0; px < PX; ++px) {
+            h16x8 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float t = fmaf(v[k][px], a[k], cc[k]);
+                if (planes == 2) { _Float16 h, l; ia::split_f16(t, h, l, watch); hi[k] = h; lo[k] = l; }
+                else hi[k] = ia::round_f16(t, watch);
+            }
+            dh[it * PX + px] = hi;
+            if (planes == 2) dl[it * PX + px] = lo;
+        }
+    }
+    watch.report();
+}
+
 // Elements of the hi plane that sit on the fp16 maximum: values the split clamped (see ia_split_saturation_count).
 __global__ __launch_bounds__(256) void split_saturation_kernel(const unsigned short* __restrict__ xs, int64_t per_batch_hi, int64_t batch_stride,
                                                               int B, unsigned int* __restrict__ count) {
@@ -821,6 +904,37 @@ extern "C" int ia_act_split(const float* x, const float* styles, const float* sh
         hipLaunchKernelGGL(act_split_kernel, dim3(ia::streaming_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, styles, shift,
                            static_cast<h16x8*>(xs), B, C, (int64_t)H * W, planes);
     return ia::check_launch("ia_act_split");
+}
+
+extern "C" int ia_bn_train_split(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                                 long long* num_batches_tracked, double* partials, int chunks, void* xs, int planes, int B, int C, int H, int W,
+                                 float eps, float momentum, void* stream) {
+    IA_REQUIRE(planes == 1 || planes == 2, "planes: 2 = hi / lo pair, 1 = one fp16 plane");
+    IA_REQUIRE(x && xs && partials, "null pointer argument");
+    IA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "empty tensor");
+    IA_REQUIRE(C % 8 == 0, "the split format stores channels in groups of 8 (C = %d)", C);
+    IA_REQUIRE((int64_t)B * H * W > 1, "batch statistics need more than one value per channel");
+    IA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var come together");
+    IA_REQUIRE(chunks >= 1 && chunks <= 1024, "chunks: 1 .. 1024 partial sums per channel");
+    IA_REQUIRE((int64_t)B * C * H * W <= INT32_MAX && B <= 65535, "tensor is too large");
+    const int64_t HW = (int64_t)H * W;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)C, (unsigned)chunks), dim3(256), 0, s, x, partials, B, C, HW, chunks);
+    int st = ia::check_launch("ia_bn_train_split(statistics)");
+    if (st != IA_OK) return st;
+    const bool quad = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const int64_t items = quad ? HW / 4 : HW;
+    int gy = (int)((items + 255) / 256);
+    const int want = (4 * ia::kNumCU + (C / 8) * B - 1) / ((C / 8) * B);       // ~4 workgroups per CU over the whole launch
+    if (gy > want) gy = want < 1 ? 1 : want;
+    const dim3 grid((unsigned)(C / 8), (unsigned)gy, (unsigned)B);
+    if (quad)
+        hipLaunchKernelGGL(bn_split_kernel<4>, grid, dim3(256), 0, s, x, partials, weight, bias, running_mean, running_var, num_batches_tracked,
+                           static_cast<h16x8*>(xs), B, C, HW, chunks, eps, momentum, planes);
+    else
+        hipLaunchKernelGGL(bn_split_kernel<1>, grid, dim3(256), 0, s, x, partials, weight, bias, running_mean, running_var, num_batches_tracked,
+                           static_cast<h16x8*>(xs), B, C, HW, chunks, eps, momentum, planes);
+    return ia::check_launch("ia_bn_train_split");
 }
 
 extern "C" int ia_split_saturation_count(const void* xs, int planes, int B, int C, int H, int W, unsigned int* count, void* stream) {

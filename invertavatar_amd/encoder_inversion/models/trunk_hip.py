@@ -46,15 +46,20 @@ class _UnitPack(_runtime.DeviceCache):
             self.key = key
         return self
 
-    def eval_affines(self, unit):
+    def eval_affines(self, unit, b):
+        """(a1 rows, c1 rows, a2 rows, c2): the eval-mode affine maps of the unit's BatchNorms, the per-(batch, channel) arguments already
+        expanded to `b` rows (a trunk pass is a chain of dependent launches: three tiny copies per unit and call were ~8 % of its nodes)."""
         bn1, bn2 = unit.res_layer[0], unit.res_layer[4]
         tensors = (bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var)
         key = tuple((t.data_ptr(), t._version) for t in tensors)
         if key != self.bn_key:
-            self.a1, self.c1 = _affine(bn1, bn1.running_mean, bn1.running_var)
-            self.a2, self.c2 = _affine(bn2, bn2.running_mean, bn2.running_var)
+            self.affine = _affine(bn1, bn1.running_mean, bn1.running_var) + _affine(bn2, bn2.running_mean, bn2.running_var)
+            self.rows = {}          # per batch size, all kept: a captured graph may hold the rows of one size while another size is in use
             self.bn_key = key
-        return self.a1, self.c1, self.a2, self.c2
+        if b not in self.rows:
+            a1, c1, a2, c2 = self.affine
+            self.rows[b] = (_rows(a1, b), _rows(c1, b), _rows(a2, b), c2)
+        return self.rows[b]
 
 
 def _affine(bn, mean, var):
@@ -80,6 +85,22 @@ def batch_norm_affine(bn, x):
 
 def _rows(v, b):
     return v.unsqueeze(0).expand(b, -1).contiguous()
+
+
+BN_SPLIT_KERNEL = True      # train-mode BatchNorm -> split staging in two launches (ia_bn_train_split) instead of ~12 small ATen launches
+
+
+def batch_norm_split(bn, x):
+    """SplitAct of ``bn(x)`` for the convolution that follows (x contiguous fp32 on the device): batch statistics through
+    ia_bn_train_split, running statistics through the cached affine map + ia_act_split."""
+    b = x.shape[0]
+    if BN_SPLIT_KERNEL and (bn.training or not bn.track_running_stats) and bn.momentum is not None:
+        track = bn.track_running_stats and bn.running_mean is not None
+        return hipops.bn_train_split(x, None if bn.weight is None else bn.weight.detach().float(), None if bn.bias is None else bn.bias.detach().float(),
+                                     bn.running_mean if track else None, bn.running_var if track else None, bn.num_batches_tracked if track else None,
+                                     bn.eps, bn.momentum)
+    a, c = batch_norm_affine(bn, x)
+    return hipops.act_split(x, _rows(a, b), shift=_rows(c, b))
 
 
 def sx_size_ok(i, o, h, w):
@@ -120,8 +141,11 @@ def unit_forward(unit, x):
     x = x.contiguous()
     stride = unit.res_layer[3].stride[0]
     batch_stats = bn1.training or bn2.training or not (bn1.track_running_stats and bn2.track_running_stats)
-    a1, c1 = batch_norm_affine(bn1, x) if batch_stats else p.eval_affines(unit)[:2]
-    xs = hipops.act_split(x, _rows(a1, b), shift=_rows(c1, b))
+    if batch_stats:
+        xs = batch_norm_split(bn1, x)
+    else:
+        a1, c1 = p.eval_affines(unit, b)[:2]
+        xs = hipops.act_split(x, a1, shift=c1)
     us = hipops.conv2d_mfma_sx(xs, p.w1, act='lrelu', prelu=p.slopes, want_f32=False, want_split=True)
     conv2, sub = hipops.conv2d_mfma_sx, stride == 2
     if stride == 2 and DOWN_TILES and hipops.conv_down_supported(b, us.shape[1], us.shape[1], *us.shape[2:]):
@@ -130,8 +154,8 @@ def unit_forward(unit, x):
         v = conv2(us, p.w2, act='linear')
         v = bn2(v[:, :, ::2, ::2].contiguous() if sub else v)
     else:
-        a2, c2 = p.eval_affines(unit)[2:]
-        v = conv2(us, p.w2, demod=_rows(a2, b), bias=c2, act='linear')
+        a2, c2 = p.eval_affines(unit, b)[2:]
+        v = conv2(us, p.w2, demod=a2, bias=c2, act='linear')
         if sub:
             v = v[:, :, ::2, ::2]
     return se_tail(unit, v, x)
@@ -200,11 +224,14 @@ def double_conv_forward(dc, x):
     bn, conv1, p1, conv2, p2, p3 = dc.double_conv
     x = x.contiguous()
     b = x.shape[0]
-    a, c = batch_norm_affine(bn, x)
-    xs = hipops.act_split(x, _rows(a, b), shift=_rows(c, b))
+    xs = batch_norm_split(bn, x)
     us = conv3x3(xs, conv1, slopes=p1.weight.detach().float().contiguous(), want_split=True)
-    a2, a3 = p2.weight.detach().float(), p3.weight.detach().float()
-    return conv3x3(us, conv2, slopes=torch.where(a2 > 0, a2 * a3, a2).contiguous())
+    st = _runtime.state(dc)
+    key = (p2.weight.data_ptr(), p2.weight._version, p3.weight.data_ptr(), p3.weight._version)
+    if getattr(st, 'slope_key', None) != key:      # (cached: three small launches per call otherwise)
+        a2, a3 = p2.weight.detach().float(), p3.weight.detach().float()
+        st.slopes, st.slope_key = torch.where(a2 > 0, a2 * a3, a2).contiguous(), key
+    return conv3x3(us, conv2, slopes=st.slopes)
 
 
 def conv_lrelu_conv_supported(seq, x):

@@ -320,6 +320,28 @@ def act_split(x, styles=None, consumer=None, planes=2, shift=None):
     return SplitAct(out, c, consumer)
 
 
+def bn_train_split(x, weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum, consumer=None, planes=2):
+    """ia_bn_train_split: train-mode BatchNorm2d (batch statistics over B, H, W; running statistics moved in place when given) folded
+    into the split staging of the convolution that follows it.  Returns the SplitAct of the normalised tensor."""
+    _f32c(x, 'x')
+    b, c, h, w = x.shape
+    if c % 8:
+        raise RuntimeError(f'the split format stores channels in groups of 8 (C = {c})')
+    for name, t in (('weight', weight), ('bias', bias), ('running_mean', running_mean), ('running_var', running_var)):
+        if t is not None and _f32c(t, name).numel() != c:
+            raise RuntimeError(f'{name} has {t.numel()} elements, expected {c}')
+    if num_batches_tracked is not None and not (num_batches_tracked.is_cuda and num_batches_tracked.dtype == torch.int64 and num_batches_tracked.numel() == 1):
+        raise RuntimeError('num_batches_tracked must be a device int64 scalar')
+    chunks = max(1, min(256, -(-(b * h * w) // 8192)))
+    partials = torch.empty(c * chunks * 2, device=x.device, dtype=torch.float64)
+    out = torch.empty(b, planes, c // 8, h, w, 8, device=x.device, dtype=torch.float16)
+    with torch.cuda.device(x.device), _Timed('bn_train_split', 3.0 * x.numel(), 4.0 * x.numel() * 2 + 2.0 * out.numel(), f'B{b} C{c} {h}x{w}'):
+        st = _lib.load().ia_bn_train_split(_p(x), _p(weight), _p(bias), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(partials), chunks,
+                                           _p(out), int(planes), b, c, h, w, float(eps), float(momentum), _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_bn_train_split')
+    return SplitAct(out, c, consumer)
+
+
 def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=None, residual=None, transposed=False, act='linear',
                    alpha=0.2, gain=1.0, clamp=None, want_f32=True, split_for=None, styles_next=None, ksplit=None, split_planes=2, prelu=None,
                    want_split=None):

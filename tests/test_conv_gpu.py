@@ -378,6 +378,35 @@ def test_tiny_stride_2_convolution(b, i, o, n, act):
         hipops.conv3x3_s2_tiny(torch.randn(1, i, 6, 6, device='cuda'), wt)
 
 
+@pytest.mark.parametrize('b,c,h,w,track', [(1, 64, 128, 128, True), (4, 72, 32, 36, True), (3, 16, 5, 7, True), (2, 8, 16, 16, False), (1, 512, 16, 16, True)])
+def test_train_mode_batch_norm_into_the_split_format(b, c, h, w, track):
+    """ia_bn_train_split (batch statistics -> affine map -> hi / lo split in two launches, running statistics moved as
+    torch.nn.BatchNorm2d moves them) against the module in fp64 and against ia_act_split of the fp64 affine map."""
+    torch.manual_seed(c + h)
+    bn = torch.nn.BatchNorm2d(c, track_running_stats=track).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+        if track:
+            bn.running_mean.normal_(0, 0.5); bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(b, c, h, w) * 1.7 + 0.4
+    ref = __import__('copy').deepcopy(bn).double()
+    want = ref(x.double())
+    bn = bn.cuda()
+    xs = hipops.bn_train_split(x.cuda(), bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None, bn.running_var if track else None,
+                               bn.num_batches_tracked if track else None, bn.eps, bn.momentum)
+    got = xs.float().cpu().double()
+    err = (got - want).abs().max().item() / max(want.abs().max().item(), 1.0)
+    print(f'bn_train_split B{b} C{c} {h}x{w}: {err:.2e} of max |ref|')
+    assert err <= 2e-6
+    if track:
+        assert (bn.running_mean.cpu().double() - ref.running_mean).abs().max().item() <= 1e-6
+        assert (bn.running_var.cpu().double() - ref.running_var).abs().max().item() <= 1e-6
+        assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    one = hipops.bn_train_split(x.cuda(), None, None, None, None, None, bn.eps, 0.1, planes=1)       # no affine parameters, one fp16 plane
+    plain = torch.nn.functional.batch_norm(x.double(), None, None, training=True, eps=bn.eps)
+    assert (one.float().cpu().double() - plain).abs().max().item() <= 2e-3 * max(plain.abs().max().item(), 1.0)      # (fp16 rounding)
+
+
 def test_stride_2_convolution_refuses_what_it_does_not_cover():
     assert not hipops.conv_down_supported(1, 64, 32, 64, 64)        # fewer than 64 output channels: no 8-wave tile
     assert not hipops.conv_down_supported(1, 512, 512, 8, 8)        # 4^2 outputs
