@@ -26,7 +26,12 @@ class GradualStyleBlock(Module):
         self.convs = nn.Sequential(*layers)
         self.linear = FullyConnectedLayer(in_features=out_c, out_features=out_c, bias=True, activation='linear', lr_multiplier=1)
 
-    def forward(self, x):
+    def forward(self, x, xs=None):
+        """`xs`: the split-format copy of `x` (hipops.SplitAct) when the caller made one for all heads that read this feature map."""
+        if FUSED_HEADS and x.is_cuda:
+            from . import trunk_hip
+            if trunk_hip.style_head_supported(self, x):
+                return self.linear(trunk_hip.style_head_forward(self, x, xs).view(-1, self.out_c))
         return self.linear(self.convs(x).view(-1, self.out_c))
 
 
@@ -47,9 +52,19 @@ class Encoder4Editing(Module):
         self.latlayer1 = Conv2d(256, 512, kernel_size=1, stride=1, padding=0)
         self.latlayer2 = Conv2d(128, 512, kernel_size=1, stride=1, padding=0)
 
+    def _shared_split(self, feats):
+        """One split-format copy of a pyramid level for all style heads that read it (device inference path), else None."""
+        if not (FUSED_HEADS and feats.is_cuda and feats.dtype == torch.float32 and not torch.is_grad_enabled()):
+            return None
+        if feats.shape[1] % 8:
+            return None
+        from ... import hipops
+        return hipops.act_split(feats.contiguous())
+
     def forward(self, x):
         _, (c1, c2, c3) = run_trunk(self.body, self.input_layer(x), (6, 20, 23))
-        w = self.styles[0](c3).repeat(self.style_count, 1, 1).permute(1, 0, 2)
+        shared = self._shared_split(c3)
+        w = self.styles[0](c3, shared).repeat(self.style_count, 1, 1).permute(1, 0, 2)
         feats = c3
         # The style heads (2 .. 6 stride-2 convolutions on 16^2 .. 1^2 images each, batch 1: ~70 latency-bound launches, 3.8 of the
         # 8.4 ms of an encode) read `feats` and nothing of each other: on the device they go round-robin to a few side streams and
@@ -60,16 +75,20 @@ class Encoder4Editing(Module):
         for i in range(1, self.style_count):
             if i == self.coarse_ind:
                 feats = p2 = _upsample_add(c3, self.latlayer1(c2))
+                shared = self._shared_split(feats)
             elif i == self.middle_ind:
                 feats = _upsample_add(p2, self.latlayer2(c1))
+                shared = self._shared_split(feats)
             if side is None:
-                w[:, i] += self.styles[i](feats)
+                w[:, i] += self.styles[i](feats, shared)
             else:
                 st = side[i % len(side)]
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
-                    deltas[i] = self.styles[i](feats)
+                    deltas[i] = self.styles[i](feats, shared)
                 deltas[i].record_stream(main)
+                if shared is not None:
+                    shared.data.record_stream(st)
         if side is not None:
             for st in side:
                 main.wait_stream(st)
@@ -78,6 +97,7 @@ class Encoder4Editing(Module):
         return w
 
 
+FUSED_HEADS = True    # device inference path of GradualStyleBlock: LeakyReLU in the convolutions' epilogues, split format from layer to layer
 STYLE_STREAMS = 4     # side streams of the style heads on the device path (1: program order on the caller's stream)
 
 

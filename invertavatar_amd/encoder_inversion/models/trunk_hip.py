@@ -314,3 +314,50 @@ def conv_forward(conv, x):
     else:
         raise RuntimeError('conv_forward: this layer is not covered (ask conv_covered first)')
     return y if s == 1 else y[:, :, ::2, ::2].contiguous()
+
+
+# ------------------------------------------------------------------ e4e style heads (e4e.GradualStyleBlock)
+def style_head_supported(block, x):
+    """GradualStyleBlock on the device path: every stage `Conv2d(3x3, stride 2, padding 1) + LeakyReLU` on ia_conv2d_down_sx or
+    ia_conv3x3_s2_tiny."""
+    if not (_device_path(x) and x.dim() == 4 and x.shape[-1] == x.shape[-2]):
+        return False
+    b, _, h, w = x.shape
+    mods = list(block.convs)
+    if len(mods) % 2 or not mods:
+        return False
+    for conv, act in zip(mods[0::2], mods[1::2]):
+        if not (isinstance(conv, torch.nn.Conv2d) and isinstance(act, torch.nn.LeakyReLU) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+                and conv.padding == (1, 1) and conv.groups == 1 and conv.dilation == (1, 1) and conv.padding_mode == 'zeros'):
+            return False
+        i, o = conv.in_channels, conv.out_channels
+        if not (hipops.conv_tiny_supported(i, o, h, w) or (i % 8 == 0 and o % 8 == 0 and h % 2 == 0 and hipops.conv_down_supported(b, i, o, h, w))):
+            return False
+        h, w = h // 2, w // 2
+    return True
+
+
+def style_head_forward(block, x, xs=None):
+    """The convolution stack of a GradualStyleBlock (e4e.py:22-45) with the LeakyReLU in each convolution's epilogue and the split
+    format handed from layer to layer (`xs`: the SplitAct of `x` when the caller shares it between the heads that read the same
+    feature map): 9 launches for a 64^2 head instead of 18 + a split."""
+    mods = list(block.convs)
+    b, _, h, w = x.shape
+    f32, split = x, xs
+    pairs = list(zip(mods[0::2], mods[1::2]))
+    for k, (conv, act) in enumerate(pairs):
+        i, o = conv.in_channels, conv.out_channels
+        bias = None if conv.bias is None else conv.bias.detach().float()
+        alpha = float(act.negative_slope)
+        if hipops.conv_tiny_supported(i, o, h, w):
+            f32, split = hipops.conv3x3_s2_tiny(f32.contiguous(), conv.weight.detach(), bias=bias, act='lrelu', alpha=alpha), None
+        else:
+            if split is None:
+                split = hipops.act_split(f32.contiguous())
+            nh = h // 2
+            nxt = pairs[k + 1][0] if k + 1 < len(pairs) else None
+            keep_split = nxt is not None and not hipops.conv_tiny_supported(nxt.in_channels, nxt.out_channels, nh, nh)
+            out = hipops.conv2d_down_sx(split, packed_weight(conv), bias=bias, act='lrelu', alpha=alpha, want_f32=not keep_split, want_split=keep_split)
+            f32, split = (None, out) if keep_split else (out, None)
+        h, w = h // 2, w // 2
+    return f32

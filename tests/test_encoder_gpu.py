@@ -68,6 +68,30 @@ def test_graphed_inversion_equals_the_eager_flow():
             assert worst <= 5e-6          # (library GEMMs may pick other kernels under capture; the fixture tolerance is TOL_FEATURES)
 
 
+@pytest.mark.parametrize('spatial', [16, 32, 64])
+def test_style_head_with_fused_epilogues_matches_the_module(spatial):
+    """e4e.GradualStyleBlock on the device path (trunk_hip.style_head_forward: LeakyReLU in the epilogues of ia_conv2d_down_sx /
+    ia_conv3x3_s2_tiny, split format handed from layer to layer, shared split of the input) against the module in fp64 on the CPU."""
+    import copy
+    from invertavatar_amd import hipops
+    from invertavatar_amd.encoder_inversion.models import e4e, trunk_hip
+    torch.manual_seed(spatial)
+    head = e4e.GradualStyleBlock(512, 512, spatial).requires_grad_(False)
+    for m in head.convs:
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.mul_(3.0)                         # keep the signal alive through 4 .. 6 stride-2 layers
+    x = torch.randn(1, 512, spatial, spatial)
+    want = copy.deepcopy(head).double()(x.double()).float()
+    head = head.cuda()
+    with torch.no_grad():
+        assert trunk_hip.style_head_supported(head, x.cuda())
+        got = head(x.cuda()).cpu()
+        shared = head(x.cuda(), hipops.act_split(x.cuda())).cpu()
+    err = (got - want).abs().max().item() / max(want.abs().max().item(), 1.0)
+    print(f'style head @{spatial}^2: {err:.2e} of max |ref| = {want.abs().max().item():.3g}')
+    assert err <= 2e-5 and torch.equal(got, shared)
+
+
 @pytest.mark.parametrize('prelu', [False, True])
 def test_convgru_cell_kernels_match_the_torch_cell(prelu):
     """ia_convgru_gates / ia_convgru_update around the two library convolutions against the cell written with ATen ops
