@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -526,6 +526,16 @@ int ia_filtered_lrelu(const void* x, const float* fu, const float* fd, const voi
 int ia_convgru_gates(const float* gates_pre, const float* x, const float* h, float* xrh, int B, int C, int H, int W, void* stream);
 int ia_convgru_update(const float* gates_pre, const float* cand_pre, const float* h, const float* prelu_weight, float* h_out,
                       const float* x_next, float* xh_next, int B, int C, int H, int W, void* stream);
+
+/*
+ * ia_convgru_gates / ia_convgru_update with the convolution inputs they produce written in SPLIT format (ia_act_split, two planes):
+ * xrh_split = split(cat[x, sigmoid(r_pre) * h]) and xh_next_split = split(cat[x_next, h']) are read by the cell's two
+ * ia_conv2d_mfma_sx launches only, so neither their fp32 copies nor the two ia_act_split launches of a step exist.  h_out stays fp32
+ * (the cell's output and the next step's state).  Same arithmetic as the fp32 forms.  C % 8 == 0, H * W % 4 == 0.
+ */
+int ia_convgru_gates_split(const float* gates_pre, const float* x, const float* h, void* xrh_split, int B, int C, int H, int W, void* stream);
+int ia_convgru_update_split(const float* gates_pre, const float* cand_pre, const float* h, const float* prelu_weight, float* h_out,
+                            const float* x_next, void* xh_next_split, int B, int C, int H, int W, void* stream);
 
 /*
  * Squeeze-and-excitation gate + residual add of an IR-SE50 unit:  out = v * sigmoid(W2 relu(W1 mean_hw(v))) + shortcut.

@@ -66,7 +66,9 @@ _SIGNATURES = {
     'ia_cond_blend_split': [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
     'ia_filtered_lrelu': [c_void_p] * 5 + [c_int] * 17 + [c_float] * 3 + [c_int, c_void_p],
     'ia_convgru_gates': [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
+    'ia_convgru_gates_split': [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
     'ia_convgru_update': [c_void_p] * 7 + [c_int] * 4 + [c_void_p],
+    'ia_convgru_update_split': [c_void_p] * 7 + [c_int] * 4 + [c_void_p],
     'ia_se_gate': [c_void_p, _i64p, c_void_p, _i64p] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
     'ia_attention_supported': [c_int] * 3,
     'ia_attention': [c_void_p] * 4 + [c_int] * 5 + [c_int64] * 8 + [c_float, c_void_p],

@@ -55,10 +55,21 @@ class ConvGRU(torch.nn.Module):
         return st.gru_w
 
     def _step_fused(self, xh, x, h, x_next):
-        """xh = cat[x, h] (made by the previous step's update launch).  Returns (h', cat[x_next, h'] or None)."""
+        """xh = cat[x, h] (made by the previous step's update launch: fp32, or a hipops.SplitAct when the cell's convolutions run on
+        ia_conv2d_mfma_sx).  Returns (h', cat[x_next, h'] in the same form or None)."""
         from ... import hipops
         conv_ih, conv_hh, act = self.ih[0], self.hh[0], self.hh[1]
         packed = self._hip_convs(x)
+        prelu_w = act.weight.detach().float().contiguous() if isinstance(act, nn.PReLU) else None
+        if packed is not None and self.channels % 8 == 0:
+            # the element-wise launches write the convolutions' operand format themselves (no fp32 cat, no ia_act_split: 4 launches per
+            # step between the two convolutions and their fix-ups instead of 6)
+            xs = xh if isinstance(xh, hipops.SplitAct) else hipops.act_split(xh)
+            gates_pre = hipops.conv2d_mfma_sx(xs, packed[0], bias=conv_ih.bias.detach().float())
+            cand_pre = hipops.conv2d_mfma_sx(hipops.convgru_gates_split(gates_pre, x, h), packed[1], bias=conv_hh.bias.detach().float())
+            return hipops.convgru_update_split(gates_pre, cand_pre, h, prelu_w, x_next)
+        if isinstance(xh, hipops.SplitAct):
+            raise RuntimeError('ConvGRU: a split-format input reached a step that runs library convolutions')
         if packed is not None:
             gates_pre = hipops.conv2d_mfma_sx(hipops.act_split(xh), packed[0], bias=conv_ih.bias.detach().float())
             xrh = hipops.convgru_gates(gates_pre, x, h)
@@ -67,7 +78,6 @@ class ConvGRU(torch.nn.Module):
             gates_pre = F.conv2d(xh, conv_ih.weight, conv_ih.bias, padding=conv_ih.padding)
             xrh = hipops.convgru_gates(gates_pre, x, h)
             cand_pre = F.conv2d(xrh, conv_hh.weight, conv_hh.bias, padding=conv_hh.padding)
-        prelu_w = act.weight.detach().float().contiguous() if isinstance(act, nn.PReLU) else None
         return hipops.convgru_update(gates_pre, cand_pre, h, prelu_w, x_next)
 
     def forward_single_frame(self, x, h):

@@ -918,6 +918,30 @@ def convgru_update(gates_pre, cand_pre, h, prelu_weight=None, x_next=None):
 
 
 
+def convgru_gates_split(gates_pre, x, h, consumer=None):
+    """SplitAct of cat[x, sigmoid(r_pre) * h] (see ia_convgru_gates_split): the input of the cell's second convolution."""
+    b, c, hh, w = x.shape
+    out = torch.empty(b, 2, 2 * c // 8, hh, w, 8, device=x.device, dtype=torch.float16)
+    with torch.cuda.device(x.device):
+        st = _lib.load().ia_convgru_gates_split(_p(_f32c(gates_pre, 'gates_pre')), _p(_f32c(x, 'x')), _p(_f32c(h, 'h')), _p(out), b, c, hh, w,
+                                                _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_convgru_gates_split')
+    return SplitAct(out, 2 * c, consumer)
+
+
+def convgru_update_split(gates_pre, cand_pre, h, prelu_weight=None, x_next=None, consumer=None):
+    """h' (fp32) and, with x_next, the SplitAct of cat[x_next, h'] for the next step's first convolution (see ia_convgru_update_split)."""
+    b, c, hh, w = h.shape
+    h_out = torch.empty_like(h)
+    xh = torch.empty(b, 2, 2 * c // 8, hh, w, 8, device=h.device, dtype=torch.float16) if x_next is not None else None
+    with torch.cuda.device(h.device):
+        st = _lib.load().ia_convgru_update_split(_p(_f32c(gates_pre, 'gates_pre')), _p(_f32c(cand_pre, 'cand_pre')), _p(_f32c(h, 'h')),
+                                                 _p(None if prelu_weight is None else _f32c(prelu_weight, 'prelu_weight')), _p(h_out),
+                                                 _p(None if x_next is None else _f32c(x_next, 'x_next')), _p(xh), b, c, hh, w, _lib.stream_ptr(h.device))
+    _lib.check(st, 'ia_convgru_update_split')
+    return h_out, (SplitAct(xh, 2 * c, consumer) if xh is not None else None)
+
+
 def stage_inputs(pairs):
     """Copy each (src, dst) pair of same-shaped contiguous device tensors in ONE launch (ia_stage_inputs): the per-frame inputs
     of a captured frame into the graph's static buffers.  Pairs the kernel cannot take (broadcast / strided / other dtype sources)
