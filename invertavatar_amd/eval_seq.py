@@ -99,17 +99,55 @@ class GraphedEncode:
         return self.ws.clone()
 
 
+BATCH_GROUP_RENDERS = True     # device path: the renders of ALL groups' source frames from the e4e features in calls of up to 8 frames
+RENDER_BATCH = 8
+
+
+def group_renders(net, ws, e4e, cams, uvcoords, sels, draws=None):
+    """The renders `y0` of every group's source frames from the e4e features, batched ACROSS groups.  Every group starts from the e4e
+    features (eval_seq.py:187), so its render does not depend on the groups before it; rendered in its own call of T = 4 a frame costs
+    1.67 ms, in a call of 8 frames 1.2 ms (r05: 13.4 -> 9.9 ms for 8 sources).  What a group's own call would share between its frames is
+    the depth range, the batch mean of |camera origin| (renderer.py:311): every frame gets its GROUP's value as `ray_dist`
+    (frame_parallel.global_ray_dist over the group's cameras), as inversion_parallel does when it deals the frames to ranks.  The
+    stochastic draws of the ray marcher come from the device generator per call, as in the sequential loop (other numbers of the same
+    distribution; the fixtures pin them through `hook`, which takes the sequential path) unless `draws` = (jitter [N, rays, samples],
+    u_importance [N * rays, samples]) gives them for the N frames in group-major order.  Returns one [T, 3, H, W] image per group."""
+    from .frame_parallel import global_ray_dist
+    g = net.generator
+    n = cams.shape[0]
+    order = torch.cat([torch.arange(n, device=cams.device)[sel] for sel in sels])
+    dist = torch.cat([global_ray_dist(cams[sel]).to(cams.device).expand(cams[sel].shape[0]) for sel in sels]).contiguous()
+    cams_o, uv_o = cams[order], uvcoords[order]
+    chunks = []
+    for lo in range(0, n, RENDER_BATCH):
+        t = min(RENDER_BATCH, n - lo)
+        kw = {}
+        if draws is not None:
+            rays = draws[1].shape[0] // n
+            kw = dict(jitter=draws[0][lo:lo + t], u_importance=draws[1][lo * rays:(lo + t) * rays])
+        chunks.append(g.synthesis_withTexture(ws.expand(t, -1, -1), [f.expand(t, -1, -1, -1) for f in e4e['texture']], cams_o[lo:lo + t],
+                                              {'uvcoords_image': uv_o[lo:lo + t]}, static_feats=[f.expand(t, -1, -1, -1) for f in e4e['static']],
+                                              noise_mode='const', ray_dist=dist[lo:lo + t], **kw)['image'])
+    y = torch.cat(chunks) if len(chunks) > 1 else chunks[0]
+    out, at = [], 0
+    for sel in sels:
+        t = cams[sel].shape[0]
+        out.append(y[at:at + t])
+        at += t
+    return out
+
+
 class GraphedInversion:
     """The few-shot inversion of one clip shape (S source frames) as captured hipGraphs, one per stage, handing over through the
     tensors they were captured with and replayed in order on the caller's stream:
         E        e4e encode + the two backbones of the identity
-        R_k      render of group k from the e4e features (synthesis_withTexture, T = 4)
+        R        renders of every group's source frames from the e4e features (group_renders: calls of up to 8 frames)
         T_k      inversionNet.trunk_features of group k: IR-SE50 trunks of both UNets
         D_k      AR_eval_forward(y0_image, trunk_feats) of group k: decoder chains (ConvGRU states carried) + conditioned static backbone
     The same calls with the same arguments as the sequential loop; a replay on new inputs is the eager call on them (the train-mode
     BatchNorms move their running statistics once per replay).  Nothing is issued from the host (~5 000 launches otherwise), and the
     stage graphs replayed alone are the GPU times of the stages (tools/profile_inversion_graph_stages.py: the table of DESIGN.md 7).
-    Only D_k depends on the previous group (every group starts from the e4e features, eval_seq.py:187), so R_k+1 / T_k+1 could run
+    Only D_k depends on the previous group (every group starts from the e4e features, eval_seq.py:187), so T_k+1 could run
     beside D_k -- but not on this runtime (r05, profiles/r05_inversion_pipeline.txt): graphs replayed on different streams run one
     after the other (T_0 and T_1 on two streams: 9.5 ms for 4.8 + 4.8), one graph over the whole flow cannot hold the pipeline
     because a captured stream that forks a stream which forks another one crashes hipStreamEndCapture
@@ -149,14 +187,14 @@ class GraphedInversion:
         ws, e4e = self.ws, self.e4e
         self.g_render, self.g_trunks, self.g_decode = [], [], []
         r_list = [None, None]
+        gr, y_groups = capture(lambda: group_renders(net, ws, e4e, cams, uvcoords, sels))
+        self.g_render.append(gr)
         for k, (im, uv, cm, uc) in enumerate(group_in):
-            t = cm.shape[0]
-            gr, y0 = capture(lambda: g.synthesis_withTexture(ws.expand(t, -1, -1), [f.expand(t, -1, -1, -1) for f in e4e['texture']], cm, {'uvcoords_image': uc},
-                                                             static_feats=[f.expand(t, -1, -1, -1) for f in e4e['static']], noise_mode='const')['image'])
+            y0 = y_groups[k]
             gt, feats = capture(lambda: net.trunk_features(im, uv, y0))
             gd, (updated, r_list) = capture(lambda: net.AR_eval_forward({'image': im, 'uv': uv}, cm, {'uvcoords_image': uc}, ws, r_list, e4e_results=e4e,
                                                                       return_fake=False, y0_image=y0, trunk_feats=feats))
-            self.g_render.append(gr); self.g_trunks.append(gt); self.g_decode.append(gd)
+            self.g_trunks.append(gt); self.g_decode.append(gd)
             self._keep = getattr(self, '_keep', []) + [y0, feats]
         self.updated, self.r_list = updated, r_list
 
@@ -167,8 +205,8 @@ class GraphedInversion:
             for dst, src in zip(bufs, self.inputs):
                 dst.copy_(src[sel])
         self.g_encode.replay()
-        for gr, gt, gd in zip(self.g_render, self.g_trunks, self.g_decode):
-            gr.replay()
+        self.g_render[0].replay()
+        for gt, gd in zip(self.g_trunks, self.g_decode):
             gt.replay()
             gd.replay()
         ws = self.ws.clone()
@@ -230,15 +268,17 @@ def _few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=Fa
             sel = slice(4 * idx, 4 * (idx + 1)) if sequential_sampling else slice(idx, None, num_iter)
             updated, r_list = step((images[sel], uvs[sel], cams[sel], uvcoords[sel]))
         return ws, updated, r_list
+    sels = [slice(4 * idx, 4 * (idx + 1)) if sequential_sampling else slice(idx, None, num_iter) for idx in range(num_iter)]
+    y0 = group_renders(net, ws, results, cams, uvcoords, sels) if (BATCH_GROUP_RENDERS and num_iter > 1 and hook is None and images.is_cuda) else None
     for idx in range(num_iter):
-        sel = slice(4 * idx, 4 * (idx + 1)) if sequential_sampling else slice(idx, None, num_iter)
+        sel = sels[idx]
         ctx = hook(idx) if hook is not None else None
         if ctx is not None:
             ctx.__enter__()
         try:
             # (every group starts from the e4e features: the script passes e4e_results=e4e_results each time, :187)
             updated, r_list = net.AR_eval_forward({'image': images[sel], 'uv': uvs[sel]}, cams[sel], {'uvcoords_image': uvcoords[sel]},
-                                                  ws, r_list, e4e_results=results, return_fake=False)
+                                                  ws, r_list, e4e_results=results, return_fake=False, y0_image=None if y0 is None else y0[idx])
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)

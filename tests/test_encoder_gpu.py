@@ -22,6 +22,38 @@ def test_few_shot_inversion_matches_reference(golden):
     assert not bad, bad
 
 
+def test_renders_batched_across_groups_equal_the_per_group_calls():
+    """eval_seq.group_renders (every group's source frames from the e4e features in one call of 8, each frame with its group's depth
+    range) against the per-group calls AR_eval_forward makes itself, with the marcher's draws given explicitly (frame k sees the same
+    numbers either way)."""
+    from encoder_common import build_inversion_net
+    from invertavatar_amd import eval_seq, synthetic
+    net = build_inversion_net('full').cuda()
+    g = net.generator
+    nrr = g.neural_rendering_resolution = 64
+    n = 8
+    src = [int(round(k * 32 / n)) for k in range(n)]
+    images = torch.cat([synthetic.source_frames(7 + k // 4, 4)[k % 4:k % 4 + 1] for k in range(n)]).cuda()
+    cams, uvc = synthetic.camera_labels(src).cuda(), synthetic.uv_conditions(src).cuda()
+    sels = [slice(k, None, 2) for k in range(2)]            # group 0 = frames 0, 2, 4, 6; group 1 = frames 1, 3, 5, 7
+    gen = torch.Generator().manual_seed(11)
+    jit = torch.rand(n, nrr * nrr, 48, generator=gen).cuda()                # group-major frame order
+    u = torch.rand(n * nrr * nrr, 48, generator=gen).cuda()
+    rays = nrr * nrr
+    with torch.no_grad():
+        ws = net.encode(images[:1])
+        tex, sta = net._backbones(ws)
+        e4e = {'w': ws, 'texture': tex, 'static': sta}
+        want = [g.synthesis_withTexture(ws.expand(4, -1, -1), [f.expand(4, -1, -1, -1) for f in tex], cams[sel], {'uvcoords_image': uvc[sel]},
+                                        static_feats=[f.expand(4, -1, -1, -1) for f in sta], noise_mode='const', jitter=jit[4 * k:4 * k + 4],
+                                        u_importance=u[4 * k * rays:(4 * k + 4) * rays])['image'] for k, sel in enumerate(sels)]
+        got = eval_seq.group_renders(net, ws, e4e, cams, uvc, sels, draws=(jit, u))
+    for k in range(2):
+        err = (got[k] - want[k]).abs().max().item()
+        print(f'group {k}: batched render vs its own call: max |d| = {err:.2e}')
+        assert got[k].shape == want[k].shape == (4, 3, 512, 512) and err <= 2e-5
+
+
 def test_graphed_inversion_equals_the_eager_flow():
     """eval_seq.GraphedInversion (encode | renders | trunks | decoder chains as captured graphs over three streams, bench.py's encoder
     leg) against the eager sequential loop of the script, on the clip it was captured with and on another one: same calls, same

@@ -40,10 +40,9 @@ with torch.no_grad():
     gi = eval_seq.GraphedInversion(net, images, uvs, cams, uvc)
     gi(images, uvs, cams, uvc)
     total = 0.0
-    rows = [('E   e4e encode + backbones of the identity', gi.g_encode)]
-    for k in range(len(gi.g_render)):
-        rows += [(f'R{k}  render of group {k} (4 frames) from the e4e features', gi.g_render[k]), (f'T{k}  IR-SE50 trunks of both UNets, group {k}', gi.g_trunks[k]),
-                 (f'D{k}  decoder chains + conditioned static backbone, group {k}', gi.g_decode[k])]
+    rows = [('E   e4e encode + backbones of the identity', gi.g_encode), (f'R   renders of all {n} source frames from the e4e features (one call of 8)', gi.g_render[0])]
+    for k in range(len(gi.g_trunks)):
+        rows += [(f'T{k}  IR-SE50 trunks of both UNets, group {k}', gi.g_trunks[k]), (f'D{k}  decoder chains + conditioned static backbone, group {k}', gi.g_decode[k])]
     for label, graph in rows:
         t = timed(graph.replay)
         total += t
@@ -64,7 +63,7 @@ with torch.no_grad():
         with torch.cuda.stream(sb):
             gb.replay()
         main.wait_stream(sa); main.wait_stream(sb)
-    for la, ga, lb, gb in (('T0', gi.g_trunks[0], 'T1', gi.g_trunks[1]), ('R0', gi.g_render[0], 'T1', gi.g_trunks[1]), ('R0', gi.g_render[0], 'R1', gi.g_render[1])):
+    for la, ga, lb, gb in (('T0', gi.g_trunks[0], 'T1', gi.g_trunks[1]), ('R', gi.g_render[0], 'T1', gi.g_trunks[1]), ('D0', gi.g_decode[0], 'T1', gi.g_trunks[1])):
         print(f'{la} and {lb} on two streams: {timed(lambda: both(ga, gb)):6.2f} ms   (alone {timed(ga.replay):.2f} + {timed(gb.replay):.2f})')
 
     # the pieces inversion_parallel shards: one frame's render and trunks (frame-parallel stages at N = 8), and the two
@@ -80,7 +79,7 @@ with torch.no_grad():
         return gr, out
     ws, e4e = gi.ws, gi.e4e
     im, uv, cm, uc = gi.group_in[0]
-    for t in (1, 2):
+    for t in (1, 2, 4):
         gr, y = graph_of(lambda: gen.synthesis_withTexture(ws.expand(t, -1, -1), [f.expand(t, -1, -1, -1) for f in e4e['texture']], cm[:t], {'uvcoords_image': uc[:t]},
                                                            static_feats=[f.expand(t, -1, -1, -1) for f in e4e['static']], noise_mode='const')['image'])
         print(f'render of {t} frame(s) from the e4e features                        {timed(gr.replay):7.2f} ms')
