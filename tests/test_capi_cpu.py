@@ -118,3 +118,42 @@ def test_compose_upfir_weight_equals_transposed_convolution_then_fir():
     wc = hipops.compose_upfir_weight(w, upfirdn2d.setup_filter([1, 3, 3, 1])).double()
     y = torch.nn.functional.conv2d(x, wc, padding=1).view(2, 2, 1, 2, 32, 9, 11).permute(0, 2, 4, 5, 1, 6, 3).reshape(2, 32, 18, 22)
     assert (y - chk.double()).abs().max().item() <= 1e-5 * chk.abs().max().item()       # and against the mirror's own upfirdn2d
+
+
+def test_stride_2_planner_and_tiny_rule_host_logic():
+    """ia_conv2d_down_plan is host-only arithmetic (r05): the stride-2 form keeps the 128-channel tile where its input windows fit the
+    LDS stages beside the weights and falls to the narrow whole-tile family otherwise; outputs below 8^2, fewer than 64 output channels
+    and channel counts outside octets are refused.  ia_conv3x3_s2_tiny_supported: square images of 2 / 4 / 8 pixels that fit the LDS."""
+    from invertavatar_amd import hipops
+    lib = _lib.load()
+
+    def down(b, i, o, h, w):
+        ks, nb = ctypes.c_int(-1), ctypes.c_size_t(0)
+        st = lib.ia_conv2d_down_plan(b, i, o, h, w, ctypes.byref(ks), ctypes.byref(nb))
+        return st, ks.value, nb.value
+    for shape in ((1, 512, 512, 32, 32), (1, 512, 512, 64, 64), (1, 512, 512, 16, 16), (4, 256, 256, 64, 64), (1, 128, 128, 128, 128)):
+        st, ks, nb = down(*shape)
+        assert st == 0 and ks >= 0 and (ks == 0) == (nb == 0), (shape, st, ks, nb)
+    assert down(1, 512, 512, 16, 16)[1] > 0                         # 8^2 outputs: one point tile, cut between stream-K workers
+    for shape in ((4, 64, 64, 256, 256), (1, 128, 128, 256, 256)):  # 258-wide windows: narrow whole tiles, no workers, no scratch
+        assert down(*shape) == (0, 0, 0), shape
+    for shape in ((1, 64, 32, 64, 64), (1, 512, 512, 8, 8), (1, 60, 64, 64, 64), (1, 64, 60, 64, 64)):
+        assert down(*shape)[0] != 0, shape
+        assert not hipops.conv_down_supported(*shape)
+    assert hipops.conv_down_supported(2, 64, 128, 33, 47)            # odd sizes: outputs (H - 1) // 2 + 1
+    assert hipops.conv_tiny_supported(512, 512, 8, 8) and hipops.conv_tiny_supported(512, 512, 2, 2) and hipops.conv_tiny_supported(8, 5, 4, 4)
+    assert not hipops.conv_tiny_supported(512, 512, 16, 16) and not hipops.conv_tiny_supported(512, 512, 8, 4) and not hipops.conv_tiny_supported(1024, 8, 8, 8)
+    assert lib.ia_conv2d_down_plan(1, 512, 512, 32, 32, None, None) == -1 and 'null' in _lib.last_error()
+
+
+def test_encoder_conv2d_keeps_torch_semantics_off_the_device_path():
+    """layers.Conv2d is torch.nn.Conv2d for CPU tensors and under autograd (same parameters, same state-dict keys, same results)."""
+    from invertavatar_amd.encoder_inversion.models import layers, trunk_hip
+    torch.manual_seed(0)
+    mine, ref = layers.Conv2d(6, 10, 3, 2, 1), torch.nn.Conv2d(6, 10, 3, 2, 1)
+    ref.load_state_dict(mine.state_dict())
+    assert list(mine.state_dict()) == list(ref.state_dict()) == ['weight', 'bias']
+    x = torch.randn(2, 6, 9, 8, requires_grad=True)
+    assert trunk_hip._conv_route(mine, x) is None and not trunk_hip.conv_covered(mine, x.detach())
+    y = mine(x)
+    assert torch.equal(y, ref(x)) and y.requires_grad
