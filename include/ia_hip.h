@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -367,6 +367,15 @@ int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_split, int wk_e
                       const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                       const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
                       int transposed, int act, float alpha, const float* prelu_alpha, float gain, float clamp, int ksplit, void* stream);
+
+/*
+ * Depth-wise 3x3 convolution (stride 1, padding 1) of a Mix-FFN on the token grid, channels-last: y[b, n, c] = bias[c] + sum_k
+ * w9c[k][c] * x[b, n + offset_k, c] over the H x W grid of tokens n, optionally followed by GELU (erf form).  Replaces DWConv.forward of
+ * the transformer-refined decoders of the one-shot encoders (encoder_inversion/models/mmseg/mix_transformer.py:49-58: transpose -> view
+ * -> nn.Conv2d(groups = C) -> flatten -> transpose) and the activation after it (:70-77).
+ *   x, y [B, H*W, C] float32; w9c [9][C]: the module's weight [C, 1, 3, 3] transposed; bias [C] or NULL; act 0 = none, 1 = GELU.  C % 4 == 0.
+ */
+int ia_dwconv3x3_tokens(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, int act, void* stream);
 
 /*
  * 3x3 convolution with stride 2 and padding 1 on an image of 2^2, 4^2 or 8^2 pixels (outputs 1^2, 2^2, 4^2): the last layers of a

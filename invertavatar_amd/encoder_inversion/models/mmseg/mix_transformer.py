@@ -12,6 +12,8 @@ import torch.nn as nn
 
 from ..layers import Conv2d
 
+HIP_DWCONV = True      # Mix-FFN's depth-wise 3x3 (+ GELU) on the token grid through ia_dwconv3x3_tokens (device inference path)
+
 
 HIP_ATTENTION = True      # device inference: softmax(QK^T)V of the 1024-dim / 4-head blocks through ia_attention
 
@@ -58,9 +60,20 @@ class DWConv(nn.Module):
         super().__init__()
         self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, gelu=False):
+        """`gelu`: also apply the GELU (erf form) that follows in Mix-FFN -- one launch on the device path (ia_dwconv3x3_tokens)."""
         B, N, C = x.shape
-        return self.dwconv(x.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)
+        conv = self.dwconv
+        if (HIP_DWCONV and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and C % 4 == 0 and conv.kernel_size == (3, 3)
+                and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.groups == C == conv.out_channels and conv.padding_mode == 'zeros'):
+            from .... import _runtime, hipops
+            st = _runtime.state(self)
+            key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.device)
+            if getattr(st, 'w9c_key', None) != key:
+                st.w9c, st.w9c_key = conv.weight.detach().float().reshape(C, 9).t().contiguous(), key
+            return hipops.dwconv3x3_tokens(x.contiguous(), st.w9c, None if conv.bias is None else conv.bias.detach().float(), H, W, gelu=gelu)
+        y = conv(x.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)
+        return torch.nn.functional.gelu(y) if gelu else y
 
 
 class Mlp(nn.Module):
@@ -78,6 +91,8 @@ class Mlp(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x, H, W):
+        if isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none':
+            return self.drop(self.fc2(self.drop(self.dwconv(self.fc1(x), H, W, gelu=True))))
         return self.drop(self.fc2(self.drop(self.act(self.dwconv(self.fc1(x), H, W)))))
 
 

@@ -253,7 +253,7 @@ def _conv_route(conv, x):
     """Which kernel takes this torch.nn.Conv2d on this input: 'gemm' (1x1, any stride, no padding), 'patch' (k x k with stride k, no
     padding: a 1x1 layer on the space-to-depth image), 'sx' (3x3 stride 1 / 2, padding 1, split-format tile), 'f32' (3x3 stride 1 / 2,
     padding 1, few input channels), 'tiny' (3x3 stride 2 on 2^2 / 4^2 / 8^2 images: ia_conv3x3_s2_tiny, the last layers of the style heads) or
-    None (library: in the one-shot decoders, the depthwise 3x3 and the 7x7 stride-4 layers of the mix-transformer blocks)."""
+    None (library: in the one-shot decoders, the 7x7 stride-2 patch embeddings of the mix-transformer stages)."""
     if not (_device_path(x) and x.dim() == 4 and conv.groups == 1 and conv.dilation == (1, 1) and conv.padding_mode == 'zeros'
             and conv.weight.dtype == torch.float32 and conv.stride[0] == conv.stride[1]):
         return None

@@ -395,6 +395,21 @@ def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=Non
     return y if want_f32 else out_s
 
 
+def dwconv3x3_tokens(x, w9c, bias, h, w, gelu=False):
+    """ia_dwconv3x3_tokens: depth-wise 3x3 convolution of tokens [B, H*W, C] on their H x W grid (+ GELU); w9c [9, C]."""
+    _f32c(x, 'x')
+    _f32c(w9c, 'w9c')
+    b, n, c = x.shape
+    if n != h * w or tuple(w9c.shape) != (9, c) or c % 4:
+        raise RuntimeError(f'dwconv3x3_tokens: tokens {tuple(x.shape)} on a {h} x {w} grid with weights {tuple(w9c.shape)} (C % 4 == 0)')
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        st = _lib.load().ia_dwconv3x3_tokens(_p(x), _p(w9c), _p(None if bias is None else _f32c(bias, 'bias')), _p(y), b, h, w, c, 1 if gelu else 0,
+                                             _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_dwconv3x3_tokens')
+    return y
+
+
 def conv_tiny_supported(i, o, h, w):
     """Shapes ia_conv3x3_s2_tiny covers (3x3, stride 2, padding 1 on 2^2 / 4^2 / 8^2 images)."""
     return bool(_lib.load().ia_conv3x3_s2_tiny_supported(int(i), int(o), int(h), int(w)))

@@ -79,6 +79,34 @@ def test_one_shot_inversion_matches_reference(golden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('b,h,w,c', [(1, 64, 64, 2048), (2, 8, 8, 2048), (1, 5, 7, 12)])
+def test_depthwise_token_convolution_matches_the_module(b, h, w, c):
+    """ia_dwconv3x3_tokens (Mix-FFN's depth-wise 3x3 on the channels-last token grid, optionally with the GELU behind it) against
+    mix_transformer.DWConv's own torch route in fp64 (mix_transformer.py:49-58, :70-77)."""
+    import copy
+    from invertavatar_amd.encoder_inversion.models.mmseg import mix_transformer
+    torch.manual_seed(c + h)
+    mod = mix_transformer.DWConv(c).requires_grad_(False)
+    mod.dwconv.weight.normal_(0, 0.4); mod.dwconv.bias.normal_(0, 0.2)
+    x = torch.randn(b, h * w, c)
+    ref = copy.deepcopy(mod).double()
+    want = ref(x.double(), h, w)
+    want_gelu = torch.nn.functional.gelu(want)
+    mod = mod.cuda()
+    with torch.no_grad():
+        got, got_gelu = mod(x.cuda(), h, w).cpu(), mod(x.cuda(), h, w, gelu=True).cpu()
+        mix_transformer.HIP_DWCONV = False
+        try:
+            lib = mod(x.cuda(), h, w, gelu=True).cpu()
+        finally:
+            mix_transformer.HIP_DWCONV = True
+    for name, a, ref_t in (('linear', got, want), ('gelu', got_gelu, want_gelu), ('library', lib, want_gelu)):
+        err = (a.double() - ref_t).abs().max().item() / max(ref_t.abs().max().item(), 1.0)
+        print(f'dwconv tokens B{b} {h}x{w} C{c} [{name}]: {err:.2e}')
+        assert a.shape == (b, h * w, c) and err <= 2e-6
+
+
+@pytest.mark.gpu
 def test_graphed_one_shot_inversion_equals_the_eager_flow():
     """eval_updated_os.GraphedOneShot (the whole one-shot inversion as one hipGraph, bench.py's oneshot leg) against the eager flow on
     the source it was captured with and on another one; the renderer's random draws pinned to device tensors made before the capture."""

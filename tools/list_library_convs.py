@@ -51,11 +51,21 @@ def wrap(name, fn):
 F.conv2d = wrap('conv2d', F.conv2d)
 F.conv_transpose2d = wrap('conv_transpose2d', F.conv_transpose2d)
 
+if '--oneshot' in sys.argv:      # the one-shot flow (eval_updated_os.py: uvnet_new with the transformer-refined decoders)
+    from invertavatar_amd import eval_updated_os
+    from invertavatar_amd.encoder_inversion.models.uvnet_new import inversionNet as OneShotNet
+    net = OneShotNet(generator=gen, encoding_triplane=True, encoding_texture=True).eval().requires_grad_(False)
+    synthetic.fill_encoder_parameters(net)
+    net = net.cuda()
+    one = (synthetic.source_frames(9, 1).cuda(), synthetic.source_uv(19, [12]).cuda(), synthetic.camera_labels([12]).cuda(), synthetic.uv_conditions([12]).cuda())
+    flow = lambda: eval_updated_os.one_shot_inversion(net, *one)      # noqa: E731
+else:
+    flow = lambda: eval_seq.few_shot_inversion(net, images, uvs, cams, uvc)      # noqa: E731
 with torch.no_grad():
-    eval_seq.few_shot_inversion(net, images, uvs, cams, uvc)
+    flow()
     torch.cuda.synchronize()
     recording[0] = True
-    eval_seq.few_shot_inversion(net, images, uvs, cams, uvc)
+    flow()
     torch.cuda.synchronize()
 
 total = sum(v[1] for v in log.values())
