@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -556,6 +556,15 @@ int ia_convgru_update_split(const float* gates_pre, const float* cand_pre, const
  */
 int ia_se_gate(const float* v, const int64_t* v_strides, const float* shortcut, const int64_t* shortcut_strides, const float* w1,
                const float* w2, float* pooled_scratch, float* out, int B, int C, int R, int H, int W, void* stream);
+
+/*
+ * ia_se_gate with the result ALSO in split format for the convolution that consumes it: ys = split(out * next_scale[b][c] +
+ * next_shift[b][c]) (ia_act_split's two-plane format; the eval-mode BatchNorm in front of the next residual unit's first convolution,
+ * helpers.py:102-124), or ys = next_scale = next_shift = NULL for the fp32 result alone.  C % 8 == 0.  Same arithmetic as ia_se_gate.
+ */
+int ia_se_gate_split(const float* v, const int64_t* v_strides, const float* shortcut, const int64_t* shortcut_strides, const float* w1,
+                     const float* w2, float* pooled_scratch, float* out, const float* next_scale, const float* next_shift, void* ys,
+                     int B, int C, int R, int H, int W, void* stream);
 
 /*
  * Multi-head self-attention in one launch: out = softmax(Q K^T * scale) V per (batch, head), without the [N, M] score matrix.

@@ -71,6 +71,7 @@ _SIGNATURES = {
     'ia_convgru_update': [c_void_p] * 7 + [c_int] * 4 + [c_void_p],
     'ia_convgru_update_split': [c_void_p] * 7 + [c_int] * 4 + [c_void_p],
     'ia_se_gate': [c_void_p, _i64p, c_void_p, _i64p] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
+    'ia_se_gate_split': [c_void_p, _i64p, c_void_p, _i64p] + [c_void_p] * 7 + [c_int] * 5 + [c_void_p],
     'ia_attention_supported': [c_int] * 3,
     'ia_attention': [c_void_p] * 4 + [c_int] * 5 + [c_int64] * 8 + [c_float, c_void_p],
     'ia_uv_rasterize': [c_void_p] * 5 + [c_int] * 8 + [c_float, c_int, c_void_p],

@@ -92,13 +92,16 @@ def run_trunk(body, x, taps):
     """Run the residual units and collect the activations after the unit indices in `taps`."""
     from . import trunk_hip
     found = {}
-    for i, unit in enumerate(body._modules.values()):
+    units = list(body._modules.values())
+    xs = None          # the staged (BatchNorm + split) input of the next unit, when the previous unit's tail wrote it (eval-mode units)
+    for i, unit in enumerate(units):
         if HIP_TRUNK and isinstance(unit, (bottleneck_IR, bottleneck_IR_SE)) and trunk_hip.unit_supported(unit, x):
-            x = trunk_hip.unit_forward(unit, x)
+            nxt = units[i + 1] if i + 1 < len(units) and isinstance(units[i + 1], bottleneck_IR_SE) else None
+            x, xs = trunk_hip.unit_forward(unit, x, xs=xs, nxt=nxt) if nxt is not None else (trunk_hip.unit_forward(unit, x, xs=xs), None)
         elif HIP_TRUNK and isinstance(unit, bottleneck_IR_SE) and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
-            x = trunk_hip.se_tail(unit, unit.res_layer[:5](x), x)      # library convolutions / BatchNorm, fused gate + shortcut + add
+            x, xs = trunk_hip.se_tail(unit, unit.res_layer[:5](x), x), None      # library convolutions / BatchNorm, fused gate + shortcut + add
         else:
-            x = unit(x)
+            x, xs = unit(x), None
         if i in taps:
             found[i] = x
     return x, [found[i] for i in taps]

@@ -130,12 +130,38 @@ def unit_supported(unit, x):
             and conv2.in_channels == o and conv2.out_channels == o)
 
 
-def unit_forward(unit, x):
-    """bottleneck_IR_SE.forward (helpers.py:121-124) with the residual branch's convolutions on the HIP kernels."""
+def _pack_of(unit):
     pack = _runtime.state(unit)
     if not hasattr(pack, 'trunk'):
         pack.trunk = _UnitPack()
-    p = pack.trunk.get(unit)
+    return pack.trunk.get(unit)
+
+
+def next_unit_affine(unit, nxt, x):
+    """The rows (scale, shift) [B, C] of `nxt`'s first BatchNorm when `nxt` will run unit_forward in EVAL mode on this unit's output
+    (then the squeeze-and-excitation tail of `unit` writes nxt's staged input itself: SE_WRITES_NEXT_SPLIT), else None."""
+    if not (SE_WRITES_NEXT_SPLIT and nxt is not None and len(nxt.res_layer) > 5 and len(unit.res_layer) > 5):
+        return None
+    bn1, bn2 = nxt.res_layer[0], nxt.res_layer[4]
+    if bn1.training or bn2.training or not (bn1.track_running_stats and bn2.track_running_stats):
+        return None
+    s_ = unit.res_layer[3].stride[0]
+    b, o = x.shape[0], unit.res_layer[3].out_channels
+    oh, ow = (x.shape[2] - 1) // s_ + 1, (x.shape[3] - 1) // s_ + 1
+    proxy = x.new_empty((b, o, oh, ow))      # (shape / device / dtype carrier for the support rule; never written)
+    if o % 8 or not unit_supported(nxt, proxy):
+        return None
+    return _pack_of(nxt).eval_affines(nxt, b)[:2]
+
+
+SE_WRITES_NEXT_SPLIT = True     # eval-mode trunks: a unit's SE tail also writes the next unit's normalised split input (one launch fewer per unit)
+
+
+def unit_forward(unit, x, xs=None, nxt=None):
+    """bottleneck_IR_SE.forward (helpers.py:121-124) with the residual branch's convolutions on the HIP kernels.  `xs`: the unit's
+    staged input (BatchNorm applied, split format) when the previous unit's tail wrote it; `nxt`: the unit that runs next (run_trunk).
+    Returns the unit's output, or (output, staged input of nxt) when `nxt` is given."""
+    p = _pack_of(unit)
     bn1, bn2 = unit.res_layer[0], unit.res_layer[4]
     b = x.shape[0]
     x = x.contiguous()
@@ -143,7 +169,7 @@ def unit_forward(unit, x):
     batch_stats = bn1.training or bn2.training or not (bn1.track_running_stats and bn2.track_running_stats)
     if batch_stats:
         xs = batch_norm_split(bn1, x)
-    else:
+    elif xs is None:
         a1, c1 = p.eval_affines(unit, b)[:2]
         xs = hipops.act_split(x, a1, shift=c1)
     us = hipops.conv2d_mfma_sx(xs, p.w1, act='lrelu', prelu=p.slopes, want_f32=False, want_split=True)
@@ -158,12 +184,16 @@ def unit_forward(unit, x):
         v = conv2(us, p.w2, demod=a2, bias=c2, act='linear')
         if sub:
             v = v[:, :, ::2, ::2]
-    return se_tail(unit, v, x)
+    if nxt is None:
+        return se_tail(unit, v, x)
+    return se_tail(unit, v, x, next_affine=next_unit_affine(unit, nxt, x), both=True)
 
 
-def se_tail(unit, v, x):
+def se_tail(unit, v, x, next_affine=None, both=False):
     """SEModule gate + shortcut + add of a residual unit (helpers.py:84-100, :121-124) in two launches (ia_se_gate); `v`: the residual
-    branch in front of the gate (may be a strided view).  Units without a gate, CPU tensors and autograd take the ATen ops."""
+    branch in front of the gate (may be a strided view).  Units without a gate, CPU tensors and autograd take the ATen ops.
+    `next_affine` = (scale rows, shift rows) [B, C]: also write split(out * scale + shift), the staged input of the next unit
+    (ia_se_gate_split); `both`: return (out, that SplitAct or None)."""
     se = unit.res_layer[5] if len(unit.res_layer) > 5 else None
     short = unit.shortcut_layer
     if (se is not None and v.is_cuda and v.dtype == torch.float32 and not torch.is_grad_enabled() and se.fc1.out_channels <= 64
@@ -174,10 +204,15 @@ def se_tail(unit, v, x):
         else:
             sc = short(x)
         c = v.shape[1]
-        return hipops.se_gate(v, sc, se.fc1.weight.detach().float().reshape(-1, c).contiguous(),
-                              se.fc2.weight.detach().float().reshape(c, -1).contiguous())
+        w1, w2 = se.fc1.weight.detach().float().reshape(-1, c).contiguous(), se.fc2.weight.detach().float().reshape(c, -1).contiguous()
+        if next_affine is not None and c % 8 == 0:
+            out, ys = hipops.se_gate_split(v, sc, w1, w2, next_affine[0], next_affine[1])
+            return (out, ys) if both else out
+        out = hipops.se_gate(v, sc, w1, w2)
+        return (out, None) if both else out
     res = se(v) if se is not None else v
-    return res + short(x)
+    out = res + short(x)
+    return (out, None) if both else out
 
 
 # ------------------------------------------------------------------ plain 3x3 convolutions of the UNet decoders / heads

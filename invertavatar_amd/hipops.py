@@ -1000,6 +1000,28 @@ def attention(q, kv, heads, scale):
     return out
 
 
+def se_gate_split(v, shortcut, w1, w2, next_scale=None, next_shift=None, consumer=None):
+    """ia_se_gate_split: (out, SplitAct of out * next_scale + next_shift or None).  next_scale / next_shift: [B, C] rows (the eval-mode
+    BatchNorm in front of the convolution that reads `out` next) or both None."""
+    b, c, h, w = v.shape
+    if not (v.is_cuda and v.dtype == torch.float32 and shortcut.dtype == torch.float32 and tuple(shortcut.shape) == (b, c, h, w)):
+        raise RuntimeError('se_gate_split: v and shortcut must be float32 device tensors of one shape')
+    if (next_scale is None) != (next_shift is None):
+        raise RuntimeError('next_scale and next_shift come together')
+    r = w1.shape[0]
+    _f32c(w1, 'w1'); _f32c(w2, 'w2')
+    if next_scale is not None and (_f32c(next_scale, 'next_scale').numel() != b * c or _f32c(next_shift, 'next_shift').numel() != b * c):
+        raise RuntimeError(f'next_scale / next_shift must have {b} x {c} elements')
+    out = torch.empty(b, c, h, w, device=v.device, dtype=torch.float32)
+    pooled = torch.empty(b * c, device=v.device, dtype=torch.float32)
+    ys = torch.empty(b, 2, c // 8, h, w, 8, device=v.device, dtype=torch.float16) if next_scale is not None else None
+    with torch.cuda.device(v.device):
+        st = _lib.load().ia_se_gate_split(v.data_ptr(), _lib.strides64(v), shortcut.data_ptr(), _lib.strides64(shortcut), _p(w1), _p(w2), _p(pooled),
+                                          _p(out), _p(next_scale), _p(next_shift), _p(ys), b, c, r, h, w, _lib.stream_ptr(v.device))
+    _lib.check(st, 'ia_se_gate_split')
+    return out, (SplitAct(ys, c, consumer) if ys is not None else None)
+
+
 def se_gate(v, shortcut, w1, w2):
     """v * sigmoid(w2 relu(w1 mean_hw(v))) + shortcut (see ia_se_gate).  v, shortcut: fp32 [B,C,H,W] views (any strides);
     w1 [R,C], w2 [C,R]."""

@@ -192,6 +192,44 @@ def test_residual_unit_on_hip_convolutions_matches_torch(in_c, depth, stride, re
         assert int(unit.res_layer[k].num_batches_tracked) == int(ref.res_layer[k].num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize('train_second', [False, True])
+def test_unit_chain_with_the_tail_writing_the_next_units_input(train_second):
+    """helpers.run_trunk over three residual units (stride 2, stride 1, stride 1) with trunk_hip.SE_WRITES_NEXT_SPLIT: a unit's
+    squeeze-and-excitation tail writes the next eval-mode unit's normalised split input (ia_se_gate_split) -- against the same chain
+    with the stand-alone split, and against the modules in fp64; a train-mode unit in the middle takes its own batch statistics."""
+    import copy
+    from invertavatar_amd.encoder_inversion.models import helpers, trunk_hip
+    torch.manual_seed(9)
+    body = torch.nn.Sequential(helpers.bottleneck_IR_SE(64, 128, 2), helpers.bottleneck_IR_SE(128, 128, 1), helpers.bottleneck_IR_SE(128, 128, 1)).requires_grad_(False).eval()
+    for unit in body:
+        _randomise_unit(unit)
+    if train_second:
+        body[1].train()
+    x = torch.randn(2, 64, 64, 64)
+    ref = copy.deepcopy(body).double()
+    want_taps = []
+    t = x.double()
+    for unit in ref:
+        t = unit(t)
+        want_taps.append(t.float())
+    body = body.cuda()
+    state = copy.deepcopy(body.state_dict())
+    outs = {}
+    for fused in (True, False):
+        body.load_state_dict(state)
+        trunk_hip.SE_WRITES_NEXT_SPLIT = fused
+        try:
+            with torch.no_grad():
+                last, taps = helpers.run_trunk(body, x.cuda(), (0, 1, 2))
+        finally:
+            trunk_hip.SE_WRITES_NEXT_SPLIT = True
+        outs[fused] = [t.cpu() for t in taps]
+        for got, want in zip(outs[fused], want_taps):
+            assert (got - want).abs().max().item() <= 3e-5 * max(want.abs().max().item(), 1.0)
+    for a, b_ in zip(outs[True], outs[False]):
+        assert (a - b_).abs().max().item() <= 2e-6 * max(b_.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize('i,o,k,s,p,b,h,w,route', [
     (256, 512, 1, 2, 0, 4, 32, 32, 'gemm'), (64, 128, 1, 2, 0, 1, 128, 128, 'gemm'), (384, 32, 1, 1, 0, 1, 32, 32, 'gemm'), (96, 256, 1, 1, 0, 1, 128, 128, 'gemm'),
     (7, 64, 3, 1, 1, 4, 256, 256, 'f32'), (3, 64, 3, 1, 1, 1, 256, 256, 'f32'), (24, 96, 3, 1, 1, 1, 256, 256, 'sx'), (96, 96, 3, 1, 1, 1, 256, 256, 'sx'),
