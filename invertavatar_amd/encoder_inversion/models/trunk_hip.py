@@ -119,11 +119,15 @@ def unit_supported(unit, x):
     """True when the unit's two 3x3 convolutions can run on ia_conv2d_mfma_sx for this input."""
     if not (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()):
         return False
-    if unit.training and (not TRAIN_UNITS or x.shape[0] * x.shape[2] * x.shape[3] <= 1):       # (torch.nn.BatchNorm2d raises on one value per channel)
+    return unit_shape_supported(unit, x.shape[0], x.shape[2], x.shape[3])
+
+
+def unit_shape_supported(unit, b, h, w):
+    """unit_supported for an fp32 device input of `b` images of h x w pixels (no tensor needed)."""
+    if unit.training and (not TRAIN_UNITS or b * h * w <= 1):       # (torch.nn.BatchNorm2d raises on one value per channel)
         return False
     conv1, conv2 = unit.res_layer[1], unit.res_layer[3]
     i, o = conv1.in_channels, conv1.out_channels
-    h, w = x.shape[-2:]
     plain = all(c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == 'zeros' for c in (conv1, conv2))
     return (plain and conv1.kernel_size == (3, 3) and conv2.kernel_size == (3, 3) and conv1.stride == (1, 1) and conv2.stride in ((1, 1), (2, 2))
             and conv1.bias is None and conv2.bias is None and sx_size_ok(i, o, h, w) and sx_size_ok(o, o, h, w)
@@ -148,8 +152,7 @@ def next_unit_affine(unit, nxt, x):
     s_ = unit.res_layer[3].stride[0]
     b, o = x.shape[0], unit.res_layer[3].out_channels
     oh, ow = (x.shape[2] - 1) // s_ + 1, (x.shape[3] - 1) // s_ + 1
-    proxy = x.new_empty((b, o, oh, ow))      # (shape / device / dtype carrier for the support rule; never written)
-    if o % 8 or not unit_supported(nxt, proxy):
+    if o % 8 or nxt.res_layer[1].in_channels != o or not unit_shape_supported(nxt, b, oh, ow):
         return None
     return _pack_of(nxt).eval_affines(nxt, b)[:2]
 
