@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -367,6 +367,13 @@ int ia_conv2d_mfma_sx(const void* xs, int planes, const void* wk_split, int wk_e
                       const float* noise_strength, const float* bias, const float* residual, float* y, void* ys, int ys_planes,
                       const float* styles_next, float* scratch, size_t scratch_bytes, int B, int I, int O, int H, int W,
                       int transposed, int act, float alpha, const float* prelu_alpha, float gain, float clamp, int ksplit, void* stream);
+
+/*
+ * y = bilinear resize of x [planes, H, W] to [planes, OH, OW] with align_corners = True (torch.nn.functional.interpolate's arithmetic)
+ * + addend [planes, OH, OW] (NULL: the resize alone).  Replaces `_upsample_add` of the e4e feature pyramid
+ * (encoder_inversion/models/e4e.py:48-65): F.interpolate(x, size=y.shape, mode='bilinear', align_corners=True) + y.
+ */
+int ia_upsample_bilinear_add(const float* x, const float* addend, float* y, int planes, int H, int W, int OH, int OW, void* stream);
 
 /*
  * Depth-wise 3x3 convolution (stride 1, padding 1) of a Mix-FFN on the token grid, channels-last: y[b, n, c] = bias[c] + sum_k

@@ -36,7 +36,10 @@ class GradualStyleBlock(Module):
 
 
 def _upsample_add(x, y):
-    """Bilinear (align_corners=True) resize of x to y's size, plus y (e4e.py:48-65)."""
+    """Bilinear (align_corners=True) resize of x to y's size, plus y (e4e.py:48-65); one launch on the device inference path."""
+    if x.is_cuda and x.dtype == y.dtype == torch.float32 and not torch.is_grad_enabled():
+        from ... import hipops
+        return hipops.upsample_bilinear_add(x.contiguous(), y.contiguous())
     return F.interpolate(x, size=y.shape[-2:], mode='bilinear', align_corners=True) + y
 
 

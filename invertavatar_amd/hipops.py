@@ -395,6 +395,20 @@ def conv2d_mfma_sx(xs, wk, demod=None, noise=None, noise_strength=None, bias=Non
     return y if want_f32 else out_s
 
 
+def upsample_bilinear_add(x, addend):
+    """ia_upsample_bilinear_add: bilinear resize (align_corners=True) of x [B, C, H, W] to addend's size, plus addend."""
+    _f32c(x, 'x')
+    _f32c(addend, 'addend')
+    b, c, h, w = x.shape
+    if addend.shape[:2] != x.shape[:2]:
+        raise RuntimeError(f'upsample_bilinear_add: {tuple(x.shape)} onto {tuple(addend.shape)}')
+    y = torch.empty_like(addend)
+    with torch.cuda.device(x.device):
+        st = _lib.load().ia_upsample_bilinear_add(_p(x), _p(addend), _p(y), b * c, h, w, addend.shape[2], addend.shape[3], _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_upsample_bilinear_add')
+    return y
+
+
 def dwconv3x3_tokens(x, w9c, bias, h, w, gelu=False):
     """ia_dwconv3x3_tokens: depth-wise 3x3 convolution of tokens [B, H*W, C] on their H x W grid (+ GELU); w9c [9, C]."""
     _f32c(x, 'x')

@@ -100,6 +100,17 @@ def test_graphed_inversion_equals_the_eager_flow():
             assert worst <= 5e-6          # (library GEMMs may pick other kernels under capture; the fixture tolerance is TOL_FEATURES)
 
 
+@pytest.mark.parametrize('b,c,h,w,oh,ow', [(1, 512, 16, 16, 32, 32), (1, 512, 32, 32, 64, 64), (2, 5, 7, 9, 20, 13), (1, 3, 4, 4, 1, 1)])
+def test_bilinear_upsample_add_matches_interpolate(b, c, h, w, oh, ow):
+    """ia_upsample_bilinear_add (the e4e pyramid's `_upsample_add`) against F.interpolate(align_corners=True) + y in fp64."""
+    from invertavatar_amd import hipops
+    torch.manual_seed(h + ow)
+    x, y = torch.randn(b, c, h, w), torch.randn(b, c, oh, ow)
+    want = torch.nn.functional.interpolate(x.double(), size=(oh, ow), mode='bilinear', align_corners=True) + y.double()
+    got = hipops.upsample_bilinear_add(x.cuda(), y.cuda()).cpu()
+    assert got.shape == want.shape and (got.double() - want).abs().max().item() <= 2e-6 * max(want.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize('spatial', [16, 32, 64])
 def test_style_head_with_fused_epilogues_matches_the_module(spatial):
     """e4e.GradualStyleBlock on the device path (trunk_hip.style_head_forward: LeakyReLU in the epilogues of ia_conv2d_down_sx /
