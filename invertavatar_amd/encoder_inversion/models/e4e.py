@@ -9,7 +9,7 @@ from torch import nn
 from torch.nn import Module
 
 from ...training.networks_stylegan2 import FullyConnectedLayer
-from .helpers import irse50_trunk, run_trunk
+from .helpers import face_pool_to, irse50_trunk, run_trunk
 from .layers import Conv2d
 
 
@@ -133,6 +133,6 @@ class e4e(nn.Module):
 
     def encode(self, x):
         if x.shape[-1] != 256:
-            x = self.face_pool(x)
+            x = face_pool_to(self.face_pool, x)
         codes = self.encoder(x)
         return codes + self.latent_avg.repeat(codes.shape[0], 1, 1)

@@ -12,7 +12,7 @@ from torch import nn
 from torch.nn import Module
 import torch.nn.functional as F
 
-from .helpers import irse50_trunk, run_trunk
+from .helpers import face_pool_to, irse50_trunk, run_trunk
 from .layers import Conv2d
 
 
@@ -168,7 +168,7 @@ class _UNetBase(Module):
 
     def _encode(self, x):
         if self.face_pool is not None and x.shape[-1] != self.res:
-            x = self.face_pool(x)
+            x = face_pool_to(self.face_pool, x)
         x, (c0, c1, c2, c3) = run_trunk(self.body, self.input_layer(x), (2, 6, 20, 21))
         return x, c0, c1, c2, c3
 

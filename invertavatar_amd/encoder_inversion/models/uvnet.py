@@ -13,6 +13,7 @@ from torch import nn
 from ... import dnnlib
 from ...torch_utils import misc
 from .e4e import Encoder4Editing
+from .helpers import face_pool_to
 from .unet_encoders import TriPlaneSFTfeat_Encoder, TriPlanefeat_Encoder
 
 
@@ -82,7 +83,7 @@ class inversionNet(nn.Module):
 
     def encode(self, x):
         if x.shape[-1] != 256:
-            x = self.face_pool(x)
+            x = face_pool_to(self.face_pool, x)
         if type(self.encoder) is nn.ModuleList:
             codes = torch.cat([enc(x) for enc in self.encoder], dim=1)
         else:
