@@ -44,3 +44,36 @@ def test_convgru_and_unet_shapes():
     assert o2.shape == (2, 3, 8, 5, 5) and torch.equal(o2[:, -1], h2)
     # GRU update is a convex combination of the state and a tanh candidate -> bounded by 1 when started from zero
     assert h2.abs().max() <= 1.0
+
+
+def test_group_renders_equal_the_per_group_calls():
+    """eval_seq.group_renders (r05: the source frames of ALL groups rendered from the e4e features in calls of up to 8, each frame with
+    its group's depth range) against the per-group calls of T = 4 that AR_eval_forward makes itself, on the CPU formulation with the
+    small generator and the marcher's draws given explicitly: group-major frame order, per-frame `ray_dist`, slicing of the draws."""
+    from invertavatar_amd import eval_seq
+    from invertavatar_amd.frame_parallel import global_ray_dist
+    from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+    g = TriPlaneGenerator(**synthetic.generator_kwargs('small')).eval().requires_grad_(False)
+    synthetic.fill_parameters(g)
+    nrr = g.neural_rendering_resolution = 16
+
+    class Net:
+        generator = g
+    n, rays = 8, nrr * nrr
+    src = [int(round(k * 32 / n)) for k in range(n)]
+    cams, uvc = synthetic.camera_labels(src), synthetic.uv_conditions(src)
+    sels = [slice(k, None, 2) for k in range(2)]          # the script's interleaved groups: frames 0 2 4 6 | 1 3 5 7
+    assert abs(float(global_ray_dist(cams[sels[0]])) - float(global_ray_dist(cams[sels[1]]))) >= 0.0
+    gen = torch.Generator().manual_seed(3)
+    jit, u = torch.rand(n, rays, 48, generator=gen), torch.rand(n * rays, 48, generator=gen)      # group-major frame order
+    with torch.no_grad():
+        ws = torch.randn(1, g.backbone.num_ws, 512, generator=gen) * 0.5
+        tex = g.texture_backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
+        sta = g.backbone.synthesis(ws, cond_list=None, return_list=True, update_emas=False, noise_mode='const')
+        got = eval_seq.group_renders(Net, ws, {'w': ws, 'texture': tex, 'static': sta}, cams, uvc, sels, draws=(jit, u))
+        for k, sel in enumerate(sels):
+            want = g.synthesis_withTexture(ws.expand(4, -1, -1), [f.expand(4, -1, -1, -1) for f in tex], cams[sel], {'uvcoords_image': uvc[sel]},
+                                           static_feats=[f.expand(4, -1, -1, -1) for f in sta], noise_mode='const', jitter=jit[4 * k:4 * k + 4],
+                                           u_importance=u[4 * k * rays:(4 * k + 4) * rays])['image']
+            assert got[k].shape == want.shape == (4, 3, 512, 512)
+            assert max_abs(got[k], want) <= 2e-5
