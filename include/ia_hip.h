@@ -13,7 +13,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *   - return value: 0 on success, negative ia_status on failure; the message of the last
  *     failure on the calling thread is available from ia_last_error();
- *   - nothing throws across the ABI; the library is re-entrant (no mutable globals).
+ *   - nothing throws across the ABI; the library is re-entrant: it keeps no mutable state that a result depends on.  The one
+ *     mutable device word per kernel module is the fp16 range watch (a sticky diagnostic flag, OR-ed by the kernels that write the
+ *     split format when a value leaves the fp16 range, read and cleared by ia_split_saturation_poll -- an errno, not an input).
  *
  * Element types are named by ia_dtype.  "f16" is IEEE binary16 (the reference's c10::Half).
  */
@@ -27,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 5      /* 5 (r05, additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 6      /* 6 (r06, additive): ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -182,6 +184,7 @@ int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B,
 #define IA_RENDER_WHITE_BACK 1
 #define IA_RENDER_RGB_CHANNEL_MAJOR 2
 #define IA_RENDER_DIST_PER_FRAME 4
+#define IA_RENDER_FLIP_Z 8            /* ia_render_rays_box only */
 
 /*
  * The fused importance renderer: one launch replaces ImportanceRenderer_bsMotion.forward(evaluation=True)
@@ -223,6 +226,38 @@ int ia_render_rays(const float* planes_cl, const float* rays_o, const float* ray
 
 /* Number of persistent workgroups ia_render_rays launches for (B, R); sizes minmax_scratch. Host-only. */
 int ia_render_rays_grid(int B, int R);
+
+/*
+ * The same fused launch for the EG3D renderer class, ImportanceRenderer.forward
+ * (training_avatar_texture/volumetric_rendering/renderer.py:129-201; run_model :195-202, sample_stratified :224-247,
+ * sample_importance / sample_pdf :249-293).  Differences from ia_render_rays:
+ *   ray_limits : [B, R, 2] per-ray (near, far) -- rendering_options['ray_start'] == ['ray_end'] == 'auto', the output of
+ *               ia_ray_limits_box -- sampled with math_utils.linspace (math_utils.py:101-118) and per-ray noise scale (:236-238);
+ *               NULL = the fixed range [ray_start, ray_end] (the options' python doubles) through torch.linspace (:240-242)
+ *   u_importance : required -- this class always draws its importance samples (sample_pdf det=False, :280); sorted per ray
+ *   flags : IA_RENDER_WHITE_BACK, IA_RENDER_RGB_CHANNEL_MAJOR as above; IA_RENDER_FLIP_Z = the class's flip_z (the z coordinate of
+ *          every sample is negated before the plane lookup, :196-197); IA_RENDER_DIST_PER_FRAME is rejected
+ * Everything else (decoder, ray marcher, batch-global depth clamp, scratch, debug outputs) as ia_render_rays.
+ */
+int ia_render_rays_box(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
+                       const float* u_importance, const float* ray_limits, double ray_start, double ray_end,
+                       const float* w0, const float* b0, const float* w1, const float* b1,
+                       float lr_multiplier, float box_warp, int flags,
+                       int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
+                       float* rgb, float* depth, float* wsum, float* minmax_scratch,
+                       float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
+                       void* stream);
+
+/*
+ * math_utils.get_ray_limits_box (volumetric_rendering/math_utils.py:46-98): slab test of n_rays rays (rays_o / rays_d [n_rays, 3])
+ * against the axis-aligned cube of side box_side_length centred at the origin -> ray_limits [n_rays, 2] = (t_near, t_far),
+ * (-1, -2) for a ray that misses.  repair_misses != 0 additionally applies ImportanceRenderer.forward's repair (renderer.py:133-136)
+ * on the device, without the reference's `.item()` round trip: if any ray hits, every missing ray gets (min, max) of the hit rays'
+ * NEAR limits.  part_scratch: 2 * ia_ray_limits_box_parts(n_rays) floats of caller scratch.
+ */
+int ia_ray_limits_box(const float* rays_o, const float* rays_d, double box_side_length, int n_rays, int repair_misses,
+                      float* ray_limits, float* part_scratch, void* stream);
+int ia_ray_limits_box_parts(int n_rays);      /* host-only */
 
 /*
  * Stage entry for parity tests: smoothed inverse-CDF importance resampling (renderer.py:410-469, det=True) and the

@@ -17,7 +17,7 @@ _lib = None
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _i64p = ctypes.POINTER(ctypes.c_int64)
 
-ABI_VERSION = 5      # IA_HIP_ABI_VERSION of include/ia_hip.h
+ABI_VERSION = 6      # IA_HIP_ABI_VERSION of include/ia_hip.h
 
 DTYPE_ID = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
 
@@ -37,6 +37,9 @@ _SIGNATURES = {
     'ia_modconv_demod': [c_void_p] * 3 + [c_int] * 3 + [c_void_p],
     'ia_render_rays': [c_void_p] * 10 + [c_float, c_float, c_int] + [c_int] * 6 + [c_void_p] * 9 + [c_void_p],
     'ia_render_rays_grid': [c_int, c_int],
+    'ia_render_rays_box': [c_void_p] * 6 + [ctypes.c_double, ctypes.c_double] + [c_void_p] * 4 + [c_float, c_float, c_int] + [c_int] * 6 + [c_void_p] * 9 + [c_void_p],
+    'ia_ray_limits_box': [c_void_p, c_void_p, ctypes.c_double, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    'ia_ray_limits_box_parts': [c_int],
     'ia_importance_stage': [c_void_p] * 5 + [c_int, c_void_p],
     'ia_fill_mouth': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'ia_mouth_edge_blur': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

@@ -187,7 +187,9 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
             // The transposed form's epilogue is the demodulation alone (FIR, noise, bias, activation follow in the FIR tail): its
             // coefficients -- 16 per fragment, the same for all four phases -- are read once, ahead of the stores (read per element
             // they are re-loaded after every store: the compiler cannot prove that y does not alias them).
-            const bool simple = IA_TR_SIMPLE_EPI && !e.noise && !e.bias && !e.residual && e.act == IA_ACT_LINEAR && e.clamp < 0.f && e.gain == 1.f;
+            // (the quad-wise stores below skip a channel quad as a whole: only for channel counts that are multiples of 4 -- a ragged count
+            // takes the per-element loop with its `o >= g.O` test)
+            const bool simple = IA_TR_SIMPLE_EPI && !e.noise && !e.bias && !e.residual && e.act == IA_ACT_LINEAR && e.clamp < 0.f && e.gain == 1.f && (g.O & 3) == 0;
             float dmv[FO][16];
 #pragma unroll
             for (int fo = 0; fo < FO; ++fo)
@@ -212,7 +214,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TR ? 4 : 1][FO][F
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const int o_first = o0 + (wo * FO + fo) * 32 + 8 * q + 4 * half;
-                                if (o_first + 3 >= g.O) continue;         // (channel counts are multiples of 8)
+                                if (o_first + 3 >= g.O) continue;         // (O % 4 == 0 here: the quad is inside or outside as a whole)
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     const int r = 4 * q + k;

@@ -277,7 +277,7 @@ __device__ __forceinline__ void store_tile_dual(const f32x16 (&acc)[1][FO][FP], 
                     a += bs[k];
                     a = a > 0.f ? a : a * sl[k];
                     a *= gain;
-                    a = fminf(fmaxf(a, -clamp), clamp);
+                    { const float c = fminf(fmaxf(a, -clamp), clamp); a = (a != a) ? a : c; }      // NaN stays NaN (fmaxf would return -clamp), as torch.clamp / bias_act.cu:144 keep it
                     a += res[k];
                     v[k] = inside ? a : 0.f;
                     t[k] = v[k] * sn[k];

@@ -65,6 +65,9 @@ struct Params {
     const float* jitter;          // [B][R][48]
     const float* u_imp;           // [B][R][48] sorted uniform draws of the importance pass, or null: linspace(0, 1, 48)
     const float* dist;            // device scalar: batch mean of |ray origin| (renderer.py:311); [B] with dist_per_frame
+    const float* limits;          // ImportanceRenderer (renderer.py:129-139): per-ray [near, far] of the 'auto' box limits [B][R][2], or null
+    double range_start, range_end;  // ... its fixed rendering_options['ray_start'/'ray_end'] (python doubles) when range_fixed
+    int range_fixed, flip_z;
     const float* w0; const float* b0; const float* w1; const float* b1;   // decoder parameters, reference layout
     float w0_gain, w1_gain, b_gain;
     float box_scale;              // 2 / box_warp
@@ -413,7 +416,8 @@ __device__ __forceinline__ void merge_sorted(float* scr, int lane, int& pos_c, i
 
 // SQ: square planes (every tri-plane generator's case).  The gather then sees PH == PW at compile time and the per-axis work of a
 // coordinate that two planes share (x: planes 0, 1 as column and plane 2 as row; z: plane 1 as row, plane 2 as column) is done once.
-template <bool SQ>
+// BOX: the ImportanceRenderer form (ia_render_rays_box: per-ray limits or a fixed range, flip_z); its scalars stay out of the generator's kernel.
+template <bool SQ, bool BOX>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -444,17 +448,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
     float* scr = lds + SCR_OFF + wave * SCR;
     float* tc = scr; float* sc = scr + NS; float* wc = scr + 2 * NS; float* tm = scr + 8 * NS;
 
-    float blk_min = INFINITY, blk_max = 0.f;
+    float blk_min = INFINITY, blk_max = -INFINITY;
     // dist_per_frame: the depth clamp is every frame's own sample range (the script renders those frames one call each), kept per wave
     // and frame in minmax[((workgroup * WAVES + wave) * B + b) * 2]: a wave meets its frames in ascending order and writes a frame's
     // range when it leaves it (lane 0 wrote the empty range to all its slots first: same lane, program order)
     int cur_b = -1;
     float* mm_wave = p.minmax + (int64_t)(blockIdx.x * WAVES + wave) * p.B * 2;
     if (p.dist_per_frame && lane == 0)
-        for (int i = 0; i < p.B; ++i) { mm_wave[2 * i] = INFINITY; mm_wave[2 * i + 1] = 0.f; }
+        for (int i = 0; i < p.B; ++i) { mm_wave[2 * i] = INFINITY; mm_wave[2 * i + 1] = -INFINITY; }
 
     const int nrays = p.B * p.R;
     const int PHs = SQ ? p.PW : p.PH;
+    const float z_scale = (BOX && p.flip_z) ? -p.box_scale : p.box_scale;      // run_model's `sample_coordinates[..., -1] *= -1` (renderer.py:196-197): exact
 #if IA_RENDER_TRACE
     int tr_ray = -1;
 #endif
@@ -468,25 +473,33 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         const int b = ray / p.R;
         if (p.dist_per_frame && b != cur_b) {
             if (cur_b >= 0 && lane == 0) { mm_wave[2 * cur_b] = blk_min; mm_wave[2 * cur_b + 1] = blk_max; }
-            blk_min = INFINITY; blk_max = 0.f; cur_b = b;
+            blk_min = INFINITY; blk_max = -INFINITY; cur_b = b;
         }
         // depth range: renderer.py:311-313,404-406 (python doubles, fp32 tensors); one value for the batch, or one per frame when the
         // caller renders several single-frame calls of the script as one batch (wave-uniform scalar work either way)
-        const double dist = (double)p.dist[p.dist_per_frame ? b : 0];
-        const float t_start = (float)(dist - 0.45), t_end = (float)(dist + 0.6);
+        // ImportanceRenderer (renderer.py:129-139): a fixed [ray_start, ray_end] takes the same torch.linspace route with the caller's doubles
+        double r_lo, r_hi;
+        if (BOX && p.range_fixed) { r_lo = p.range_start; r_hi = p.range_end; }
+        else if (BOX) { r_lo = 0.0; r_hi = 0.0; }
+        else { const double dist = (double)p.dist[p.dist_per_frame ? b : 0]; r_lo = dist - 0.45; r_hi = dist + 0.6; }
+        const float t_start = (float)r_lo, t_end = (float)r_hi;
         const float t_step = (t_end - t_start) / (float)(NS - 1);
-        const float t_delta = (float)(((dist + 0.6) - (dist - 0.45)) / (double)(NS - 1));
+        const float t_delta = (float)((r_hi - r_lo) / (double)(NS - 1));
         const float* planes_b = p.planes + (int64_t)b * 3 * p.PH * p.PW * 32;
         const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
         const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
 
         // ---- coarse pass: density only
-        if (lane < NS) tc[lane] = linspace_at(t_start, t_end, t_step, lane, NS) + p.jitter[(int64_t)ray * NS + lane] * t_delta;
+        if (BOX && p.limits) {      // (kernel-uniform) per-ray box limits: math_utils.linspace (math_utils.py:101-118) = start + (k / 47) * (stop - start)
+            // in fp32 tensor arithmetic, noise scaled by the fp32 tensor (end - start) / 47 (renderer.py:236-238)
+            const float lo = p.limits[(int64_t)ray * 2], hi = p.limits[(int64_t)ray * 2 + 1];
+            if (lane < NS) tc[lane] = (lo + ((float)lane / (float)(NS - 1)) * (hi - lo)) + p.jitter[(int64_t)ray * NS + lane] * ((hi - lo) / (float)(NS - 1));
+        } else if (lane < NS) tc[lane] = linspace_at(t_start, t_end, t_step, lane, NS) + p.jitter[(int64_t)ray * NS + lane] * t_delta;
         wave_sync();
         float4 raw[24]; float wgt[12];
         {
             const float t = tc[gj];
-            gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+            gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * z_scale, raw, wgt);
         }
 #pragma unroll 1
         for (int g = 0; g < NS / 16; ++g) {
@@ -494,14 +507,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             asm volatile("" ::: "memory");   // decoder weights are re-read from LDS every group: their registers hold the prefetched texels
             {
                 const float t = tc[16 * g + gj];
-                gather_issue<kEarlyPlanes, 3>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                gather_issue<kEarlyPlanes, 3>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * z_scale, raw, wgt);
             }
             gather_reduce(raw, wgt, f);
             features_to_operand(scr + COL_OFF + (16 * g) * CS, gj, gc, s, q, f);
             IA_RSTAMP(1 + 4 * g);
             if (g + 1 < NS / 16) {      // next group's loads fly under this group's decoder
                 const float t = tc[16 * (g + 1) + gj];
-                gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * z_scale, raw, wgt);
             }
             decoder_hidden(lds, lane, q, f, h);
             IA_RSTAMP(2 + 4 * g);
@@ -566,20 +579,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
             const float* tf = scr + 7 * NS;
             {
                 const float t = tf[gj];
-                gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * z_scale, raw, wgt);
             }
 #pragma unroll 1
             for (int g = 0; g < NS / 16; ++g) {
                 const float t = tf[16 * g + gj];
                 float f[8]; f32x4 h[4], col[2];
                 asm volatile("" ::: "memory");
-                gather_issue<kEarlyPlanes, 3>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * p.box_scale, raw, wgt);
+                gather_issue<kEarlyPlanes, 3>(planes_b, PHs, p.PW, gc, (ox + t * dx) * p.box_scale, (oy + t * dy) * p.box_scale, (oz + t * dz) * z_scale, raw, wgt);
                 gather_reduce(raw, wgt, f);
                 features_to_operand(scr + COL_OFF + (NS + 16 * g) * CS, gj, gc, s, q, f);
                 IA_RSTAMP(16 + 4 * g);
                 if (g + 1 < NS / 16) {
                     const float tn = tf[16 * (g + 1) + gj];
-                    gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * p.box_scale, raw, wgt);
+                    gather_issue<0, kEarlyPlanes>(planes_b, PHs, p.PW, gc, (ox + tn * dx) * p.box_scale, (oy + tn * dy) * p.box_scale, (oz + tn * dz) * z_scale, raw, wgt);
                 }
                 decoder_hidden(lds, lane, q, f, h);
                 IA_RSTAMP(17 + 4 * g);
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
 // depth = clamp(depth, min over all sample depths, max over all sample depths)
 __global__ __launch_bounds__(256) void render_finalize_kernel(float* depth, const float* minmax, int nblocks, int n) {
     __shared__ float s_mn[256], s_mx[256];
-    float mn = INFINITY, mx = 0.f;
+    float mn = INFINITY, mx = -INFINITY;
     for (int i = threadIdx.x; i < nblocks; i += 256) { mn = fminf(mn, minmax[2 * i]); mx = fmaxf(mx, minmax[2 * i + 1]); }
     s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
     __syncthreads();
@@ -718,7 +731,7 @@ __global__ __launch_bounds__(256) void render_finalize_kernel(float* depth, cons
 __global__ __launch_bounds__(256) void render_finalize_frames_kernel(float* depth, const float* minmax, int nslots, int R, int B) {
     __shared__ float s_mn[256], s_mx[256];
     const int b = blockIdx.y;
-    float mn = INFINITY, mx = 0.f;
+    float mn = INFINITY, mx = -INFINITY;
     for (int i = threadIdx.x; i < nslots; i += 256) { mn = fminf(mn, minmax[((int64_t)i * B + b) * 2]); mx = fmaxf(mx, minmax[((int64_t)i * B + b) * 2 + 1]); }
     s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
     __syncthreads();
@@ -761,14 +774,17 @@ extern "C" int ia_render_rays_grid(int B, int R) {
     return (int)(quads < cap ? quads : cap);
 }
 
-extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
-                              const float* u_importance, const float* dist, const float* w0, const float* b0, const float* w1, const float* b1,
-                              float lr_multiplier, float box_warp, int flags,
-                              int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
-                              float* rgb, float* depth, float* wsum, float* minmax_scratch,
-                              float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
-                              void* stream) {
-    IA_REQUIRE(planes_cl && rays_o && rays_d && jitter && dist && w0 && b0 && w1 && b1, "null input pointer");
+namespace {
+
+int launch_render(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
+                  const float* u_importance, const float* dist, const float* limits, bool range_fixed, double range_start, double range_end,
+                  const float* w0, const float* b0, const float* w1, const float* b1,
+                  float lr_multiplier, float box_warp, int flags,
+                  int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
+                  float* rgb, float* depth, float* wsum, float* minmax_scratch,
+                  float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
+                  const char* what, void* stream) {
+    IA_REQUIRE(planes_cl && rays_o && rays_d && jitter && w0 && b0 && w1 && b1, "null input pointer");
     IA_REQUIRE(rgb && depth && wsum && minmax_scratch, "null output pointer");
     IA_REQUIRE(B > 0 && R > 0 && plane_h > 0 && plane_w > 0, "empty tensor");
     if (n_coarse != NS || n_importance != NS)
@@ -779,6 +795,8 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
                "planes of one batch element must stay below 4 GiB (32-bit texel offsets)");
     Params p;
     p.planes = planes_cl; p.rays_o = rays_o; p.rays_d = rays_d; p.jitter = jitter; p.u_imp = u_importance; p.dist = dist;
+    p.limits = limits; p.range_fixed = range_fixed; p.range_start = range_start; p.range_end = range_end;
+    p.flip_z = (flags & IA_RENDER_FLIP_Z) != 0;
     p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
     p.w0_gain = lr_multiplier / sqrtf(32.f); p.w1_gain = lr_multiplier / sqrtf(64.f); p.b_gain = lr_multiplier;
     p.box_scale = 2.f / box_warp;
@@ -791,17 +809,127 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
     const int grid = ia_render_rays_grid(B, R);
     hipStream_t s = (hipStream_t)stream;
     static_assert(LDS_FLOATS * sizeof(float) <= 160 * 1024, "one workgroup must fit a CU's LDS");
-    const auto kernel = plane_h == plane_w ? render_rays_kernel<true> : render_rays_kernel<false>;
+    const bool box = limits != nullptr || range_fixed;
+    const auto kernel = box ? (plane_h == plane_w ? render_rays_kernel<true, true> : render_rays_kernel<false, true>)
+                            : (plane_h == plane_w ? render_rays_kernel<true, false> : render_rays_kernel<false, false>);
     if (const int rs = ia::reserve_lds((const void*)kernel, (size_t)(LDS_FLOATS * sizeof(float)), "render_rays")) return rs;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), LDS_FLOATS * sizeof(float), s, p);
-    int st = ia::check_launch("ia_render_rays");
+    int st = ia::check_launch(what);
     if (st != IA_OK) return st;
     if (p.dist_per_frame)
         hipLaunchKernelGGL(render_finalize_frames_kernel, dim3(ia::streaming_grid((int64_t)R, 256), B), dim3(256), 0, s, depth, minmax_scratch,
                            grid * WAVES, R, B);
     else
         hipLaunchKernelGGL(render_finalize_kernel, dim3(ia::streaming_grid((int64_t)B * R, 256)), dim3(256), 0, s, depth, minmax_scratch, grid, B * R);
-    return ia::check_launch("ia_render_rays(finalize)");
+    return ia::check_launch(what);
+}
+
+__device__ __forceinline__ float nan_max(float a, float b) { return (a != a || b != b) ? NAN : fmaxf(a, b); }
+__device__ __forceinline__ float nan_min(float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); }
+
+// get_ray_limits_box (math_utils.py:46-98): slab test of every ray against the cube of side `side` centred at the origin, the three
+// slabs chained axis by axis as the reference chains them; a ray that misses gets (-1, -2).  Each workgroup also leaves the range of
+// its hit rays' near limits in part[2 * blockIdx.x ..] for the second kernel.
+__global__ __launch_bounds__(256) void ray_limits_box_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bb_min, float bb_max,
+                                                             float* __restrict__ limits, float* __restrict__ part, int n) {
+    __shared__ float s_mn[256], s_mx[256];
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float near_ax[3], far_ax[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {      // the bound a ray enters through is picked by the sign of 1 / d (math_utils.py:64-69)
+            const float o = rays_o[(int64_t)i * 3 + a], inv = 1.0f / rays_d[(int64_t)i * 3 + a];
+            const bool neg = inv < 0.f;
+            near_ax[a] = ((neg ? bb_max : bb_min) - o) * inv;
+            far_ax[a] = ((neg ? bb_min : bb_max) - o) * inv;
+        }
+        float tmin = near_ax[0], tmax = far_ax[0];
+        bool miss = false;
+#pragma unroll
+        for (int a = 1; a < 3; ++a) {
+            miss = miss || (tmin > far_ax[a]) || (near_ax[a] > tmax);
+            tmin = nan_max(tmin, near_ax[a]); tmax = nan_min(tmax, far_ax[a]);      // torch.max / torch.min propagate NaN (:78-79, :89-90)
+        }
+        if (miss) { tmin = -1.f; tmax = -2.f; }
+        limits[(int64_t)i * 2] = tmin; limits[(int64_t)i * 2 + 1] = tmax;
+        if (tmax > tmin) { mn = fminf(mn, tmin); mx = fmaxf(mx, tmin); }
+    }
+    s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { s_mn[threadIdx.x] = fminf(s_mn[threadIdx.x], s_mn[threadIdx.x + off]); s_mx[threadIdx.x] = fmaxf(s_mx[threadIdx.x], s_mx[threadIdx.x + off]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = s_mn[0]; part[2 * blockIdx.x + 1] = s_mx[0]; }
+}
+
+// ImportanceRenderer.forward's repair of the rays that miss the box (renderer.py:133-136): when any ray hits, a missing ray runs from
+// the smallest to the LARGEST NEAR limit of the hit rays (`ray_end[~valid] = ray_start[valid].max()`, as the reference has it).
+__global__ __launch_bounds__(256) void ray_limits_patch_kernel(float* __restrict__ limits, const float* __restrict__ part, int nparts, int n) {
+    __shared__ float s_mn[256], s_mx[256];
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < nparts; i += 256) { mn = fminf(mn, part[2 * i]); mx = fmaxf(mx, part[2 * i + 1]); }
+    s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { s_mn[threadIdx.x] = fminf(s_mn[threadIdx.x], s_mn[threadIdx.x + off]); s_mx[threadIdx.x] = fmaxf(s_mx[threadIdx.x], s_mx[threadIdx.x + off]); }
+        __syncthreads();
+    }
+    mn = s_mn[0]; mx = s_mx[0];
+    if (!(mn <= mx)) return;      // no ray hits the box: limits stay (-1, -2)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        if (!(limits[(int64_t)i * 2 + 1] > limits[(int64_t)i * 2])) { limits[(int64_t)i * 2] = mn; limits[(int64_t)i * 2 + 1] = mx; }
+}
+
+}  // namespace
+
+extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
+                              const float* u_importance, const float* dist, const float* w0, const float* b0, const float* w1, const float* b1,
+                              float lr_multiplier, float box_warp, int flags,
+                              int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
+                              float* rgb, float* depth, float* wsum, float* minmax_scratch,
+                              float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
+                              void* stream) {
+    IA_REQUIRE(dist, "null input pointer");
+    IA_REQUIRE(!(flags & IA_RENDER_FLIP_Z), "IA_RENDER_FLIP_Z belongs to ia_render_rays_box");
+    return launch_render(planes_cl, rays_o, rays_d, jitter, u_importance, dist, nullptr, false, 0.0, 0.0, w0, b0, w1, b1, lr_multiplier, box_warp, flags,
+                         B, R, plane_h, plane_w, n_coarse, n_importance, rgb, depth, wsum, minmax_scratch,
+                         dbg_z_fine, dbg_inds, dbg_order, dbg_w_coarse, dbg_sigma_coarse, "ia_render_rays", stream);
+}
+
+extern "C" int ia_render_rays_box(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
+                                  const float* u_importance, const float* ray_limits, double ray_start, double ray_end,
+                                  const float* w0, const float* b0, const float* w1, const float* b1,
+                                  float lr_multiplier, float box_warp, int flags,
+                                  int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
+                                  float* rgb, float* depth, float* wsum, float* minmax_scratch,
+                                  float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
+                                  void* stream) {
+    IA_REQUIRE(!(flags & IA_RENDER_DIST_PER_FRAME), "IA_RENDER_DIST_PER_FRAME belongs to ia_render_rays");
+    IA_REQUIRE(u_importance, "ImportanceRenderer draws its importance samples (renderer.py:280): u_importance must be given");
+    return launch_render(planes_cl, rays_o, rays_d, jitter, u_importance, nullptr, ray_limits, ray_limits == nullptr, ray_start, ray_end,
+                         w0, b0, w1, b1, lr_multiplier, box_warp, flags,
+                         B, R, plane_h, plane_w, n_coarse, n_importance, rgb, depth, wsum, minmax_scratch,
+                         dbg_z_fine, dbg_inds, dbg_order, dbg_w_coarse, dbg_sigma_coarse, "ia_render_rays_box", stream);
+}
+
+extern "C" int ia_ray_limits_box_parts(int n_rays) {
+    const int64_t g = ((int64_t)n_rays + 255) / 256;
+    return (int)(g < 1024 ? (g < 1 ? 1 : g) : 1024);
+}
+
+extern "C" int ia_ray_limits_box(const float* rays_o, const float* rays_d, double box_side_length, int n_rays, int repair_misses,
+                                 float* ray_limits, float* part_scratch, void* stream) {
+    IA_REQUIRE(rays_o && rays_d && ray_limits && part_scratch, "null pointer");
+    IA_REQUIRE(n_rays > 0, "empty tensor");
+    const int parts = ia_ray_limits_box_parts(n_rays);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ray_limits_box_kernel, dim3(parts), dim3(256), 0, s, rays_o, rays_d,
+                       (float)(-1 * (box_side_length / 2)), (float)(1 * (box_side_length / 2)), ray_limits, part_scratch, n_rays);
+    int st = ia::check_launch("ia_ray_limits_box");
+    if (st != IA_OK || !repair_misses) return st;
+    hipLaunchKernelGGL(ray_limits_patch_kernel, dim3(ia::streaming_grid((int64_t)n_rays, 256)), dim3(256), 0, s, ray_limits, part_scratch, parts, n_rays);
+    return ia::check_launch("ia_ray_limits_box(repair)");
 }
 
 extern "C" int ia_importance_stage(const float* z_coarse, const float* w_coarse, float* z_fine, int* inds, int* order,

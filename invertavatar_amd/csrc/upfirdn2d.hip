@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void fir_tail_split_dma_kernel(const float* __
             acc += t_bias[ch];                                                                                                 \
             acc = acc > 0.f ? acc : acc * slope;               /* (linear: slope 1) */                                         \
             acc *= tail.gain;                                                                                                  \
-            acc = fminf(fmaxf(acc, -clamp), clamp);            /* (no clamp: +-inf) */                                         \
+            { const float c = fminf(fmaxf(acc, -clamp), clamp); acc = (acc != acc) ? acc : c; }   /* (no clamp: +-inf; NaN stays NaN) */ \
             const float t = acc * sn[ch];                      /* (no styles: 1) */                                            \
             _Float16 h, l;                                                                                                     \
             ia::split_f16(t, h, l, watch);                                                                                     \

@@ -132,10 +132,24 @@ class inversionNet(nn.Module):
             out['x_input'] = torch.clamp(x_input, min=-1, max=1)
         return out
 
+    def trunks_in_eval_mode(self):
+        """True when no BatchNorm of the two IR-SE50 trunks is in training mode -- what the script arranges (eval_seq.py:96-97:
+        input_layer.eval() / body.eval() after .train()) and what makes a frame's trunk features independent of the other frames."""
+        bn = torch.nn.modules.batchnorm._BatchNorm
+        return not any(m.training for unet in (self.unet_encoder.texture_unet, self.unet_encoder.triplane_unet)
+                       for part in (unet.input_layer, unet.body) for m in part.modules() if isinstance(m, bn))      # (both attributes: unet_encoders.py:162)
+
+    def require_eval_trunks(self):
+        if not self.trunks_in_eval_mode():
+            raise RuntimeError('trunk_features runs the IR-SE50 trunks frame by frame: their BatchNorms must be in eval mode '
+                               '(eval_seq.py:96-97 calls input_layer.eval() and body.eval()); in training mode the batch statistics '
+                               'span the group and the running statistics would diverge per rank')
+
     @torch.no_grad()
     def trunk_features(self, image, uv, y0_image):
         """IR-SE50 trunk features of both UNets for source frames [T, ...] given their renders from the e4e features: the per-frame
         half of AR_eval_forward (eval-mode BatchNorm: no coupling between frames).  Returns {'texture': [5 tensors], 'triplane': [5]}."""
+        self.require_eval_trunks()
         delta_x = y0_image - image[:, :3]
         tri_input = torch.cat([image[:, :3], delta_x], dim=-3)
         # two latency-bound launch chains (3.3 ms each on one frame, 3.6 ms on four: r05 stage profile) that read delta_x and nothing

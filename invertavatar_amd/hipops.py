@@ -339,6 +339,9 @@ def bn_train_split(x, weight, bias, running_mean, running_var, num_batches_track
         st = _lib.load().ia_bn_train_split(_p(x), _p(weight), _p(bias), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(partials), chunks,
                                            _p(out), int(planes), b, c, h, w, float(eps), float(momentum), _lib.stream_ptr(x.device))
     _lib.check(st, 'ia_bn_train_split')
+    for t in (running_mean, running_var, num_batches_tracked):      # written through raw pointers: tell torch (the eval-mode affine caches of
+        if t is not None:                                           # trunk_hip._UnitPack are keyed on the version counters)
+            torch.autograd.graph.increment_version(t)
     return SplitAct(out, c, consumer)
 
 
@@ -734,6 +737,59 @@ def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_mult
                                 _p(aux.get('inds')), _p(aux.get('order')), _p(aux.get('w_coarse')), _p(aux.get('sigma_coarse')),
                                 _lib.stream_ptr(dev))
     _lib.check(st, 'ia_render_rays')
+    return (rgb, depth, wsum, aux) if debug else (rgb, depth, wsum)
+
+
+def ray_limits_box(rays_o, rays_d, box_side_length, repair_misses=False):
+    """math_utils.get_ray_limits_box on the device (see ia_ray_limits_box) -> limits [..., 2] = (t_near, t_far); repair_misses: with
+    ImportanceRenderer.forward's repair of the rays that miss the box (renderer.py:133-136), no host round trip."""
+    _f32c(rays_o, 'rays_o'); _f32c(rays_d, 'rays_d')
+    n = rays_o.numel() // 3
+    lib = _lib.load()
+    limits = torch.empty(*rays_o.shape[:-1], 2, device=rays_o.device)
+    part = torch.empty(2 * lib.ia_ray_limits_box_parts(n), device=rays_o.device)
+    with torch.cuda.device(rays_o.device):
+        st = lib.ia_ray_limits_box(_p(rays_o), _p(rays_d), float(box_side_length), n, int(bool(repair_misses)), _p(limits), _p(part),
+                                   _lib.stream_ptr(rays_o.device))
+    _lib.check(st, 'ia_ray_limits_box')
+    return limits
+
+
+def render_rays_box(planes_cl, rays_o, rays_d, jitter, u_importance, w0, b0, w1, b1, ray_limits=None, ray_start=0.0, ray_end=0.0,
+                    flip_z=False, lr_multiplier=1.0, box_warp=1.0, white_back=False, n_coarse=48, n_importance=48, debug=False):
+    """ImportanceRenderer.forward as one launch (see ia_render_rays_box): `ray_limits` [B,R,2] (the 'auto' box limits) or the fixed
+    [ray_start, ray_end]; `u_importance` [B*R, 48] sorted draws.  Returns (rgb [B,R,32], depth [B,R,1], wsum [B,R,1][, aux])."""
+    for name, t in (('planes', planes_cl), ('rays_o', rays_o), ('rays_d', rays_d), ('jitter', jitter), ('u_importance', u_importance),
+                    ('w0', w0), ('b0', b0), ('w1', w1), ('b1', b1)):
+        _f32c(t, name)
+    b, three, ph, pw, c = planes_cl.shape
+    if three != 3 or c != 32:
+        raise RuntimeError(f'planes must be [B,3,H,W,32] channels-last, got {tuple(planes_cl.shape)}')
+    r = rays_o.shape[1]
+    if tuple(jitter.shape[:3]) != (b, r, n_coarse):
+        raise RuntimeError(f'jitter must be [B,R,{n_coarse}(,1)], got {tuple(jitter.shape)}')
+    if u_importance.numel() != b * r * n_importance:
+        raise RuntimeError(f'u_importance must hold B * R * {n_importance} sorted uniform draws')
+    if ray_limits is not None and _f32c(ray_limits, 'ray_limits').numel() != b * r * 2:
+        raise RuntimeError('ray_limits must be [B,R,2]')
+    dev = planes_cl.device
+    lib = _lib.load()
+    rgb, depth, wsum = torch.empty(b, r, 32, device=dev), torch.empty(b, r, 1, device=dev), torch.empty(b, r, 1, device=dev)
+    scratch = torch.empty(2 * lib.ia_render_rays_grid(b, r), device=dev)
+    aux = {}
+    if debug:
+        aux = dict(z_fine=torch.empty(b, r, 48, device=dev), inds=torch.empty(b, r, 48, device=dev, dtype=torch.int32),
+                   order=torch.empty(b, r, 96, device=dev, dtype=torch.int32), w_coarse=torch.empty(b, r, 47, device=dev),
+                   sigma_coarse=torch.empty(b, r, 48, device=dev))
+    flops = b * r * 96 * 2.0 * (32 * 64 + 64 * 33)
+    traffic = 4.0 * (planes_cl.numel() + 2 * rays_o.numel() + jitter.numel() + u_importance.numel() + b * r * 36)
+    with torch.cuda.device(dev), _Timed('render_rays', flops, traffic, 'box'):
+        st = lib.ia_render_rays_box(_p(planes_cl), _p(rays_o), _p(rays_d), _p(jitter), _p(u_importance), _p(ray_limits), float(ray_start), float(ray_end),
+                                    _p(w0), _p(b0), _p(w1), _p(b1), float(lr_multiplier), float(box_warp),
+                                    int(bool(white_back)) | (8 if flip_z else 0), b, r, ph, pw, int(n_coarse), int(n_importance),
+                                    _p(rgb), _p(depth), _p(wsum), _p(scratch), _p(aux.get('z_fine')), _p(aux.get('inds')), _p(aux.get('order')),
+                                    _p(aux.get('w_coarse')), _p(aux.get('sigma_coarse')), _lib.stream_ptr(dev))
+    _lib.check(st, 'ia_render_rays_box')
     return (rgb, depth, wsum, aux) if debug else (rgb, depth, wsum)
 
 

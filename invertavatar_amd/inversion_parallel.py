@@ -117,6 +117,10 @@ def few_shot_inversion_sharded(net, images, uvs, cams, uvcoords, rank=0, world_s
     # frame's render only, SURVEY 8e iii names train-mode BatchNorm in the DECODERS).  Each rank runs the two trunks on its frames of the
     # group-major list; one all-gather of the flattened features (7.9 MB per frame and UNet at 256^2 inputs) hands them to the owners.
     trunk_all = None
+    if shard_trunks and world_size > 1 and not net.trunks_in_eval_mode():
+        #  train-mode trunk BatchNorms take batch statistics over the group's frames: a per-frame trunk pass would differ
+        # from the one-process result and update the running statistics differently on every rank.  The groups then stay whole.
+        shard_trunks = False
     if shard_trunks and world_size > 1:
         mine_feats, like = [], None
         for j, (gi, t) in enumerate(items[lo:hi]):

@@ -3,7 +3,9 @@
 ``ImportanceRenderer_bsMotion`` (renderer.py:295-469) is what the v20 generator calls.  For device
 tensors with the standard options (48 + 48 samples, softplus clamp, OSG decoder) the whole forward
 is ONE launch of ``ia_render_rays``; otherwise the torch definition below runs (that is the
-reference's own arithmetic, used for CPU tensors).  The stratified-sampling noise that the
+reference's own arithmetic, used for CPU tensors).  ``ImportanceRenderer`` (renderer.py:122-293, the
+EG3D class: per-ray box limits or a fixed range, ``flip_z``, drawn importance samples) takes the same
+kernel through ``ia_ray_limits_box`` + ``ia_render_rays_box`` under the same rule.  The stratified-sampling noise that the
 reference draws with ``torch.rand_like`` even in evaluation mode (renderer.py:406) can be injected
 through ``forward(..., jitter=...)`` or ``set_jitter`` so that runs are reproducible.
 
@@ -156,7 +158,40 @@ class ImportanceRenderer(_RendererBase):
         self.plane_axes = generate_planes()
         self.flip_z = flip_z
 
+    def _fused_ok(self, planes, decoder, options):
+        """Device tensors with the standard options: the whole forward is ia_ray_limits_box (+ repair) and ONE ia_render_rays_box launch."""
+        auto = options['ray_start'] == options['ray_end'] == 'auto'
+        return (planes.is_cuda and planes.dtype == torch.float32 and planes.shape[1] == 3 and planes.shape[2] == 32
+                and options['depth_resolution'] == 48 and options['depth_resolution_importance'] == 48
+                and not options['disparity_space_sampling'] and options.get('clamp_mode') == 'softplus'
+                and options.get('density_noise', 0) == 0 and _is_osg_decoder(decoder) and not torch.is_grad_enabled()
+                and (auto or not any(isinstance(options[k], (str, torch.Tensor)) for k in ('ray_start', 'ray_end'))))
+
+    def _forward_fused(self, planes, decoder, ray_origins, ray_directions, options):
+        b, r, _ = ray_origins.shape
+        dev = planes.device
+        ro, rd = ray_origins.float().contiguous(), ray_directions.float().contiguous()
+        limits, start, end = None, 0.0, 0.0
+        if options['ray_start'] == options['ray_end'] == 'auto':
+            limits = hipops.ray_limits_box(ro, rd, options['box_warp'], repair_misses=True)
+        else:
+            start, end = float(options['ray_start']), float(options['ray_end'])
+        # the two draws in the reference's order and call shapes: rand_like(depths_coarse) (:238/:242), then rand(n_rays, N_importance)
+        # (:280); the importance draws go to the kernel sorted (monotone inverse CDF: same set of fine samples, same merged order)
+        jitter = torch.rand_like(torch.empty((b, r, 48, 1), device=dev)).to(torch.float32).reshape(b, r, 48).contiguous()
+        u = torch.rand(b * r, 48, device=dev).to(device=dev, dtype=torch.float32).sort(dim=-1).values.contiguous()
+        planes_cl = planes.permute(0, 1, 3, 4, 2)
+        if not planes_cl.is_contiguous():
+            planes_cl = planes_cl.contiguous()
+        net = decoder.net
+        return hipops.render_rays_box(planes_cl, ro, rd, jitter, u, net[0].weight.detach(), net[0].bias.detach(), net[2].weight.detach(),
+                                      net[2].bias.detach(), ray_limits=limits, ray_start=start, ray_end=end, flip_z=bool(self.flip_z),
+                                      lr_multiplier=float(net[0].bias_gain), box_warp=options['box_warp'],
+                                      white_back=options.get('white_back', False))
+
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
+        if self._fused_ok(planes, decoder, rendering_options):
+            return self._forward_fused(planes, decoder, ray_origins, ray_directions, rendering_options)
         self.plane_axes = self.plane_axes.to(ray_origins.device)
         if rendering_options['ray_start'] == rendering_options['ray_end'] == 'auto':
             ray_start, ray_end = math_utils.get_ray_limits_box(ray_origins, ray_directions, box_side_length=rendering_options['box_warp'])

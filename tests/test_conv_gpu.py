@@ -41,6 +41,7 @@ CASES = [  # B, I, O, res, up
     (1, 16, 32, 4, 1), (2, 24, 40, 8, 1), (1, 64, 128, 16, 1), (1, 32, 32, 32, 1), (2, 16, 16, 64, 1),
     (1, 8, 136, 128, 1), (1, 32, 96, 33, 1),
     (1, 16, 32, 4, 2), (2, 24, 40, 8, 2), (1, 32, 64, 16, 2), (1, 16, 16, 64, 2), (1, 8, 72, 37, 2),
+    (1, 16, 10, 16, 2), (2, 8, 6, 21, 2), (1, 16, 35, 32, 2),      # transposed form, channel counts that are not multiples of 4
 ]
 
 

@@ -65,6 +65,8 @@ class _UNet(torch.nn.Module):
         g = torch.Generator().manual_seed(seed)
         self.w = [torch.randn(ch, in_ch, generator=g) * 0.2 for ch, _ in levels]
         self.levels = levels
+        # the attributes the product inspects for the mode of the trunk BatchNorms (unet_encoders.py:162); identity here
+        self.input_layer, self.body = torch.nn.Sequential(torch.nn.BatchNorm2d(in_ch)).eval(), torch.nn.Sequential().eval()
 
     def forward_onlyEncoder(self, x):
         t = x.flatten(0, 1)                                 # [T, C, H, W]
@@ -90,6 +92,8 @@ class _Toy(torch.nn.Module):
     AR_eval_forward = inversionNet.AR_eval_forward          # the product's own group update and UV-space residual
     get_unet_uvinput = inversionNet.get_unet_uvinput
     trunk_features = inversionNet.trunk_features           # ... and the per-frame half the sharded flow deals to the ranks
+    trunks_in_eval_mode = inversionNet.trunks_in_eval_mode
+    require_eval_trunks = inversionNet.require_eval_trunks
 
     def __init__(self):
         super().__init__()
@@ -167,3 +171,15 @@ def test_sharded_inversion_reproduces_the_one_process_flow(tmp_path, world, shar
     # a mis-routed draw would show: other draws give other features
     other = inversion_parallel.few_shot_inversion_sharded(_Toy(), *_inputs(), draws=inversion_parallel.seeded_draws(8, NRR * NRR))
     assert not _same(other, one, tol=1e-4)[0]
+
+
+def test_train_mode_trunks_are_not_dealt_by_frame():
+    """per-frame trunk passes equal the one-process result only with eval-mode trunk BatchNorms (eval_seq.py:96-97).
+    trunk_features refuses a train-mode trunk, and the sharded flow then keeps the groups whole on the chains' owners."""
+    net = _Toy()
+    assert net.trunks_in_eval_mode()
+    net.unet_encoder.texture_unet.input_layer.train()
+    assert not net.trunks_in_eval_mode()
+    images, uvs, cams, uvcoords = _inputs(4)
+    with pytest.raises(RuntimeError, match='eval mode'):
+        net.trunk_features(images[:1], uvs[:1], images[:1])

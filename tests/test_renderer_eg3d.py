@@ -100,10 +100,74 @@ def test_flip_z_and_auto_limits_change_the_image(golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', list(CASES))
-def test_product_eg3d_renderer_on_device_vs_reference(golden, case):
-    """Tolerance 5e-5 on colours / 2e-4 on depth (fp32 sums in another order than the CPU reference's; BASELINE: 1e-3 on RGB)."""
+def test_product_eg3d_renderer_on_device_vs_reference(golden, case, monkeypatch):
+    """The device route of the class is this repo's kernels -- ia_ray_limits_box + ONE ia_render_rays_box launch, no grid_sample / sort
+    from the library.  Tolerance 5e-5 on colours / 2e-4 on depth (fp32 sums in another order than the CPU reference's; BASELINE: 1e-3
+    on RGB)."""
+    from invertavatar_amd import hipops
     g = golden('renderer_eg3d.npz')
+
+    def no_library(*a, **k):
+        raise AssertionError('the device route must not reach torch.nn.functional.grid_sample')
+    monkeypatch.setattr(torch.nn.functional, 'grid_sample', no_library)
+    monkeypatch.setattr(hipops, 'PROFILE', [])
     rgb, depth, wsum = _run_product(g, case, 'cuda')
+    assert [rec[0] for rec in hipops.PROFILE] == ['render_rays']
     assert rgb.is_cuda and rgb.shape == g[f'{case}/rgb'].shape
     assert max_abs(rgb.cpu(), g[f'{case}/rgb']) <= 5e-5 and max_abs(wsum.cpu(), g[f'{case}/wsum']) <= 5e-5
     assert max_abs(depth.cpu(), g[f'{case}/depth']) <= 2e-4
+
+
+@pytest.mark.gpu
+def test_ray_limits_box_on_device(golden):
+    """ia_ray_limits_box: bit-equal to the reference's get_ray_limits_box on the fixture's rays (hits and misses) and on axis-parallel
+    rays; with the repair, equal to the reference's `ray_start[~valid] = ray_start[valid].min()` / `ray_end[~valid] = ray_start[valid].max()`."""
+    from invertavatar_amd import hipops
+    g = golden('renderer_eg3d.npz')
+    ro, rd = g['rays_o'].cuda().contiguous(), g['rays_d'].cuda().contiguous()
+    lim = hipops.ray_limits_box(ro, rd, 1)
+    assert torch.equal(lim[..., :1].cpu(), g['box_near']) and torch.equal(lim[..., 1:].cpu(), g['box_far'])
+    o = torch.tensor([[[0.1, -0.2, 2.0], [0.7, 0.0, 2.0], [0.0, 0.0, -3.0], [0.2, 0.3, 0.1]]])
+    d = torch.tensor([[[0.0, 0.0, -1.0], [0.0, 0.0, -1.0], [-0.0, 0.0, 1.0], [1.0, 0.0, -0.0]]])
+    a0, a1 = OR.ray_limits_box(o, d, 1)
+    lim = hipops.ray_limits_box(o.cuda(), d.cuda(), 1).cpu()
+    assert torch.equal(lim[..., :1], a0) and torch.equal(lim[..., 1:], a1)
+    # the repair, against the reference's three lines on the fixture's limits
+    near, far = g['box_near'].clone(), g['box_far'].clone()
+    valid = far > near
+    near[~valid], far[~valid] = g['box_near'][valid].min(), g['box_near'][valid].max()
+    lim = hipops.ray_limits_box(ro, rd, 1, repair_misses=True).cpu()
+    assert torch.equal(lim[..., :1], near) and torch.equal(lim[..., 1:], far)
+    # no ray hits: nothing to repair with, the limits stay (-1, -2)
+    o = torch.tensor([[[3.0, 3.0, 3.0], [-3.0, 3.0, 3.0]]])
+    d = torch.tensor([[[1.0, 0.5, 0.25], [-1.0, 0.5, 0.25]]])
+    lim = hipops.ray_limits_box(o.cuda(), d.cuda(), 1, repair_misses=True).cpu()
+    assert lim.reshape(-1, 2).tolist() == [[-1.0, -2.0], [-1.0, -2.0]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', list(CASES))
+def test_eg3d_kernel_stage_buffers_vs_reference(golden, case):
+    """Stage outputs of the ia_render_rays_box launch on the fixture's own draws: coarse weights of the reference within 2e-5, and its
+    searchsorted indices read in the order of the sorted draws (the kernel takes the draws sorted; the set is the same)."""
+    from invertavatar_amd import hipops
+    g = golden('renderer_eg3d.npz')
+    planes, jit, ro, rd = _inputs(g)
+    flip, start, end = CASES[case]
+    sd = {k: v.cuda() for k, v in _decoder_state().items()}
+    b, r = ro.shape[:2]
+    u = _uniform(b * r).cuda().sort(dim=-1).values.contiguous()
+    ro, rd = ro.cuda().contiguous(), rd.cuda().contiguous()
+    limits = hipops.ray_limits_box(ro, rd, 1, repair_misses=True) if start == 'auto' else None
+    rgb, depth, wsum, aux = hipops.render_rays_box(
+        planes.cuda().permute(0, 1, 3, 4, 2).contiguous(), ro, rd, jit.cuda().reshape(b, r, 48).contiguous(), u,
+        sd['net.0.weight'], sd['net.0.bias'], sd['net.2.weight'], sd['net.2.bias'], ray_limits=limits,
+        ray_start=0.0 if limits is not None else start, ray_end=0.0 if limits is not None else end, flip_z=flip, debug=True)
+    assert max_abs(aux['w_coarse'].cpu().reshape(-1, 47), g[f'{case}/w_coarse'].reshape(-1, 47)) <= 2e-5
+    assert max_abs(rgb.cpu(), g[f'{case}/rgb']) <= 5e-5
+    # searchsorted indices: the reference's, read in the order of the sorted draws (whole-kernel level: the cdf comes from the kernel's own
+    # coarse weights, so a draw within an ulp of a cdf entry may land in the neighbouring bin)
+    perm = _uniform(b * r).sort(dim=-1).indices
+    ref_inds = torch.gather(g[f'{case}/inds'], 1, perm)
+    got = aux['inds'].cpu().reshape(-1, 48).long()
+    assert (got != ref_inds).float().mean().item() <= 2e-3 and (got - ref_inds).abs().max().item() <= 1
