@@ -54,6 +54,7 @@ FRAMES_PER_RANK_SHARDED = 8     # configs[3]: B = 64 over 8 GPUs
 PMC_FILE = next((p for p in (os.path.join(REPO, 'profiles', f'r{r:02d}_pmc_frame_hbm_traffic.json') for r in (5, 4)) if os.path.exists(p)),
                 os.path.join(REPO, 'profiles', 'r05_pmc_frame_hbm_traffic.json'))      # newest committed PMC collection
 DEV = torch.device('cuda')      # set by setup_distributed
+DIST = False                    # a process group is up (N > 1, or --force-dist at N = 1): steps end in the all-gather, timing brackets in barriers
 
 
 def sync():
@@ -76,6 +77,9 @@ def parse():
     ap.add_argument('--cpu-frames', type=int, default=3)
     ap.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL over xGMI (the product); gloo: rehearsal plumbing')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='N = 1 only: bring up the process group anyway (RCCL at world size 1, communicator bound to the GPU) and end every step '
+                         'in the same all_gather_into_tensor as N > 1 -- the collective path executed on a one-GPU box')
     ap.add_argument('--device', default='cuda', choices=['cuda', 'cpu'], help='cpu: CPU formulation of the API mirror (test-suite plumbing)')
     ap.add_argument('--nrr', type=int, default=128, help='neural rendering resolution (BASELINE: 128)')
     ap.add_argument('--features', default='encoder', choices=['encoder', 'backbone'],
@@ -97,7 +101,7 @@ def parse():
 
 
 def setup_distributed(args):
-    global DEV, NRR
+    global DEV, NRR, DIST
     NRR = args.nrr
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -108,7 +112,8 @@ def setup_distributed(args):
         DEV = torch.device('cuda', idx)
     else:
         DEV = torch.device('cpu')
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_dist:
+        DIST = True
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         kw = {'device_id': DEV} if args.dist_backend == 'nccl' and DEV.type == 'cuda' else {}      # bind the communicator to this rank's GPU at once
@@ -157,7 +162,7 @@ def make_step(gen, wl, graphed, gather_dtype):
     """Returns step(k): render this rank's frames of step k and (N > 1) all-gather the frames of the step."""
     from invertavatar_amd.output import to_uint8_hwc
     world, per = wl.world, wl.per_rank
-    if world > 1:
+    if DIST:
         shape = (world * per, 512, 512, 3) if gather_dtype == 'u8' else (world * per, 3, 512, 512)
         gathered = torch.empty(shape, device=DEV, dtype=torch.uint8 if gather_dtype == 'u8' else torch.float32)
 
@@ -165,7 +170,7 @@ def make_step(gen, wl, graphed, gather_dtype):
         s = k % wl.n_sets
         out = wl.replay(graphed, s) if graphed is not None else wl.eager(gen, s)
         img = out['image']
-        if world > 1:
+        if DIST:
             part = to_uint8_hwc(img) if gather_dtype == 'u8' else img.contiguous()
             return all_gather_frames(gathered, part)
         return img
@@ -175,17 +180,17 @@ def make_step(gen, wl, graphed, gather_dtype):
 def timed(step, steps, warmup, world):
     for k in range(warmup):
         step(k)
-    if world > 1:
+    if DIST:
         torch.distributed.barrier()
     sync()
     t0 = time.perf_counter()
     for k in range(steps):
         step(k)
     sync()
-    if world > 1:
+    if DIST:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if DIST:
         t = torch.tensor([dt], device=DEV, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
@@ -549,7 +554,7 @@ def drive_main(args, rank, world):
         ws8 = ws.expand(per, -1, -1).contiguous()
         tex8 = [t.expand(per, -1, -1, -1).contiguous() for t in tex]
         sta8 = [t.expand(per, -1, -1, -1).contiguous() for t in sta]
-        gathered = torch.empty(world * per, 3, 512, 512, device=DEV) if world > 1 else None
+        gathered = torch.empty(world * per, 3, 512, 512, device=DEV) if DIST else None
 
         def eager(s):
             return gen.synthesis_withTexture(ws8, tex8, wl.cams[s], {'uvcoords_image': wl.uvs[s]}, static_feats=sta8, neural_rendering_resolution=NRR,
@@ -570,7 +575,7 @@ def drive_main(args, rank, world):
         def step(k):
             s = k % wl.n_sets
             img = graphed(wl.cams[s], wl.uvs[s], wl.jits[s], wl.frame_dists[s] if per > 1 else None)['image'] if graphed is not None else eager(s)
-            if world > 1:
+            if DIST:
                 return all_gather_frames(gathered, img.contiguous())
             return img
         dt = timed(step, args.steps, args.warmup, world)
@@ -583,7 +588,7 @@ def drive_main(args, rank, world):
                                   f'synthesis_withTexture, {per} frames per rank per call, SR head fp16',
                       'width': args.width, 'nrr': NRR, 'frames_per_rank_per_step': per, 'global_batch': per * world,
                       'identity_features': features, 'parallelism': f'frame-sharded dp{world}', 'launch': launch,
-                      'collective': f'one all_gather of the step\'s [{per * world},3,512,512] f32 frames' if world > 1 else 'none'}}
+                      'collective': f'one all_gather of the step\'s [{per * world},3,512,512] f32 frames' if DIST else 'none'}}
     if inversion_ms is not None:
         n = args.drive_frames
         out['inversion_ms'] = round(inversion_ms, 2)
@@ -620,7 +625,7 @@ def main():
         result = drive_main(args, rank, world)
         if rank == 0:
             print(json.dumps(result), flush=True)
-        if world > 1:
+        if DIST:
             torch.distributed.destroy_process_group()
         return
     gen = TriPlaneGenerator(**synthetic.generator_kwargs(args.width)).eval().requires_grad_(False)
@@ -649,12 +654,14 @@ def main():
                                    'backbones + rasterize + fused renderer + SR 8XDC recomputed every frame',
                        'width': args.width, 'frames_per_rank_per_step': per, 'global_batch': per * world,
                        'parallelism': f'frame-sharded dp{world}',
-                       'collective': f'one all_gather of the step\'s [{per * world},3,512,512] frames as {args.gather}' if world > 1 else 'none',
+                       'collective': f'one all_gather of the step\'s [{per * world},3,512,512] frames as {args.gather}' if DIST else 'none',
                        'launch': launch_mode},
         }
         if args.dist_backend != 'nccl' or args.device != 'cuda':
             result['config']['rehearsal'] = f'backend {args.dist_backend}, device {args.device}: plumbing run, not a measurement'
-        if rank == 0 and world == 1 and per == 1 and DEV.type == 'cuda':
+        if DIST and world == 1:
+            result['config']['force_dist'] = f'process group up at world size 1 (backend {torch.distributed.get_backend()}): every timed step ends in all_gather_into_tensor'
+        if rank == 0 and world == 1 and per == 1 and DEV.type == 'cuda' and not DIST:
             # keep the GPU busy for >= 2 s with the same step (the timed K steps alone can be shorter than a sampler's period)
             n, t_s = 0, time.perf_counter()
             while time.perf_counter() - t_s < 2.0:
@@ -678,7 +685,7 @@ def main():
                     result['cpu_baseline'] = dict(value=None, unit='frames/s', cores=host_physical_cores(), kind='port', sample=f'failed: {exc!r}')
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if DIST:
         torch.distributed.destroy_process_group()
 
 

@@ -103,3 +103,62 @@ def test_bench_n_gt_1_path_two_ranks_on_one_gpu(workload, extra):
                     '--frames-per-rank', '2', '--workload', workload, *extra, timeout=1500)
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['value'] > 0
     assert out['config']['launch'].startswith('hipGraph replay'), out['config']['launch']
+
+
+def _run_bench_one_rank(*flags, timeout=1500):
+    import json
+    import os
+    import subprocess
+    import sys
+    from test_bench_cpu import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR')}
+    env['MASTER_PORT'] = '29647'
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', *flags], cwd=REPO, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('workload,extra', [('reenact', ()), ('drive', ('--features', 'backbone', '--drive-frames', '16'))])
+def test_bench_force_dist_runs_rccl_at_world_size_one(workload, extra):
+    """RCCL itself executes on the one-GPU box.  `bench.py --gpus 1 --force-dist` brings up
+    init_process_group('nccl', world_size=1, device_id=cuda:0) with HSA_ENABLE_IPC_MODE_LEGACY=0 and ends every timed step in the
+    all_gather_into_tensor of the N > 1 path (+ its barriers and the max-over-ranks all-reduce)."""
+    out = _run_bench_one_rank('--force-dist', '--steps', '3', '--warmup', '1', '--frames-per-rank', '2', '--workload', workload, *extra)
+    assert out['n_gpus'] == 1 and out['value'] > 0 and 'all_gather' in out['config']['collective']
+    assert 'nccl' in out['config'].get('force_dist', '') or workload == 'drive'
+    assert out['config']['launch'].startswith('hipGraph replay'), out['config']['launch']
+
+
+@pytest.mark.timeout(900)
+def test_render_sharded_over_rccl_world_size_one_equals_the_plain_call():
+    """frame_parallel.render_sharded with a live RCCL process group (world size 1): all_gather_blocks goes through
+    all_gather_into_tensor on the device communicator and returns the frames of the plain synthesis call, bit for bit."""
+    import os
+    from invertavatar_amd import frame_parallel
+    from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', '29649'
+    g = synthetic.fill_parameters(TriPlaneGenerator(**synthetic.generator_kwargs('small')).eval().requires_grad_(False)).cuda()
+    frames, nrr = [3, 77, 140], 32
+    c, uv, jit = _drive_inputs(frames, nrr)
+    torch.distributed.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        with torch.no_grad():
+            ws = g.mapping(synthetic.latent(5, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14)
+            kw = dict(neural_rendering_resolution=nrr, noise_mode='const', evaluation=True)
+            ref = g.synthesis(ws.expand(3, -1, -1), c, {'uvcoords_image': uv}, jitter=jit, **kw)['image']
+            # world_size 1 returns before the collective: call the collective itself on the rank's block, then the sharded entry
+            got = frame_parallel.all_gather_blocks(ref.contiguous(), [3])
+            assert torch.equal(got, ref)
+            t = torch.ones(4, device='cuda')
+            torch.distributed.all_reduce(t)
+            torch.distributed.barrier()
+            assert t.tolist() == [1.0] * 4
+            again = frame_parallel.render_sharded(g, ws, c, {'uvcoords_image': uv}, rank=0, world_size=1, jitter=jit, **kw)
+            assert torch.equal(again, ref)
+    finally:
+        torch.distributed.destroy_process_group()
