@@ -51,7 +51,7 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense fp16 MFMA
 PEAK_HBM_GBS = 8000.0
 NRR = 128
 FRAMES_PER_RANK_SHARDED = 8     # configs[3]: B = 64 over 8 GPUs
-PMC_FILE = next((p for p in (os.path.join(REPO, 'profiles', f'r{r:02d}_pmc_frame_hbm_traffic.json') for r in (5, 4)) if os.path.exists(p)),
+PMC_FILE = next((p for p in (os.path.join(REPO, 'profiles', f'r{r:02d}_pmc_frame_hbm_traffic.json') for r in (6, 5, 4)) if os.path.exists(p)),
                 os.path.join(REPO, 'profiles', 'r05_pmc_frame_hbm_traffic.json'))      # newest committed PMC collection
 DEV = torch.device('cuda')      # set by setup_distributed
 DIST = False                    # a process group is up (N > 1, or --force-dist at N = 1): steps end in the all-gather, timing brackets in barriers
@@ -290,6 +290,7 @@ def roofline_leg(gen, wl, frames=3):
                        note='with the 8^2 / 16^2 layers (r03): the launch set of `traffic` (PMC kernel names do not separate layers)',
                        launches_per_frame=split_all['launches'] // frames, avg_launch_us=round(split_all['ms'] * 1e3 / split_all['launches'], 2),
                        mfma_util=round(3 * split_all['flops'] / (split_all['ms'] * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, 4),
+                       algorithmic_gflop_per_frame=round(split_all['flops'] / frames / 1e9, 1),
                        algorithmic_bytes_per_launch=round(split_all['bytes'] / split_all['launches'])),
                    whole_conv_family=dict(algorithmic_f32_tflops=round(achieved, 2), launches_per_frame=d['launches'] // frames,
                                           ms_per_frame=round(d['ms'] / frames, 3),
@@ -307,6 +308,9 @@ def roofline_leg(gen, wl, frames=3):
         others['render_rays']['frac_fp32_peak'] = round(r['flops'] / (r['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
         others['render_rays']['frac_hbm_peak'] = round(r['bytes'] / (r['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
         others['render_rays']['avg_launch_us'] = round(r['ms'] * 1e3 / r['launches'], 1)
+    out['note'] = ('`frac` / `kernels.*` are ONE-STREAM per-launch times (the frame\'s launches in program order on one stream, the condition '
+                   'rocprofv3 imposes on the committed kernel stats): an upper bound on each kernel\'s share, not a decomposition of the timed '
+                   'step, which replays four concurrent branches; `frame_mfma_util` (added by main) is the whole timed step')
     return out, others
 
 
@@ -677,6 +681,14 @@ def main():
                 extra_legs(result, gen, wl, args)
             if not args.no_roofline:
                 result['roofline'], result['kernels'] = roofline_leg(gen, wl)
+                rf = result['roofline']
+                if 'all_fp16_pair_launches' in rf:
+                    # the whole timed step: 3 x the fp16-pair family's algorithmic FLOPs of a frame / ms_per_step / the fp16 pipe's peak
+                    a = rf['all_fp16_pair_launches']
+                    gf = a.get('algorithmic_gflop_per_frame')
+                    if gf:
+                        rf['frame_mfma_util'] = round(3 * gf * 1e9 / (result['ms_per_step'] * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, 4)
+                    rf['frac_all_fp16_pair_launches'] = a['mfma_util']
             if not args.no_cpu_baseline:
                 try:
                     result['cpu_baseline'], parity = cpu_baseline_leg(gen, wl, args.cpu_frames)

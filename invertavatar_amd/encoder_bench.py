@@ -53,7 +53,7 @@ def encoder_leg(gen, n_sources=8, n_drive=32, group_graph=False, whole_graph=Tru
     finally:
         gen.train(was_training)
     return dict(workload=f'BASELINE configs[2]: encode + {n_sources // 4} AR_eval_forward groups of 4 sources (ConvGRU) + {n_drive} drive frames '
-                         '(synthesis_withTexture, B=1 per call, eager launches); the inversion replayed as hipGraphs, one per stage '
+                         '(synthesis_withTexture, eval_seq.drive_sequence default: captured calls of 8 frames, every frame with the depth range of its own B=1 call); the inversion replayed as hipGraphs, one per stage '
                          '(eval_seq.GraphedInversion; inversion_ms_eager = e4e encode captured, everything else eager launches, UNet chains on two '
                          'streams), generator in train() mode as eval_seq.py leaves it; min of 3 runs after 2 warm-ups',
                 inversion_ms=round(inv_ms, 2), inversion_ms_runs=[round(r[0], 2) for r in runs], inversion_ms_eager=round(eager_ms, 2), drive_ms=round(drive_ms, 2), drive_frames_per_s=round(n_drive / (drive_ms * 1e-3), 2),
@@ -99,5 +99,5 @@ def oneshot_leg(gen, n_drive=8):
         gen.train(was_training)
     return dict(workload='SURVEY 8(f)4: eval_updated_os.py one-shot inversion (uvnet_new: e4e + 2 IR-SE50 UNets with 13 + 12 transformer '
                          f'blocks, attention through ia_attention) of 1 source frame, replayed as ONE hipGraph (eval_updated_os.GraphedOneShot; '
-                         f'inversion_ms_eager = the same flow as eager launches), + {n_drive} drive frames (eager launches); min of 3 after 2 warm-ups',
+                         f'inversion_ms_eager = the same flow as eager launches), + {n_drive} drive frames (eval_seq.drive_sequence default: one captured call of 8, capture included in this one timing); min of 3 after 2 warm-ups',
                 inversion_ms=round(inv_ms, 2), inversion_ms_runs=[round(t, 2) for t in times], inversion_ms_eager=round(min(eager_times), 2), drive_frames_per_s=round(n_drive / (drive_ms * 1e-3), 2), finite=ok)

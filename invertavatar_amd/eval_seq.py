@@ -285,17 +285,78 @@ def _few_shot_inversion(net, images, uvs, cams, uvcoords, sequential_sampling=Fa
     return ws, updated, r_list
 
 
+# Drive loop on the device: captured calls (graphed.GraphedDrive) instead of ~150 eager launches per frame.  The script renders one frame
+# per call (eval_seq.py:206-219); here the frames go out in calls of DRIVE_GRAPH_BATCH with every frame's OWN depth range (per-frame
+# `ray_dist`, frame_parallel.per_frame_ray_dist: the value its one-frame call computes, renderer.py:311), the remainder in one-frame calls.
+# r05 measured the same frame at 445 frames/s eager, 516 replayed one per call, 813 in calls of 8.  The graphs are kept per network
+# (`_runtime.state(net).drive_graphs`) and per (frames per call, nrr, precision switches); they hold the packed weights of the moment of
+# capture -- `clear_drive_graphs(net)` after changing parameters.  Clips shorter than DRIVE_GRAPH_MIN_FRAMES are not worth a capture.
+DRIVE_GRAPHS = True
+DRIVE_GRAPH_BATCH = 8
+DRIVE_GRAPH_MIN_FRAMES = 8
+
+
+def clear_drive_graphs(net):
+    from . import _runtime
+    _runtime.state(net).drive_graphs = {}
+
+
+def _drive_graph(net, ws, results, batch, nrr):
+    from . import _runtime
+    from .graphed import GraphedDrive
+    from .training import networks_stylegan2 as sg2
+    g = net.generator
+    st = _runtime.state(net)
+    cache = getattr(st, 'drive_graphs', None)
+    if cache is None:
+        cache = st.drive_graphs = {}
+    key = (batch, nrr, bool(sg2.FP16_BLOCKS_COMPUTE_FP32), bool(sg2.SPLIT_FP16_PRODUCTS), bool(g.training), ws.device,
+           tuple(tuple(t.shape[1:]) for t in list(results['texture']) + list(results['static'])))
+    gd = cache.get(key)
+    if gd is None:
+        gd = cache[key] = GraphedDrive(g, ws, results['texture'], results['static'], batch=batch, neural_rendering_resolution=nrr,
+                                       ray_dist_elems=batch if batch > 1 else 0)
+        gd.identity = None
+    ident = tuple((t.data_ptr(), t._version) for t in [ws] + list(results['texture']) + list(results['static']))
+    if gd.identity != ident:
+        gd.set_identity(ws, results['texture'], results['static'])
+        gd.identity = ident
+    return gd
+
+
 @torch.no_grad()
-def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=None, neural_rendering_resolution=None):
+def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=None, neural_rendering_resolution=None, graphed=None):
     """Drive loop (:206-219) over cams [F,25] / uvcoords [F,256,256,3] in calls of `batch` frames (the script uses 1; with
     batch > 1 every frame keeps the depth range of its own call: per-frame `ray_dist`, frame_parallel.per_frame_ray_dist).
-    Returns (images [F,3,H,W], mosaics or None): mosaics are the uint8 [gt | rendered] pictures when `gt` [F,3,H,W] is given."""
+    `graphed`: None = the default (DRIVE_GRAPHS: device tensors, batch 1, >= DRIVE_GRAPH_MIN_FRAMES frames -> captured calls, see above),
+    True / False force it.  Returns (images [F,3,H,W], mosaics or None): mosaics are the uint8 [gt | rendered] pictures when `gt`
+    [F,3,H,W] is given."""
     from .frame_parallel import per_frame_ray_dist
     from .reenact_avatar_next3d import _check_split_range
     g = net.generator
     n = cams.shape[0]
     imgs, mosaics = [], ([] if gt is not None else None)
+
+    def mosaic(images, lo):
+        if gt is not None:
+            for k in range(images.shape[0]):
+                mosaics.append(layout_grid(torch.cat([gt[lo + k:lo + k + 1, :3], images[k:k + 1]], dim=0), grid_w=2, grid_h=1))
     _check_split_range(net, start=True)
+    use_graphs = graphed if graphed is not None else (DRIVE_GRAPHS and n >= DRIVE_GRAPH_MIN_FRAMES)
+    if use_graphs and batch == 1 and cams.is_cuda and not torch.is_grad_enabled():
+        nrr = neural_rendering_resolution or g.neural_rendering_resolution
+        lo = 0
+        while lo < n:
+            b = DRIVE_GRAPH_BATCH if n - lo >= DRIVE_GRAPH_BATCH else 1
+            call = _drive_graph(net, ws, results, b, nrr)
+            # the stratified noise the renderer draws per call (torch.rand_like, renderer.py:406) when the caller pins none
+            jit = jitter[lo:lo + b] if jitter is not None else torch.rand(b, nrr * nrr, 48, device=cams.device)
+            out = call(cams[lo:lo + b], uvcoords[lo:lo + b], jit, per_frame_ray_dist(cams[lo:lo + b]) if b > 1 else None)
+            imgs.append(out['image'].clone())             # (the call's static output: the next replay overwrites it)
+            mosaic(imgs[-1], lo)
+            lo += b
+        _check_split_range(net)
+        return torch.cat(imgs, 0), mosaics
     for lo in range(0, n, batch):
         hi = min(lo + batch, n)
         b = hi - lo
@@ -312,8 +373,6 @@ def drive_sequence(net, ws, results, cams, uvcoords, jitter=None, batch=1, gt=No
         out = g.synthesis_withTexture(ws_b, tex, cams[lo:hi], {'uvcoords_image': uvcoords[lo:hi]}, noise_mode='const', static_feats=sta,
                                       evaluation=True, **kw)
         imgs.append(out['image'])
-        if gt is not None:
-            for k in range(b):
-                mosaics.append(layout_grid(torch.cat([gt[lo + k:lo + k + 1, :3], out['image'][k:k + 1]], dim=0), grid_w=2, grid_h=1))
+        mosaic(out['image'], lo)
     _check_split_range(net)      # (one device -> host read per drive sequence: see hipops.split_saturation_poll)
     return torch.cat(imgs, 0), mosaics

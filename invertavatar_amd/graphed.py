@@ -101,6 +101,15 @@ class GraphedDrive:
     _capture = GraphedSynthesis._capture
 
     @torch.no_grad()
+    def set_identity(self, ws, texture_feats, static_feats):
+        """Another identity of the same network: its features go into the tensors the call was captured with (one copy per pyramid level,
+        broadcast over the call's frames)."""
+        self.ws.copy_(ws.expand_as(self.ws))
+        for dst, src in zip(self.tex + self.sta, list(texture_feats) + list(static_feats)):
+            dst.copy_(src.expand_as(dst))
+        return self
+
+    @torch.no_grad()
     def __call__(self, c, uvcoords_image, jitter, ray_dist=None):
         if (ray_dist is None) != (self.ray_dist is None):
             raise ValueError('ray_dist must be passed exactly when the graph was built with ray_dist_elems > 0')

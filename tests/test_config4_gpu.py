@@ -48,12 +48,15 @@ def test_config4_drive_block_of_eight_fp16_sr_on_inverted_features(inverted):
     saved, sg2.FP16_BLOCKS_COMPUTE_FP32 = sg2.FP16_BLOCKS_COMPUTE_FP32, False
     try:
         with torch.no_grad():
-            one, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=1, neural_rendering_resolution=nrr)     # the script: B = 1
+            one, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=1, neural_rendering_resolution=nrr, graphed=False)   # the script: B = 1, eager
             blk, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=8, neural_rendering_resolution=nrr)     # one call of 8
+            dflt, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, neural_rendering_resolution=nrr)             # the harness default: captured calls of 8
+            dflt9, _ = eval_seq.drive_sequence(net, ws, res, torch.cat([c, c[:1]]), torch.cat([uv, uv[:1]]), jitter=torch.cat([jit, jit[:1]]),
+                                               neural_rendering_resolution=nrr)                                            # 8 + a one-frame call
             graphed = GraphedDrive(net.generator, ws, res['texture'], res['static'], batch=8, neural_rendering_resolution=nrr, ray_dist_elems=8)
             rep = graphed(c, uv, jit, per_frame_ray_dist(c))['image'].clone()
             sg2.FP16_BLOCKS_COMPUTE_FP32 = True                                                                               # fp32 head, same features
-            one32, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=1, neural_rendering_resolution=nrr)
+            one32, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=1, neural_rendering_resolution=nrr, graphed=False)
             f32, _ = eval_seq.drive_sequence(net, ws, res, c, uv, jitter=jit, batch=8, neural_rendering_resolution=nrr)
     finally:
         sg2.FP16_BLOCKS_COMPUTE_FP32 = saved
@@ -67,6 +70,9 @@ def test_config4_drive_block_of_eight_fp16_sr_on_inverted_features(inverted):
     assert d_batch32 <= TOL_BATCH
     assert d_batch16 <= TOL_RGB_FP16_SR
     assert d_graph == 0.0                                    # the captured call replays the eager call bit for bit
+    # eval_seq.drive_sequence's default: captured calls of 8 with per-frame depth ranges = the eager call of 8, bit for
+    # bit; a ninth frame goes through the captured one-frame call = the script's own call
+    assert max_abs(dflt, blk) == 0.0 and max_abs(dflt9[:8], blk) == 0.0 and max_abs(dflt9[8], one[0]) == 0.0
     assert 0.0 < d_f32 <= TOL_RGB_FP16_SR                    # (> 0: the fp16 mode really ran)
     assert max_abs(blk[0], blk[1]) > 1e-2                    # different drive frames differ
 

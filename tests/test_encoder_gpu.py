@@ -20,6 +20,19 @@ def test_few_shot_inversion_matches_reference(golden):
     assert image.shape == (1, 3, 512, 512) and image2.shape == (1, 3, 512, 512)
     bad = {k: v for k, v in dev.items() if v > (TOL_DRIVE_RGB if k.startswith('drive_image') else TOL_FEATURES)}
     assert not bad, bad
+    # ... and through the harness' default for clips: >= 8 drive frames go out as captured calls of 8 (+ one-frame
+    # calls), every frame with its own depth range.  Nine copies of the fixture's nrr-128 drive frame: each is the recorded frame.
+    from encoder_common import drive_frame2
+    from invertavatar_amd import eval_seq
+    d2 = drive_frame2(128)
+    rep = lambda t: t.cuda().expand(9, *t.shape[1:]).contiguous()
+    clip, _ = eval_seq.drive_sequence(net, ws, res, rep(d2['c']), rep(d2['uvcoords']), jitter=rep(d2['jitter'].squeeze(-1)), neural_rendering_resolution=128)
+    from invertavatar_amd import _runtime
+    assert sorted(k[0] for k in _runtime.state(net).drive_graphs) == [1, 8]          # the captured calls really ran
+    for k in (0, 5, 8):
+        dev_k = fixture_deviations(golden('encoder_fewshot.npz'), ws, res, r_list, image, clip[k:k + 1])
+        assert dev_k['drive_image_nrr128'] <= TOL_DRIVE_RGB and dev_k['drive_image_nrr128_crop'] <= TOL_DRIVE_RGB, (k, dev_k)
+    net.generator.neural_rendering_resolution = 32
 
 
 def test_renders_batched_across_groups_equal_the_per_group_calls():
