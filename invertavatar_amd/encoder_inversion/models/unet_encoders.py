@@ -172,6 +172,14 @@ class _UNetBase(Module):
         x, (c0, c1, c2, c3) = run_trunk(self.body, self.input_layer(x), (2, 6, 20, 21))
         return x, c0, c1, c2, c3
 
+    def gru_state_shapes(self, feats):
+        """Shapes of the four ConvGRU states from the trunk features [x, c0, c1, c2, c3]: stage k (up1 .. up4) keeps one state of its
+        cell's channel count at the resolution of the skip feature it concatenates (c3, c2, c1, c0) -- what a rank that does not own
+        the chain needs to receive them (inversion_parallel)."""
+        assert self.use_gru
+        skips = (feats[4], feats[3], feats[2], feats[1])
+        return [(1, up.conv_gru.channels) + tuple(skip.shape[-2:]) for up, skip in zip((self.up1, self.up2, self.up3, self.up4), skips)]
+
     def _decode(self, feats, T, r_list):
         """Yields the four decoder activations (16, 32, 64, 128^2); fills r_list in place when recurrent."""
         x, c0, c1, c2, c3 = feats

@@ -164,13 +164,23 @@ def few_shot_inversion_sharded(net, images, uvs, cams, uvcoords, rank=0, world_s
         texture = _broadcast_list([t.clone() for t in (updated['texture'] if rank == tex_owner else tex)], tex_owner, group)
         static = _broadcast_list([t.clone() for t in (updated['static'] if rank == tri_owner else sta)], tri_owner, group)
         updated = {'w': ws, 'texture': texture, 'static': static}
-        r_list = [_broadcast_states(r_list[0], tex_owner, rank, dev, group), _broadcast_states(r_list[1], tri_owner, rank, dev, group)]
+        unets = (net.unet_encoder.texture_unet, net.unet_encoder.triplane_unet)
+        if trunk_all is not None and all(hasattr(u, 'gru_state_shapes') for u in unets):
+            # every rank holds the trunk features' shapes (`like`) and the UNet derives its ConvGRU states' shapes from them
+            # (_UNetBase.gru_state_shapes): ONE payload per owner, no header, no host round trip
+            like = trunk_all[1]
+            shapes = [unets[0].gru_state_shapes(like['texture']), unets[1].gru_state_shapes(like['triplane'])]
+            r_list = [_broadcast_list([h.contiguous() for h in r_list[u]] if rank == owner else [torch.empty(sh, device=dev) for sh in shapes[u]],
+                                      owner, group, dev) for u, owner in enumerate((tex_owner, tri_owner))]
+        else:
+            r_list = [_broadcast_states(r_list[0], tex_owner, rank, dev, group), _broadcast_states(r_list[1], tri_owner, rank, dev, group)]
     _check_split_range(net)
     return ws, updated, r_list
 
 
 def _broadcast_states(states, src, rank, device, group=None):
-    """ConvGRU states of one UNet (a list of tensors known on `src` only): shapes first (int64 header), then one flat buffer."""
+    """ConvGRU states of one UNet (a list of tensors known on `src` only) when the other ranks cannot derive their shapes (trunks not
+    dealt by frame): shapes first (int64 header), then one flat buffer."""
     if rank == src:
         shapes = [list(h.shape) for h in states]
         dtype_code = _STATE_DTYPES.index(states[0].dtype) if states else 0

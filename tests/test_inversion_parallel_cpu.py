@@ -72,6 +72,9 @@ class _UNet(torch.nn.Module):
         t = x.flatten(0, 1)                                 # [T, C, H, W]
         return [torch.einsum('oc,tchw->tohw', w, torch.tanh(torch.nn.functional.adaptive_avg_pool2d(t, res))) for w, (ch, res) in zip(self.w, self.levels)]
 
+    def gru_state_shapes(self, feats):                      # (what the product's UNets answer from their trunk features)
+        return [(1, ch, res, res) for ch, res in self.levels]
+
     def forward_onlyDecoder(self, T, feats, r_list=None):
         if r_list is None:
             r_list = [torch.zeros(1, ch, res, res) for ch, res in self.levels]
