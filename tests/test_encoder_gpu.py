@@ -33,6 +33,13 @@ def test_few_shot_inversion_matches_reference(golden):
         dev_k = fixture_deviations(golden('encoder_fewshot.npz'), ws, res, r_list, image, clip[k:k + 1])
         assert dev_k['drive_image_nrr128'] <= TOL_DRIVE_RGB and dev_k['drive_image_nrr128_crop'] <= TOL_DRIVE_RGB, (k, dev_k)
     net.generator.neural_rendering_resolution = 32
+    # the ConvGRU state shapes a rank derives from the trunk features (inversion_parallel's header-free state broadcast) are the states' own
+    from encoder_common import source_batch
+    src = source_batch('cuda')
+    with torch.no_grad():
+        tf = net.trunk_features(src['image'][:1], src['uv'][:1], image2)
+    for u, (unet, key) in enumerate(((net.unet_encoder.texture_unet, 'texture'), (net.unet_encoder.triplane_unet, 'triplane'))):
+        assert unet.gru_state_shapes(tf[key]) == [tuple(h.shape) for h in r_list[u]], key
 
 
 def test_renders_batched_across_groups_equal_the_per_group_calls():
