@@ -29,6 +29,17 @@ __host__ __device__ constexpr int pair_t0(bool tr, int s) { return tr ? (s == 0 
 __host__ __device__ constexpr int pair_t1(bool tr, int s) { return tr ? (s == 0 ? 2 : s == 1 ? 8 : s == 2 ? 7 : s == 3 ? 5 : kZeroTap) : (s == 4 ? kZeroTap : 2 * s + 1); }
 __host__ __device__ constexpr int pair_phase(bool tr, int s) { return tr ? (s < 2 ? 0 : s - 1) : 0; }
 
+// Low-resolution 3x3 stride-1 layers of the split-DMA form (at most kSmallMaxPoints points) whose tile plan would be stream-K: the K
+// range is dealt to the waves of a workgroup instead (csrc/conv_small.h) -- no scratch, no fix-up launch.  The planner (conv_mfma.hip)
+// and the dispatcher (conv_split.hip) both ask here.  IA_CONV_SMALL = 0: A/B builds that keep those layers on the stream-K tiles.
+#ifndef IA_CONV_SMALL
+#define IA_CONV_SMALL 1
+#endif
+constexpr int kSmallMaxPoints = 256;
+__host__ inline bool conv_small_shape(int H, int W, int ksize, int transposed, int stride) {
+    return IA_CONV_SMALL && ksize == 3 && !transposed && stride == 1 && H * W <= kSmallMaxPoints;
+}
+
 struct Geo {
     int B, I, O, H, W;     // input
     int GH, GW;            // point grid: conv H x W, transposed (H+1) x (W+1)

@@ -21,6 +21,7 @@
 // (training/networks_stylegan2.py:34-91, torch_utils/ops/conv2d_resample.py:114-136).
 #include "conv_common.h"
 #include "lds_dma.h"
+#include "conv_small.h"
 #include <cstdlib>
 
 // Compile-time ablations for tools/ablate_conv_split.sh (never set in the product build): 1 = no DMA after the first chunk of a
@@ -992,7 +993,8 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
         return ia::fail(IA_ERR_UNSUPPORTED, "the fused ToRGB needs a stride-1 layer whose tiles hold every output channel and run in whole rounds "
                         "(O %d, %d channel tiles, %d of %d tiles in whole rounds)", O, g.TO, g.T_dp, g.T);
     g.G = 0;
-    if (g.T_dp < g.T) {
+    const bool small = g.T_dp < g.T && conv_small_shape(H, W, 3, transposed, stride) && !rgb.out && !d2s;
+    if (g.T_dp < g.T && !small) {
         IA_REQUIRE(ksplit >= 1, "this layer has stream-K tiles: pass the worker count from ia_conv2d_plan");
         const int64_t Ur = (int64_t)(g.T - g.T_dp) * g.C;
         g.G = (int)(ksplit > Ur ? Ur : ksplit);
@@ -1013,6 +1015,7 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
         e.rgb_w = rgb.w; e.rgb_styles = rgb.styles; e.rgb_bias = rgb.bias; e.rgb_res = rgb.res; e.rgb_out = rgb.out; e.rgb_n = rgb.n; e.rgb_clamp = rgb.clamp;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (small) return conv_small_launch(xs, planes, wk_split, y, g, e, s);      // low-resolution layers: K split inside the workgroup, no slabs, no fix-up (conv_small.h)
     const h16x8* x8 = static_cast<const h16x8*>(xs);
     const h16x8* w8 = static_cast<const h16x8*>(wk_split);
     if (planes == 1) {

@@ -287,6 +287,47 @@ def test_split_dma_convolution_equals_the_register_staged_form(i, o, h, w, tr, b
     assert torch.equal(only_s.data, got_s.data)
 
 
+@pytest.mark.parametrize('b,i,o,h,w,prelu,residual', [(1, 512, 512, 8, 8, False, False), (1, 1024, 1024, 16, 16, True, True), (3, 24, 136, 12, 10, False, True),
+                                                       (2, 72, 200, 9, 14, True, False), (1, 8, 128, 16, 16, False, False), (1, 512, 512, 16, 16, False, False)])
+def test_low_resolution_layers_split_k_inside_the_workgroup(b, i, o, h, w, prelu, residual):
+    """r06 (csrc/conv_small.h): 3x3 layers of at most 256 points -- the K range dealt to the eight waves of a workgroup, partial tiles summed
+    in LDS, no slabs and no fix-up launch -- against the fp64 convolution of the operands the kernel sees: ragged point / channel counts
+    (last fragments partly outside), fewer channel octets than waves, per-channel PReLU slopes, clamp, residual, both outputs; and the same
+    bits on every launch."""
+    assert hipops.conv_sx_supported(i, o, h, w, 3, False)
+    g = torch.Generator(device='cuda').manual_seed(23 + i + h)
+    x = torch.randn(b, i, h, w, device='cuda', generator=g) * 2
+    wt = torch.randn(o, i, 3, 3, device='cuda', generator=g)
+    s = torch.rand(b, i, device='cuda', generator=g) + 0.5
+    sn = torch.rand(b, o, device='cuda', generator=g) + 0.5
+    d = hipops.modconv_demod(s, hipops.weight_sq_sum(wt))
+    xs = hipops.act_split(x, s)
+    wk = hipops.pack_conv_weight_split(wt)
+    bias = torch.randn(o, device='cuda', generator=g)
+    noise = torch.randn(h * w, device='cuda', generator=g)
+    ns = torch.full((1,), 0.3, device='cuda')
+    slopes = (torch.rand(o, device='cuda', generator=g) * 0.5) if prelu else None
+    res = torch.randn(b, o, h, w, device='cuda', generator=g) if residual else None
+    hipops.PROFILE = []
+    try:
+        got, got_s = hipops.conv2d_mfma_sx(xs, wk, demod=d, noise=noise, noise_strength=ns, bias=bias, residual=res, act='lrelu', gain=1.3, clamp=6.0,
+                                           styles_next=sn, prelu=slopes)
+        again, _ = hipops.conv2d_mfma_sx(xs, wk, demod=d, noise=noise, noise_strength=ns, bias=bias, residual=res, act='lrelu', gain=1.3, clamp=6.0,
+                                         styles_next=sn, prelu=slopes)
+    finally:
+        hipops.PROFILE = None
+    ref = torch.nn.functional.conv2d(xs.float().double(), wt.double(), padding=1) * d.double()[:, :, None, None] + (noise.double() * 0.3).view(1, 1, h, w)
+    ref = ref + bias.double()[None, :, None, None]
+    slope = slopes.double()[None, :, None, None] if prelu else 0.2
+    pre = (torch.where(ref > 0, ref, ref * slope) * 1.3)
+    ref = pre.clamp(-6.0, 6.0) + (res.double() if residual else 0.0)
+    assert got.shape == ref.shape and (got.double() - ref).abs().max().item() <= 3e-6 * pre.abs().max().item()
+    assert torch.equal(got, again)
+    hi, lo = _split_reference(got, sn)
+    assert torch.equal(got_s.data[:, 0].permute(0, 1, 4, 2, 3).reshape(got.shape), hi)
+    assert torch.equal(got_s.data[:, 1].permute(0, 1, 4, 2, 3).reshape(got.shape), lo)
+
+
 @pytest.mark.parametrize('b,i,o,res,tr', [(1, 512, 512, 8, False), (2, 512, 512, 16, False), (1, 256, 128, 16, False), (1, 512, 512, 8, True),
                                           (2, 512, 512, 16, True), (1, 64, 64, 16, True)])
 def test_split_dma_convolution_on_the_small_layers(b, i, o, res, tr):
