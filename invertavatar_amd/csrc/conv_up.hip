@@ -35,6 +35,9 @@
 #ifndef IA_UP_TRACE
 #define IA_UP_TRACE 0
 #endif
+#ifndef IA_UP_CHUNK_INTERVALS
+#define IA_UP_CHUNK_INTERVALS 1      // 0: a k-step per barrier interval for every tile (the r04 / r05 schedule; A/B builds)
+#endif
 #if IA_UP_TRACE
 #define IA_STAMP(slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && tr_n < 64) \
     reinterpret_cast<unsigned long long*>(slabs)[(wave * 64 + tr_n) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(512, 2) void up_rows_kernel(const h16x8* __restrict
     constexpr int WGI = WSLOTS / 64, JW = WGI / NWAVES; // weight DMA instructions per chunk / per wave
     static_assert(WGI % NWAVES == 0, "weight pieces divide evenly over the waves");
     constexpr int NACC = 2 * FO * FP * 16;
+    constexpr bool CI = IA_UP_CHUNK_INTERVALS && FP == 1;      // whole-chunk barrier intervals (see the K loop)
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -332,6 +336,75 @@ __global__ __launch_bounds__(512, 2) void up_rows_kernel(const h16x8* __restrict
         const int fill_chunk = issued, fill_stage = cur == 0 ? NS - 1 : cur - 1;
         const h16x8* wh = reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(lds) + cur * stage_bytes);
         const h16x8* ph = wh + WSLOTS;
+        if constexpr (CI) {
+            // Whole-chunk intervals (r06, the 128-point tiles of the backbones' up-sampling layers): ONE LOAD segment reads the operands
+            // of all three k-steps of the chunk and issues the wave's refill pieces, ONE COMPUTE segment runs their 18 MFMAs -- two
+            // barriers per chunk instead of six.  With a k-step per interval these tiles spent 1 380 cycles on 6 MFMAs (192 cycles of the
+            // pipe): a 360 - 500-cycle LOAD segment and ~200 cycles of barrier per interval whatever the segment holds (r05 ablation:
+            // 58 us with, 46 us without the MFMAs).  Hazards as before, per chunk: the stage refilled here (chunk ch - 1's) was last read
+            // by the lagging group in ITS load segment of chunk ch - 1, which ended at the barrier in front of this segment; every wave
+            // waits for its own pieces of chunk ch + 1 in front of the barrier that ends its load segment of chunk ch, and the leading
+            // group starts reading chunk ch + 1 two barriers later.
+            h16x8 a_all[3][NP * FO], b_all[3][NP * FP];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int fo = 0; fo < FO; ++fo) a_all[s][pl * FO + fo] = wh[pl * NU * BO + arow[s] + (wo * FO + fo) * 32 + l31];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp) b_all[s][pl * FP + fp] = ph[pl * cap + bpos[fp] + boff[s]];
+            }
+            // (the wait goes IN FRONT of this chunk's pieces, see below: chunks ch + 2 .. issued - 1 may stay in flight)
+            if (ch + 1 < c_hi && IA_UP_ABLATE != 4) wait_chunks_in_flight<n_dma>(issued - ch - 2);
+            if (fill) { IA_UP_ISSUE(fill_chunk, fill_stage, 0, 1); ++issued; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            ia_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#if IA_UP_ABLATE == 2
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                for (int q = 0; q < NP * FO; ++q) asm volatile("" ::"v"(a_all[s][q]));
+#pragma unroll
+                for (int q = 0; q < NP * FP; ++q) asm volatile("" ::"v"(b_all[s][q]));
+            }
+#else
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                constexpr int kPxC[3] = {0, 0, 1};
+                const int px = kPxC[s];
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp)      // lo * hi
+                        acc[px][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_all[s][FO + fo], b_all[s][fp], acc[px][fo][fp], 0, 0, 0);
+                h16x8 a_sc[FO];
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo) a_sc[fo] = a_all[s][fo] * (_Float16)(1.0f / kLoScale);
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp)      // (hi * 2^-11) * (lo * 2^11)
+                        acc[px][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[fo], b_all[s][FP + fp], acc[px][fo][fp], 0, 0, 0);
+#pragma unroll
+                for (int fo = 0; fo < FO; ++fo)
+#pragma unroll
+                    for (int fp = 0; fp < FP; ++fp)      // hi * hi
+                        acc[px][fo][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_all[s][fo], b_all[s][fp], acc[px][fo][fp], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            ia_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur + 1 == NS ? 0 : cur + 1;
+            continue;
+        }
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             // LOAD segment: the k-step's operand reads (and, at the chunk's last k-step, the wait for the next chunk's DMA)
