@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 6      /* 6 (r06, additive): ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 6      /* 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -212,6 +212,10 @@ int ia_modconv_demod(const float* styles, const float* wsq, float* demod, int B,
  *          one-call-per-frame script computes);  wsum : [B, R] sum of compositing weights
  *   minmax_scratch : 2 * ia_render_rays_grid(B, R) floats of caller scratch; with IA_RENDER_DIST_PER_FRAME 8 * B times that
  *          (one range per wave and frame)
+ *   rgb_split : NULL, or a second copy of rgb in the operand format of the convolution that consumes the feature image (the SR head's
+ *          first layer, superresolution.py:287 -> block0.conv0): fp16 [B, rgb_split_planes, 4, R, 8] (ia_act_split's format: 2 = hi / lo
+ *          planes, 1 = one rounded plane) of rgb[b, c, r] * rgb_split_styles[b, c] ([B, 32] or NULL = unscaled) -- bit for bit what
+ *          ia_act_split makes of the channel-major image, without the launch between the renderer and the head (r06)
  *   dbg_* : optional stage outputs for parity tests (NULL in production): fine depths [B,R,48], searchsorted
  *          indices [B,R,48] (int32), merge order [B,R,96] (int32, < 48 = coarse sample, >= 48 = fine sample),
  *          coarse weights [B,R,47], coarse densities [B,R,48]
@@ -222,7 +226,7 @@ int ia_render_rays(const float* planes_cl, const float* rays_o, const float* ray
                    int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
                    float* rgb, float* depth, float* wsum, float* minmax_scratch,
                    float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
-                   void* stream);
+                   void* rgb_split, const float* rgb_split_styles, int rgb_split_planes, void* stream);
 
 /* Number of persistent workgroups ia_render_rays launches for (B, R); sizes minmax_scratch. Host-only. */
 int ia_render_rays_grid(int B, int R);

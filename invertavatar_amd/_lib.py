@@ -35,7 +35,7 @@ _SIGNATURES = {
     'ia_conv2d_mfma_s': [c_void_p] * 2 + [c_int] + [c_void_p] * 8 + [ctypes.c_size_t] + [c_int] * 8 + [c_float, c_float, c_float, c_int, c_void_p],
     'ia_conv2d_plan': [c_int] * 8 + [ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_size_t)],
     'ia_modconv_demod': [c_void_p] * 3 + [c_int] * 3 + [c_void_p],
-    'ia_render_rays': [c_void_p] * 10 + [c_float, c_float, c_int] + [c_int] * 6 + [c_void_p] * 9 + [c_void_p],
+    'ia_render_rays': [c_void_p] * 10 + [c_float, c_float, c_int] + [c_int] * 6 + [c_void_p] * 9 + [c_void_p, c_void_p, c_int] + [c_void_p],
     'ia_render_rays_grid': [c_int, c_int],
     'ia_render_rays_box': [c_void_p] * 6 + [ctypes.c_double, ctypes.c_double] + [c_void_p] * 4 + [c_float, c_float, c_int] + [c_int] * 6 + [c_void_p] * 9 + [c_void_p],
     'ia_ray_limits_box': [c_void_p, c_void_p, ctypes.c_double, c_int, c_int, c_void_p, c_void_p, c_void_p],

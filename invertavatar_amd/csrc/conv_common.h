@@ -36,8 +36,13 @@ __host__ __device__ constexpr int pair_phase(bool tr, int s) { return tr ? (s < 
 #define IA_CONV_SMALL 1
 #endif
 constexpr int kSmallMaxPoints = 256;
-__host__ inline bool conv_small_shape(int H, int W, int ksize, int transposed, int stride) {
-    return IA_CONV_SMALL && ksize == 3 && !transposed && stride == 1 && H * W <= kSmallMaxPoints;
+// ... as long as its workgroups (32 channels x 32 points each, all of K) fit the machine in one round: measured r06 on one box against the
+// stream-K tiles + fix-up (graph replay, us): 512 -> 512 @8^2 24.9 -> 15.0, @16^2 25.5 -> 18.8, 8 frames @8^2 41.6 -> 16.2, 256 -> 256 @16^2
+// 19.8 -> 10.5, 1024 -> 512 @16^2 30.9 -> 28.7; but 8 frames @16^2 (1024 workgroups) 44.6 -> 68.6 and 1024 -> 1024 @16^2 (256 workgroups of
+// twice the K) 42.7 -> 45.7: every workgroup streams its own copy of the operands through its CU's 64 B/clk vector-memory path.
+__host__ inline bool conv_small_shape(int B, int I, int O, int H, int W, int ksize, int transposed, int stride) {
+    const int64_t wgs = (int64_t)B * ((H * W + 31) / 32) * ((O + 31) / 32);
+    return IA_CONV_SMALL && ksize == 3 && !transposed && stride == 1 && H * W <= kSmallMaxPoints && wgs * (I > 512 ? 2 : 1) <= ia::kNumCU;
 }
 
 struct Geo {

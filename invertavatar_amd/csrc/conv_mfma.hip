@@ -612,7 +612,7 @@ extern "C" int ia_conv2d_plan(int B, int I, int O, int H, int W, int ksize, int 
     IA_REQUIRE(B > 0 && I > 0 && O > 0 && H > 0 && W > 0, "empty tensor");
     IA_REQUIRE(form >= 0 && form <= 3, "form: 0 = ia_conv2d_mfma, 1 = ia_conv2d_mfma_h, 2 = ia_conv2d_mfma_s, 3 = ia_conv2d_mfma_sx");
     const Plan p = make_plan(B, I, O, H, W, ksize, transposed, form);
-    if (form == 3 && p.T_dp < p.T && conv_small_shape(H, W, ksize, transposed, 1)) {      // K split inside the workgroup (conv_small.h): no workers, no slabs
+    if (form == 3 && p.T_dp < p.T && conv_small_shape(B, I, O, H, W, ksize, transposed, 1)) {      // K split inside the workgroup (conv_small.h): no workers, no slabs
         *h_ksplit = 0;
         *h_scratch_bytes = 0;
         return IA_OK;

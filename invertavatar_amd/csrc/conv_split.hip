@@ -993,7 +993,7 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
         return ia::fail(IA_ERR_UNSUPPORTED, "the fused ToRGB needs a stride-1 layer whose tiles hold every output channel and run in whole rounds "
                         "(O %d, %d channel tiles, %d of %d tiles in whole rounds)", O, g.TO, g.T_dp, g.T);
     g.G = 0;
-    const bool small = g.T_dp < g.T && conv_small_shape(H, W, 3, transposed, stride) && !rgb.out && !d2s;
+    const bool small = g.T_dp < g.T && conv_small_shape(B, I, O, H, W, 3, transposed, stride) && !rgb.out && !d2s;
     if (g.T_dp < g.T && !small) {
         IA_REQUIRE(ksplit >= 1, "this layer has stream-K tiles: pass the worker count from ia_conv2d_plan");
         const int64_t Ur = (int64_t)(g.T - g.T_dp) * g.C;

@@ -586,7 +586,7 @@ int plan_up(int B, int I, int O, int H, int W, UpPlan* out) {
     // range is cut just enough for that -- ~16 chunks per worker.  (The first version cut 16-way: 16 slabs of 128 ch x 128 / 256 pt per
     // edge tile were 205 MB of slab writes + reads per frame, PMC r04: more than the images these layers write.)
     const int c0 = I / 8;
-    const int gpe = c0 / 16 < 2 ? 2 : (c0 / 16 > 4 ? 4 : c0 / 16);
+    int gpe = c0 / 16 < 2 ? 2 : (c0 / 16 > 4 ? 4 : c0 / 16);
     // whole-tile grids (interior of either row phase), then the edge grids
     const bool one_round = (int64_t)B * 2 * npt * g.TO <= ia::kNumCU;
     // K-deep layers whose tiles leave most of the machine idle (512 input channels at 64^2: 64 long tiles of 192 k-steps): the long
@@ -594,6 +594,14 @@ int plan_up(int B, int I, int O, int H, int W, UpPlan* out) {
     // anyway -- and the py 1 tiles run one per workgroup: every workgroup then has 96 k-steps (same-box 93 -> see DESIGN 4.7)
     const bool split_long = one_round && I >= 512 && (int64_t)B * 3 * npt * g.TO <= ia::kNumCU;
     constexpr int kColPts = 64;      // points per tile of the one-column grids
+    // r06: a layer whose interior tiles leave CUs idle anyway (one round, no K-split interior: 256 -> 128 @128^2, 192 workgroups) runs its
+    // edge tiles WHOLE beside them -- an edge tile has the K range of an interior tile and a CU of its own, so it ends with them; no slabs
+    // and no up_edge_fixup launch (one launch and one graph edge less on the chain of every such layer)
+    {
+        const int64_t interior = (int64_t)B * g.TO * (npt + (npt + 1) / 2);
+        const int64_t edges = (int64_t)B * g.TO * (ia::ceil_div(W, BP) + ia::ceil_div(H + 1, kColPts) + ia::ceil_div(H, kColPts));
+        if (one_round && !split_long && interior + edges <= ia::kNumCU) gpe = 0;
+    }
     const UpSub subs[kMaxSub] = {
         // first_wg n_wg n_pt tp reps gpe edge_first slab_first GH GW r_off c_off py
         {0, 0, npt, BP, 1, split_long ? 2 : 0, 0, 0, H, W, 0, 0, 0},
@@ -645,6 +653,7 @@ int launch_up(const UpPlan& p, const h16x8* xs, const h16x8* wk, float* y, float
     if (const int rs = ia::reserve_lds((const void*)k, p.lds, "upconv_rows")) return rs;
     hipLaunchKernelGGL(k, dim3(p.n_wg, p.g.B), dim3(512), p.lds, s, xs, wk, y, scratch, demod, p.g);
     if (const int st = ia::check_launch("ia_upconv2d_rows_sx")) return st;
+    if (p.g.E == 0) return IA_OK;      // every tile whole: nothing to sum
     hipLaunchKernelGGL((up_edge_fixup_kernel<FP>), dim3(p.g.E, p.g.B, 2 * FP * 4), dim3(512), 0, s, scratch, y, demod, p.g);
     return ia::check_launch("ia_upconv2d_rows_sx(edge fix-up)");
 }
@@ -669,7 +678,7 @@ extern "C" int ia_upconv2d_rows_sx(const void* xs, const void* wk_split, int wk_
     UpPlan p;
     if (plan_up(B, I, O, H, W, &p) != IA_OK)
         return ia::fail(IA_ERR_UNSUPPORTED, "row-phase up-convolution: needs I %% 16 == 0, O %% 128 == 0, 16 <= H, W <= 1024 (I %d O %d %dx%d)", I, O, H, W);
-    IA_REQUIRE(scratch && scratch_bytes >= p.scratch, "the edge tiles need %zu bytes of scratch, got %zu", p.scratch, scratch_bytes);
+    IA_REQUIRE(p.scratch == 0 || (scratch && scratch_bytes >= p.scratch), "the edge tiles need %zu bytes of scratch, got %zu", p.scratch, scratch_bytes);
     p.g.acc_scale = ldexpf(1.f, -wk_exp);
     hipStream_t s = (hipStream_t)stream;
     const h16x8* x8 = static_cast<const h16x8*>(xs);

@@ -74,6 +74,11 @@ struct Params {
     int B, R, PH, PW;
     int white_back, channel_major, dist_per_frame;
     float* rgb;                   // [B][R][32], or [B][32][R] when channel_major
+    // optional second copy of rgb in the operand format of the convolution that reads it (the SR head's first layer): fp16 hi / lo planes
+    // [B][planes][4][R][8] of rgb * split_styles[b][channel] -- what ia_act_split would make of the [B][32][R] image (null: not written)
+    void* split_out;
+    const float* split_styles;    // [B][32] or null (unscaled)
+    int split_planes;
     float* depth;                 // [B][R]   un-clamped (may be +inf), see ia_render_finalize
     float* wsum;                  // [B][R]
     float* minmax;                // [gridDim.x][2] per-workgroup min / max of all sample depths; dist_per_frame: [gridDim.x * WAVES][B][2]
@@ -680,11 +685,35 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         if (s == 0) {
             const int64_t ch_stride = p.channel_major ? p.R : 1;
             float* out = p.channel_major ? p.rgb + (int64_t)b * 32 * p.R + (ray - b * p.R) : p.rgb + (int64_t)ray * 32;
+            float fin[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 float v = acc_c[c];
                 if (p.white_back) v = v + 1.f - acc_w;
-                out[(16 * (c >> 2) + 4 * q + (c & 3)) * ch_stride] = v * 2.f - 1.f;
+                fin[c] = v * 2.f - 1.f;
+                out[(16 * (c >> 2) + 4 * q + (c & 3)) * ch_stride] = fin[c];
+            }
+            if (p.split_out) {      // (kernel-uniform) the same values in the split format, multiplied by the consumer's styles: see Params
+                typedef _Float16 h16x4r __attribute__((ext_vector_type(4)));
+                ia::SatWatch watch;
+                char* base = static_cast<char*>(p.split_out);
+                const int64_t pix = ray - b * p.R;
+#pragma unroll
+                for (int U = 0; U < 2; ++U) {      // this lane's channels 16 U + 4 q .. + 3: half of the 16-byte unit of octet 2 U + (q >> 1)
+                    h16x4r hi, lo;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ch = 16 * U + 4 * q + k;
+                        const float t = p.split_styles ? fin[4 * U + k] * p.split_styles[b * 32 + ch] : fin[4 * U + k];
+                        _Float16 h, l;
+                        if (p.split_planes == 2) { ia::split_f16(t, h, l, watch); hi[k] = h; lo[k] = l; }
+                        else hi[k] = ia::round_f16(t, watch);
+                    }
+                    const int64_t slot = ((int64_t)(b * p.split_planes) * 4 + 2 * U + (q >> 1)) * p.R + pix;
+                    *reinterpret_cast<h16x4r*>(base + slot * 16 + (q & 1) * 8) = hi;
+                    if (p.split_planes == 2) *reinterpret_cast<h16x4r*>(base + (slot + (int64_t)4 * p.R) * 16 + (q & 1) * 8) = lo;
+                }
+                watch.report();
             }
             if (q == 0) {
                 float dpt = acc_z / acc_w;
@@ -783,7 +812,9 @@ int launch_render(const float* planes_cl, const float* rays_o, const float* rays
                   int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
                   float* rgb, float* depth, float* wsum, float* minmax_scratch,
                   float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
+                  void* rgb_split, const float* rgb_split_styles, int rgb_split_planes,
                   const char* what, void* stream) {
+    IA_REQUIRE(!rgb_split || rgb_split_planes == 1 || rgb_split_planes == 2, "rgb_split_planes: 2 = hi / lo pair, 1 = one fp16 plane");
     IA_REQUIRE(planes_cl && rays_o && rays_d && jitter && w0 && b0 && w1 && b1, "null input pointer");
     IA_REQUIRE(rgb && depth && wsum && minmax_scratch, "null output pointer");
     IA_REQUIRE(B > 0 && R > 0 && plane_h > 0 && plane_w > 0, "empty tensor");
@@ -804,6 +835,7 @@ int launch_render(const float* planes_cl, const float* rays_o, const float* rays
     p.white_back = (flags & IA_RENDER_WHITE_BACK) != 0; p.channel_major = (flags & IA_RENDER_RGB_CHANNEL_MAJOR) != 0;
     p.dist_per_frame = (flags & IA_RENDER_DIST_PER_FRAME) != 0;
     p.rgb = rgb; p.depth = depth; p.wsum = wsum; p.minmax = minmax_scratch;
+    p.split_out = rgb_split; p.split_styles = rgb_split_styles; p.split_planes = rgb_split_planes;
     p.dbg_z_fine = dbg_z_fine; p.dbg_inds = dbg_inds; p.dbg_order = dbg_order; p.dbg_w_coarse = dbg_w_coarse;
     p.dbg_sigma_coarse = dbg_sigma_coarse;
     const int grid = ia_render_rays_grid(B, R);
@@ -889,12 +921,12 @@ extern "C" int ia_render_rays(const float* planes_cl, const float* rays_o, const
                               int B, int R, int plane_h, int plane_w, int n_coarse, int n_importance,
                               float* rgb, float* depth, float* wsum, float* minmax_scratch,
                               float* dbg_z_fine, int* dbg_inds, int* dbg_order, float* dbg_w_coarse, float* dbg_sigma_coarse,
-                              void* stream) {
+                              void* rgb_split, const float* rgb_split_styles, int rgb_split_planes, void* stream) {
     IA_REQUIRE(dist, "null input pointer");
     IA_REQUIRE(!(flags & IA_RENDER_FLIP_Z), "IA_RENDER_FLIP_Z belongs to ia_render_rays_box");
     return launch_render(planes_cl, rays_o, rays_d, jitter, u_importance, dist, nullptr, false, 0.0, 0.0, w0, b0, w1, b1, lr_multiplier, box_warp, flags,
                          B, R, plane_h, plane_w, n_coarse, n_importance, rgb, depth, wsum, minmax_scratch,
-                         dbg_z_fine, dbg_inds, dbg_order, dbg_w_coarse, dbg_sigma_coarse, "ia_render_rays", stream);
+                         dbg_z_fine, dbg_inds, dbg_order, dbg_w_coarse, dbg_sigma_coarse, rgb_split, rgb_split_styles, rgb_split_planes, "ia_render_rays", stream);
 }
 
 extern "C" int ia_render_rays_box(const float* planes_cl, const float* rays_o, const float* rays_d, const float* jitter,
@@ -910,7 +942,7 @@ extern "C" int ia_render_rays_box(const float* planes_cl, const float* rays_o, c
     return launch_render(planes_cl, rays_o, rays_d, jitter, u_importance, nullptr, ray_limits, ray_limits == nullptr, ray_start, ray_end,
                          w0, b0, w1, b1, lr_multiplier, box_warp, flags,
                          B, R, plane_h, plane_w, n_coarse, n_importance, rgb, depth, wsum, minmax_scratch,
-                         dbg_z_fine, dbg_inds, dbg_order, dbg_w_coarse, dbg_sigma_coarse, "ia_render_rays_box", stream);
+                         dbg_z_fine, dbg_inds, dbg_order, dbg_w_coarse, dbg_sigma_coarse, nullptr, nullptr, 2, "ia_render_rays_box", stream);
 }
 
 extern "C" int ia_ray_limits_box_parts(int n_rays) {

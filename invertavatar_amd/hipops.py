@@ -697,7 +697,7 @@ def planes_channels_last(planes):
 
 
 def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_multiplier=1.0, box_warp=1.0, white_back=False,
-                n_coarse=48, n_importance=48, debug=False, channel_major=False, u_importance=None):
+                n_coarse=48, n_importance=48, debug=False, channel_major=False, u_importance=None, split_styles=None, split_planes=0):
     """Fused importance renderer (see ia_render_rays).  Returns (rgb [B,R,32], depth [B,R,1], wsum [B,R,1][, aux]).
     channel_major=True stores rgb as [B,32,R] (the feature image the super-resolution head reads) and returns the [B,R,32] VIEW of
     it: same values and shape, and `rgb.permute(0, 2, 1).reshape(B, 32, nrr, nrr)` is then contiguous without a copy."""
@@ -721,6 +721,10 @@ def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_mult
     depth = torch.empty(b, r, 1, device=dev)
     wsum = torch.empty(b, r, 1, device=dev)
     scratch = torch.empty(2 * lib.ia_render_rays_grid(b, r) * (8 * b if dist_per_frame else 1), device=dev)      # (8 waves per workgroup: include/ia_hip.h)
+    # split_planes = 1 | 2: the composited features ALSO in the split format (x split_styles [B,32]) as `rgb.split_data` [B, planes, 4, R, 8]
+    split = torch.empty(b, split_planes, 4, r, 8, device=dev, dtype=torch.float16) if split_planes else None
+    if split_styles is not None and (_f32c(split_styles, 'split_styles').numel() != b * 32 or not split_planes):
+        raise RuntimeError('split_styles: [B,32] styles of the layer that consumes the split copy (with split_planes = 1 or 2)')
     aux = {}
     if debug:
         aux = dict(z_fine=torch.empty(b, r, 48, device=dev), inds=torch.empty(b, r, 48, device=dev, dtype=torch.int32),
@@ -735,8 +739,10 @@ def render_rays(planes_cl, rays_o, rays_d, jitter, dist, w0, b0, w1, b1, lr_mult
                                 int(n_coarse),
                                 int(n_importance), _p(rgb), _p(depth), _p(wsum), _p(scratch), _p(aux.get('z_fine')),
                                 _p(aux.get('inds')), _p(aux.get('order')), _p(aux.get('w_coarse')), _p(aux.get('sigma_coarse')),
-                                _lib.stream_ptr(dev))
+                                _p(split), _p(split_styles), int(split_planes or 2), _lib.stream_ptr(dev))
     _lib.check(st, 'ia_render_rays')
+    if split is not None:
+        rgb.split_data = split
     return (rgb, depth, wsum, aux) if debug else (rgb, depth, wsum)
 
 

@@ -36,6 +36,7 @@ LAUNCH_ORDER = 'tmfs'           # capture order of the frame's four independent 
 
 FRAME_STYLE_BATCH = True        # synthesis(): the styles of all three backbones + the SR head in one launch pair at the top of the frame
 
+RENDER_WRITES_SR_INPUT = True   # the fused renderer also writes its features in the SR head's operand format (no ia_act_split between them)
 SINGLE_STREAM = False           # True: no side streams (every launch of a frame in program order on the caller's stream); used by
                                 # bench.py to time kernels without neighbours from other streams
 
@@ -345,13 +346,42 @@ class TriPlaneGenerator(torch.nn.Module):
             torch.cuda.current_stream(ws.device).wait_stream(pending[1])
         return self._blend_planes(stitch, full_alpha, static_plane)
 
+    def _sr_input_consumer(self, ws, nrr):
+        """(layer, styles [B,32], planes) of the convolution that reads the rendered features in split format -- block0.conv0 of a two-block
+        head fed at its own input resolution, with its styles parked by the frame-level style batch -- or (None, None, 0)."""
+        from ..training import networks_stylegan2 as sg2
+        sr = self.superresolution
+        block0 = getattr(sr, 'block0', None)
+        conv0 = getattr(block0, 'conv0', None)
+        if (not isinstance(block0, sg2.SynthesisBlock) or conv0 is None or conv0._pre is None or getattr(sr, 'input_resolution', None) != nrr
+                or conv0.in_channels != 32 or block0.architecture == 'resnet' or self.rendering_kwargs.get('superresolution_noise_mode') == 'random'):
+            return None, None, 0
+        half = block0._half_ops(ws.device)
+        if not conv0._takes_split_input(nrr, self.rendering_kwargs.get('superresolution_noise_mode', 'const'), half):
+            return None, None, 0
+        styles = conv0._pre[0]
+        if styles.shape != (ws.shape[0], 32) or styles.dtype != torch.float32 or not styles.is_contiguous():
+            return None, None, 0
+        return conv0, styles, (1 if half else 2)
+
     def _render(self, ws, planes, origins, dirs, nrr, evaluation, jitter, synthesis_kwargs, ray_dist=None, u_importance=None):
         if evaluation:
             assert synthesis_kwargs.get('noise_mode') == 'const', ('noise_mode' in synthesis_kwargs, synthesis_kwargs.get('noise_mode'))
+        # The head's first convolution reads the features as fp16 planes multiplied by its styles (hipops.SplitAct): when those styles
+        # exist already (computed at the top of the frame) the renderer writes that copy itself -- no ia_act_split launch between the
+        # renderer and the head (r06; the bits of ia_act_split on the stored image)
+        split_kw, consumer = {}, None
+        if RENDER_WRITES_SR_INPUT and planes.is_cuda and not torch.is_grad_enabled():
+            consumer, styles, n_planes = self._sr_input_consumer(ws, nrr)
+            if consumer is not None:
+                split_kw = dict(split_styles=styles, split_planes=n_planes)
         feats, depth, _ = self.renderer(planes, self.decoder, origins, dirs, self.rendering_kwargs, evaluation=evaluation, jitter=jitter,
-                                        dist=ray_dist, **({} if u_importance is None else {'u_importance': u_importance}))
+                                        dist=ray_dist, **({} if u_importance is None else {'u_importance': u_importance}), **split_kw)
         n = ws.shape[0]
         feature_image = feats.permute(0, 2, 1).reshape(n, feats.shape[-1], nrr, nrr).contiguous()
+        split_data = getattr(feats, 'split_data', None)
+        if consumer is not None and split_data is not None:
+            feature_image._ia_split = hipops.SplitAct(split_data.reshape(n, split_data.shape[1], 4, nrr, nrr, 8), feats.shape[-1], consumer)
         depth_image = depth.permute(0, 2, 1).reshape(n, 1, nrr, nrr)
         rgb = feature_image[:, :3]
         sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'noise_mode'}

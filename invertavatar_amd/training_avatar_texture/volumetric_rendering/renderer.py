@@ -224,11 +224,13 @@ class ImportanceRenderer_bsMotion(_RendererBase):
                 and options.get('density_noise', 0) == 0 and _is_osg_decoder(decoder) and not torch.is_grad_enabled())
 
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, evaluation=False, jitter=None, dist=None,
-                u_importance=None):
+                u_importance=None, split_styles=None, split_planes=0):
         """`u_importance` ([B*R, 48] uniform draws, any order) replaces the importance pass's own torch.rand (:453) when the call is
         not `evaluation`: callers that shard a stochastic render over ranks hand every frame the draws it gets in the one-process call.
         `dist` overrides the batch mean of |ray origin| (:311).  One element: a sharded batch passes the value of the whole batch
-        so that the depth range does not depend on the sharding.  B elements: frame b uses dist[b] -- a batch of frames that the
+        so that the depth range does not depend on the sharding.  `split_planes` (1 | 2, fused device route only): the composited features also
+        come back in the operand format of the convolution that reads them, multiplied by its `split_styles` [B,32], as the attribute
+        `split_data` of the first result (hipops.render_rays).  B elements: frame b uses dist[b] -- a batch of frames that the
         caller's script renders one call each (eval_seq.py:206-212) keeps the per-call results, the depth image included (its clamp
         range, ray_marcher.py:50, is then every frame's own sample range: tests/test_renderer_gpu.py)."""
         if jitter is None:
@@ -263,7 +265,7 @@ class ImportanceRenderer_bsMotion(_RendererBase):
                                       decoder.net[2].weight.detach(), decoder.net[2].bias.detach(), lr_multiplier=lr_mul,
                                       box_warp=rendering_options['box_warp'], white_back=rendering_options.get('white_back', False),
                                       channel_major=True,     # [B,R,32] view of a [B,32,R] image: the caller's permute is free
-                                      u_importance=u_imp)
+                                      u_importance=u_imp, split_styles=split_styles, split_planes=split_planes)
         # torch definition (CPU tensors, training, non-standard options)
         if per_frame:      # one reference-shaped call per frame (the depth clamp bounds are then per frame too, as in those calls)
             parts = [self.forward(planes[k:k + 1], decoder, ray_origins[k:k + 1], ray_directions[k:k + 1], rendering_options, evaluation,

@@ -385,3 +385,30 @@ def test_capture_order_of_the_branches_does_not_change_the_frame(small):
             assert torch.equal(out['image'], ref['image']) and torch.equal(out['image_depth'], ref['image_depth'])
     finally:
         triplane_v20.LAUNCH_ORDER, triplane_v20.SINGLE_STREAM = saved
+
+
+def test_renderer_hands_the_sr_head_its_operand_format():
+    """r06: with the head's styles parked at the top of the frame, the fused renderer writes block0.conv0's split input itself: no
+    ia_act_split launch between render_rays and the head, and the frame is the frame of the two-launch route bit for bit."""
+    from invertavatar_amd import hipops
+    from invertavatar_amd.training_avatar_texture import triplane_v20
+    from invertavatar_amd.training_avatar_texture.triplane_v20 import TriPlaneGenerator
+    g = synthetic.fill_parameters(TriPlaneGenerator(**synthetic.generator_kwargs('small')).eval().requires_grad_(False)).cuda()
+    frames, nrr = [5, 90], 128
+    c, uv = synthetic.camera_labels(frames).cuda(), synthetic.uv_conditions(frames).cuda()
+    jit = synthetic.jitter(frames, nrr * nrr).squeeze(-1).cuda()
+    images = {}
+    with torch.no_grad():
+        ws = g.mapping(synthetic.latent(1, 1).cuda(), synthetic.conditioning_camera().cuda(), truncation_psi=0.7, truncation_cutoff=14).expand(2, -1, -1)
+        for on in (False, True):
+            triplane_v20.RENDER_WRITES_SR_INPUT = on
+            hipops.PROFILE = []
+            try:
+                images[on] = g.synthesis(ws, c, {'uvcoords_image': uv}, neural_rendering_resolution=nrr, noise_mode='const', evaluation=True, jitter=jit)['image'].clone()
+                names = [rec[0] for rec in hipops.PROFILE]
+            finally:
+                hipops.PROFILE = None
+                triplane_v20.RENDER_WRITES_SR_INPUT = True
+            after = names[names.index('render_rays') + 1:]
+            assert ('act_split' in after) == (not on), after
+    assert torch.equal(images[True], images[False])

@@ -184,3 +184,26 @@ def test_per_frame_dist_batch_equals_one_call_per_frame():
         assert torch.equal(rgb[k:k + 1], rgb1) and torch.equal(wsum[k:k + 1], wsum1)
         assert torch.equal(depth[k:k + 1], depth1), f'frame {k}: depth clamp range differs from the one-frame call'
     assert not torch.equal(depth[1].clamp(depth[0].min(), depth[0].max()), depth[1])       # (the frames' ranges really differ)
+
+
+@pytest.mark.parametrize('planes_out,styled,channel_major', [(2, True, True), (1, True, True), (2, False, False)])
+def test_renderer_writes_the_consumer_split_format(golden, planes_out, styled, channel_major):
+    """r06: ia_render_rays' second copy of the composited features -- fp16 hi / lo (or one rounded) planes multiplied by the styles of the
+    convolution that reads them -- is bit for bit what ia_act_split makes of the fp32 image the same launch wrote."""
+    g = golden('renderer.npz')
+    frames, nrr = g['frames'].tolist(), g['nrr']
+    planes = hipops.planes_channels_last(rnd(20, 2, 3, 32, 64, 64).cuda())
+    jit = synthetic.jitter(frames, nrr * nrr).cuda().reshape(2, -1, 48).contiguous()
+    ro, rd = g['rays_o'].cuda().contiguous(), g['rays_d'].cuda().contiguous()
+    dec = {k: v.cuda() for k, v in _decoder().items()}
+    dist = torch.norm(ro, dim=-1).mean().reshape(1)
+    styles = (torch.rand(2, 32, device='cuda', generator=torch.Generator(device='cuda').manual_seed(4)) + 0.5) if styled else None
+    rgb, _, _ = hipops.render_rays(planes, ro, rd, jit, dist, dec['net.0.weight'], dec['net.0.bias'], dec['net.2.weight'], dec['net.2.bias'],
+                                   channel_major=channel_major, split_styles=styles, split_planes=planes_out)
+    plain, _, _ = hipops.render_rays(planes, ro, rd, jit, dist, dec['net.0.weight'], dec['net.0.bias'], dec['net.2.weight'], dec['net.2.bias'],
+                                     channel_major=channel_major)
+    assert torch.equal(rgb, plain) and not hasattr(plain, 'split_data')
+    image = rgb.permute(0, 2, 1).reshape(2, 32, nrr, nrr).contiguous()
+    want = hipops.act_split(image, styles, planes=planes_out)
+    got = rgb.split_data.reshape(2, planes_out, 4, nrr, nrr, 8)
+    assert got.shape == want.data.shape and torch.equal(got, want.data)
