@@ -22,7 +22,7 @@ def fetch_factor(kernel):
     """MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports half of the bytes of a 16-byte-per-lane coalesced read (`global_load_dwordx4`
     and `buffer_load_dwordx4 ... lds` alike).  conv_split_kernel fetches everything that way (LDS-DMA); conv_fixup_kernel reads its slabs
     as float4.  The register-staged kernels read dwords (uncalibrated: factor 1, flagged)."""
-    if any(n in kernel for n in ('conv_split_kernel', 'conv_fixup_kernel', 'up_rows_kernel', 'up_edge_fixup_kernel')):
+    if any(n in kernel for n in ('conv_split_kernel', 'conv_small_kernel', 'conv_fixup_kernel', 'up_rows_kernel', 'up_edge_fixup_kernel')):
         return 2.0
     return 1.0
 
@@ -33,6 +33,8 @@ def in_pair_family(kernel):
         return 'conv_split_kernelILi2E' in kernel or 'conv_split_kernel<2,' in kernel
     if 'up_rows_kernel' in kernel or 'up_edge_fixup_kernel' in kernel:      # r04: the row-phase form of the large transposed layers
         return True
+    if 'conv_small_kernel' in kernel:      # r06: the low-resolution layers (K split inside the workgroup), two operand planes
+        return 'conv_small_kernelILi2E' in kernel or 'conv_small_kernel<2,' in kernel
     if 'conv_fixup_kernel' in kernel:
         t = kernel.split('<')[-1].split('>')[0].replace(' ', '').split(',')
         return len(t) >= 5 and t[3] == '2'
@@ -43,7 +45,7 @@ def in_pair_family(kernel):
 # divided by the frames of ITS pass, counted on a once-per-frame kernel (profile_round.sh records dispatches per pass since r05)
 once = next((e for k, e in d.items() if 'render_rays_kernel' in k), {})
 frames_fetch, frames_write = once.get('dispatches_fetch', frames), once.get('dispatches_write', frames)
-conv = {k: e for k, e in d.items() if any(s in k for s in ('conv_split_kernel', 'conv_mfma_kernel', 'conv_fixup_kernel', 'up_rows_kernel', 'up_edge_fixup_kernel', 'conv1x1_kernel'))}
+conv = {k: e for k, e in d.items() if any(s in k for s in ('conv_split_kernel', 'conv_small_kernel', 'conv_mfma_kernel', 'conv_fixup_kernel', 'up_rows_kernel', 'up_edge_fixup_kernel', 'conv1x1_kernel'))}
 per_kernel, fam = {}, dict(fetch_raw=0.0, fetch_corrected=0.0, write=0.0, dispatches=0)
 for k, e in conv.items():
     f_raw, w = e.get('FETCH_SIZE', 0.0) * 1e3 / frames_fetch, e.get('WRITE_SIZE', 0.0) * 1e3 / frames_write
