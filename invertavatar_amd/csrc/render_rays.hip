@@ -49,9 +49,32 @@
 #define IA_RSTAMP(slot) do { } while (0)
 #endif
 
+// IA_RENDER_F16X3 (r06): both decoder layers form their fp32 products from fp16 hi / lo pairs on v_mfma_f32_16x16x32_f16 (three products per
+// k-step, lo * lo dropped: the arithmetic of the convolutions, csrc/conv_split.hip) instead of v_mfma_f32_16x16x4_f32: 24 matrix
+// instructions of ~17 cycles per group of 16 samples instead of 64 of 32 cycles -- the fp32 pipe was 35 % of the kernel's issue time and did
+// not overlap its vector work (profiles/r05_render_rays_variants.txt).  0 builds the exact-fp32 decoder of r02 - r05 (A/B builds).
+#ifndef IA_RENDER_F16X3
+#define IA_RENDER_F16X3 1
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8r __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2r __attribute__((ext_vector_type(2)));
+
+// Scales of the fp16 pair form.  Activations are split at 2^8 (|v| < 255: plane features and softplus outputs; their low parts stay
+// normal fp16 numbers down to |v| ~ 5e-4, below that the dropped bits are < 2.4e-7 absolute) and weights at 2^12 (|w| < 16), both
+// low parts UNscaled, so the three products of a k-step share one accumulator at 2^20; it starts from bias * 2^20 and one multiply by
+// 2^-20 brings the sums back.  Power-of-two scalings: exact.
+constexpr float kActScale = 256.f, kWgtScale = 4096.f, kAccScale = kActScale * kWgtScale;
+
+// (hi, lo) of two scaled values: hi = fp16(v) towards zero (v_cvt_pkrtz: any rounding of hi is exact as long as lo is its residual),
+// lo = fp16(v - hi).
+__device__ __forceinline__ void split2(float v0, float v1, h16x2r& hi, h16x2r& lo) {
+    hi = __builtin_bit_cast(h16x2r, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+    lo = __builtin_bit_cast(h16x2r, __builtin_amdgcn_cvt_pkrtz(v0 - (float)hi[0], v1 - (float)hi[1]));
+}
 
 constexpr int NS = 48;            // coarse samples == importance samples (depth_resolution[_importance])
 constexpr int NM = 2 * NS;        // merged
@@ -141,6 +164,8 @@ __device__ __forceinline__ float add_across_rows(float x) {
     const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);       // {lower half twice ; upper half twice}
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+
+constexpr float kMeanScale = (1.f / 3.f) * (IA_RENDER_F16X3 ? kActScale : 1.f);      // fl(1/3) times a power of two: the mean's bits, shifted
 
 // CPU torch.linspace bit rule.
 __device__ __forceinline__ float linspace_at(float s, float e, float step, int k, int n) {
@@ -235,7 +260,7 @@ __device__ __forceinline__ void gather_reduce(const float4 (&raw)[24], const flo
         }
     }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) f[c] = (acc[0][c] + acc[1][c] + acc[2][c]) * (1.f / 3.f);
+    for (int c = 0; c < 8; ++c) f[c] = (acc[0][c] + acc[1][c] + acc[2][c]) * kMeanScale;      // mean over the planes (x kActScale in the fp16 pair form: exact)
 }
 
 // Gather layout -> MFMA operand layout, through the sample's colour slot in LDS (the colours overwrite it afterwards).
@@ -251,11 +276,33 @@ __device__ __forceinline__ void features_to_operand(float* group_slots, int gj, 
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
-// Layer 1 (32 -> 64, softplus) on MFMA.  In: f[8] = channels 8q..8q+7 of this lane's sample.
+// Layer 1 (32 -> 64, softplus) on MFMA.  In: f[8] = channels 8q..8q+7 of this lane's sample (x kActScale in the fp16 pair form).
 // Out: h[T][r] = hidden unit 16T + 4q + r of this lane's sample.
 __device__ __forceinline__ void decoder_hidden(const float* __restrict__ lds, int lane, int q, const float (&f)[8], f32x4 (&h)[4]) {
 #pragma unroll
     for (int T = 0; T < 4; ++T) h[T] = *reinterpret_cast<const f32x4*>(lds + B0_OFF + 16 * T + 4 * q);      // accumulate onto the bias
+#if IA_RENDER_F16X3
+    // one k-step of 32: this lane's eight channels ARE its B fragment (k = 8q + j); A fragments [plane][tile][lane] staged in that order
+    h16x8r f_hi, f_lo;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        h16x2r a, b;
+        split2(__builtin_amdgcn_fmed3f(f[j], -65000.f, 65000.f), __builtin_amdgcn_fmed3f(f[j + 1], -65000.f, 65000.f), a, b);
+        f_hi[j] = a[0]; f_hi[j + 1] = a[1]; f_lo[j] = b[0]; f_lo[j + 1] = b[1];
+    }
+    const h16x8r* a1 = reinterpret_cast<const h16x8r*>(lds + A1_OFF);
+#pragma unroll
+    for (int T = 0; T < 4; ++T) h[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[(4 + T) * 64 + lane], f_hi, h[T], 0, 0, 0);      // lo * hi
+#pragma unroll
+    for (int T = 0; T < 4; ++T) h[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[T * 64 + lane], f_lo, h[T], 0, 0, 0);            // hi * lo
+#pragma unroll
+    for (int T = 0; T < 4; ++T) h[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[T * 64 + lane], f_hi, h[T], 0, 0, 0);            // hi * hi
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            h[T][r] = softplus2_fast(h[T][r] * (1.f / kAccScale));
+#else
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -266,6 +313,7 @@ __device__ __forceinline__ void decoder_hidden(const float* __restrict__ lds, in
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             h[T][r] = softplus2_fast(h[T][r]);
+#endif
 }
 
 // Density: output row 0 of layer 2.  Each lane owns 16 of the 64 hidden units; butterfly over the 4 quarters.
@@ -283,6 +331,33 @@ __device__ __forceinline__ float decoder_sigma(const float* __restrict__ lds, in
 __device__ __forceinline__ void decoder_rgb(const float* __restrict__ lds, int lane, int q, const f32x4 (&h)[4], f32x4 (&c)[2]) {
     c[0] = *reinterpret_cast<const f32x4*>(lds + B1C_OFF + 4 * q);
     c[1] = *reinterpret_cast<const f32x4*>(lds + B1C_OFF + 16 + 4 * q);
+#if IA_RENDER_F16X3
+    // two k-steps of 32 hidden units: step t2 takes this lane's h[2 t2][0..3], h[2 t2 + 1][0..3] (k = 8q + j <-> unit 16 (2 t2 + (j >> 2)) + 4q + (j & 3),
+    // the weight side is staged with the same permutation); A fragments [plane][tile U][step t2][lane]
+    const h16x8r* a2 = reinterpret_cast<const h16x8r*>(lds + A2_OFF);
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+        h16x8r b_hi, b_lo;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            h16x2r a, b;
+            split2(h[2 * t2 + (j >> 2)][j & 3] * kActScale, h[2 * t2 + (j >> 2)][(j & 3) + 1] * kActScale, a, b);
+            b_hi[j] = a[0]; b_hi[j + 1] = a[1]; b_lo[j] = b[0]; b_lo[j + 1] = b[1];
+        }
+#pragma unroll
+        for (int U = 0; U < 2; ++U) c[U] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[((2 + U) * 2 + t2) * 64 + lane], b_hi, c[U], 0, 0, 0);   // lo * hi
+#pragma unroll
+        for (int U = 0; U < 2; ++U) c[U] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[(U * 2 + t2) * 64 + lane], b_lo, c[U], 0, 0, 0);         // hi * lo
+#pragma unroll
+        for (int U = 0; U < 2; ++U) c[U] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[(U * 2 + t2) * 64 + lane], b_hi, c[U], 0, 0, 0);         // hi * hi
+    }
+#pragma unroll
+    for (int U = 0; U < 2; ++U)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            c[U][r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(c[U][r] * (1.f / kAccScale))) * 1.002f - 0.001f;      // c = -log2(e) * logit
+        }
+#else
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -296,7 +371,9 @@ __device__ __forceinline__ void decoder_rgb(const float* __restrict__ lds, int l
         for (int r = 0; r < 4; ++r) {
             c[U][r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(c[U][r])) * 1.002f - 0.001f;      // c = -log2(e) * logit
         }
+#endif
 }
+
 
 // Data-parallel-primitive moves inside a row of 16 lanes (the 16 samples of a group live in one DPP row per quarter): register
 // moves on the VALU instead of ds_bpermute round trips through the LDS crossbar.
@@ -433,6 +510,32 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
     // the colour rows need -log2(e) * ln 2 = -1: an exact negation
     constexpr float kIn = 1.44269504088896340736f, kHid = 0.693147180559945309417f, kRgb = -1.f;
     // ---- stage decoder weights in MFMA-fragment order
+#if IA_RENDER_F16X3
+    {
+        // fp16 pair form: element (fragment, lane, j) -> halves hi / lo of the weight x kWgtScale, planes [hi | lo] of [fragment][lane][8]
+        _Float16* a1 = reinterpret_cast<_Float16*>(lds + A1_OFF);
+        for (int e = tid; e < 4 * 64 * 8; e += WAVES * 64) {
+            const int j = e & 7, l = (e >> 3) & 63, T = e >> 9;
+            const float w = p.w0[(16 * T + (l & 15)) * 32 + 8 * (l >> 4) + j] * p.w0_gain * kIn * kWgtScale;
+            const _Float16 hi = (_Float16)w;
+            a1[(T * 64 + l) * 8 + j] = hi;
+            a1[((4 + T) * 64 + l) * 8 + j] = (_Float16)(w - (float)hi);
+        }
+        _Float16* a2 = reinterpret_cast<_Float16*>(lds + A2_OFF);
+        for (int e = tid; e < 4 * 64 * 8; e += WAVES * 64) {
+            const int j = e & 7, l = (e >> 3) & 63, t2 = (e >> 9) & 1, U = e >> 10;
+            const float w = p.w1[(1 + 16 * U + (l & 15)) * 64 + 16 * (2 * t2 + (j >> 2)) + 4 * (l >> 4) + (j & 3)] * p.w1_gain * kRgb * kWgtScale;
+            const _Float16 hi = (_Float16)w;
+            a2[((U * 2 + t2) * 64 + l) * 8 + j] = hi;
+            a2[(((2 + U) * 2 + t2) * 64 + l) * 8 + j] = (_Float16)(w - (float)hi);
+        }
+    }
+    if (tid < 64) {
+        const int k = tid >> 2, qq = tid & 3;
+        lds[WS_OFF + tid] = p.w1[16 * (k >> 2) + 4 * qq + (k & 3)] * p.w1_gain * kHid;
+        lds[B0_OFF + tid] = p.b0[tid] * p.b_gain * kIn * kAccScale;
+    }
+#else
     for (int e = tid; e < 4 * 8 * 64; e += WAVES * 64) {
         const int l = e & 63, t = (e >> 6) & 7, T = e >> 9;
         lds[A1_OFF + e] = p.w0[(16 * T + (l & 15)) * 32 + 8 * (l >> 4) + t] * p.w0_gain * kIn;
@@ -446,8 +549,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void render_rays_kernel(Para
         lds[WS_OFF + tid] = p.w1[16 * (k >> 2) + 4 * qq + (k & 3)] * p.w1_gain * kHid;
         lds[B0_OFF + tid] = p.b0[tid] * p.b_gain * kIn;
     }
+#endif
     if (tid < 33) lds[B1_OFF + tid] = p.b1[tid] * p.b_gain;
-    if (tid < 32) lds[B1C_OFF + tid] = p.b1[1 + tid] * p.b_gain * -1.44269504088896340736f;
+    if (tid < 32) lds[B1C_OFF + tid] = p.b1[1 + tid] * p.b_gain * -1.44269504088896340736f * (IA_RENDER_F16X3 ? kAccScale : 1.f);
     __syncthreads();
 
     float* scr = lds + SCR_OFF + wave * SCR;
