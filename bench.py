@@ -308,6 +308,10 @@ def roofline_leg(gen, wl, frames=3):
         others['render_rays']['frac_fp32_peak'] = round(r['flops'] / (r['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
         others['render_rays']['frac_hbm_peak'] = round(r['bytes'] / (r['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
         others['render_rays']['avg_launch_us'] = round(r['ms'] * 1e3 / r['launches'], 1)
+        others['render_rays']['note'] = ('r06: the decoder layers form their fp32 products from fp16 hi / lo pairs on v_mfma_f32_16x16x32_f16 (three products '
+                                         'per k-step), so frac_fp32_peak = algorithmic fp32 FLOPs / time / the FP32 peak is a statement about the work, not '
+                                         'about the fp32 pipe; on the fp16 pipe the same launch is 3 x that / 2500 TF')
+        others['render_rays']['frac_f16_pipe'] = round(3 * r['flops'] / (r['ms'] * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, 4)
     out['note'] = ('`frac` / `kernels.*` are ONE-STREAM per-launch times (the frame\'s launches in program order on one stream, the condition '
                    'rocprofv3 imposes on the committed kernel stats): an upper bound on each kernel\'s share, not a decomposition of the timed '
                    'step, which replays four concurrent branches; `frame_mfma_util` (added by main) is the whole timed step')
@@ -652,8 +656,8 @@ def main():
             'metric': 'frames/sec (512^2 out, 128^2 neural render); max |dRGB|', 'value': round(world * per * args.steps / dt, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (3x3 convolutions >= 32^2 form their f32 products from fp16 hi/lo pairs on the f16 MFMA, f32 accumulate; '
-                     'all other arithmetic f32)', 'data': 'synthetic',
+            'dtype': 'f32 (3x3 convolutions >= 8^2 and the two layers of the ray decoder form their f32 products from fp16 hi/lo pairs on the f16 '
+                     'MFMA -- three products per term, lo x lo ~ 2^-22 dropped -- with f32 accumulation; all other arithmetic f32)', 'data': 'synthetic',
             'config': {'workload': f'TriPlaneGenerator.synthesis, BASELINE {cfg}: 512^2 out, neural_rendering_resolution={NRR}, all three '
                                    'backbones + rasterize + fused renderer + SR 8XDC recomputed every frame',
                        'width': args.width, 'frames_per_rank_per_step': per, 'global_batch': per * world,

@@ -91,6 +91,41 @@ struct Epi {
     // styles_next are indexed by the real channel and the output pixel
     int d2s = 0;
 };
+// A by-value kernel argument re-read from the kernarg segment WHERE IT IS USED (s_load through the kernarg pointer the dispatch leaves in
+// s[0:1]): the epilogue descriptor of the convolution kernels is 36 dwords that the compiler otherwise loads at kernel entry and keeps --
+// spilled to VGPR lanes (v_writelane / v_readlane + s_nop) -- across the whole K loop (r05: 60 - 142 SGPR spills in every
+// conv_split_kernel instantiation, 220 v_readlane + 140 s_nop in the epilogue).  OFF = offsetof(the kernel's argument list, the argument).
+// Each s_load is waited for inside its own asm statement: scalar loads may return out of order, and the compiler is free to overlap the
+// registers of outputs it considers dead.
+typedef unsigned int ia_u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int ia_u32x4 __attribute__((ext_vector_type(4)));
+template <class T, int OFF>
+__device__ __forceinline__ T reload_kernarg() {
+    static_assert(sizeof(T) % 16 == 0 && OFF % 4 == 0, "whole 16-byte groups at a dword offset");
+    constexpr int ND = sizeof(T) / 4;
+    typedef __attribute__((address_space(4))) const char kchar;
+    kchar* ka = (kchar*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned int d[ND];
+    constexpr int N16 = ND / 16;
+#pragma unroll
+    for (int i = 0; i < N16; ++i) {
+        ia_u32x16 v;
+        asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "n"(OFF + 64 * i));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d[16 * i + j] = v[j];
+    }
+#pragma unroll
+    for (int i = 16 * N16; i < ND; i += 4) {
+        ia_u32x4 v;
+        asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "n"(OFF + 4 * i));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i + j] = v[j];
+    }
+    T out;
+    __builtin_memcpy(&out, d, sizeof(T));
+    return out;
+}
+
 constexpr int kMaxRgb = 3;      // (ToRGB proper: three colours; a fourth accumulator per point fragment spilled in the 256-register epilogue)
 
 typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));

@@ -22,6 +22,10 @@
 #include "conv_common.h"
 #include "lds_dma.h"
 #include "conv_small.h"
+#include <cstddef>
+#ifndef IA_EPI_RELOAD
+#define IA_EPI_RELOAD 1      // 0: the epilogue reads the by-value kernel argument (r02 - r05; A/B builds)
+#endif
 #include <cstdlib>
 
 // Compile-time ablations for tools/ablate_conv_split.sh (never set in the product build): 1 = no DMA after the first chunk of a
@@ -803,9 +807,17 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
                     for (int r = 0; r < 16; ++r) sink += acc[ph][fo][fp][r];
         if (sink == 123.456f) y[0] = sink;
     } else if (!SK || (c_lo == 0 && c_hi == g.C)) {
-        if constexpr (TR) store_tile<TR, FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);
-        else if constexpr (RGB) store_tile_rgb<FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid, lds);
-        else store_tile_dual<FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid, lds);
+#if IA_EPI_RELOAD
+        // the epilogue descriptor comes back from the kernarg segment here (see reload_kernarg): nothing of `e` is live in the K loop
+        struct KArgs { const h16x8* xs; const h16x8* wk; float* y; float* slabs; Geo g; Epi e; };
+        static_assert(sizeof(Epi) % 16 == 0 && offsetof(KArgs, e) % 8 == 0, "Epi travels as whole 16-byte groups");
+        const Epi e_now = reload_kernarg<Epi, offsetof(KArgs, e)>();
+#else
+        const Epi& e_now = e;
+#endif
+        if constexpr (TR) store_tile<TR, FO, FP, WO, WP>(acc, y, g, e_now, b, o0, p0, tid);
+        else if constexpr (RGB) store_tile_rgb<FO, FP, WO, WP>(acc, y, g, e_now, b, o0, p0, tid, lds);
+        else store_tile_dual<FO, FP, WO, WP>(acc, y, g, e_now, b, o0, p0, tid, lds);
     } else if constexpr (SK) {
         const int slot = (tile_l == first_tile) ? 0 : 1;
         float4* slab = reinterpret_cast<float4*>(slabs + (((int64_t)b * g.G + worker) * 2 + slot) * ((int64_t)NACC * NTHREADS)) + tid;
