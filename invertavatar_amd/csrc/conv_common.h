@@ -41,8 +41,11 @@ constexpr int kSmallMaxPoints = 256;
 // 19.8 -> 10.5, 1024 -> 512 @16^2 30.9 -> 28.7; but 8 frames @16^2 (1024 workgroups) 44.6 -> 68.6 and 1024 -> 1024 @16^2 (256 workgroups of
 // twice the K) 42.7 -> 45.7: every workgroup streams its own copy of the operands through its CU's 64 B/clk vector-memory path.
 __host__ inline bool conv_small_shape(int B, int I, int O, int H, int W, int ksize, int transposed, int stride) {
-    const int64_t wgs = (int64_t)B * ((H * W + 31) / 32) * ((O + 31) / 32);
-    return IA_CONV_SMALL && ksize == 3 && !transposed && stride == 1 && H * W <= kSmallMaxPoints && wgs * (I > 512 ? 2 : 1) <= ia::kNumCU;
+    const int npts = transposed ? (H + 1) * (W + 1) : H * W;
+    const int64_t wgs = (int64_t)B * ((npts + 31) / 32) * ((O + 31) / 32);
+    // (transposed: the four-phase form of the 8^2 / 16^2 up-sampling layers -- 81 / 289 points -- which ran on a 64-channel x 64-point
+    // stream-K tile at 0.05 of the matrix pipe with 0.29 LDS bank conflicts, r05 PMC)
+    return IA_CONV_SMALL && ksize == 3 && stride == 1 && npts <= (transposed ? 17 * 17 : kSmallMaxPoints) && wgs * (I > 512 ? 2 : 1) <= ia::kNumCU;
 }
 
 struct Geo {

@@ -37,15 +37,19 @@ __device__ __forceinline__ h16x8 load16(__amdgpu_buffer_rsrc_t r, int voffset, i
 }
 
 // NP = operand planes (2: hi / lo pairs, three products; 1: one fp16 plane, one product); FP = point fragments (32 points each) per workgroup.
-template <int NP, int FP>
+// TR: the stride-2 transposed convolution of an up-sampling layer in its four-phase form (conv_common.h: point (r, c) of the (H+1) x (W+1)
+// grid reads input (r - ky/2, c - kx/2) and owns output pixels (2r + py, 2c + px); the tap pairs of a k-step feed ONE phase) -- four
+// accumulator fragments per wave, one octet's five k-steps in flight (the registers the second octet of the stride-1 ring takes), the
+// epilogue is the demodulation alone (FIR + noise + bias + activation follow in ia_fir_tail_split) into the (2H+1) x (2W+1) fp32 image.
+template <int NP, int FP, bool TR>
 __global__ __launch_bounds__(kSmallWaves * 64) void conv_small_kernel(const h16x8* __restrict__ xs, const h16x8* __restrict__ wk,
                                                                        float* __restrict__ y, Geo g, Epi e) {
-    constexpr int NT = 9, NQ = FP * 4;
+    constexpr int NT = 9, NPH = TR ? 4 : 1, NQ = NPH * FP * 4, RING = TR ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float part[];      // [kSmallWaves][NQ][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int b = blockIdx.z, o0 = blockIdx.y * 32, p0 = blockIdx.x * (32 * FP);
-    const int HW = g.H * g.W, npts = HW, I8 = g.I / 8;
+    const int HW = g.H * g.W, npts = g.GH * g.GW, I8 = g.I / 8;
     const int plane_bytes = I8 * HW * 16, wplane_bytes = NT * I8 * g.O * 16;
     constexpr int kOutside = 0x7ffffff0;
 
@@ -60,30 +64,32 @@ __global__ __launch_bounds__(kSmallWaves * 64) void conv_small_kernel(const h16x
     const int o_ld = o0 + l31;
 #pragma unroll
     for (int s = 0; s < kPairs; ++s) {
-        const int tap = half ? pair_t1(false, s) : pair_t0(false, s);
+        const int tap = half ? pair_t1(TR, s) : pair_t0(TR, s);
         a_off[s] = (tap == kZeroTap || o_ld >= g.O) ? kOutside : ((tap * I8) * g.O + o_ld) * 16;
         const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
         for (int fp = 0; fp < FP; ++fp) {
             const int p = p0 + fp * 32 + l31;
-            const int r = p / g.W, c = p - r * g.W;
-            const int iy = r + ky - 1, ix = c + kx - 1;
+            const int r = p / g.GW, c = p - r * g.GW;
+            const int iy = TR ? r - (ky >> 1) : r + ky - 1, ix = TR ? c - (kx >> 1) : c + kx - 1;
             const bool ok = tap != kZeroTap && p < npts && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
             b_off[fp][s] = ok ? (iy * g.W + ix) * 16 : kOutside;
         }
     }
 
-    f32x16 acc[FP];
+    f32x16 acc[NPH][FP];
 #pragma unroll
-    for (int fp = 0; fp < FP; ++fp)
+    for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[fp][r] = 0.f;
+        for (int fp = 0; fp < FP; ++fp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][fp][r] = 0.f;
 
     // ring of TWO octets' k-steps (2 x 5 slots of 4 loads): nine slots are in flight ahead of the one being multiplied.
     // `live` = false: the same instructions with every lane outside the buffers (zeros, no memory traffic) -- the last rounds refill
     // nothing, and a loop body without branches around its loads lets the compiler count them (s_waitcnt vmcnt(36) in the steady
     // state: loads return in order); the sched_barriers pin "multiply slot, refill slot" so that the count is the program's.
-    h16x8 ra[2][kPairs][NP], rb[2][kPairs][NP][FP];
+    h16x8 ra[RING][kPairs][NP], rb[RING][kPairs][NP][FP];
     auto load_step = [&](int par, int c8, int s, bool live) {
         const int wso = c8 * g.O * 16, pso = c8 * HW * 16;
         const int dead = live ? 0 : kOutside;      // (a scalar OR-ed into the lane offsets: an offset >= kOutside is outside every buffer)
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(kSmallWaves * 64) void conv_small_kernel(const h16x
         }
     };
 #pragma unroll
-    for (int par = 0; par < 2; ++par) {
+    for (int par = 0; par < RING; ++par) {
         const int c = wave + par * kSmallWaves;
         const bool live = c < I8;
 #pragma unroll
@@ -107,14 +113,15 @@ __global__ __launch_bounds__(kSmallWaves * 64) void conv_small_kernel(const h16x
             __builtin_amdgcn_sched_barrier(0);      // (the ring is filled in the order the loop consumes it: the loop's counted waits hold from its first round)
         }
     }
-    for (int c8 = wave; c8 < I8; c8 += 2 * kSmallWaves) {
+    for (int c8 = wave; c8 < I8; c8 += RING * kSmallWaves) {
 #pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int nxt = c8 + (par + 2) * kSmallWaves;
+        for (int par = 0; par < RING; ++par) {
+            const int nxt = c8 + (par + RING) * kSmallWaves;
             const bool more = nxt < I8;
             const int nxt_c = more ? nxt : 0;
 #pragma unroll
             for (int s = 0; s < kPairs; ++s) {
+                const int ph = TR ? (s < 2 ? 0 : s - 1) : 0;      // pair_phase(TR, s): a constant once the loop is unrolled
                 const h16x8 a_hi = ra[par][s][0];
                 h16x8 b_hi[FP];
 #pragma unroll
@@ -123,12 +130,12 @@ __global__ __launch_bounds__(kSmallWaves * 64) void conv_small_kernel(const h16x
                     const h16x8 a_lo = ra[par][s][1];
                     const h16x8 a_sc = a_hi * (_Float16)(1.0f / kLoScale);      // weight high parts at 2^-11: they meet the activations' low parts (scaled by 2^11)
 #pragma unroll
-                    for (int fp = 0; fp < FP; ++fp) acc[fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi[fp], acc[fp], 0, 0, 0);                 // lo * hi
+                    for (int fp = 0; fp < FP; ++fp) acc[ph][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi[fp], acc[ph][fp], 0, 0, 0);                 // lo * hi
 #pragma unroll
-                    for (int fp = 0; fp < FP; ++fp) acc[fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc, rb[par][s][NP - 1][fp], acc[fp], 0, 0, 0);   // (hi * 2^-11) * (lo * 2^11)
+                    for (int fp = 0; fp < FP; ++fp) acc[ph][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc, rb[par][s][NP - 1][fp], acc[ph][fp], 0, 0, 0);   // (hi * 2^-11) * (lo * 2^11)
                 }
 #pragma unroll
-                for (int fp = 0; fp < FP; ++fp) acc[fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[fp], acc[fp], 0, 0, 0);                     // hi * hi
+                for (int fp = 0; fp < FP; ++fp) acc[ph][fp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[fp], acc[ph][fp], 0, 0, 0);                     // hi * hi
                 __builtin_amdgcn_sched_barrier(0);
                 load_step(par, nxt_c, s, more);                             // refill the slot (the MFMAs above have read its registers)
                 __builtin_amdgcn_sched_barrier(0);
@@ -136,15 +143,17 @@ __global__ __launch_bounds__(kSmallWaves * 64) void conv_small_kernel(const h16x
         }
     }
 
-    // ---- the eight partial tiles meet in LDS: part[wave][quad q = fp * 4 + rq][lane] = registers 4 rq .. 4 rq + 3 of fragment fp
+    // ---- the eight partial tiles meet in LDS: part[wave][quad q = (ph * FP + fp) * 4 + rq][lane] = registers 4 rq .. 4 rq + 3 of fragment (ph, fp)
     float4* pw = reinterpret_cast<float4*>(part) + (wave * NQ) * 64 + lane;
 #pragma unroll
-    for (int fp = 0; fp < FP; ++fp)
+    for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-            pw[(fp * 4 + rq) * 64] = make_float4(acc[fp][4 * rq], acc[fp][4 * rq + 1], acc[fp][4 * rq + 2], acc[fp][4 * rq + 3]);
+        for (int fp = 0; fp < FP; ++fp)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                pw[((ph * FP + fp) * 4 + rq) * 64] = make_float4(acc[ph][fp][4 * rq], acc[ph][fp][4 * rq + 1], acc[ph][fp][4 * rq + 2], acc[ph][fp][4 * rq + 3]);
     __syncthreads();
-    const int64_t ohw = HW;
+    const int64_t ohw = (int64_t)g.OH * g.OW;
     const float ns = e.noise ? (e.noise_strength ? *e.noise_strength : 1.f) : 0.f;
     for (int q = wave; q < NQ; q += kSmallWaves) {
         const float4* pr = reinterpret_cast<const float4*>(part) + q * 64 + lane;
@@ -154,41 +163,56 @@ __global__ __launch_bounds__(kSmallWaves * 64) void conv_small_kernel(const h16x
             const float4 u = pr[(w * NQ) * 64];
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
-        const int fp = q >> 2, rq = q & 3;
+        const int frag = q >> 2, rq = q & 3, fp = frag % FP, ph = frag / FP;
         const int p = p0 + fp * 32 + l31;
         if (p >= npts) continue;
         // channels of registers 4 rq + k: (r & 3) + 8 * (r >> 2) + 4 * half = 8 rq + 4 half + k (the C/D map of the 32 x 32 MFMA)
         const int o_first = o0 + 8 * rq + 4 * half;
         const float vin[4] = {v.x * g.acc_scale, v.y * g.acc_scale, v.z * g.acc_scale, v.w * g.acc_scale};
-        float outv[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (TR) {
+            const int pr_ = p / g.GW, pc = p - pr_ * g.GW;
+            const int oy = 2 * pr_ + (ph >> 1), ox = 2 * pc + (ph & 1);
+            if (oy >= g.OH || ox >= g.OW) continue;
+            const int64_t pix = (int64_t)oy * g.OW + ox;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int o = o_first + k;
-            if (o >= g.O) continue;
-            outv[k] = epilogue(vin[k], b, o, p, ohw, g, e, ns);
-            if (y) y[((int64_t)b * g.O + o) * ohw + p] = outv[k];
-        }
-        if (e.ys && o_first + 3 < g.O) {
-            ia::SatWatch watch;
-            split_store4(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, p, outv, watch);
-            watch.report();
+            for (int k = 0; k < 4; ++k) {
+                const int o = o_first + k;
+                if (o < g.O) y[((int64_t)b * g.O + o) * ohw + pix] = epilogue(vin[k], b, o, pix, ohw, g, e, ns);
+            }
+        } else {
+            float outv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int o = o_first + k;
+                if (o >= g.O) continue;
+                outv[k] = epilogue(vin[k], b, o, p, ohw, g, e, ns);
+                if (y) y[((int64_t)b * g.O + o) * ohw + p] = outv[k];
+            }
+            if (e.ys && o_first + 3 < g.O) {
+                ia::SatWatch watch;
+                split_store4(e.ys, e.styles_next, e.ys_planes, b, g.O, ohw, o_first, p, outv, watch);
+                watch.report();
+            }
         }
     }
 }
 
-template <int NP>
+template <int NP, bool TR>
 int conv_small_launch_np(const h16x8* x8, const h16x8* w8, float* y, const Geo& g, const Epi& e, hipStream_t s) {
     constexpr int FP = 1;
-    const size_t lds = (size_t)kSmallWaves * FP * 4 * 64 * 4 * sizeof(float);
-    const int npts = g.H * g.W;
-    hipLaunchKernelGGL((conv_small_kernel<NP, FP>), dim3((npts + 32 * FP - 1) / (32 * FP), (g.O + 31) / 32, g.B), dim3(kSmallWaves * 64), lds, s, x8, w8, y, g, e);
+    const size_t lds = (size_t)kSmallWaves * (TR ? 4 : 1) * FP * 4 * 64 * 4 * sizeof(float);
+    const int npts = g.GH * g.GW;
+    auto k = conv_small_kernel<NP, FP, TR>;
+    if (const int rs = ia::reserve_lds((const void*)k, lds, "conv_small")) return rs;
+    hipLaunchKernelGGL(k, dim3((npts + 32 * FP - 1) / (32 * FP), (g.O + 31) / 32, g.B), dim3(kSmallWaves * 64), lds, s, x8, w8, y, g, e);
     return ia::check_launch("ia_conv2d_mfma_sx(small)");
 }
 
-inline int conv_small_launch(const void* xs, int planes, const void* wk_split, float* y, const Geo& g, const Epi& e, hipStream_t s) {
+inline int conv_small_launch(const void* xs, int planes, const void* wk_split, float* y, const Geo& g, const Epi& e, bool transposed, hipStream_t s) {
     const h16x8* x8 = static_cast<const h16x8*>(xs);
     const h16x8* w8 = static_cast<const h16x8*>(wk_split);
-    return planes == 2 ? conv_small_launch_np<2>(x8, w8, y, g, e, s) : conv_small_launch_np<1>(x8, w8, y, g, e, s);
+    if (transposed) return planes == 2 ? conv_small_launch_np<2, true>(x8, w8, y, g, e, s) : conv_small_launch_np<1, true>(x8, w8, y, g, e, s);
+    return planes == 2 ? conv_small_launch_np<2, false>(x8, w8, y, g, e, s) : conv_small_launch_np<1, false>(x8, w8, y, g, e, s);
 }
 
 }  // namespace

@@ -807,17 +807,21 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
                     for (int r = 0; r < 16; ++r) sink += acc[ph][fo][fp][r];
         if (sink == 123.456f) y[0] = sink;
     } else if (!SK || (c_lo == 0 && c_hi == g.C)) {
+        if constexpr (TR) store_tile<TR, FO, FP, WO, WP>(acc, y, g, e, b, o0, p0, tid);      // (demodulation only: by value; the reload measured 4 - 7 % slower here)
+        else {
 #if IA_EPI_RELOAD
-        // the epilogue descriptor comes back from the kernarg segment here (see reload_kernarg): nothing of `e` is live in the K loop
-        struct KArgs { const h16x8* xs; const h16x8* wk; float* y; float* slabs; Geo g; Epi e; };
-        static_assert(sizeof(Epi) % 16 == 0 && offsetof(KArgs, e) % 8 == 0, "Epi travels as whole 16-byte groups");
-        const Epi e_now = reload_kernarg<Epi, offsetof(KArgs, e)>();
+            // the epilogue descriptor comes back from the kernarg segment here (see reload_kernarg): nothing of `e` is live in the K loop.
+            // r06, same box: 37 - 56 fewer SGPR spills per stride-1 instantiation (main tile 96 -> 59, antiphase narrow tile 56 -> 17), layer
+            // times unchanged within 0.5 % (profiles/r06_epilogue_descriptor_reload.txt): the spills were never on the critical path.
+            struct KArgs { const h16x8* xs; const h16x8* wk; float* y; float* slabs; Geo g; Epi e; };
+            static_assert(sizeof(Epi) % 16 == 0 && offsetof(KArgs, e) % 8 == 0, "Epi travels as whole 16-byte groups");
+            const Epi e_now = reload_kernarg<Epi, offsetof(KArgs, e)>();
 #else
-        const Epi& e_now = e;
+            const Epi& e_now = e;
 #endif
-        if constexpr (TR) store_tile<TR, FO, FP, WO, WP>(acc, y, g, e_now, b, o0, p0, tid);
-        else if constexpr (RGB) store_tile_rgb<FO, FP, WO, WP>(acc, y, g, e_now, b, o0, p0, tid, lds);
-        else store_tile_dual<FO, FP, WO, WP>(acc, y, g, e_now, b, o0, p0, tid, lds);
+            if constexpr (RGB) store_tile_rgb<FO, FP, WO, WP>(acc, y, g, e_now, b, o0, p0, tid, lds);
+            else store_tile_dual<FO, FP, WO, WP>(acc, y, g, e_now, b, o0, p0, tid, lds);
+        }
     } else if constexpr (SK) {
         const int slot = (tile_l == first_tile) ? 0 : 1;
         float4* slab = reinterpret_cast<float4*>(slabs + (((int64_t)b * g.G + worker) * 2 + slot) * ((int64_t)NACC * NTHREADS)) + tid;
@@ -1027,7 +1031,7 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
         e.rgb_w = rgb.w; e.rgb_styles = rgb.styles; e.rgb_bias = rgb.bias; e.rgb_res = rgb.res; e.rgb_out = rgb.out; e.rgb_n = rgb.n; e.rgb_clamp = rgb.clamp;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (small) return conv_small_launch(xs, planes, wk_split, y, g, e, s);      // low-resolution layers: K split inside the workgroup, no slabs, no fix-up (conv_small.h)
+    if (small) return conv_small_launch(xs, planes, wk_split, y, g, e, transposed != 0, s);      // low-resolution layers: K split inside the workgroup, no slabs, no fix-up (conv_small.h)
     const h16x8* x8 = static_cast<const h16x8*>(xs);
     const h16x8* w8 = static_cast<const h16x8*>(wk_split);
     if (planes == 1) {

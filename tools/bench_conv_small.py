@@ -61,5 +61,31 @@ def main():
         print(line + f'   rel err vs fp64 {err:.1e}   {note}', flush=True)
 
 
+def main_transposed():
+    print('-- transposed (up-sampling layers, four-phase form; demodulation only)')
+    for i, o, r, b in [(512, 512, 8, 1), (512, 512, 16, 1), (512, 512, 8, 8), (256, 256, 16, 1)]:
+        x = torch.randn(b, i, r, r, device='cuda')
+        wt = torch.randn(o, i, 3, 3, device='cuda')
+        wk = hipops.pack_conv_weight_split(wt)
+        xs = hipops.act_split(x, torch.rand(b, i, device='cuda') + 0.5)
+        d = torch.rand(b, o, device='cuda') + 0.5
+        fn = lambda: hipops.conv2d_mfma_sx(xs, wk, demod=d, transposed=True)
+        y = fn()
+        ref = torch.nn.functional.conv_transpose2d(xs.float().double(), wt.double().transpose(0, 1), stride=2) * d.double()[:, :, None, None]
+        err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+        us = bench(fn)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                fn()
+        print(f'I={i:4d} O={o:4d} {r:3d}x{r:<3d} B={b}  eager {us:7.1f} us   graph {bench(g.replay, 20) / 20:7.1f} us   rel err vs fp64 {err:.1e}', flush=True)
+
+
 if __name__ == '__main__':
     main()
+    main_transposed()
