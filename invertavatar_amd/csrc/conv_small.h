@@ -48,7 +48,10 @@ __global__ __launch_bounds__(kSmallWaves * 64) void conv_small_kernel(const h16x
     extern __shared__ __attribute__((aligned(16))) float part[];      // [kSmallWaves][NQ][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int b = blockIdx.z, o0 = blockIdx.y * 32, p0 = blockIdx.x * (32 * FP);
+    // blockIdx.x = the channel tile: workgroups go to the 8 XCDs round-robin by linear id, so (with a multiple of 8 channel tiles) ALL point
+    // tiles of a channel tile land on one XCD and its 590 KB weight slice is fetched into ONE L2 (point tiles on x: every XCD fetched every
+    // slice -- PMC r06: 47 MB per launch for 9.4 MB of weights)
+    const int b = blockIdx.z, o0 = blockIdx.x * 32, p0 = blockIdx.y * (32 * FP);
     const int HW = g.H * g.W, npts = g.GH * g.GW, I8 = g.I / 8;
     const int plane_bytes = I8 * HW * 16, wplane_bytes = NT * I8 * g.O * 16;
     constexpr int kOutside = 0x7ffffff0;
@@ -204,7 +207,7 @@ int conv_small_launch_np(const h16x8* x8, const h16x8* w8, float* y, const Geo& 
     const int npts = g.GH * g.GW;
     auto k = conv_small_kernel<NP, FP, TR>;
     if (const int rs = ia::reserve_lds((const void*)k, lds, "conv_small")) return rs;
-    hipLaunchKernelGGL(k, dim3((npts + 32 * FP - 1) / (32 * FP), (g.O + 31) / 32, g.B), dim3(kSmallWaves * 64), lds, s, x8, w8, y, g, e);
+    hipLaunchKernelGGL(k, dim3((g.O + 31) / 32, (npts + 32 * FP - 1) / (32 * FP), g.B), dim3(kSmallWaves * 64), lds, s, x8, w8, y, g, e);
     return ia::check_launch("ia_conv2d_mfma_sx(small)");
 }
 

@@ -9,8 +9,8 @@ out=$repo/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*\|SQ_LDS_[A-Z_]*\|SQ_BUSY_CYCLES\|SQ_WAVE_CYCLES\|SQ_ACTIVE_INST_[A-Z]*\|GRBM_GUI_ACTIVE" | sort -u > $out/${tag}_counters_available.txt
 rm -rf /tmp/prof_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python $repo/bench.py > $out/${tag}_bench_under_rocprof.json 2> /tmp/prof_stats.err
-cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv 2>/dev/null || tail -5 /tmp/prof_stats.err
+[ -n "$PMC_ONLY" ] || rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python $repo/bench.py > $out/${tag}_bench_under_rocprof.json 2> /tmp/prof_stats.err
+[ -n "$PMC_ONLY" ] || cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv 2>/dev/null || tail -5 /tmp/prof_stats.err
 declare -A SETS=( [fetch]="FETCH_SIZE" [write]="WRITE_SIZE" [sq]="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE" )
 for s in ${PMC_PASSES:-fetch write sq}; do
   rm -rf /tmp/pmc_$s
