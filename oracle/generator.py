@@ -164,8 +164,8 @@ def _modconv_fp16(x, weight, styles, up, resample_filter, demodulate):
     are pre-normalised by their max-norms when demodulating (:54-56), the per-sample weight w * s * d is formed in fp32 and ROUNDED
     to fp16 (`w.to(x.dtype)`, :87), the convolution runs on fp16 operands (fp32 accumulation in the library) and every tensor it
     writes is fp16: the conv output, and for up = 2 the stride-2 transposed conv output AND the FIR output
-    (conv2d_resample.py:114-131).  PARITY UNPINNED: the CPU reference forces fp32 (networks_stylegan2.py:437), so no fixture of
-    this path can be generated here; this follows the cited lines."""
+    (conv2d_resample.py:114-131).  Pinned since r06 by tests/golden/sr_fp16.npz: the reference head itself run in fp16 on CPU tensors
+    with its fp32 forcing (networks_stylegan2.py:421-422) lifted in the fixture script; see superresolution_8xdc_fp16(per_op_bias_act)."""
     o, i, kh, kw = weight.shape
     if demodulate:
         weight = weight * (1 / math.sqrt(i * kh * kw) / weight.abs().amax(dim=[1, 2, 3], keepdim=True))
@@ -185,7 +185,21 @@ def _modconv_fp16(x, weight, styles, up, resample_filter, demodulate):
     return torch.cat(outs, 0)
 
 
-def synthesis_block_fp16(sd, x, img, ws, conv_clamp=256):
+def _bias_act_fp16(y, b, act, gain, clamp, per_op):
+    """bias_act on an fp16 tensor.  per_op=False: computed in fp32 and rounded once on store, as the CUDA plugin does (bias_act.cu:19-22,
+    149) -- the deployed path.  per_op=True: the reference's `_bias_act_ref` (bias_act.py:93-122), which is what runs when the fp16 blocks
+    are executed on CPU tensors: every step (add bias, activation, gain) is a torch op on the fp16 tensor, i.e. rounds to fp16."""
+    if not per_op:
+        return _h(ops.bias_act(y, _h(b), act=act, gain=gain, clamp=clamp))
+    x = _h(y + _h(b).reshape(1, -1, 1, 1))
+    if act == 'lrelu':
+        x = _h(F.leaky_relu(x, 0.2))
+    if gain != 1:
+        x = _h(x * gain)
+    return x.clamp(-clamp, clamp) if clamp is not None else x
+
+
+def synthesis_block_fp16(sd, x, img, ws, conv_clamp=256, per_op_bias_act=False):
     """SynthesisBlock.forward with use_fp16 on a CUDA device, noise_mode 'none' (training/networks_stylegan2.py:417-460): x is cast
     to fp16 at the top (:436-437); each SynthesisLayer = fp16 modulated conv -> bias_act computed in fp32, stored fp16, clamp 256
     (:327-329); ToRGB likewise (no demodulation: no pre-normalisation) and its result goes to fp32 before the skip add (:456-458)."""
@@ -195,23 +209,26 @@ def synthesis_block_fp16(sd, x, img, ws, conv_clamp=256):
         lsd = sub(sd, name)
         styles = ops.fully_connected(ws[:, wi], lsd['affine.weight'], lsd['affine.bias']); wi += 1
         y = _modconv_fp16(x, lsd['weight'], styles, up, lsd['resample_filter'], True)
-        x = _h(ops.bias_act(y, _h(lsd['bias']), act='lrelu', gain=ops.SQRT2, clamp=conv_clamp))
+        x = _bias_act_fp16(y, lsd['bias'], 'lrelu', ops.SQRT2, conv_clamp, per_op_bias_act)
     img = ops.upsample2d(img, sd['resample_filter'])
     tsd = sub(sd, 'torgb')
     styles = ops.fully_connected(ws[:, wi], tsd['affine.weight'], tsd['affine.bias']) * (1 / math.sqrt(tsd['weight'].shape[1]))
     y = _modconv_fp16(x, tsd['weight'], styles, 1, None, False)
-    y = _h(ops.bias_act(y, _h(tsd['bias']), clamp=conv_clamp))
+    y = _bias_act_fp16(y, tsd['bias'], 'linear', 1, conv_clamp, per_op_bias_act)
     return x, img + y
 
 
-def superresolution_8xdc_fp16(sd, rgb, x, ws):
-    """SuperresolutionHybrid8XDC with sr_num_fp16_res > 0 as deployed (superresolution.py:263-289, use_fp16 + conv_clamp 256)."""
+def superresolution_8xdc_fp16(sd, rgb, x, ws, per_op_bias_act=False):
+    """SuperresolutionHybrid8XDC with sr_num_fp16_res > 0 as deployed (superresolution.py:263-289, use_fp16 + conv_clamp 256).
+    per_op_bias_act=True: the same head as the reference runs it on CPU tensors once its fp32 forcing is lifted (`_bias_act_ref` rounds after
+    every step) -- the form tests/golden/sr_fp16.npz records from the reference itself (make_golden.py:gen_sr_fp16), which pins everything
+    else of this restatement: the pre-normalisation, the fp16 rounding of w * s * d, the fp16 storage of every tensor, the clamp."""
     ws3 = ws[:, -1:, :].repeat(1, 3, 1)
     if x.shape[-1] != 128:
         x = ops.resize_bilinear_aa(x, (128, 128))
         rgb = ops.resize_bilinear_aa(rgb, (128, 128))
-    x, rgb = synthesis_block_fp16(sub(sd, 'block0'), x, rgb, ws3)
-    x, rgb = synthesis_block_fp16(sub(sd, 'block1'), x, rgb, ws3)
+    x, rgb = synthesis_block_fp16(sub(sd, 'block0'), x, rgb, ws3, per_op_bias_act=per_op_bias_act)
+    x, rgb = synthesis_block_fp16(sub(sd, 'block1'), x, rgb, ws3, per_op_bias_act=per_op_bias_act)
     return rgb
 
 

@@ -370,6 +370,51 @@ def gen_generator_bench():
     npz('generator_full_nrr128.npz', **arrays)
 
 
+@contextlib.contextmanager
+def fp16_blocks_on_cpu():
+    """The reference forces every SynthesisBlock to fp32 when its tensors are not on a CUDA device (training/networks_stylegan2.py:421-422).
+    For ONE fixture the check is taken out of SynthesisBlock.forward (the method's own source, compiled with that line replaced, in this
+    process only), so that the blocks built with use_fp16 run the reference's fp16 path -- its own rounding points: x, w * s * d and every
+    stored tensor in fp16, conv_clamp 256 -- on CPU tensors.  Backbones (g_num_fp16_res = 0) are unaffected."""
+    import inspect
+    import textwrap
+    import training.networks_stylegan2 as ref_sg2
+    base = ref_sg2.SynthesisBlock
+    base = [c for c in base.__mro__ if 'forward' in c.__dict__][0]
+    needle = "if ws.device.type != 'cuda':"
+    src = textwrap.dedent(inspect.getsource(base.forward))
+    assert src.count(needle) == 1, 'the device check of SynthesisBlock.forward moved'
+    ns = dict(sys.modules[base.__module__].__dict__)
+    exec(src.replace(needle, 'if False:'), ns)
+    orig, base.forward = base.forward, ns['forward']
+    try:
+        yield
+    finally:
+        base.forward = orig
+
+
+def gen_sr_fp16():
+    """VERDICT r5 hygiene 9b: the SR head in its DEPLOYED precision (sr_num_fp16_res = 4, train_avatar_texture.py:215) pinned to the reference's
+    own fp16 arithmetic.  Inputs: seeded features [1,32,128,128] (rnd(31) * 0.5) and the mapped ws; outputs of the reference head in fp16
+    mode (device check lifted, see fp16_blocks_on_cpu) and in the fp32 mode it takes on CPU otherwise."""
+    from training_avatar_texture.triplane_v20 import TriPlaneGenerator
+    g = TriPlaneGenerator(**synthetic.generator_kwargs('full', sr_num_fp16_res=4)).eval().requires_grad_(False)
+    synthetic.fill_parameters(g)
+    feat = rnd(31, 1, 32, 128, 128) * 0.5
+    ws = g.mapping(synthetic.latent(0, 1), synthetic.conditioning_camera(), truncation_psi=0.7, truncation_cutoff=14)
+    nm = g.rendering_kwargs['superresolution_noise_mode']
+    with fp16_blocks_on_cpu():
+        img16 = g.superresolution(feat[:, :3].contiguous(), feat, ws, noise_mode=nm).float()
+    img32 = g.superresolution(feat[:, :3].contiguous(), feat, ws, noise_mode=nm).float()
+    assert (img16 - img32).abs().max().item() > 1e-4, 'the fp16 path did not run'
+    arrays = dict(ws=ws)
+    for tag, img in (('fp16', img16), ('fp32', img32)):
+        arrays[f'{tag}_image_sub4'] = sub4(img)
+        arrays[f'{tag}_image_crop'] = img[..., 224:288, 224:288]
+        arrays[f'{tag}_image_block_means'] = block_means(img)
+    npz('sr_fp16.npz', **arrays)
+
+
 FLR_CASES = {   # name: (shape, fu taps (0 = None; negative = 2-D of that size), fd taps, up, down, padding, gain, slope, clamp, flip)
     'sg3_up2_down2': ((2, 3, 20, 24), 12, 12, 2, 2, [10, 11, 9, 10], 2 ** 0.5, 0.2, 256.0, False),
     'up4_down2_flip': ((1, 4, 9, 13), 8, 6, 4, 2, [5, 6, 7, 4], 1.7, 0.1, None, True),
@@ -633,7 +678,7 @@ def gen_names():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='ops,flr,camera,renderer,eg3d,small,extra,full,bench,harness,names,encoder,encoder_new')
+    ap.add_argument('--only', default='ops,flr,camera,renderer,eg3d,small,extra,full,bench,sr16,harness,names,encoder,encoder_new')
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -649,6 +694,7 @@ def main():
         if 'extra' in todo: gen_generator_extra()
         if 'full' in todo: gen_generator('full')
         if 'bench' in todo: gen_generator_bench()
+        if 'sr16' in todo: gen_sr_fp16()
         if 'harness' in todo: gen_harness()
         if 'names' in todo: gen_names()
         if 'encoder' in todo: gen_encoder()

@@ -126,8 +126,8 @@ def test_bench_configuration_batched_vs_reference(golden, full):
 
 # SR head in the reference's deployed precision (sr_num_fp16_res = 4).  Two statements of "fp16": this backend rounds x * style and w
 # (fp16 operands, fp32 accumulate, demodulation in the fp32 epilogue, activations stored as one fp16 plane between the convolutions);
-# the reference rounds x, w * s * d and every stored tensor (oracle/generator.py:superresolution_8xdc_fp16, a restatement -- the CPU
-# reference forces fp32, so that leg is "parity unpinned").  Measured r02 (full width, nrr 64): this backend 1.66e-3 from the fp32
+# the reference rounds x, w * s * d and every stored tensor (oracle/generator.py:superresolution_8xdc_fp16; since r06 that restatement is
+# pinned by tests/golden/sr_fp16.npz, the reference head itself in fp16 on CPU tensors: tests/test_sr_fp16.py).  Measured r02 (full width, nrr 64): this backend 1.66e-3 from the fp32
 # fixture, the restated reference path 3.42e-3 from it, the two 4.68e-3 from each other (bounded by the sum of the former two).
 TOL_RGB_FP16_SR = 4e-3            # vs the reference's fp32 output (r01: 2e-2)
 TOL_RGB_FP16_SR_VS_RESTATEMENT = 7e-3
