@@ -7,6 +7,7 @@
 #define IA_TR_SIMPLE_EPI 1      // 0: the transposed store evaluates the generic epilogue per element (A/B builds in tools/)
 #endif
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -29,23 +30,32 @@ __host__ __device__ constexpr int pair_t0(bool tr, int s) { return tr ? (s == 0 
 __host__ __device__ constexpr int pair_t1(bool tr, int s) { return tr ? (s == 0 ? 2 : s == 1 ? 8 : s == 2 ? 7 : s == 3 ? 5 : kZeroTap) : (s == 4 ? kZeroTap : 2 * s + 1); }
 __host__ __device__ constexpr int pair_phase(bool tr, int s) { return tr ? (s < 2 ? 0 : s - 1) : 0; }
 
-// Low-resolution 3x3 stride-1 layers of the split-DMA form (at most kSmallMaxPoints points) whose tile plan would be stream-K: the K
+// Low-resolution 3x3 layers of the split-DMA form (at most kSmallMaxPoints points; 17^2 in the transposed form) whose tile plan would be stream-K: the K
 // range is dealt to the waves of a workgroup instead (csrc/conv_small.h) -- no scratch, no fix-up launch.  The planner (conv_mfma.hip)
 // and the dispatcher (conv_split.hip) both ask here.  IA_CONV_SMALL = 0: A/B builds that keep those layers on the stream-K tiles.
 #ifndef IA_CONV_SMALL
 #define IA_CONV_SMALL 1
 #endif
-constexpr int kSmallMaxPoints = 256;
-// ... as long as its workgroups (32 channels x 32 points each, all of K) fit the machine in one round: measured r06 on one box against the
-// stream-K tiles + fix-up (graph replay, us): 512 -> 512 @8^2 24.9 -> 15.0, @16^2 25.5 -> 18.8, 8 frames @8^2 41.6 -> 16.2, 256 -> 256 @16^2
-// 19.8 -> 10.5, 1024 -> 512 @16^2 30.9 -> 28.7; but 8 frames @16^2 (1024 workgroups) 44.6 -> 68.6 and 1024 -> 1024 @16^2 (256 workgroups of
-// twice the K) 42.7 -> 45.7: every workgroup streams its own copy of the operands through its CU's 64 B/clk vector-memory path.
+constexpr int kSmallMaxPoints = 1024;      // (32^2: 512 -> 512 42.9 -> 33.4 us, 256 -> 256 23.2 -> 11.7, 384 -> 384 33.2 -> 25.4, same box; r06)
+// ... as long as its workgroups (32 channels x 32 points each, all of K) stay within two rounds of the machine.  Measured r06, one box,
+// graph replay, us, against the stream-K tiles + fix-up (channel tiles on blockIdx.x: one L2 per weight slice): 512 -> 512 @8^2 24.9 -> 15.0,
+// @16^2 25.5 -> 15.8, 8 frames @8^2 41.6 -> 16.6, 256 -> 256 @16^2 19.8 -> 10.5, 1024 -> 1024 @16^2 (256 workgroups) 41.6 -> 28.0,
+// 1024 -> 512 @16^2 30.9 -> 23.8, 4 frames 512 -> 512 @16^2 (512 workgroups) 35.2 -> 30.9; transposed @8^2 21.8 -> 15.3, @16^2 38.3 -> 15.8,
+// 8 frames @8^2 (384 workgroups) 37.1 -> 29.5; but 8 frames @16^2 (1024 workgroups) 44.7 -> 59.3: every workgroup streams its own copy
+// of the operands through its CU's 64 B/clk vector-memory path (profiles/r06_conv_small.txt).
 __host__ inline bool conv_small_shape(int B, int I, int O, int H, int W, int ksize, int transposed, int stride) {
     const int npts = transposed ? (H + 1) * (W + 1) : H * W;
     const int64_t wgs = (int64_t)B * ((npts + 31) / 32) * ((O + 31) / 32);
     // (transposed: the four-phase form of the 8^2 / 16^2 up-sampling layers -- 81 / 289 points -- which ran on a 64-channel x 64-point
     // stream-K tile at 0.05 of the matrix pipe with 0.29 LDS bank conflicts, r05 PMC)
-    return IA_CONV_SMALL && ksize == 3 && stride == 1 && npts <= (transposed ? 17 * 17 : kSmallMaxPoints) && wgs * (I > 512 ? 2 : 1) <= ia::kNumCU;
+    // (IA_CONV_SMALL_WGS: experiment override of the limit, read per call -- the sweep of profiles/r06_conv_small.txt)
+    const char* ew = getenv("IA_CONV_SMALL_WGS");
+    const int64_t max_wgs = ew ? atoll(ew) : 2 * (int64_t)ia::kNumCU;
+    const char* ep = getenv("IA_CONV_SMALL_PTS");
+    const int max_pts = ep ? atoi(ep) : kSmallMaxPoints;
+    constexpr int k_weight = 1;
+    (void)I;
+    return IA_CONV_SMALL && ksize == 3 && stride == 1 && npts <= (transposed ? 17 * 17 : max_pts) && wgs * k_weight <= max_wgs;
 }
 
 struct Geo {

@@ -1,4 +1,4 @@
-// conv_small_kernel (included by conv_split.hip, whose entry points dispatch to it): the 3x3 convolutions of the LOW-RESOLUTION layers (8^2 .. 16^2 images: 512 -> 512 channels on 64 / 256 points in
+// conv_small_kernel (included by conv_split.hip, whose entry points dispatch to it): the 3x3 convolutions of the LOW-RESOLUTION layers (8^2 .. 32^2 images: 512 -> 512 channels on 64 .. 1024 points in
 // the three backbones of a frame, the ConvGRU cells and residual units of the inversion encoders) on split-format (fp16 hi / lo)
 // operands -- the arithmetic of conv_split_kernel (csrc/conv_split.hip), another decomposition.
 //

@@ -10,6 +10,8 @@ import torch
 from invertavatar_amd import hipops
 
 # (in, out, H, W, batch, note)
+LAYERS32 = [(512, 512, 32, 32, 1, 'backbone b32.conv1'), (256, 256, 32, 32, 1, ''), (128, 128, 32, 32, 1, ''), (384, 384, 32, 32, 1, 'ConvGRU @32^2 (384)'),
+            (768, 768, 32, 32, 1, 'ConvGRU ih @32^2'), (256, 256, 32, 32, 4, '4 sources')]
 LAYERS = [(512, 512, 8, 8, 1, 'backbone b8.conv1'), (512, 512, 16, 16, 1, 'backbone b16.conv1'), (512, 512, 8, 8, 8, 'b8.conv1, 8 frames'),
           (512, 512, 16, 16, 8, 'b16.conv1, 8 frames'), (1024, 1024, 16, 16, 1, 'ConvGRU ih @16^2'), (1024, 512, 16, 16, 1, 'ConvGRU hh @16^2'),
           (512, 512, 16, 16, 4, 'trunk unit @16^2, 4 sources'), (256, 256, 16, 16, 1, ''), (128, 128, 12, 20, 2, 'ragged')]
@@ -31,7 +33,7 @@ def bench(fn, n=50):
 def main():
     print('library:', os.environ.get('IA_HIP_LIB', 'in-tree'))
     graph = os.environ.get('BENCH_GRAPH', '1') == '1'
-    for i, o, h, w, b, note in LAYERS:
+    for i, o, h, w, b, note in (LAYERS32 if os.environ.get('BENCH_32') == '1' else LAYERS):
         x = torch.randn(b, i, h, w, device='cuda')
         st = torch.rand(b, i, device='cuda') + 0.5
         wt = torch.randn(o, i, 3, 3, device='cuda')
