@@ -36,6 +36,10 @@ __host__ __device__ constexpr int pair_phase(bool tr, int s) { return tr ? (s < 
 #ifndef IA_CONV_SMALL
 #define IA_CONV_SMALL 1
 #endif
+// Above 16^2 only launches of at most 1.5 rounds: the 512-workgroup launch of a backbone's 512 -> 512 @32^2 layer is faster alone (42.9 -> 33.4 us)
+// but costs the FRAME 1.5 % -- it fills every CU twice while the other networks' streams wait (same-box three-way A/B, frames/s: up to 32^2
+// 385.4, up to 16^2 391.1, never 387.9; one-shot inversion 28.8 / 29.9 / 30.1 ms: its 32^2 layers are 256 - 384 workgroups and keep the form).
+constexpr int kSmallMaxWgsAbove256 = 384;
 constexpr int kSmallMaxPoints = 1024;      // (32^2: 512 -> 512 42.9 -> 33.4 us, 256 -> 256 23.2 -> 11.7, 384 -> 384 33.2 -> 25.4, same box; r06)
 // ... as long as its workgroups (32 channels x 32 points each, all of K) stay within two rounds of the machine.  Measured r06, one box,
 // graph replay, us, against the stream-K tiles + fix-up (channel tiles on blockIdx.x: one L2 per weight slice): 512 -> 512 @8^2 24.9 -> 15.0,
@@ -55,7 +59,7 @@ __host__ inline bool conv_small_shape(int B, int I, int O, int H, int W, int ksi
     const int max_pts = ep ? atoi(ep) : kSmallMaxPoints;
     constexpr int k_weight = 1;
     (void)I;
-    return IA_CONV_SMALL && ksize == 3 && stride == 1 && npts <= (transposed ? 17 * 17 : max_pts) && wgs * k_weight <= max_wgs;
+    return IA_CONV_SMALL && ksize == 3 && stride == 1 && npts <= (transposed ? 17 * 17 : max_pts) && wgs * k_weight <= (npts > 256 && !ew ? kSmallMaxWgsAbove256 : max_wgs);
 }
 
 struct Geo {
