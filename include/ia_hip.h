@@ -125,11 +125,7 @@ int ia_upfirdn2d_bias_act(const void* x, const float* f, const float* noise, con
  *              cut into `ksplit` equal ranges, and tiles shared between workers are summed in worker order by a
  *              deterministic fix-up pass
  *   scratch  : caller-owned accumulator slabs for that pass, `scratch_bytes` >= the planned size (NULL/0 when the plan needs
- *              none).  Launches that may run concurrently must not share a scratch buffer.  r06: the first 16 KB of a scratch buffer
- *              are per-tile tickets of the split forms' in-launch reduction (ia_conv2d_mfma_sx / ia_conv2d_down_sx: the workgroup that
- *              draws a tile's last ticket sums the slabs and runs the epilogue -- no second launch); they must be ZERO when a buffer is
- *              handed over for the first time and every launch leaves them zero; every entry point that takes `scratch` skips them
- *              (the planned sizes include them), so one buffer may serve all of them in turn.
+ *              none).  Launches that may run concurrently must not share a scratch buffer.
  */
 int ia_conv2d_mfma(const float* x, const float* wk, const float* styles, const float* demod,
                    const float* noise, const float* noise_strength, const float* bias, const float* residual,

@@ -62,16 +62,6 @@ __host__ inline bool conv_small_shape(int B, int I, int O, int H, int W, int ksi
     return IA_CONV_SMALL && ksize == 3 && stride == 1 && npts <= (transposed ? 17 * 17 : max_pts) && wgs * k_weight <= (npts > 256 && !ew ? kSmallMaxWgsAbove256 : max_wgs);
 }
 
-// Stream-K tiles finished INSIDE the launch (r06, conv_split.hip): the first kTicketWords 32-bit words of the caller's scratch are per-tile
-// tickets, the accumulator slabs follow.  Contract: the words are ZERO when the buffer is handed over for the first time (the Python side
-// allocates scratch with torch.zeros); every launch leaves them zero (the workgroup that draws a tile's last ticket resets it).  Every
-// scratch user of the library skips the header, so slabs of other launches on the same buffer never touch it.
-constexpr int kTicketWords = 4096;
-constexpr size_t kTicketBytes = (size_t)kTicketWords * 4;
-#ifndef IA_SK_IN_KERNEL
-#define IA_SK_IN_KERNEL 1      // 0: stream-K partial tiles are summed by conv_fixup_kernel in a second launch (r01 - r05; A/B builds)
-#endif
-
 struct Geo {
     int B, I, O, H, W;     // input
     int GH, GW;            // point grid: conv H x W, transposed (H+1) x (W+1)
@@ -83,7 +73,6 @@ struct Geo {
     int patch_cap;         // floats per channel reserved for the patch in LDS
     int xcd_bands = 0;     // conv_split.hip: 1 = whole-tile launches give each XCD a contiguous band of tiles
     int stride = 1;        // conv_split.hip, stride-1 tile families: 2 = the point grid is every second pixel of the padded input (3x3 stride-2 convolution)
-    int sk_in_kernel = 0;  // conv_split.hip: stream-K partial tiles are summed by the last workgroup to arrive (tickets in front of the slabs)
     float acc_scale;       // fp16-pair form: 2^-wk_exp, takes the accumulators back from the scale of the packed weights
 };
 

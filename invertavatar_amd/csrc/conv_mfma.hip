@@ -535,10 +535,7 @@ static Plan make_plan(int B, int I, int O, int H, int W, int ksize, int transpos
     if (form == 3 && !force_whole && !transposed && ksize == 3 && p.waves == 8 && O % 32 == 0) {
         const int64_t t_wide = (int64_t)B * ((npts + 255) / 256) * ((O + 127) / 128), t_narrow = (int64_t)B * ((npts + 255) / 256) * (O / 32);
         constexpr int min_tiles = ia::kNumCU;
-        // (IA_SK_WIDE=1, experiment: keep the 128 x 256 tile for these layers and cut every tile between two stream-K workers that meet inside
-        //  the launch -- the in-kernel reduction of r06 -- instead of 32-channel whole tiles)
-        const char* sk_wide = getenv("IA_SK_WIDE");
-        if (t_wide < ia::kNumCU && t_narrow >= min_tiles && !(sk_wide && atoi(sk_wide) == 1 && t_wide * 2 >= ia::kNumCU / 2)) { p.bo = 32; p.bp = 256; force_whole = true; }
+        if (t_wide < ia::kNumCU && t_narrow >= min_tiles) { p.bo = 32; p.bp = 256; force_whole = true; }
     }
     p.TO = (O + p.bo - 1) / p.bo;
     p.T = ((npts + p.bp - 1) / p.bp) * p.TO;
@@ -592,8 +589,7 @@ extern "C" int ia_conv2d_sx_supported(int I, int O, int H, int W, int ksize, int
     return (O >= 128 && npts >= kSplitMinPoints && W <= 512) ? 1 : 0;
 }
 
-// (the first kTicketBytes of a scratch buffer are the tile tickets of the in-launch stream-K reduction, conv_common.h: every user skips them)
-static size_t scratch_bytes_for(int B, int G, int slab_floats) { return G > 0 ? (size_t)B * G * 2 * slab_floats * sizeof(float) + kTicketBytes : 0; }
+static size_t scratch_bytes_for(int B, int G, int slab_floats) { return (size_t)B * G * 2 * slab_floats * sizeof(float); }
 
 extern "C" int ia_conv2d_down_plan(int B, int I, int O, int H, int W, int* h_ksplit, size_t* h_scratch_bytes) {
     IA_REQUIRE(h_ksplit && h_scratch_bytes, "null output pointer");
@@ -655,7 +651,6 @@ static int conv2d_entry(const float* x, const void* wk_any, const float* styles,
         const size_t need = scratch_bytes_for(B, g.G, p.slab_floats);
         const bool whole_tiles = Ur % g.G == 0 && (Ur / g.G) % g.C == 0;
         IA_REQUIRE(whole_tiles || (scratch && scratch_bytes >= need), "stream-K needs %zu bytes of scratch, got %zu", need, scratch_bytes);
-        if (scratch) scratch += kTicketWords;
     }
     g.patch_cap = 0;
     g.acc_scale = ldexpf(1.f, -wk_exp);

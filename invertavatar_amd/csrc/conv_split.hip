@@ -824,75 +824,12 @@ __global__ __launch_bounds__(WO * WP * 64, WO * WP == 4 ? 2 : WO * WP / 4) void 
         }
     } else if constexpr (SK) {
         const int slot = (tile_l == first_tile) ? 0 : 1;
-        const int64_t slab4 = (int64_t)NACC * NTHREADS / 4;
-        float4* slab = reinterpret_cast<float4*>(slabs) + (((int64_t)b * g.G + worker) * 2 + slot) * slab4 + tid;
-        if (!TR && g.sk_in_kernel) {      // (stride-1 forms: the four-phase transposed tiles spill ~340 registers with a second epilogue inlined and keep the fix-up launch)
-            // ---- the tile is finished inside the launch (r06; the hand-off of cdna_hip_programming.md 6 G16 in its counter
-            // form).  Every contributor writes its partial tile with write-through (sc1) stores, waits for them, and one lane draws a
-            // ticket (relaxed, agent scope); the workgroup that draws the last ticket acquires, adds the slabs of ALL contributors in worker
-            // order (its own included, from memory: the sum does not depend on who arrives last), resets the ticket and runs the epilogue.
-            // Nobody waits for anybody: no co-residency assumption.
-            float4* slab_wg = reinterpret_cast<float4*>(slabs) + (((int64_t)b * g.G + worker) * 2 + slot) * slab4;      // (wave-uniform base)
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab_wg, 0, (int)(slab4 * 16), 0x00020000);
+        float4* slab = reinterpret_cast<float4*>(slabs + (((int64_t)b * g.G + worker) * 2 + slot) * ((int64_t)NACC * NTHREADS)) + tid;
 #pragma unroll
-            for (int q = 0; q < NACC / 4; ++q) {
-                const int fr = q >> 2, r0 = (q & 3) * 4;
-                const f32x16& a = acc[fr / (FP * FO)][(fr / FP) % FO][fr % FP];
-                ia_u32x4 v;
-                v[0] = __float_as_uint(a[r0]); v[1] = __float_as_uint(a[r0 + 1]); v[2] = __float_as_uint(a[r0 + 2]); v[3] = __float_as_uint(a[r0 + 3]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (q * NTHREADS + tid) * 16, 0, /*sc1: write-through*/ 16);
-            }
-            // contributors of this tile: workers w_first .. w_last (the arithmetic of conv_fixup_kernel)
-            const int64_t t_begin = (int64_t)tile_l * g.C, t_end = t_begin + g.C;
-            int w_first = (int)((t_begin * g.G) / U);
-            while (w_first > 0 && range_begin(w_first, U, g.G) > t_begin) --w_first;
-            while (range_begin(w_first + 1, U, g.G) <= t_begin) ++w_first;
-            int w_last = w_first;
-            while (range_begin(w_last + 1, U, g.G) < t_end) ++w_last;
-            unsigned int* ticket = reinterpret_cast<unsigned int*>(slabs) - kTicketWords + ((int64_t)b * (g.T - g.T_dp) + tile_l);
-            int* flag = reinterpret_cast<int*>(lds);               // (the K loop's stage memory: free by now; ONE shared array, G16 item 4a)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slab stores have left
-            __syncthreads();                                        // ... everybody's (and the K loop's last operand reads are done)
-            if (tid == 0) flag[0] = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const bool last = flag[0] == w_last - w_first;
-            __syncthreads();                                        // (flag[0] is read before the epilogue re-uses the LDS)
-            if (last) {
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch finds it zero
-                }
-                __syncthreads();
-                const float4* base = reinterpret_cast<const float4*>(slabs) + ((int64_t)b * g.G) * 2 * slab4 + tid;
-                const int slot_first = (tile_l == (int)(range_begin(w_first, U, g.G) / g.C)) ? 0 : 1;
-#pragma unroll
-                for (int q = 0; q < NACC / 4; ++q) {
-                    const int fr = q >> 2, r0 = (q & 3) * 4;
-                    float4 sum = base[((int64_t)w_first * 2 + slot_first) * slab4 + (int64_t)q * NTHREADS];
-                    for (int w = w_first + 1; w <= w_last; ++w) {
-                        const float4 v = base[((int64_t)w * 2) * slab4 + (int64_t)q * NTHREADS];
-                        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-                    }
-                    f32x16& a = acc[fr / (FP * FO)][(fr / FP) % FO][fr % FP];
-                    a[r0] = sum.x; a[r0 + 1] = sum.y; a[r0 + 2] = sum.z; a[r0 + 3] = sum.w;
-                }
-                if constexpr (!TR) {
-#if IA_EPI_RELOAD
-                    struct KArgs2 { const h16x8* xs; const h16x8* wk; float* y; float* slabs; Geo g; Epi e; };
-                    const Epi e_sk = reload_kernarg<Epi, offsetof(KArgs2, e)>();
-#else
-                    const Epi& e_sk = e;
-#endif
-                    store_tile_dual<FO, FP, WO, WP>(acc, y, g, e_sk, b, o0, p0, tid, lds);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < NACC / 4; ++q) {
-                const int fr = q >> 2, r0 = (q & 3) * 4;
-                const f32x16& a = acc[fr / (FP * FO)][(fr / FP) % FO][fr % FP];
-                slab[(int64_t)q * NTHREADS] = make_float4(a[r0], a[r0 + 1], a[r0 + 2], a[r0 + 3]);
-            }
+        for (int q = 0; q < NACC / 4; ++q) {
+            const int fr = q >> 2, r0 = (q & 3) * 4;
+            const f32x16& a = acc[fr / (FP * FO)][(fr / FP) % FO][fr % FP];
+            slab[(int64_t)q * NTHREADS] = make_float4(a[r0], a[r0 + 1], a[r0 + 2], a[r0 + 3]);
         }
     }
   }   // segments of this worker
@@ -932,13 +869,11 @@ int launch_jp(const h16x8* xs, const h16x8* wk, float* y, float* scratch, const 
     } else if (st == IA_OK && g.T > g.T_dp) {
         auto k = conv_split_kernel<NP, TR, FO, FP, WO, WP, JP, true>;
         if (const int rs = ia::reserve_lds((const void*)k, (size_t)(lds), "conv_split")) return rs;
-        const int64_t U = (int64_t)(g.T - g.T_dp) * g.C;
-        const bool whole_tiles = U % g.G == 0 && (U / g.G) % g.C == 0;
-        // partial tiles are summed inside the launch by the workgroup that arrives last (tickets in the scratch header), when they fit the header
-        g.sk_in_kernel = (IA_SK_IN_KERNEL && !TR && !whole_tiles && (int64_t)g.B * (g.T - g.T_dp) <= kTicketWords) ? 1 : 0;
         hipLaunchKernelGGL(k, dim3(g.G, g.B), dim3(WO * WP * 64), lds, s, xs, wk, y, scratch, g, e);
         st = ia::check_launch("ia_conv2d_mfma_sx(stream-K)");
-        if (st == IA_OK && !whole_tiles && !g.sk_in_kernel) {
+        const int64_t U = (int64_t)(g.T - g.T_dp) * g.C;
+        const bool whole_tiles = U % g.G == 0 && (U / g.G) % g.C == 0;
+        if (st == IA_OK && !whole_tiles) {
             constexpr int NACC = (TR ? 4 : 1) * FO * FP * 16;
             hipLaunchKernelGGL((conv_fixup_kernel<TR, FO, FP, WO, WP>), dim3(g.T - g.T_dp, g.B, NACC / (TR ? 8 : 4)), dim3(WO * WP * 64), 0, s,
                                scratch, y, g, e);
@@ -1079,10 +1014,9 @@ static int conv_sx_impl(const void* xs, int planes, const void* wk_split, int wk
         IA_REQUIRE(ksplit >= 1, "this layer has stream-K tiles: pass the worker count from ia_conv2d_plan");
         const int64_t Ur = (int64_t)(g.T - g.T_dp) * g.C;
         g.G = (int)(ksplit > Ur ? Ur : ksplit);
-        const size_t need = (size_t)B * g.G * 2 * slab_floats * sizeof(float) + kTicketBytes;      // (tile tickets in front of the slabs: conv_common.h)
+        const size_t need = (size_t)B * g.G * 2 * slab_floats * sizeof(float);
         const bool whole_tiles = Ur % g.G == 0 && (Ur / g.G) % g.C == 0;
         IA_REQUIRE(whole_tiles || (scratch && scratch_bytes >= need), "stream-K needs %zu bytes of scratch, got %zu", need, scratch_bytes);
-        if (scratch) scratch += kTicketWords;
     }
     g.patch_cap = 0;
     g.acc_scale = ldexpf(1.f, -wk_exp);

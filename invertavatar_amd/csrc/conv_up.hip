@@ -643,7 +643,6 @@ int plan_up(int B, int I, int O, int H, int W, UpPlan* out) {
 
     p.lds = stage * g.stages + 1024;       // (+ the dummy target of all-outside DMA pieces)
     p.scratch = (size_t)B * g.n_slabs * (2 * 2 * p.fp * 16) * 512 * sizeof(float);
-    if (p.scratch) p.scratch += kTicketBytes;      // (the tile tickets every scratch user skips: conv_common.h)
     *out = p;
     return IA_OK;
 }
@@ -681,7 +680,6 @@ extern "C" int ia_upconv2d_rows_sx(const void* xs, const void* wk_split, int wk_
         return ia::fail(IA_ERR_UNSUPPORTED, "row-phase up-convolution: needs I %% 16 == 0, O %% 128 == 0, 16 <= H, W <= 1024 (I %d O %d %dx%d)", I, O, H, W);
     IA_REQUIRE(p.scratch == 0 || (scratch && scratch_bytes >= p.scratch), "the edge tiles need %zu bytes of scratch, got %zu", p.scratch, scratch_bytes);
     p.g.acc_scale = ldexpf(1.f, -wk_exp);
-    if (scratch && p.scratch) scratch += kTicketWords;
     hipStream_t s = (hipStream_t)stream;
     const h16x8* x8 = static_cast<const h16x8*>(xs);
     const h16x8* w8 = static_cast<const h16x8*>(wk_split);

@@ -133,9 +133,7 @@ def _scratch_buffer(device, nbytes):
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = reg.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
-        # zeros: the first 16 KB are the tile tickets of the in-launch stream-K reduction (include/ia_hip.h: zero when the buffer is first
-        # handed over; every launch leaves them zero)
-        buf = torch.zeros((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
         reg[key] = buf
     return buf
 
