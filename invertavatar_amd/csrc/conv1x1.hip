@@ -15,6 +15,7 @@
 // KS waves of a workgroup split the input channels (small images have too few pixel tiles to fill the machine) and add
 // their accumulators through LDS in wave order.
 #include "ia_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -177,6 +178,10 @@ struct TParams {
 };
 
 constexpr int kTU = 32;      // channel pairs per register block (two blocks are in flight)
+constexpr int kWideMinPixels = 16384;     // torgb_wide_kernel from 128^2 up
+#ifndef IA_TORGB_F16X3
+#define IA_TORGB_F16X3 1      // 64 / 96 output channels on the fp16 pipe (three products per term); 0: fp32 MFMAs for every block count
+#endif
 
 template <int KS>
 __global__ __launch_bounds__(512) void torgb_kernel(TParams p) {
@@ -294,6 +299,248 @@ __global__ __launch_bounds__(512) void torgb_kernel(TParams p) {
             s += a;
         }
         yb[(int64_t)o * p.P] = s;
+    }
+}
+
+// ---- ia_torgb on the large images (128^2, 256^2): torgb_kernel with the activations read ONCE for all output channels (r06).
+// torgb_kernel gives each block of 32 output channels its own workgroup: the 96-channel layers of the texture network read their
+// activations three times and launch three times the waves, and every lane fetches its 64 .. 128 weights from global memory beside
+// its 64 .. 128 activations.  Here the workgroup first stages (weight x style) for ALL output channels in LDS (C_in x 32 * blocks
+// values, 16 .. 96 KB; the activation loads are already in flight), then a wave walks the channel blocks over the activations it holds in
+// registers.
+//   F16 = false (one block of 32 channels): fp32 MFMAs; the A operand of each is one conflict-free ds_read_b32.  Products, k order, the
+//     KS-wave sum and the epilogue are torgb_kernel's: bit-identical results.
+//   F16 = true (64 / 96 channels, where 128 .. 192 dependent fp32 MFMAs per wave were the launch): the fp32 products are formed from fp16
+//     hi / lo pairs on v_mfma_f32_32x32x16_f16 like the 3x3 layers' (hi x hi into one accumulator, hi x lo' + lo' x hi into a second one
+//     that enters with 2^-11; lo x lo ~ 2^-22 dropped): 24 MFMAs of 8 passes per block instead of 64 of 16.  A lane loads the eight
+//     channels 16 kb + 8 half + j of its pixel -- the B fragment of k-block kb -- and splits them in registers (hi = fp16(x), lo' =
+//     fp16((x - hi) * 2^11), round to nearest); the weights are staged as (w x style x 2^10) split the same way, 16-byte
+//     A fragments [octet][channel][8].  Activations outside the fp16 range raise the library's range-watch word like every other
+//     producer of fp16 pairs (ia_split_saturation_poll).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
+constexpr float kWideWScale = 1024.f, kWideLoScale = 2048.f;
+
+__device__ __forceinline__ void wide_split8(const float (&v)[8], h8& hi, h8& lo) {
+    union { pk2 p[4]; h8 v; } uh, ul;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // (a high part that would be an fp16 denormal is flushed by the MFMA: such a value rides entirely in the scaled low part, like ia::split_f16)
+        const float h0 = fabsf(v[2 * j]) < 6.103515625e-5f ? 0.f : v[2 * j], h1 = fabsf(v[2 * j + 1]) < 6.103515625e-5f ? 0.f : v[2 * j + 1];
+        uh.p[j] = pk2{(__fp16)h0, (__fp16)h1};                   // (round to nearest: residuals <= 2^-12 of the value, so lo x lo <= 2^-24 .. 2^-22)
+        const float r0 = (v[2 * j] - (float)uh.p[j][0]) * kWideLoScale, r1 = (v[2 * j + 1] - (float)uh.p[j][1]) * kWideLoScale;
+        ul.p[j] = pk2{(__fp16)r0, (__fp16)r1};                   // (round to nearest: truncation here would bias every term the same way)
+    }
+    hi = uh.v;
+    lo = ul.v;
+}
+
+template <int KS, int EPI, int OB, bool F16>      // EPI: 0 bias + clamp only, 1 + residual image, 2 + up-sampled skip image; OB blocks of 32 output channels
+__global__ __launch_bounds__(512) void torgb_wide_kernel(TParams p) {
+    constexpr int NG = 8 / KS, NR = 16 / KS;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    constexpr int OP = OB * 32;                                  // (compile-time: every weight read is one base register + an immediate)
+    float* s_w = s_dyn;                                          // fp32: [I][OP] wk * style, zero beyond O; fp16 pairs: hi [I/8][OP][8], then lo
+    float* s_red = s_dyn + (int64_t)p.I * OP;                    // [8][16][64] (KS > 1)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+    const int grp = wave / KS, ks = wave - grp * KS;
+    const int b = blockIdx.y;
+    const int64_t pix = ((int64_t)blockIdx.x * NG + grp) * 32 + l31;
+    const bool pvalid = pix < p.P;
+    const int kw = p.I / KS, k_begin = ks * kw;                  // this wave's input channels: 128 of them
+    // fp32: register u of block a / b is channel 2u + half (+ 64); fp16 pairs: register 8 kb + j is channel 16 kb + 8 half + j
+    const float* xp = p.x + ((int64_t)b * p.I + k_begin + (F16 ? 8 * half : half)) * p.P + (pvalid ? pix : 0);
+    float xa[kTU], xb[kTU];
+#pragma unroll
+    for (int u = 0; u < kTU; ++u) xa[u] = pvalid ? xp[(int64_t)(F16 ? 16 * (u >> 3) + (u & 7) : 2 * u) * p.P] : 0.f;
+#pragma unroll
+    for (int u = 0; u < kTU; ++u) xb[u] = pvalid ? xp[(int64_t)(64 + (F16 ? 16 * (u >> 3) + (u & 7) : 2 * u)) * p.P] : 0.f;
+
+    // (w * s), the reference's order, for every output channel
+    {
+        const float* sp = p.styles ? p.styles + (int64_t)b * p.I : nullptr;
+        if constexpr (!F16) {                                    // 512 threads walk the [I][OP] image, OP / 4 float4 columns per row
+            const int cols = OP >> 2, total = p.I * cols;
+            const bool vec_ok = (p.O & 3) == 0;
+            for (int e = tid; e < total; e += 512) {
+                const int k = e / cols, o = (e - k * cols) * 4;
+                const float st = sp ? sp[k] : 1.f;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (vec_ok) {
+                    if (o < p.O) w = *reinterpret_cast<const float4*>(p.wk + (int64_t)k * p.O + o);
+                } else {
+                    const float* wr = p.wk + (int64_t)k * p.O;
+                    w.x = o < p.O ? wr[o] : 0.f; w.y = o + 1 < p.O ? wr[o + 1] : 0.f; w.z = o + 2 < p.O ? wr[o + 2] : 0.f; w.w = o + 3 < p.O ? wr[o + 3] : 0.f;
+                }
+                *reinterpret_cast<float4*>(s_w + (int64_t)k * OP + o) = make_float4(w.x * st, w.y * st, w.z * st, w.w * st);
+            }
+        } else {                                                 // one (octet of input channels, output channel) per step: a 16-byte A fragment
+            h8* s_hi = reinterpret_cast<h8*>(s_w);
+            h8* s_lo = s_hi + (p.I >> 3) * OP;
+            const int total = (p.I >> 3) * OP;
+            for (int e = tid; e < total; e += 512) {
+                const int oct = e / OP, o = e - oct * OP;
+                float w8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = oct * 8 + j;
+                    const float w = o < p.O ? p.wk[(int64_t)k * p.O + o] : 0.f;
+                    w8[j] = (w * (sp ? sp[k] : 1.f)) * kWideWScale;
+                    w8[j] = fminf(fmaxf(w8[j], -65504.f), 65504.f);
+                }
+                h8 hi, lo;
+                wide_split8(w8, hi, lo);
+                s_hi[e] = hi;
+                s_lo[e] = lo;
+            }
+        }
+    }
+
+    // the 2 x 2 real taps of the up-sampling at this pixel (see torgb_kernel)
+    int soff[4];
+    float sk[4];
+    const int Ws = p.W >> 1, Hs = p.H >> 1;
+    if constexpr (EPI == 2) {
+        const int64_t pp = pvalid ? pix : 0;
+        const int oy = (int)(pp / p.W), ox = (int)(pp - (int64_t)oy * p.W);
+        const int my = ((oy + (oy & 1)) >> 1) - 1, mx = ((ox + (ox & 1)) >> 1) - 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int iy = (oy & 1) + 2 * t, ix = (ox & 1) + 2 * u;
+                const bool in = my + t >= 0 && my + t < Hs && mx + u >= 0 && mx + u < Ws;
+                soff[2 * t + u] = in ? (my + t) * Ws + mx + u : 0;
+                sk[2 * t + u] = in ? p.filt[(3 - iy) * 4 + (3 - ix)] * 4.f : 0.f;
+            }
+    }
+
+    // fp16 pairs: the wave's activations become B fragments (8 k-blocks x hi, lo') as they land
+    h8 xh[F16 ? 8 : 1], xl[F16 ? 8 : 1];
+    if constexpr (F16) {
+        float amax = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            float v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v8[j] = kb < 4 ? xa[8 * kb + j] : xb[8 * (kb - 4) + j];
+                amax = fmaxf(amax, fabsf(v8[j]));
+            }
+            wide_split8(v8, xh[kb], xl[kb]);
+        }
+        if (!(amax <= 65504.f)) atomicOr(&ia_tu_saturated, 1u);
+    }
+    __syncthreads();
+
+    float* yb = p.y + (int64_t)b * p.O * p.P + (pvalid ? pix : 0);
+    for (int ob = 0; ob < OB; ++ob) {
+        const int o0 = ob * 32;
+        // the epilogue's operands of this block go out ahead of its MFMAs
+        float e_bias[NR], e_add[NR], e_tap[EPI == 2 ? NR : 1][4];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int r = ks * NR + j;
+            const int o = min(o0 + (r & 3) + 8 * (r >> 2) + 4 * half, p.O - 1);
+            e_bias[j] = p.bias ? p.bias[o] : 0.f;
+            e_add[j] = 0.f;
+            if constexpr (EPI == 1) e_add[j] = pvalid ? p.residual[((int64_t)b * p.O + o) * p.P + pix] : 0.f;
+            if constexpr (EPI == 2) {
+                const float* sb = p.skip + ((int64_t)b * p.O + o) * Hs * Ws;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e_tap[j][q] = sb[soff[q]];
+            }
+        }
+        auto fold_taps = [&]() {                                 // four taps become one value per row
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a = fmaf(e_tap[j][q], sk[q], a);
+                    e_add[j] = a;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if constexpr (!F16) {
+            const float* wo = s_w + (int64_t)(k_begin + half) * OP + l31 + o0;
+            // weights: eight ds_reads one group of eight MFMAs (512 cycles) ahead, pinned so that the scheduler does not hoist all 64
+            constexpr int WG8 = 8;
+            float wq[2][WG8];
+#pragma unroll
+            for (int u = 0; u < WG8; ++u) wq[0][u] = wo[(2 * u) * OP];
+#pragma unroll
+            for (int g = 0; g < 2 * kTU / WG8; ++g) {
+                if (g + 1 < 2 * kTU / WG8) {
+#pragma unroll
+                    for (int u = 0; u < WG8; ++u) wq[(g + 1) & 1][u] = wo[(2 * ((g + 1) * WG8 + u)) * OP];
+                }
+#pragma unroll
+                for (int u = 0; u < WG8; ++u) {
+                    const int uu = g * WG8 + u;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[g & 1][u], uu < kTU ? xa[uu] : xb[uu - kTU], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (g == 2 * kTU / WG8 / 2 - 1) fold_taps();     // half way: the taps have landed
+            }
+        } else {
+            const h8* wh = reinterpret_cast<const h8*>(s_w) + (int64_t)((k_begin >> 3) + half) * OP + l31 + o0;
+            const h8* wlo = wh + (p.I >> 3) * OP;
+            f32x16 acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+            h8 qh[2], ql[2];
+            qh[0] = wh[0];
+            ql[0] = wlo[0];
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                if (kb + 1 < 8) {
+                    qh[(kb + 1) & 1] = wh[(2 * (kb + 1)) * OP];
+                    ql[(kb + 1) & 1] = wlo[(2 * (kb + 1)) * OP];
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[kb & 1], xh[kb], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[kb & 1], xl[kb], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[kb & 1], xh[kb], acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb == 3) fold_taps();
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + acc1[r] * (1.f / kWideLoScale)) * (1.f / kWideWScale);
+        }
+
+        float v[NR];
+        if constexpr (KS > 1) {
+            if (ob) __syncthreads();                             // the previous block's sums have been read
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc[r];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                float s = s_red[((grp * KS) * 16 + ks * NR + j) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < KS; ++w) s += s_red[((grp * KS + w) * 16 + ks * NR + j) * 64 + lane];
+                v[j] = s;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) v[j] = acc[j];
+        }
+        if (pvalid) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = ks * NR + j;
+                const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (o >= p.O) continue;
+                float s = v[j] + e_bias[j];
+                if (p.clamp >= 0.f) s = fminf(fmaxf(s, -p.clamp), p.clamp);
+                if constexpr (EPI != 0) s += e_add[j];
+                yb[(int64_t)o * p.P] = s;
+            }
+        }
     }
 }
 
@@ -458,8 +705,25 @@ extern "C" int ia_torgb(const float* x, const float* wk, const float* styles, co
         return ia::check_launch("ia_torgb");
     }
     const int ng = 8 / ks;
-    const dim3 grid((unsigned)((P + 32 * ng - 1) / (32 * ng)), (unsigned)B, (unsigned)((O + 31) / 32));
     const hipStream_t s = (hipStream_t)stream;
+    // large images, 128 channels per wave: the activations are read once for all output channels (weights x styles in LDS)
+    static const int wide_min_p = getenv("IA_TORGB_WIDE_P") ? atoi(getenv("IA_TORGB_WIDE_P")) : kWideMinPixels;
+    const size_t wide_lds = ((size_t)I * (((O + 31) / 32) * 32) + (ks > 1 ? 8 * 16 * 64 : 0)) * sizeof(float);
+    if (P >= wide_min_p && I / ks == 128 && ks <= 2 && wide_lds <= 144 * 1024) {
+        const dim3 wgrid((unsigned)((P + 32 * ng - 1) / (32 * ng)), (unsigned)B);
+        const int epi = skip ? 2 : residual ? 1 : 0, ob = (O + 31) / 32;
+        auto go = [&](auto kern) -> int {
+            if (const int st = ia::reserve_lds((const void*)kern, wide_lds, "ia_torgb")) return st;
+            hipLaunchKernelGGL(kern, wgrid, dim3(512), wide_lds, s, p);
+            return ia::check_launch("ia_torgb");
+        };
+#define IA_WIDE_OB(KS_, EPI_) (ob == 1 ? go(torgb_wide_kernel<KS_, EPI_, 1, false>) : ob == 2 ? go(torgb_wide_kernel<KS_, EPI_, 2, IA_TORGB_F16X3 != 0>) : go(torgb_wide_kernel<KS_, EPI_, 3, IA_TORGB_F16X3 != 0>))
+#define IA_WIDE_EPI(KS_) (epi == 2 ? IA_WIDE_OB(KS_, 2) : epi == 1 ? IA_WIDE_OB(KS_, 1) : IA_WIDE_OB(KS_, 0))
+        return ks == 2 ? IA_WIDE_EPI(2) : IA_WIDE_EPI(1);
+#undef IA_WIDE_EPI
+#undef IA_WIDE_OB
+    }
+    const dim3 grid((unsigned)((P + 32 * ng - 1) / (32 * ng)), (unsigned)B, (unsigned)((O + 31) / 32));
     switch (ks) {
         case 8: hipLaunchKernelGGL((torgb_kernel<8>), grid, dim3(512), 0, s, p); break;
         case 4: hipLaunchKernelGGL((torgb_kernel<4>), grid, dim3(512), 0, s, p); break;

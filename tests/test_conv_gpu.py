@@ -584,7 +584,8 @@ def test_conv1x1_streaming_matches_torch(b, i, o, h, w):
 
 
 @pytest.mark.parametrize('b,i,o,h,w', [(1, 512, 32, 4, 4), (1, 512, 96, 8, 8), (2, 512, 32, 16, 16), (1, 512, 96, 32, 32), (1, 512, 32, 64, 64),
-                                       (1, 256, 96, 128, 128), (2, 128, 32, 256, 256), (1, 128, 3, 512, 512), (1, 1024, 8, 6, 10), (1, 256, 5, 2, 2), (1, 256, 3, 256, 256), (2, 512, 4, 128, 128)])
+                                       (1, 256, 96, 128, 128), (2, 128, 32, 256, 256), (1, 128, 3, 512, 512), (1, 1024, 8, 6, 10), (1, 256, 5, 2, 2), (1, 256, 3, 256, 256), (2, 512, 4, 128, 128),
+                                       (1, 128, 96, 256, 256), (1, 128, 35, 128, 128), (2, 256, 64, 128, 128), (1, 128, 20, 136, 124), (1, 256, 32, 128, 128)])
 def test_torgb_with_fused_skip_upsampling(b, i, o, h, w):
     """ia_torgb (ToRGB + upsample2d(previous image) + add in one launch) against the reference's op order in torch fp64, against the
     two-launch route it replaces (ia_conv1x1 + ia_upfirdn2d: the same up-sampled image bit for bit), and with a plain residual."""
@@ -613,6 +614,29 @@ def test_torgb_with_fused_skip_upsampling(b, i, o, h, w):
     assert max_abs(plain.double(), torch.einsum('bihw,oi->bohw', x.double(), wgt.double()[:, :, 0, 0])) <= 2e-5
     with pytest.raises(RuntimeError, match='ia_torgb covers'):
         hipops.torgb(torch.zeros(1, 48, 8, 8, device='cuda'), torch.zeros(1, 48, 8, device='cuda'))
+
+
+@pytest.mark.parametrize('i,o,r', [(128, 96, 128), (256, 64, 128)])
+def test_torgb_wide_channel_blocks_on_fp16_pairs(i, o, r):
+    """ia_torgb with 64 / 96 output channels on a large image (torgb_wide_kernel, r06) forms its fp32 products from fp16 hi / lo pairs:
+    activations over eight decades (tiny ones ride in the scaled low part), error against fp64 at the level of fp32 rounding; an
+    activation outside the fp16 range raises the library's range-watch word and nothing else does."""
+    from conftest import rnd
+    mag = 10.0 ** (rnd(31, 1, i, r, r) * 2.0 - 2.0).clamp(-6, 2.5)
+    x = (rnd(32, 1, i, r, r) * mag).cuda()
+    wgt = (rnd(33, o, i, 1, 1) / i ** 0.5).cuda()
+    styles, bias = (rnd(34, 1, i) * 0.3 + 1).cuda(), rnd(35, o).cuda()
+    wk = hipops.pack_conv_weight(wgt)
+    ref = torch.einsum('bihw,boi->bohw', x.double(), wgt.double()[None, :, :, 0, 0] * styles.double()[:, None, :]) + bias.double()[None, :, None, None]
+    bound = torch.einsum('bihw,boi->bohw', x.double().abs(), (wgt.double()[None, :, :, 0, 0] * styles.double()[:, None, :]).abs())
+    hipops.split_saturation_poll()
+    got = hipops.torgb(x, wk, styles, bias=bias)
+    ratio = ((got.double() - ref).abs() / (6e-7 * bound + 1e-7 * ref.abs() + 1e-9)).max().item()
+    assert ratio <= 1.0, ratio
+    assert not hipops.split_saturation_poll()
+    x[0, 5, 7, 9] = 1e5
+    hipops.torgb(x, wk, styles, bias=bias)
+    assert hipops.split_saturation_poll()
 
 
 def test_conv1x1_rejects_unsupported_shapes():
