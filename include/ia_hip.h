@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 6      /* 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split, ia_linear_sx; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -630,6 +630,26 @@ int ia_attention(const float* q, const float* k, const float* v, float* out, int
                  int64_t q_batch_stride, int64_t q_row_stride, int64_t k_batch_stride, int64_t k_row_stride,
                  int64_t v_batch_stride, int64_t v_row_stride, int64_t out_batch_stride, int64_t out_row_stride,
                  float scale, void* stream);
+
+/*
+ * Token-major linear layers of the transformer blocks (encoder_inversion/models/mmseg/mix_transformer.py:18-116: Mlp.fc1 / fc2,
+ * Attention.q / kv / proj -- nn.Linear on [B, tokens, C]; :158-190 the blocks that chain them) as fp32-equivalent GEMMs on the fp16
+ * pipe: fp32 products from fp16 hi / lo pairs like the 3x3 convolutions (three v_mfma_f32_32x32x16_f16 per k-step, fp32
+ * accumulation, lo x lo ~ 2^-22 dropped).  Replaces F.linear (rocBLAS fp32 GEMM) + bias [+ GELU] [+ the residual add of Block.forward].
+ *   ia_tokens_split: x [M][K] float32 (M = B * tokens, rows contiguous) -> xs fp16 [2][K/8][M][8]: hi = fp16(v),
+ *       lo = fp16((v - hi) * 2^11) -- the split format of the convolutions with the token in the pixel's place.  One call serves
+ *       every linear layer that reads x (q and kv; fc1).  |v| >= 65504 saturates and raises the range-watch word
+ *       (ia_split_saturation_poll).  K % 16 == 0, x 16-byte aligned, else IA_ERR_UNSUPPORTED.
+ *   ia_linear_sx: y [M][N] float32 = act(xs . w^T * 2^-wk_exp + bias) + residual
+ *       w_split : fp16 [2][1][K/8][N][8], the nn.Linear weight [N][K] as a 1x1 kernel in the convolution weight format
+ *                 (hi = fp16(w * 2^wk_exp), lo = fp16(w * 2^wk_exp - hi); the host-side packing of ia_conv2d_mfma_s)
+ *       bias    : [N] or NULL;  residual: [M][N] or NULL, added after the activation (x + drop_path(f(x)) of Block.forward)
+ *       act     : 0 none, 1 GELU (erf form, nn.GELU default)
+ *       deterministic (fixed summation order for a given shape); no workspace.
+ */
+int ia_tokens_split(const float* x, void* xs, int M, int K, void* stream);
+int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, const float* bias, const float* residual, float* y, int M, int K, int N,
+                 int act, void* stream);
 
 /*
  * Driver-side UV rasteriser: projected FaceVerse mesh -> uvcoords_image, the mesh condition of TriPlaneGenerator.synthesis.

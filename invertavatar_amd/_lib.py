@@ -17,7 +17,7 @@ _lib = None
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _i64p = ctypes.POINTER(ctypes.c_int64)
 
-ABI_VERSION = 6      # IA_HIP_ABI_VERSION of include/ia_hip.h
+ABI_VERSION = 7      # IA_HIP_ABI_VERSION of include/ia_hip.h
 
 DTYPE_ID = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
 
@@ -78,6 +78,8 @@ _SIGNATURES = {
     'ia_se_gate_split': [c_void_p, _i64p, c_void_p, _i64p] + [c_void_p] * 7 + [c_int] * 5 + [c_void_p],
     'ia_attention_supported': [c_int] * 3,
     'ia_attention': [c_void_p] * 4 + [c_int] * 5 + [c_int64] * 8 + [c_float, c_void_p],
+    'ia_tokens_split': [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    'ia_linear_sx': [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'ia_uv_rasterize': [c_void_p] * 5 + [c_int] * 8 + [c_float, c_int, c_void_p],
     'ia_layout_grid_u8': [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     'ia_stage_inputs': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), _i64p, c_int, c_void_p],

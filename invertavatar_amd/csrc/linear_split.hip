@@ -1,0 +1,274 @@
+// ia_tokens_split / ia_linear_sx: the token-major linear layers of the one-shot inversion's transformer blocks
+// (reference: encoder_inversion/models/mmseg/mix_transformer.py:18-116 -- Mlp.fc1 / fc2, Attention.q / kv / proj at 1 024 dims on
+// 64 .. 4 096 tokens; unet_transformer.py calls them through MixVisionTransformer blocks) as fp32-equivalent GEMMs on the fp16 pipe.
+//
+// y[m][n] = act(sum_k x[m][k] * w[n][k] + bias[n]) (+ residual[m][n]), x fp32 [M][K] tokens, w the nn.Linear weight [N][K].
+// The library route these replace runs fp32 MFMAs (rocBLAS Cijk_*_MI16x16x1: 115 - 135 TFLOP/s on 4 096 x 1 024 x 4 096, r05
+// one-shot kernel table).  Here the fp32 products come from fp16 hi / lo pairs like the 3x3 convolutions' (conv_common.h): three
+// v_mfma_f32_32x32x16_f16 per k-step -- hi x hi, hi x lo, lo' x (hi * 2^-11) -- into fp32 accumulators (the cross terms in their own, see the kernel), lo x lo (~2^-24) dropped.
+//   * ia_tokens_split turns the token matrix into the split format once per consumer set: [2][K/8][M][8] fp16, hi = fp16(v),
+//     lo' = fp16((v - hi) * 2^11) (ia::split_f16, range watch included) -- the layout of the convolutions' activations with the
+//     token index in the place of the pixel, so a lane's A fragment (its token, eight consecutive k) is ONE 16-byte load.
+//   * the weight is split once on the host side in the convolution weight format of a 1x1 kernel ([2][1][K/8][N][8], pre-scaled
+//     by 2^wk_exp: hipops.pack_conv_weight_split) -- a lane's B fragment is one 16-byte load too.
+//   * linear_split_kernel: a wave owns 32 FA tokens x 32 FB output features over all of K and loads its fragments straight into the
+//     MFMA operand registers with raw buffer loads (rows past M / N read zeros through the range check): no LDS, no barriers; RING
+//     k-steps are in flight ahead of the one being multiplied (branch-free loop, counted waits).  Tokens are the MFMA's rows, so a
+//     lane's accumulator registers are tokens and its lane index the output feature: stores are 128-byte runs of a token row, bias
+//     is one value per lane.  Four waves (2 x 2) form a workgroup and share fragments through L1 / L2 only.
+//   * KS = 4 (few tokens): the four waves take the k-steps round-robin on ONE 32 FA x 32 FB tile and meet in LDS in wave order.
+#include "ia_common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kOutside = 0x7ffffff0;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lin_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ h16x8 lin_load16(__amdgpu_buffer_rsrc_t r, int voffset, int soffset) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0);
+    return __builtin_bit_cast(h16x8, v);
+}
+
+// ---- tokens [M][K] fp32 -> [2][K/8][M][8] fp16 pairs.  A workgroup turns 32 tokens x 8 octets: 256-byte runs of a token row in,
+// 512-byte runs of an octet plane out, the transposition through LDS.
+__global__ __launch_bounds__(256) void tokens_split_kernel(const float* __restrict__ x, h16x8* __restrict__ xs, int M, int K8) {
+    __shared__ h16x8 s_hi[8][33], s_lo[8][33];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * 32, o0 = blockIdx.y * 8;
+    {
+        const int ml = tid >> 3, ol = tid & 7, m = m0 + ml, o = o0 + ol;
+        ia::SatWatch watch;
+        h16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; lo[j] = (_Float16)0.f; }
+        if (m < M && o < K8) {
+            const float4* p = reinterpret_cast<const float4*>(x + (int64_t)m * K8 * 8 + o * 8);
+            const float4 a = p[0], b = p[1];
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 h, l;
+                ia::split_f16(v[j], h, l, watch);
+                hi[j] = h;
+                lo[j] = l;
+            }
+        }
+        watch.report();
+        s_hi[ol][ml] = hi;
+        s_lo[ol][ml] = lo;
+    }
+    __syncthreads();
+    const int ol = tid >> 5, ml = tid & 31, m = m0 + ml, o = o0 + ol;
+    if (m < M && o < K8) {
+        xs[(int64_t)o * M + m] = s_hi[ol][ml];
+        xs[((int64_t)K8 + o) * M + m] = s_lo[ol][ml];
+    }
+}
+
+struct LinParams {
+    const h16x8* xs;         // [2][K8][M][8]
+    const h16x8* ws;         // [2][K8][N][8], scaled by 2^wk_exp
+    const float* bias;       // [N] or null
+    const float* residual;   // [M][N] or null (added after the activation)
+    float* y;                // [M][N]
+    int M, N, K8;
+    float acc_scale;         // 2^-wk_exp
+    int gelu;
+};
+
+__device__ __forceinline__ float lin_finish(float v, float bias, int gelu) {
+    v += bias;
+    if (gelu) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));      // nn.GELU(approximate='none')
+    return v;
+}
+
+// FA x FB fragments of 32 tokens x 32 features per wave.  KS = 1: four waves as 2 x 2 tiles; KS = 4: four waves on one tile, k-steps round-robin.
+template <int FA, int FB, int KS, int RING>
+__global__ __launch_bounds__(256, 2) void linear_split_kernel(LinParams p) {      // (two workgroups per CU: 256 registers per lane, accumulators included)
+    __shared__ float4 s_part[KS > 1 ? 4 * FA * FB * 4 * 64 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+    const int wm = KS > 1 ? 0 : wave >> 1, wn = KS > 1 ? 0 : wave & 1;
+    constexpr int TM = (KS > 1 ? 1 : 2) * 32 * FA, TN = (KS > 1 ? 1 : 2) * 32 * FB;
+    const int m0 = blockIdx.y * TM + wm * 32 * FA, n0 = blockIdx.x * TN + wn * 32 * FB;
+    const int steps = p.K8 >> 1;                                  // one k-step = 16 input features: lanes 0-31 the even octet, 32-63 the odd one
+    const unsigned a_plane = (unsigned)p.K8 * (unsigned)p.M * 16u, b_plane = (unsigned)p.K8 * (unsigned)p.N * 16u;
+    const char* ab = reinterpret_cast<const char*>(p.xs);
+    const char* bb = reinterpret_cast<const char*>(p.ws);
+    const __amdgpu_buffer_rsrc_t ra0 = lin_rsrc(ab, a_plane), ra1 = lin_rsrc(ab + a_plane, a_plane);
+    const __amdgpu_buffer_rsrc_t rb0 = lin_rsrc(bb, b_plane), rb1 = lin_rsrc(bb + b_plane, b_plane);
+    int a_off[FA], b_off[FB];
+#pragma unroll
+    for (int f = 0; f < FA; ++f) {
+        const int m = m0 + f * 32 + l31;
+        a_off[f] = m < p.M ? (half * p.M + m) * 16 : kOutside;
+    }
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+        const int n = n0 + f * 32 + l31;
+        b_off[f] = n < p.N ? (half * p.N + n) * 16 : kOutside;
+    }
+    const int a_step = 2 * p.M * 16, b_step = 2 * p.N * 16;
+
+    // two accumulators per fragment: the MFMA's accumulate truncates, so a chain of n MFMAs drifts by ~n / 2 ulp of the SUM (measured:
+    // 3e-6 on 0.6 after 192 MFMAs in one register, 1e-6 after 48) -- the cross terms (2^-11 of the sum) get their own register and
+    // enter once at the end; the hi x hi chain is K / 16 long
+    f32x16 acc[FA][FB], acx[FA][FB];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acx[i][j][r] = 0.f; }
+
+    h16x8 qa[RING][2][FA], qb[RING][2][FB];
+    auto load_step = [&](int slot, int st, bool live) {
+        const int dead = live ? 0 : kOutside;
+        const int sa = st * a_step, sb = st * b_step;
+#pragma unroll
+        for (int f = 0; f < FA; ++f) {
+            qa[slot][0][f] = lin_load16(ra0, a_off[f] | dead, sa);
+            qa[slot][1][f] = lin_load16(ra1, a_off[f] | dead, sa);
+        }
+#pragma unroll
+        for (int f = 0; f < FB; ++f) {
+            qb[slot][0][f] = lin_load16(rb0, b_off[f] | dead, sb);
+            qb[slot][1][f] = lin_load16(rb1, b_off[f] | dead, sb);
+        }
+    };
+    const int first = KS > 1 ? wave : 0;
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {
+        const int st = first + s * KS;
+        const bool live = st < steps;
+        load_step(s, live ? st : 0, live);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int st0 = first; st0 < steps; st0 += RING * KS) {
+#pragma unroll
+        for (int s = 0; s < RING; ++s) {
+            const int nxt = st0 + (s + RING) * KS;
+            const bool more = nxt < steps;
+            h16x8 b_sc[FB];
+#pragma unroll
+            for (int j = 0; j < FB; ++j) b_sc[j] = qb[s][0][j] * (_Float16)(1.0f / 2048.0f);      // weight high parts at 2^-11 meet the tokens' low parts (at 2^11)
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < FB; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s][0][i], qb[s][1][j], acx[i][j], 0, 0, 0);     // hi x lo
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < FB; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s][1][i], b_sc[j], acx[i][j], 0, 0, 0);          // lo' x (hi * 2^-11)
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < FB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s][0][i], qb[s][0][j], acc[i][j], 0, 0, 0);     // hi x hi
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(s, more ? nxt : 0, more);                      // refill the slot (the MFMAs above have read its registers)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // C/D map of the 32 x 32 MFMA: row (token) = (r & 3) + 8 * (r >> 2) + 4 * half, column (feature) = l31
+    if constexpr (KS > 1) {
+        float4* pw = s_part + (wave * FA * FB * 4) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < FB; ++j)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    pw[((i * FB + j) * 4 + rq) * 64] = make_float4(acc[i][j][4 * rq] + acx[i][j][4 * rq], acc[i][j][4 * rq + 1] + acx[i][j][4 * rq + 1],
+                                                                   acc[i][j][4 * rq + 2] + acx[i][j][4 * rq + 2], acc[i][j][4 * rq + 3] + acx[i][j][4 * rq + 3]);
+        __syncthreads();
+        constexpr int NQ = FA * FB * 4;
+        for (int q = wave; q < NQ; q += 4) {
+            const float4* pr = s_part + q * 64 + lane;
+            float4 v = pr[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {                            // wave order: the same bits on every launch
+                const float4 u = pr[(w * NQ) * 64];
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            const int frag = q >> 2, rq = q & 3, i = frag / FB, j = frag - i * FB;
+            const int n = n0 + j * 32 + l31;
+            if (n >= p.N) continue;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+            const float vin[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = m0 + i * 32 + 8 * rq + 4 * half + k;
+                if (m >= p.M) continue;
+                float o = lin_finish(vin[k] * p.acc_scale, bias, p.gelu);
+                if (p.residual) o += p.residual[(int64_t)m * p.N + n];
+                p.y[(int64_t)m * p.N + n] = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+            const int n = n0 + j * 32 + l31;
+            if (n >= p.N) continue;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < FA; ++i) {
+                float res[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    res[r] = (p.residual && m < p.M) ? p.residual[(int64_t)m * p.N + n] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m >= p.M) continue;
+                    p.y[(int64_t)m * p.N + n] = lin_finish((acc[i][j][r] + acx[i][j][r]) * p.acc_scale, bias, p.gelu) + res[r];
+                }
+                __builtin_amdgcn_sched_barrier(0);               // (one fragment's 32 accumulator registers through the VGPRs at a time)
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ia_tokens_split(const float* x, void* xs, int M, int K, void* stream) {
+    IA_REQUIRE(x && xs, "x and xs must be device pointers");
+    IA_REQUIRE(M > 0 && K > 0, "empty matrix");
+    if (K % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0)
+        return ia::fail(IA_ERR_UNSUPPORTED, "ia_tokens_split needs K %% 16 == 0 and a 16-byte aligned matrix (got K = %d)", K);
+    IA_REQUIRE((int64_t)M * K <= (int64_t)1 << 30, "matrix too large for 32-bit plane offsets");
+    const int K8 = K / 8;
+    hipLaunchKernelGGL(tokens_split_kernel, dim3((unsigned)((M + 31) / 32), (unsigned)((K8 + 7) / 8)), dim3(256), 0, (hipStream_t)stream, x,
+                       static_cast<h16x8*>(xs), M, K8);
+    return ia::check_launch("ia_tokens_split");
+}
+
+extern "C" int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, const float* bias, const float* residual, float* y, int M, int K, int N,
+                            int act, void* stream) {
+    IA_REQUIRE(xs && w_split && y, "xs, w_split and y must be device pointers");
+    IA_REQUIRE(M > 0 && K > 0 && N > 0, "empty matrix");
+    IA_REQUIRE(act == 0 || act == 1, "act: 0 none, 1 GELU (erf)");
+    if (K % 16 != 0) return ia::fail(IA_ERR_UNSUPPORTED, "ia_linear_sx needs K %% 16 == 0 (got %d)", K);
+    IA_REQUIRE((int64_t)M * K <= (int64_t)1 << 30 && (int64_t)N * K <= (int64_t)1 << 30, "matrix too large for 32-bit plane offsets");
+    LinParams p{static_cast<const h16x8*>(xs), static_cast<const h16x8*>(w_split), bias, residual, y, M, N, K / 8, ldexpf(1.f, -wk_exp), act};
+    const hipStream_t s = (hipStream_t)stream;
+    // 128 x 128 workgroup tiles (four waves of 64 x 64) from one tile per CU up; below that one 32 x 64 tile per workgroup with K over its
+    // four waves (r06, tools/bench_linear.py: 4 096 x 1 024 x 1 024 39.5 vs 46.2 us, 1 024^3 31.0 vs 14.2; a 64 x 64 form of the first
+    // kind won nowhere)
+    static const int force = getenv("IA_LINEAR_TILE") ? atoi(getenv("IA_LINEAR_TILE")) : 0;
+    const bool big = force ? force == 2 : ia::ceil_div(M, 128) * ia::ceil_div(N, 128) >= ia::kNumCU;
+    if (big)
+        hipLaunchKernelGGL((linear_split_kernel<2, 2, 1, 3>), dim3((unsigned)ia::ceil_div(N, 128), (unsigned)ia::ceil_div(M, 128)), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((linear_split_kernel<1, 2, 4, 3>), dim3((unsigned)ia::ceil_div(N, 64), (unsigned)ia::ceil_div(M, 32)), dim3(256), 0, s, p);
+    return ia::check_launch("ia_linear_sx");
+}

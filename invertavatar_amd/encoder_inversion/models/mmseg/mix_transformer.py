@@ -18,6 +18,24 @@ HIP_DWCONV = True      # Mix-FFN's depth-wise 3x3 (+ GELU) on the token grid thr
 HIP_ATTENTION = True      # device inference: softmax(QK^T)V of the 1024-dim / 4-head blocks through ia_attention
 
 
+HIP_LINEAR = True      # device inference: the blocks' nn.Linear layers (q / kv / proj, fc1 / fc2) as fp16-pair GEMMs through ia_linear_sx
+
+
+def _hip_linear_ok(x, *linears):
+    return (HIP_LINEAR and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and all(m.in_features % 16 == 0 and m.weight.dtype == torch.float32 for m in linears))
+
+
+def _hip_linear(lin, xs, gelu=False, residual=None):
+    """nn.Linear on tokens already in the split format (hipops.tokens_split): weight split once per parameter version."""
+    from .... import _runtime, hipops
+    st = _runtime.state(lin)
+    key = (lin.weight.data_ptr(), lin.weight._version, lin.weight.device)
+    if getattr(st, 'wsplit_key', None) != key:
+        st.wsplit, st.wsplit_key = hipops.pack_linear_weight_split(lin.weight), key
+    return hipops.linear_sx(xs, st.wsplit, None if lin.bias is None else lin.bias.detach(), residual=residual, gelu=gelu)
+
+
 def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
@@ -90,10 +108,18 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
         self.apply(_init_weights)
 
-    def forward(self, x, H, W):
-        if isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none':
-            return self.drop(self.fc2(self.drop(self.dwconv(self.fc1(x), H, W, gelu=True))))
-        return self.drop(self.fc2(self.drop(self.act(self.dwconv(self.fc1(x), H, W)))))
+    def forward(self, x, H, W, residual=None):
+        """`residual`: added to the result (Block.forward's x + mlp(norm2(x)); in fc2's epilogue on the device path)."""
+        exact_gelu = isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none'
+        if exact_gelu and _hip_linear_ok(x, self.fc1, self.fc2) and not (self.training and self.drop.p > 0):
+            from .... import hipops
+            h = self.dwconv(_hip_linear(self.fc1, hipops.tokens_split(x.contiguous())), H, W, gelu=True)
+            return _hip_linear(self.fc2, hipops.tokens_split(h.contiguous()), residual=None if residual is None else residual.contiguous())
+        if exact_gelu:
+            y = self.drop(self.fc2(self.drop(self.dwconv(self.fc1(x), H, W, gelu=True))))
+        else:
+            y = self.drop(self.fc2(self.drop(self.act(self.dwconv(self.fc1(x), H, W)))))
+        return y if residual is None else residual + y
 
 
 class Attention(nn.Module):
@@ -115,23 +141,38 @@ class Attention(nn.Module):
             self.norm = nn.LayerNorm(dim)
         self.apply(_init_weights)
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, residual=None):
+        """`residual`: added to the result (Block.forward's x + attn(norm1(x)); in proj's epilogue on the device path)."""
         B, N, C = x.shape
         heads, hd = self.num_heads, C // self.num_heads
-        qp = self.q(x)
+        lin = _hip_linear_ok(x, self.q, self.kv, self.proj) and not (self.training and self.proj_drop.p > 0)
+        if lin:
+            from .... import hipops
+            xs = hipops.tokens_split(x.contiguous())          # one split for q and (sr_ratio 1) kv
+            qp = _hip_linear(self.q, xs)
+        else:
+            qp = self.q(x)
         src = x
         if self.sr_ratio > 1:
             src = self.norm(self.sr(x.permute(0, 2, 1).reshape(B, C, H, W)).reshape(B, C, -1).permute(0, 2, 1))
-        kv = self.kv(src)
+        if lin:
+            kv = _hip_linear(self.kv, xs if self.sr_ratio == 1 else hipops.tokens_split(src.contiguous()))
+        else:
+            kv = self.kv(src)
+
+        def project(out):
+            if lin:
+                return _hip_linear(self.proj, hipops.tokens_split(out.contiguous()), residual=None if residual is None else residual.contiguous())
+            y = self.proj_drop(self.proj(out))
+            return y if residual is None else residual + y
         if (HIP_ATTENTION and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not (self.training and self.attn_drop.p > 0)):
             from .... import _lib, hipops
             if _lib.load().ia_attention_supported(hd, N, kv.shape[1]):      # one launch: no [N, M] score matrix, no head permutes
-                out = hipops.attention(qp.contiguous(), kv.contiguous(), heads, self.scale)
-                return self.proj_drop(self.proj(out))
+                return project(hipops.attention(qp.contiguous(), kv.contiguous(), heads, self.scale))
         q = qp.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
         k, v = kv.reshape(B, -1, 2, heads, hd).permute(2, 0, 3, 1, 4)
         attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1))
-        return self.proj_drop(self.proj((attn @ v).transpose(1, 2).reshape(B, N, C)))
+        return project((attn @ v).transpose(1, 2).reshape(B, N, C))
 
 
 class Block(nn.Module):
@@ -147,6 +188,9 @@ class Block(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x, H, W):
+        if isinstance(self.drop_path, nn.Identity) or not self.training:      # (stochastic depth is the identity: the sums go into the projections)
+            x = self.attn(self.norm1(x), H, W, residual=x)
+            return self.mlp(self.norm2(x), H, W, residual=x)
         x = x + self.drop_path(self.attn(self.norm1(x), H, W))
         return x + self.drop_path(self.mlp(self.norm2(x), H, W))
 
@@ -234,7 +278,11 @@ class MLP(nn.Module):
         self.proj = nn.Linear(input_dim, embed_dim)
 
     def forward(self, x):
-        return self.proj(x.flatten(2).transpose(1, 2))
+        t = x.flatten(2).transpose(1, 2)
+        if _hip_linear_ok(t, self.proj):
+            from .... import hipops
+            return _hip_linear(self.proj, hipops.tokens_split(t.contiguous()))
+        return self.proj(t)
 
 
 class transformer_block(nn.Module):

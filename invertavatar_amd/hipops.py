@@ -1076,6 +1076,57 @@ def attention(q, kv, heads, scale):
     return out
 
 
+class SplitTokens:
+    """A token matrix [M, K] stored as fp16 hi / lo pairs [2, K/8, M, 8] (ia_tokens_split): the operand of linear_sx."""
+
+    def __init__(self, data, rows, cols, lead_shape):
+        self.data, self.rows, self.cols, self.lead_shape = data, rows, cols, tuple(lead_shape)
+
+
+def linear_supported(in_features):
+    return in_features % 16 == 0
+
+
+def pack_linear_weight_split(w):
+    """nn.Linear weight [N, K] -> the convolution weight format of a 1x1 kernel, fp16 [2, 1, K/8, N, 8] with its scale as `.wk_exp`
+    (pack_conv_weight_split): the weight operand of linear_sx."""
+    n, k = w.shape
+    return pack_conv_weight_split(w.detach().reshape(n, k, 1, 1))
+
+
+def tokens_split(x):
+    """fp32 [..., K] (rows contiguous) -> SplitTokens (see ia_tokens_split).  One split serves every linear layer that reads x."""
+    _f32c(x, 'x')
+    k = x.shape[-1]
+    m = x.numel() // k
+    out = torch.empty(2, k // 8, m, 8, device=x.device, dtype=torch.float16)
+    with torch.cuda.device(x.device), _Timed('tokens_split', 0.0, 8.0 * x.numel(), f'M{m} K{k}'):
+        st = _lib.load().ia_tokens_split(_p(x), _p(out), m, k, _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_tokens_split')
+    return SplitTokens(out, m, k, x.shape[:-1])
+
+
+def linear_sx(xs, w_split, bias=None, residual=None, gelu=False):
+    """act(x @ w^T + bias) + residual on the fp16-pair GEMM (see ia_linear_sx).  xs: SplitTokens; w_split: pack_linear_weight_split(w);
+    residual: fp32 [..., N] like the output.  Returns fp32 [*lead, N]."""
+    if not (w_split.dtype == torch.float16 and w_split.dim() == 5 and w_split.shape[0] == 2 and w_split.shape[1] == 1 and hasattr(w_split, 'wk_exp')):
+        raise RuntimeError('linear_sx: the weight must come from pack_linear_weight_split')
+    k8, n = w_split.shape[2], w_split.shape[3]
+    if k8 * 8 != xs.cols:
+        raise RuntimeError(f'linear_sx: {xs.cols} input features against a weight of {k8 * 8}')
+    y = torch.empty(*xs.lead_shape, n, device=xs.data.device, dtype=torch.float32)
+    if residual is not None:
+        _f32c(residual, 'residual')
+        if residual.shape != y.shape:
+            raise RuntimeError(f'linear_sx: residual {tuple(residual.shape)} against an output of {tuple(y.shape)}')
+    with torch.cuda.device(y.device), _Timed('linear_sx', 2.0 * xs.rows * xs.cols * n, 4.0 * (xs.rows * xs.cols + xs.cols * n + y.numel()),
+                                             f'M{xs.rows} K{xs.cols} N{n}'):
+        st = _lib.load().ia_linear_sx(_p(xs.data), _p(w_split), int(w_split.wk_exp), _p(None if bias is None else _f32c(bias, 'bias')),
+                                      _p(residual), _p(y), xs.rows, xs.cols, n, int(bool(gelu)), _lib.stream_ptr(y.device))
+    _lib.check(st, 'ia_linear_sx')
+    return y
+
+
 def se_gate_split(v, shortcut, w1, w2, next_scale=None, next_shift=None, consumer=None):
     """ia_se_gate_split: (out, SplitAct of out * next_scale + next_shift or None).  next_scale / next_shift: [B, C] rows (the eval-mode
     BatchNorm in front of the convolution that reads `out` next) or both None."""

@@ -22,7 +22,7 @@ def test_library_builds_and_exports_header_symbols():
 
 def test_version_and_error_text():
     lib = _lib.load()
-    assert lib.ia_version() == _lib.ABI_VERSION == 6
+    assert lib.ia_version() == _lib.ABI_VERSION == 7
     # invalid argument is reported through the status code + ia_last_error, never an exception
     st = lib.ia_bias_act(None, None, None, None, None, None, 0, 16, 0, 1, 0, 3, 0.2, 1.0, -1.0, None)
     assert st == -1

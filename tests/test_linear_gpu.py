@@ -1,0 +1,83 @@
+"""ia_tokens_split / ia_linear_sx (csrc/linear_split.hip): the transformer blocks' nn.Linear layers as fp16-pair GEMMs, against torch fp64
+(reference: encoder_inversion/models/mmseg/mix_transformer.py:18-116 -- F.linear + bias, GELU, the residual sums of Block.forward)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(m_shape, k, n, seed):
+    from conftest import rnd
+    x = (rnd(seed, *m_shape, k) * 10.0 ** (rnd(seed + 1, *m_shape, k) * 1.5 - 1.0).clamp(-5, 2)).cuda()
+    w = (rnd(seed + 2, n, k) * 0.02).cuda()
+    return x, w, rnd(seed + 3, n).cuda(), rnd(seed + 4, *m_shape, n).cuda()
+
+
+# the three tile forms: 128 x 128 workgroup tiles (>= 256 of them), 64 x 64, one 32 x 64 tile with K over the four waves; ragged M / N
+@pytest.mark.parametrize('m_shape,k,n', [((1, 4096), 1024, 4096), ((2, 1024), 1024, 1024), ((1, 64), 1024, 2048), ((1, 4096), 2048, 1024),
+                                         ((3, 37), 48, 72), ((1, 1000), 64, 200), ((1, 2100), 32, 2100)])
+def test_linear_on_fp16_pairs_matches_fp64(m_shape, k, n):
+    from invertavatar_amd import hipops
+    x, w, bias, res = _case(m_shape, k, n, 50)
+    xs = hipops.tokens_split(x)
+    ws = hipops.pack_linear_weight_split(w)
+    ref = x.double() @ w.double().t()
+    bound = x.double().abs() @ w.double().abs().t()
+
+    parts = bound + bias.double().abs() + res.double().abs()        # magnitudes the fp32 sums of the epilogue round at
+
+    def close(got, want, what):
+        ratio = ((got.double() - want).abs() / (5e-7 * bound + 2e-7 * parts + 1e-9)).max().item()
+        assert got.shape == want.shape and ratio <= 1.0, (what, ratio)
+    hipops.split_saturation_poll()
+    close(hipops.linear_sx(xs, ws), ref, 'bare')
+    close(hipops.linear_sx(xs, ws, bias), ref + bias.double(), 'bias')
+    close(hipops.linear_sx(xs, ws, bias, residual=res), ref + bias.double() + res.double(), 'bias + residual')
+    g = torch.nn.functional.gelu(ref + bias.double())
+    got = hipops.linear_sx(xs, ws, bias, residual=res, gelu=True)
+    # (GELU's slope is <= 1.13: the pre-activation bound carries over; erff itself is good to a few ulp)
+    ratio = ((got.double() - (g + res.double())).abs() / (6e-7 * bound + 4e-7 * parts + 1e-7)).max().item()
+    assert ratio <= 1.0, ratio
+    assert not hipops.split_saturation_poll()
+    assert torch.equal(hipops.linear_sx(xs, ws, bias), hipops.linear_sx(xs, ws, bias))        # fixed summation order
+
+
+def test_tokens_split_is_the_split_format():
+    """hi + lo * 2^-11 reproduces the tokens to 2^-22; values outside the fp16 range saturate and raise the range-watch word."""
+    from conftest import rnd
+    from invertavatar_amd import hipops
+    x = (rnd(60, 2, 50, 48) * 10.0 ** (rnd(61, 2, 50, 48) * 2 - 1).clamp(-6, 3)).cuda()
+    hipops.split_saturation_poll()
+    xs = hipops.tokens_split(x)
+    assert xs.data.shape == (2, 6, 100, 8) and xs.rows == 100 and xs.cols == 48 and xs.lead_shape == (2, 50)
+    back = (xs.data[0].float() + xs.data[1].float() / 2048.0).permute(1, 0, 2).reshape(100, 48)
+    # (|v| < 2^-14 rides entirely in the low part: 11 bits of a value that small, <= 1.5e-8 absolute)
+    assert ((back - x.reshape(100, 48)).abs() <= 2.0 ** -21 * x.reshape(100, 48).abs() + 1.5e-8).all()
+    assert not hipops.split_saturation_poll()
+    x[1, 3, 5] = 7e4
+    hipops.tokens_split(x)
+    assert hipops.split_saturation_poll()
+    with pytest.raises(RuntimeError, match='ia_tokens_split needs'):
+        hipops.tokens_split(torch.zeros(4, 40, device='cuda'))
+
+
+def test_transformer_block_on_hip_linears_matches_torch():
+    """Block.forward with the linear layers, the attention and the depth-wise convolution on the device kernels against the same module
+    with every switch off (ATen / rocBLAS), at the flow's dimensions (1 024 dims, 4 heads, mlp_ratio 2) on a 16 x 16 token grid."""
+    from invertavatar_amd.encoder_inversion.models.mmseg import mix_transformer as mt
+    from conftest import rnd
+    torch.manual_seed(0)
+    blk = mt.Block(dim=1024, num_heads=4, mlp_ratio=2, sr_ratio=1).cuda().eval()
+    for p in blk.parameters():
+        if p.dim() == 2:
+            p.data.normal_(0, 0.03)
+    x = rnd(70, 1, 256, 1024).cuda()
+    with torch.no_grad():
+        got = blk(x, 16, 16)
+        saved = mt.HIP_LINEAR, mt.HIP_ATTENTION, mt.HIP_DWCONV
+        try:
+            mt.HIP_LINEAR = mt.HIP_ATTENTION = mt.HIP_DWCONV = False
+            ref = blk.double()(x.double(), 16, 16)
+        finally:
+            mt.HIP_LINEAR, mt.HIP_ATTENTION, mt.HIP_DWCONV = saved
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
