@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split, ia_linear_sx; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split, ia_im2col_split, ia_linear_sx; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -648,6 +648,15 @@ int ia_attention(const float* q, const float* k, const float* v, float* out, int
  *       deterministic (fixed summation order for a given shape); no workspace.
  */
 int ia_tokens_split(const float* x, void* xs, int M, int K, void* stream);
+/*
+ * The overlapping patch embeddings of the same encoders (mix_transformer.py:155-190 OverlapPatchEmbed: a 7x7 stride-2 / stride-4
+ * convolution whose output is flattened to tokens) as im2col-free GEMMs: ia_im2col_split writes the patches of an NCHW float32 image
+ * straight into the split format of a token matrix -- row m = (b, oy, ox), column k = (c, ky, kx) in the order of
+ * conv.weight.reshape(N, C * ksize * ksize), zero columns up to Kp = K rounded up to 16 -- and ia_linear_sx (M = B * OH * OW, K = Kp,
+ * weight rows zero-padded the same way) produces the tokens [B, OH * OW, N] + bias directly: no NCHW result, no flatten / transpose.
+ *   xs: fp16 [2][Kp/8][M][8];  ksize 7 or 3, zero padding;  OH = (H + 2 pad - ksize) / stride + 1.
+ */
+int ia_im2col_split(const float* x, void* xs, int B, int C, int H, int W, int ksize, int stride, int pad, void* stream);
 int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, const float* bias, const float* residual, float* y, int M, int K, int N,
                  int act, void* stream);
 

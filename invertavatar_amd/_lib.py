@@ -79,6 +79,7 @@ _SIGNATURES = {
     'ia_attention_supported': [c_int] * 3,
     'ia_attention': [c_void_p] * 4 + [c_int] * 5 + [c_int64] * 8 + [c_float, c_void_p],
     'ia_tokens_split': [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    'ia_im2col_split': [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     'ia_linear_sx': [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'ia_uv_rasterize': [c_void_p] * 5 + [c_int] * 8 + [c_float, c_int, c_void_p],
     'ia_layout_grid_u8': [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],

@@ -73,6 +73,35 @@ __global__ __launch_bounds__(256) void tokens_split_kernel(const float* __restri
     }
 }
 
+// ---- patches of an NCHW image -> the split format of a token matrix: row m = (b, oy, ox), column k = (c, ky, kx) in the order of
+// conv.weight.reshape(N, C * ks * ks); columns K .. Kp - 1 (Kp = K rounded up to 16) are zero.  One thread = one (octet, row): eight
+// gathers (the image lives in L2), 16-byte stores that are contiguous over the rows of a workgroup.  blockIdx.y = the octet, so the
+// (c, ky, kx) of its eight columns are scalar arithmetic.
+template <int KS_>
+__global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restrict__ x, h16x8* __restrict__ xs, int B, int C, int H, int W, int OH, int OW,
+                                                           int stride, int pad, int K8) {
+    const int m = blockIdx.x * 256 + threadIdx.x, M = B * OH * OW, oct = blockIdx.y;
+    if (m >= M) return;
+    const int b = m / (OH * OW), r = m - b * OH * OW, oy = r / OW, ox = r - oy * OW;
+    const float* xb = x + (int64_t)b * C * H * W;
+    const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+    ia::SatWatch watch;
+    h16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = oct * 8 + j, c = k / (KS_ * KS_), t = k - c * (KS_ * KS_), ky = t / KS_, kx = t - ky * KS_;
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        const float v = (c < C && iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((int64_t)c * H + iy) * W + ix] : 0.f;
+        _Float16 h, l;
+        ia::split_f16(v, h, l, watch);
+        hi[j] = h;
+        lo[j] = l;
+    }
+    watch.report();
+    xs[(int64_t)oct * M + m] = hi;
+    xs[((int64_t)K8 + oct) * M + m] = lo;
+}
+
 struct LinParams {
     const h16x8* xs;         // [2][K8][M][8]
     const h16x8* ws;         // [2][K8][N][8], scaled by 2^wk_exp
@@ -250,6 +279,21 @@ extern "C" int ia_tokens_split(const float* x, void* xs, int M, int K, void* str
     hipLaunchKernelGGL(tokens_split_kernel, dim3((unsigned)((M + 31) / 32), (unsigned)((K8 + 7) / 8)), dim3(256), 0, (hipStream_t)stream, x,
                        static_cast<h16x8*>(xs), M, K8);
     return ia::check_launch("ia_tokens_split");
+}
+
+extern "C" int ia_im2col_split(const float* x, void* xs, int B, int C, int H, int W, int ksize, int stride, int pad, void* stream) {
+    IA_REQUIRE(x && xs, "x and xs must be device pointers");
+    IA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && stride > 0 && pad >= 0, "empty image");
+    if (ksize != 7 && ksize != 3) return ia::fail(IA_ERR_UNSUPPORTED, "ia_im2col_split covers 7x7 and 3x3 patches (got %d)", ksize);
+    const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
+    IA_REQUIRE(OH > 0 && OW > 0, "patch larger than the padded image");
+    const int64_t M = (int64_t)B * OH * OW, Kp = ((int64_t)C * ksize * ksize + 15) / 16 * 16;
+    IA_REQUIRE(M * Kp <= (int64_t)1 << 30 && Kp / 8 <= 65535, "matrix too large for 32-bit plane offsets");
+    const dim3 grid((unsigned)((M + 255) / 256), (unsigned)(Kp / 8));
+    const hipStream_t s = (hipStream_t)stream;
+    if (ksize == 7) hipLaunchKernelGGL(im2col_split_kernel<7>, grid, dim3(256), 0, s, x, static_cast<h16x8*>(xs), B, C, H, W, OH, OW, stride, pad, (int)(Kp / 8));
+    else hipLaunchKernelGGL(im2col_split_kernel<3>, grid, dim3(256), 0, s, x, static_cast<h16x8*>(xs), B, C, H, W, OH, OW, stride, pad, (int)(Kp / 8));
+    return ia::check_launch("ia_im2col_split");
 }
 
 extern "C" int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, const float* bias, const float* residual, float* y, int M, int K, int N,

@@ -18,6 +18,10 @@ HIP_DWCONV = True      # Mix-FFN's depth-wise 3x3 (+ GELU) on the token grid thr
 HIP_ATTENTION = True      # device inference: softmax(QK^T)V of the 1024-dim / 4-head blocks through ia_attention
 
 
+HIP_PATCH_EMBED = True      # device inference: OverlapPatchEmbed's strided convolution as ia_im2col_split + ia_linear_sx (tokens directly)
+HIP_PATCH_EMBED_MIN_TOKENS = 256
+
+
 HIP_LINEAR = True      # device inference: the blocks' nn.Linear layers (q / kv / proj, fc1 / fc2) as fp16-pair GEMMs through ia_linear_sx
 
 
@@ -209,6 +213,20 @@ class OverlapPatchEmbed(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x):
+        conv = self.proj
+        if (HIP_PATCH_EMBED and HIP_LINEAR and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and conv.kernel_size in ((7, 7), (3, 3)) and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
+                and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros' and isinstance(conv.padding, tuple)):
+            from .... import _runtime, hipops
+            xs = hipops.im2col_split(x.contiguous(), conv.kernel_size[0], conv.stride[0], conv.padding[0])
+            if xs.rows >= HIP_PATCH_EMBED_MIN_TOKENS:          # (fewer rows leave the GEMM a handful of workgroups for a very long K)
+                st = _runtime.state(conv)
+                key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.device)
+                if getattr(st, 'patch_w_key', None) != key:
+                    st.patch_w, st.patch_w_key = hipops.pack_patch_weight_split(conv.weight), key
+                H, W = xs.grid
+                tokens = hipops.linear_sx(xs, st.patch_w, None if conv.bias is None else conv.bias.detach())      # [B, H * W, C]: tokens directly
+                return self.norm(tokens), H, W
         x = self.proj(x)
         H, W = x.shape[-2:]
         return self.norm(x.flatten(2).transpose(1, 2)), H, W

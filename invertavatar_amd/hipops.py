@@ -1106,6 +1106,33 @@ def tokens_split(x):
     return SplitTokens(out, m, k, x.shape[:-1])
 
 
+def pack_patch_weight_split(w):
+    """Conv2d weight [N, C, k, k] -> pack_linear_weight_split of its [N, C*k*k] matrix, columns zero-padded to a multiple of 16: the
+    weight operand of linear_sx over im2col_split tokens."""
+    n = w.shape[0]
+    w2 = w.detach().reshape(n, -1)
+    kp = (w2.shape[1] + 15) // 16 * 16
+    if kp != w2.shape[1]:
+        w2 = torch.nn.functional.pad(w2, (0, kp - w2.shape[1]))
+    return pack_linear_weight_split(w2.contiguous())
+
+
+def im2col_split(x, ksize, stride, pad):
+    """NCHW fp32 image -> SplitTokens of its ksize x ksize patches (see ia_im2col_split); lead shape (B, OH * OW)."""
+    _f32c(x, 'x')
+    b, c, h, w = x.shape
+    oh, ow = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    kp = (c * ksize * ksize + 15) // 16 * 16
+    m = b * oh * ow
+    out = torch.empty(2, kp // 8, m, 8, device=x.device, dtype=torch.float16)
+    with torch.cuda.device(x.device), _Timed('im2col_split', 0.0, 4.0 * x.numel() + 4.0 * m * kp, f'B{b} C{c} {h}x{w} k{ksize} s{stride}'):
+        st = _lib.load().ia_im2col_split(_p(x), _p(out), b, c, h, w, int(ksize), int(stride), int(pad), _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_im2col_split')
+    t = SplitTokens(out, m, kp, (b, oh * ow))
+    t.grid = (oh, ow)
+    return t
+
+
 def linear_sx(xs, w_split, bias=None, residual=None, gelu=False):
     """act(x @ w^T + bias) + residual on the fp16-pair GEMM (see ia_linear_sx).  xs: SplitTokens; w_split: pack_linear_weight_split(w);
     residual: fp32 [..., N] like the output.  Returns fp32 [*lead, N]."""

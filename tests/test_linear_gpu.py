@@ -81,3 +81,38 @@ def test_transformer_block_on_hip_linears_matches_torch():
         finally:
             mt.HIP_LINEAR, mt.HIP_ATTENTION, mt.HIP_DWCONV = saved
     assert (got.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('b,c,h,ks,stride,n', [(1, 128, 64, 7, 2, 256), (2, 24, 40, 7, 4, 96), (1, 5, 33, 3, 2, 40), (1, 224, 32, 7, 2, 1024)])
+def test_patch_embedding_as_im2col_free_gemm(b, c, h, ks, stride, n):
+    """OverlapPatchEmbed's strided convolution (mix_transformer.py:155-190) through ia_im2col_split + ia_linear_sx: tokens [B, OH * OW, N]
+    against conv2d in fp64, flattened the reference's way; channel counts whose K = C * ks^2 is not a multiple of 16 are zero-padded."""
+    from conftest import rnd
+    from invertavatar_amd import hipops
+    x = rnd(80, b, c, h, h + 6).cuda()
+    w = (rnd(81, n, c, ks, ks) / (c * ks * ks) ** 0.5).cuda()
+    bias = rnd(82, n).cuda()
+    xs = hipops.im2col_split(x, ks, stride, ks // 2)
+    got = hipops.linear_sx(xs, hipops.pack_patch_weight_split(w), bias)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), stride=stride, padding=ks // 2)
+    assert xs.grid == tuple(ref.shape[-2:])
+    ref = ref.flatten(2).transpose(1, 2)
+    assert got.shape == ref.shape and (got.double() - ref).abs().max().item() <= 3e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_overlap_patch_embed_routes():
+    from invertavatar_amd.encoder_inversion.models.mmseg import mix_transformer as mt
+    from conftest import rnd
+    torch.manual_seed(1)
+    pe = mt.OverlapPatchEmbed(img_size=0, stride=2, in_chans=128, embed_dim=256).cuda().eval()
+    x = rnd(83, 1, 128, 48, 48).cuda()
+    with torch.no_grad():
+        got, H, W = pe(x)
+        saved = mt.HIP_PATCH_EMBED
+        try:
+            mt.HIP_PATCH_EMBED = False
+            ref, H2, W2 = pe(x)
+        finally:
+            mt.HIP_PATCH_EMBED = saved
+    assert (H, W) == (H2, W2) == (24, 24) and got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-5
