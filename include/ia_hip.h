@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split, ia_im2col_split, ia_linear_sx; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split / _t, ia_im2col_split, ia_linear_sx, ia_matmul_sx, ia_softmax_split; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -636,10 +636,10 @@ int ia_attention(const float* q, const float* k, const float* v, float* out, int
  * Attention.q / kv / proj -- nn.Linear on [B, tokens, C]; :158-190 the blocks that chain them) as fp32-equivalent GEMMs on the fp16
  * pipe: fp32 products from fp16 hi / lo pairs like the 3x3 convolutions (three v_mfma_f32_32x32x16_f16 per k-step, fp32
  * accumulation, lo x lo ~ 2^-22 dropped).  Replaces F.linear (rocBLAS fp32 GEMM) + bias [+ GELU] [+ the residual add of Block.forward].
- *   ia_tokens_split: x [M][K] float32 (M = B * tokens, rows contiguous) -> xs fp16 [2][K/8][M][8]: hi = fp16(v),
+ *   ia_tokens_split: x [M][K] float32 (M = B * tokens; rows `ld` floats apart, ld = K for a dense matrix) -> xs fp16 [2][K/8][M][8]: hi = fp16(v),
  *       lo = fp16((v - hi) * 2^11) -- the split format of the convolutions with the token in the pixel's place.  One call serves
  *       every linear layer that reads x (q and kv; fc1).  |v| >= 65504 saturates and raises the range-watch word
- *       (ia_split_saturation_poll).  K % 16 == 0, x 16-byte aligned, else IA_ERR_UNSUPPORTED.
+ *       (ia_split_saturation_poll).  K % 16 == 0, ld % 4 == 0, x 16-byte aligned, else IA_ERR_UNSUPPORTED.
  *   ia_linear_sx: y [M][N] float32 = act(xs . w^T * 2^-wk_exp + bias) + residual
  *       w_split : fp16 [2][1][K/8][N][8], the nn.Linear weight [N][K] as a 1x1 kernel in the convolution weight format
  *                 (hi = fp16(w * 2^wk_exp), lo = fp16(w * 2^wk_exp - hi); the host-side packing of ia_conv2d_mfma_s)
@@ -647,7 +647,7 @@ int ia_attention(const float* q, const float* k, const float* v, float* out, int
  *       act     : 0 none, 1 GELU (erf form, nn.GELU default)
  *       deterministic (fixed summation order for a given shape); no workspace.
  */
-int ia_tokens_split(const float* x, void* xs, int M, int K, void* stream);
+int ia_tokens_split(const float* x, int64_t ld, void* xs, int M, int K, void* stream);
 /*
  * The overlapping patch embeddings of the same encoders (mix_transformer.py:155-190 OverlapPatchEmbed: a 7x7 stride-2 / stride-4
  * convolution whose output is flattened to tokens) as im2col-free GEMMs: ia_im2col_split writes the patches of an NCHW float32 image
@@ -659,6 +659,27 @@ int ia_tokens_split(const float* x, void* xs, int M, int K, void* stream);
 int ia_im2col_split(const float* x, void* xs, int B, int C, int H, int W, int ksize, int stride, int pad, void* stream);
 int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, const float* bias, const float* residual, float* y, int M, int K, int N,
                  int act, void* stream);
+
+/*
+ * Attention of the same blocks on token grids too large for ia_attention (32^2 / 64^2 tokens: Attention.forward,
+ * mix_transformer.py:83-116 -- q @ k^T * scale, softmax, attn @ v as two batched rocBLAS GEMMs, an elementwise scale, a softmax over
+ * [heads, N, M] and the head permutes) as three launches on the fp16-pair GEMM, the score matrix in HBM once:
+ *   S[z] = scale * Q[z] K[z]^T   (ia_matmul_sx on ia_tokens_split(q), ia_tokens_split(k): head z = columns [z * hd, (z + 1) * hd))
+ *   P = softmax(S) written as the next product's operand  (ia_softmax_split)
+ *   O[:, z * hd : (z + 1) * hd] = P[z] V[z]   (ia_matmul_sx on P and ia_tokens_split_t(v)), straight into the [N, C] token layout.
+ * ia_tokens_split_t: v [M keys][ld] float32, C columns -> vt fp16 [2][M/8][C][8], octets ALONG THE KEYS (M % 16 == 0).
+ * ia_softmax_split: s [Z][N][M] float32 -> ps fp16 [2][Z][M/8][N][8]; M % 16 == 0, M <= 4096.
+ * ia_matmul_sx: y[z][m][n] = scale * sum_k a[z][m][k] b[z][n][k] for z < batch, both operands token-side splits (low parts at 2^11):
+ *   a_rows / b_rows      : rows of the split tensors the operands live in (their octet stride is rows * 16 bytes)
+ *   a_plane / b_plane    : bytes from the hi plane to the lo plane;  a_batch / b_batch: bytes per z inside a plane
+ *                          (head z of [2][C/8][rows][8]: z * (hd / 8) * rows * 16;  P: (M / 8) * N * 16;  vt: z * hd * 16)
+ *   y_batch_stride / y_row_stride in floats.  K % 16 == 0.  Deterministic; no workspace.
+ */
+int ia_tokens_split_t(const float* v, int64_t ld, void* vt, int M, int C, void* stream);
+int ia_softmax_split(const float* s, void* ps, int Z, int N, int M, void* stream);
+int ia_matmul_sx(const void* a_split, const void* b_split, float* y, int batch, int M, int N, int K, int a_rows, int64_t a_plane_bytes,
+                 int64_t a_batch_bytes, int b_rows, int64_t b_plane_bytes, int64_t b_batch_bytes, int64_t y_batch_stride, int64_t y_row_stride,
+                 float scale, void* stream);
 
 /*
  * Driver-side UV rasteriser: projected FaceVerse mesh -> uvcoords_image, the mesh condition of TriPlaneGenerator.synthesis.

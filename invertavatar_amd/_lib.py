@@ -78,7 +78,10 @@ _SIGNATURES = {
     'ia_se_gate_split': [c_void_p, _i64p, c_void_p, _i64p] + [c_void_p] * 7 + [c_int] * 5 + [c_void_p],
     'ia_attention_supported': [c_int] * 3,
     'ia_attention': [c_void_p] * 4 + [c_int] * 5 + [c_int64] * 8 + [c_float, c_void_p],
-    'ia_tokens_split': [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    'ia_tokens_split': [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p],
+    'ia_tokens_split_t': [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p],
+    'ia_softmax_split': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    'ia_matmul_sx': [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_int64, c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p],
     'ia_im2col_split': [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     'ia_linear_sx': [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'ia_uv_rasterize': [c_void_p] * 5 + [c_int] * 8 + [c_float, c_int, c_void_p],

@@ -39,7 +39,7 @@ __device__ __forceinline__ h16x8 lin_load16(__amdgpu_buffer_rsrc_t r, int voffse
 
 // ---- tokens [M][K] fp32 -> [2][K/8][M][8] fp16 pairs.  A workgroup turns 32 tokens x 8 octets: 256-byte runs of a token row in,
 // 512-byte runs of an octet plane out, the transposition through LDS.
-__global__ __launch_bounds__(256) void tokens_split_kernel(const float* __restrict__ x, h16x8* __restrict__ xs, int M, int K8) {
+__global__ __launch_bounds__(256) void tokens_split_kernel(const float* __restrict__ x, int64_t ld, h16x8* __restrict__ xs, int M, int K8) {
     __shared__ h16x8 s_hi[8][33], s_lo[8][33];
     const int tid = threadIdx.x;
     const int m0 = blockIdx.x * 32, o0 = blockIdx.y * 8;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void tokens_split_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; lo[j] = (_Float16)0.f; }
         if (m < M && o < K8) {
-            const float4* p = reinterpret_cast<const float4*>(x + (int64_t)m * K8 * 8 + o * 8);
+            const float4* p = reinterpret_cast<const float4*>(x + (int64_t)m * ld + o * 8);
             const float4 a = p[0], b = p[1];
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -102,6 +102,82 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restri
     xs[((int64_t)K8 + oct) * M + m] = lo;
 }
 
+struct NoWatch { __device__ __forceinline__ void see(float) const {} };
+
+// ---- V of an attention layer, split ALONG THE KEYS: v [M keys][ld] (C columns) -> [2][M/8][C][8]: the B operand of P . V, whose k index is
+// the key.  One thread = (key octet, column): eight reads that are contiguous over the columns of a wave, one 16-byte store per plane.
+__global__ __launch_bounds__(256) void tokens_split_t_kernel(const float* __restrict__ v, int64_t ld, h16x8* __restrict__ vt, int M8, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x, mo = blockIdx.y;
+    if (c >= C) return;
+    ia::SatWatch watch;
+    h16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        _Float16 h, l;
+        ia::split_f16(v[(int64_t)(mo * 8 + j) * ld + c], h, l, watch);
+        hi[j] = h;
+        lo[j] = l;
+    }
+    watch.report();
+    vt[(int64_t)mo * C + c] = hi;
+    vt[((int64_t)M8 + mo) * C + c] = lo;
+}
+
+// ---- softmax over the keys of one score row, written as the A operand of P . V: s [Z][N][M] fp32 (already scaled) -> [2][Z][M/8][N][8].
+// One wave per row: lane l holds the octets l, 64 + l, ... of its row (two 16-byte loads each), max and sum by wave reductions, the
+// probabilities leave as fp16 pairs.  The four waves of a workgroup take four consecutive rows.
+template <int IT>
+__global__ __launch_bounds__(256) void softmax_split_kernel(const float* __restrict__ s, h16x8* __restrict__ ps, int Z, int N, int M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= (int64_t)Z * N) return;
+    const int z = (int)(row / N), n = (int)(row - (int64_t)z * N), M8 = M >> 3;
+    const float4* sp = reinterpret_cast<const float4*>(s + row * M);
+    float v[IT][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int oct = i * 64 + lane;
+        const bool ok = oct < M8;
+        const float4 a = ok ? sp[oct * 2] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        const float4 b = ok ? sp[oct * 2 + 1] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w; v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[i][j]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[i][j] = expf(v[i][j] - mx);
+            sum += v[i][j];
+        }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    const float inv = 1.f / sum;
+    NoWatch nw;
+    h16x8* hi_p = ps + ((int64_t)z * M8) * N + n;
+    h16x8* lo_p = hi_p + (int64_t)Z * M8 * N;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int oct = i * 64 + lane;
+        if (oct >= M8) continue;
+        h16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 h, l;
+            ia::split_f16(v[i][j] * inv, h, l, nw);
+            hi[j] = h;
+            lo[j] = l;
+        }
+        hi_p[(int64_t)oct * N] = hi;
+        lo_p[(int64_t)oct * N] = lo;
+    }
+}
+
 struct LinParams {
     const h16x8* xs;         // [2][K8][M][8]
     const h16x8* ws;         // [2][K8][N][8], scaled by 2^wk_exp
@@ -111,6 +187,12 @@ struct LinParams {
     int M, N, K8;
     float acc_scale;         // 2^-wk_exp
     int gelu;
+    // general operand placement (ia_matmul_sx; the linear layers use the dense defaults): rows of the split tensors (the octet stride is
+    // rows * 16 bytes), bytes between the hi and lo planes, bytes per batch inside a plane; output row / batch strides in floats;
+    // b_lo_scaled: B's low parts carry 2^11 like A's (two token matrices) instead of the weights' unscaled ones
+    int a_rows, b_rows;
+    int64_t a_plane, b_plane, a_batch, b_batch, y_batch, ldy;
+    int b_lo_scaled;
 };
 
 __device__ __forceinline__ float lin_finish(float v, float bias, int gelu) {
@@ -128,23 +210,26 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinParams p) {    
     constexpr int TM = (KS > 1 ? 1 : 2) * 32 * FA, TN = (KS > 1 ? 1 : 2) * 32 * FB;
     const int m0 = blockIdx.y * TM + wm * 32 * FA, n0 = blockIdx.x * TN + wn * 32 * FB;
     const int steps = p.K8 >> 1;                                  // one k-step = 16 input features: lanes 0-31 the even octet, 32-63 the odd one
-    const unsigned a_plane = (unsigned)p.K8 * (unsigned)p.M * 16u, b_plane = (unsigned)p.K8 * (unsigned)p.N * 16u;
-    const char* ab = reinterpret_cast<const char*>(p.xs);
-    const char* bb = reinterpret_cast<const char*>(p.ws);
-    const __amdgpu_buffer_rsrc_t ra0 = lin_rsrc(ab, a_plane), ra1 = lin_rsrc(ab + a_plane, a_plane);
-    const __amdgpu_buffer_rsrc_t rb0 = lin_rsrc(bb, b_plane), rb1 = lin_rsrc(bb + b_plane, b_plane);
+    const int z = blockIdx.z;
+    const unsigned a_bytes = (unsigned)p.K8 * (unsigned)p.a_rows * 16u, b_bytes = (unsigned)p.K8 * (unsigned)p.b_rows * 16u;
+    const char* ab = reinterpret_cast<const char*>(p.xs) + z * p.a_batch;
+    const char* bb = reinterpret_cast<const char*>(p.ws) + z * p.b_batch;
+    const __amdgpu_buffer_rsrc_t ra0 = lin_rsrc(ab, a_bytes), ra1 = lin_rsrc(ab + p.a_plane, a_bytes);
+    const __amdgpu_buffer_rsrc_t rb0 = lin_rsrc(bb, b_bytes), rb1 = lin_rsrc(bb + p.b_plane, b_bytes);
     int a_off[FA], b_off[FB];
 #pragma unroll
     for (int f = 0; f < FA; ++f) {
         const int m = m0 + f * 32 + l31;
-        a_off[f] = m < p.M ? (half * p.M + m) * 16 : kOutside;
+        a_off[f] = m < p.M ? (half * p.a_rows + m) * 16 : kOutside;
     }
 #pragma unroll
     for (int f = 0; f < FB; ++f) {
         const int n = n0 + f * 32 + l31;
-        b_off[f] = n < p.N ? (half * p.N + n) * 16 : kOutside;
+        b_off[f] = n < p.N ? (half * p.b_rows + n) * 16 : kOutside;
     }
-    const int a_step = 2 * p.M * 16, b_step = 2 * p.N * 16;
+    const int a_step = 2 * p.a_rows * 16, b_step = 2 * p.b_rows * 16;
+    float* yz = p.y + z * p.y_batch;
+    const float b_sc_mul = p.b_lo_scaled ? 1.f : 1.0f / 2048.0f, x_mul = p.b_lo_scaled ? 1.0f / 2048.0f : 1.f;
 
     // two accumulators per fragment: the MFMA's accumulate truncates, so a chain of n MFMAs drifts by ~n / 2 ulp of the SUM (measured:
     // 3e-6 on 0.6 after 192 MFMAs in one register, 1e-6 after 48) -- the cross terms (2^-11 of the sum) get their own register and
@@ -187,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinParams p) {    
             const bool more = nxt < steps;
             h16x8 b_sc[FB];
 #pragma unroll
-            for (int j = 0; j < FB; ++j) b_sc[j] = qb[s][0][j] * (_Float16)(1.0f / 2048.0f);      // weight high parts at 2^-11 meet the tokens' low parts (at 2^11)
+            for (int j = 0; j < FB; ++j) b_sc[j] = qb[s][0][j] * (_Float16)b_sc_mul;      // weight high parts at 2^-11 meet the tokens' low parts (at 2^11); two token matrices: both cross terms stay at 2^11
 #pragma unroll
             for (int i = 0; i < FA; ++i)
 #pragma unroll
@@ -215,8 +300,8 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinParams p) {    
             for (int j = 0; j < FB; ++j)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq)
-                    pw[((i * FB + j) * 4 + rq) * 64] = make_float4(acc[i][j][4 * rq] + acx[i][j][4 * rq], acc[i][j][4 * rq + 1] + acx[i][j][4 * rq + 1],
-                                                                   acc[i][j][4 * rq + 2] + acx[i][j][4 * rq + 2], acc[i][j][4 * rq + 3] + acx[i][j][4 * rq + 3]);
+                    pw[((i * FB + j) * 4 + rq) * 64] = make_float4(acc[i][j][4 * rq] + acx[i][j][4 * rq] * x_mul, acc[i][j][4 * rq + 1] + acx[i][j][4 * rq + 1] * x_mul,
+                                                                   acc[i][j][4 * rq + 2] + acx[i][j][4 * rq + 2] * x_mul, acc[i][j][4 * rq + 3] + acx[i][j][4 * rq + 3] * x_mul);
         __syncthreads();
         constexpr int NQ = FA * FB * 4;
         for (int q = wave; q < NQ; q += 4) {
@@ -238,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinParams p) {    
                 if (m >= p.M) continue;
                 float o = lin_finish(vin[k] * p.acc_scale, bias, p.gelu);
                 if (p.residual) o += p.residual[(int64_t)m * p.N + n];
-                p.y[(int64_t)m * p.N + n] = o;
+                yz[(int64_t)m * p.ldy + n] = o;
             }
         }
     } else {
@@ -259,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinParams p) {    
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (m >= p.M) continue;
-                    p.y[(int64_t)m * p.N + n] = lin_finish((acc[i][j][r] + acx[i][j][r]) * p.acc_scale, bias, p.gelu) + res[r];
+                    yz[(int64_t)m * p.ldy + n] = lin_finish((acc[i][j][r] + acx[i][j][r] * x_mul) * p.acc_scale, bias, p.gelu) + res[r];
                 }
                 __builtin_amdgcn_sched_barrier(0);               // (one fragment's 32 accumulator registers through the VGPRs at a time)
             }
@@ -269,14 +354,14 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinParams p) {    
 
 }  // namespace
 
-extern "C" int ia_tokens_split(const float* x, void* xs, int M, int K, void* stream) {
+extern "C" int ia_tokens_split(const float* x, int64_t ld, void* xs, int M, int K, void* stream) {
     IA_REQUIRE(x && xs, "x and xs must be device pointers");
-    IA_REQUIRE(M > 0 && K > 0, "empty matrix");
-    if (K % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0)
-        return ia::fail(IA_ERR_UNSUPPORTED, "ia_tokens_split needs K %% 16 == 0 and a 16-byte aligned matrix (got K = %d)", K);
+    IA_REQUIRE(M > 0 && K > 0 && ld >= K, "empty matrix, or a row stride shorter than a row");
+    if (K % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || ld % 4 != 0)
+        return ia::fail(IA_ERR_UNSUPPORTED, "ia_tokens_split needs K %% 16 == 0, a row stride %% 4 == 0 and a 16-byte aligned matrix (got K = %d, ld = %lld)", K, (long long)ld);
     IA_REQUIRE((int64_t)M * K <= (int64_t)1 << 30, "matrix too large for 32-bit plane offsets");
     const int K8 = K / 8;
-    hipLaunchKernelGGL(tokens_split_kernel, dim3((unsigned)((M + 31) / 32), (unsigned)((K8 + 7) / 8)), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL(tokens_split_kernel, dim3((unsigned)((M + 31) / 32), (unsigned)((K8 + 7) / 8)), dim3(256), 0, (hipStream_t)stream, x, ld,
                        static_cast<h16x8*>(xs), M, K8);
     return ia::check_launch("ia_tokens_split");
 }
@@ -296,6 +381,62 @@ extern "C" int ia_im2col_split(const float* x, void* xs, int B, int C, int H, in
     return ia::check_launch("ia_im2col_split");
 }
 
+extern "C" int ia_tokens_split_t(const float* v, int64_t ld, void* vt, int M, int C, void* stream) {
+    IA_REQUIRE(v && vt, "v and vt must be device pointers");
+    IA_REQUIRE(M > 0 && C > 0 && ld >= C, "empty matrix, or a row stride shorter than a row");
+    if (M % 16 != 0) return ia::fail(IA_ERR_UNSUPPORTED, "ia_tokens_split_t needs M %% 16 == 0 (got %d)", M);
+    IA_REQUIRE((int64_t)M * C <= (int64_t)1 << 30 && M / 8 <= 65535, "matrix too large for 32-bit plane offsets");
+    hipLaunchKernelGGL(tokens_split_t_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)(M / 8)), dim3(256), 0, (hipStream_t)stream, v, ld,
+                       static_cast<h16x8*>(vt), M / 8, C);
+    return ia::check_launch("ia_tokens_split_t");
+}
+
+extern "C" int ia_softmax_split(const float* s, void* ps, int Z, int N, int M, void* stream) {
+    IA_REQUIRE(s && ps, "s and ps must be device pointers");
+    IA_REQUIRE(Z > 0 && N > 0 && M > 0, "empty matrix");
+    if (M % 16 != 0 || M > 4096 || (reinterpret_cast<uintptr_t>(s) & 15) != 0)
+        return ia::fail(IA_ERR_UNSUPPORTED, "ia_softmax_split covers rows of M %% 16 == 0, M <= 4096 keys (got %d)", M);
+    IA_REQUIRE((int64_t)Z * N * M <= (int64_t)1 << 31, "score tensor too large");
+    const dim3 grid((unsigned)(((int64_t)Z * N + 3) / 4));
+    const hipStream_t st = (hipStream_t)stream;
+    h16x8* out = static_cast<h16x8*>(ps);
+    const int it = (M / 8 + 63) / 64;
+    if (it <= 1) hipLaunchKernelGGL(softmax_split_kernel<1>, grid, dim3(256), 0, st, s, out, Z, N, M);
+    else if (it <= 2) hipLaunchKernelGGL(softmax_split_kernel<2>, grid, dim3(256), 0, st, s, out, Z, N, M);
+    else if (it <= 4) hipLaunchKernelGGL(softmax_split_kernel<4>, grid, dim3(256), 0, st, s, out, Z, N, M);
+    else hipLaunchKernelGGL(softmax_split_kernel<8>, grid, dim3(256), 0, st, s, out, Z, N, M);
+    return ia::check_launch("ia_softmax_split");
+}
+
+namespace {
+int lin_launch(const LinParams& p, int batch, hipStream_t s) {
+    // 128 x 128 workgroup tiles (four waves of 64 x 64) from one tile per CU up; below that one 32 x 64 tile per workgroup with K over its
+    // four waves (r06, tools/bench_linear.py: 4 096 x 1 024 x 1 024 39.5 vs 46.2 us, 1 024^3 31.0 vs 14.2; a 64 x 64 form of the first
+    // kind won nowhere)
+    static const int force = getenv("IA_LINEAR_TILE") ? atoi(getenv("IA_LINEAR_TILE")) : 0;
+    const bool big = force ? force == 2 : ia::ceil_div(p.M, 128) * ia::ceil_div(p.N, 128) * batch >= ia::kNumCU;
+    if (big)
+        hipLaunchKernelGGL((linear_split_kernel<2, 2, 1, 3>), dim3((unsigned)ia::ceil_div(p.N, 128), (unsigned)ia::ceil_div(p.M, 128), (unsigned)batch), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((linear_split_kernel<1, 2, 4, 3>), dim3((unsigned)ia::ceil_div(p.N, 64), (unsigned)ia::ceil_div(p.M, 32), (unsigned)batch), dim3(256), 0, s, p);
+    return IA_OK;
+}
+}  // namespace
+
+extern "C" int ia_matmul_sx(const void* a_split, const void* b_split, float* y, int batch, int M, int N, int K, int a_rows, int64_t a_plane_bytes,
+                            int64_t a_batch_bytes, int b_rows, int64_t b_plane_bytes, int64_t b_batch_bytes, int64_t y_batch_stride, int64_t y_row_stride,
+                            float scale, void* stream) {
+    IA_REQUIRE(a_split && b_split && y, "a_split, b_split and y must be device pointers");
+    IA_REQUIRE(batch > 0 && batch <= 65535 && M > 0 && N > 0 && K > 0, "empty product");
+    IA_REQUIRE(a_rows >= M && b_rows >= N && y_row_stride >= N, "rows of the split tensors / the output row stride are too short");
+    if (K % 16 != 0) return ia::fail(IA_ERR_UNSUPPORTED, "ia_matmul_sx needs K %% 16 == 0 (got %d)", K);
+    IA_REQUIRE((int64_t)a_rows * K <= (int64_t)1 << 30 && (int64_t)b_rows * K <= (int64_t)1 << 30, "matrix too large for 32-bit plane offsets");
+    LinParams p{static_cast<const h16x8*>(a_split), static_cast<const h16x8*>(b_split), nullptr, nullptr, y, M, N, K / 8, scale, 0,
+                a_rows, b_rows, a_plane_bytes, b_plane_bytes, a_batch_bytes, b_batch_bytes, y_batch_stride, y_row_stride, 1};
+    lin_launch(p, batch, (hipStream_t)stream);
+    return ia::check_launch("ia_matmul_sx");
+}
+
 extern "C" int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, const float* bias, const float* residual, float* y, int M, int K, int N,
                             int act, void* stream) {
     IA_REQUIRE(xs && w_split && y, "xs, w_split and y must be device pointers");
@@ -303,16 +444,8 @@ extern "C" int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, con
     IA_REQUIRE(act == 0 || act == 1, "act: 0 none, 1 GELU (erf)");
     if (K % 16 != 0) return ia::fail(IA_ERR_UNSUPPORTED, "ia_linear_sx needs K %% 16 == 0 (got %d)", K);
     IA_REQUIRE((int64_t)M * K <= (int64_t)1 << 30 && (int64_t)N * K <= (int64_t)1 << 30, "matrix too large for 32-bit plane offsets");
-    LinParams p{static_cast<const h16x8*>(xs), static_cast<const h16x8*>(w_split), bias, residual, y, M, N, K / 8, ldexpf(1.f, -wk_exp), act};
-    const hipStream_t s = (hipStream_t)stream;
-    // 128 x 128 workgroup tiles (four waves of 64 x 64) from one tile per CU up; below that one 32 x 64 tile per workgroup with K over its
-    // four waves (r06, tools/bench_linear.py: 4 096 x 1 024 x 1 024 39.5 vs 46.2 us, 1 024^3 31.0 vs 14.2; a 64 x 64 form of the first
-    // kind won nowhere)
-    static const int force = getenv("IA_LINEAR_TILE") ? atoi(getenv("IA_LINEAR_TILE")) : 0;
-    const bool big = force ? force == 2 : ia::ceil_div(M, 128) * ia::ceil_div(N, 128) >= ia::kNumCU;
-    if (big)
-        hipLaunchKernelGGL((linear_split_kernel<2, 2, 1, 3>), dim3((unsigned)ia::ceil_div(N, 128), (unsigned)ia::ceil_div(M, 128)), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL((linear_split_kernel<1, 2, 4, 3>), dim3((unsigned)ia::ceil_div(N, 64), (unsigned)ia::ceil_div(M, 32)), dim3(256), 0, s, p);
+    LinParams p{static_cast<const h16x8*>(xs), static_cast<const h16x8*>(w_split), bias, residual, y, M, N, K / 8, ldexpf(1.f, -wk_exp), act,
+                M, N, (int64_t)(K / 8) * M * 16, (int64_t)(K / 8) * N * 16, 0, 0, 0, N, 0};
+    lin_launch(p, 1, (hipStream_t)stream);
     return ia::check_launch("ia_linear_sx");
 }

@@ -173,6 +173,8 @@ class Attention(nn.Module):
             from .... import _lib, hipops
             if _lib.load().ia_attention_supported(hd, N, kv.shape[1]):      # one launch: no [N, M] score matrix, no head permutes
                 return project(hipops.attention(qp.contiguous(), kv.contiguous(), heads, self.scale))
+            if HIP_LINEAR and hipops.attention_sx_supported(hd, N, kv.shape[1]):      # larger grids: the two products on the fp16-pair GEMM
+                return project(hipops.attention_sx(qp.contiguous(), kv.contiguous(), heads, self.scale))
         q = qp.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
         k, v = kv.reshape(B, -1, 2, heads, hd).permute(2, 0, 3, 1, 4)
         attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1))

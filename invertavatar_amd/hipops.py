@@ -1095,15 +1095,55 @@ def pack_linear_weight_split(w):
 
 
 def tokens_split(x):
-    """fp32 [..., K] (rows contiguous) -> SplitTokens (see ia_tokens_split).  One split serves every linear layer that reads x."""
-    _f32c(x, 'x')
+    """fp32 [..., K] (rows contiguous, or a column slice of such a tensor: rows x.stride(-2) apart) -> SplitTokens (see ia_tokens_split).
+    One split serves every linear layer that reads x."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.stride(-1) == 1):
+        raise RuntimeError('tokens_split: x must be a float32 device tensor with contiguous rows')
     k = x.shape[-1]
     m = x.numel() // k
+    ld = k
+    if not x.is_contiguous():
+        ld = x.stride(-2)
+        if x.dim() < 2 or any(x.stride(d) != x.stride(d + 1) * x.shape[d + 1] for d in range(x.dim() - 2)):
+            raise RuntimeError('tokens_split: rows must be evenly spaced')
     out = torch.empty(2, k // 8, m, 8, device=x.device, dtype=torch.float16)
     with torch.cuda.device(x.device), _Timed('tokens_split', 0.0, 8.0 * x.numel(), f'M{m} K{k}'):
-        st = _lib.load().ia_tokens_split(_p(x), _p(out), m, k, _lib.stream_ptr(x.device))
+        st = _lib.load().ia_tokens_split(_p(x), int(ld), _p(out), m, k, _lib.stream_ptr(x.device))
     _lib.check(st, 'ia_tokens_split')
     return SplitTokens(out, m, k, x.shape[:-1])
+
+
+def attention_sx_supported(head_dim, n, m):
+    return head_dim % 16 == 0 and m % 16 == 0 and m <= 4096
+
+
+def attention_sx(q, kv, heads, scale):
+    """softmax(Q K^T * scale) V per head through the fp16-pair GEMM (see ia_matmul_sx): q [B, N, C], kv [B, M, 2C] (k = kv[..., :C],
+    v = kv[..., C:]); returns [B, N, C].  The score matrix [heads, N, M] passes through HBM once (fp32) and once as fp16 pairs."""
+    _f32c(q, 'q')
+    _f32c(kv, 'kv')
+    b, n, c = q.shape
+    m = kv.shape[1]
+    hd = c // heads
+    if kv.shape[0] != b or kv.shape[2] != 2 * c or c % heads or not attention_sx_supported(hd, n, m):
+        raise RuntimeError(f'attention_sx: q {tuple(q.shape)} / kv {tuple(kv.shape)} / {heads} heads are not covered')
+    lib, dev = _lib.load(), q.device
+    out = torch.empty_like(q)
+    with torch.cuda.device(dev), _Timed('attention_sx', 4.0 * b * n * m * c, 4.0 * (q.numel() + kv.numel() + out.numel()) + 16.0 * b * heads * n * m,
+                                        f'B{b} N{n} M{m} C{c}'):
+        s_ = _lib.stream_ptr(dev)
+        scores = torch.empty(heads, n, m, device=dev, dtype=torch.float32)
+        probs = torch.empty(2, heads, m // 8, n, 8, device=dev, dtype=torch.float16)
+        vt = torch.empty(2, m // 8, c, 8, device=dev, dtype=torch.float16)
+        for i in range(b):
+            qs, ks = tokens_split(q[i]), tokens_split(kv[i, :, :c])
+            _lib.check(lib.ia_tokens_split_t(kv[i, :, c:].data_ptr(), kv.stride(1), _p(vt), m, c, s_), 'ia_tokens_split_t')
+            _lib.check(lib.ia_matmul_sx(_p(qs.data), _p(ks.data), _p(scores), heads, n, m, hd, n, (c // 8) * n * 16, (hd // 8) * n * 16,
+                                        m, (c // 8) * m * 16, (hd // 8) * m * 16, n * m, m, float(scale), s_), 'ia_matmul_sx')
+            _lib.check(lib.ia_softmax_split(_p(scores), _p(probs), heads, n, m, s_), 'ia_softmax_split')
+            _lib.check(lib.ia_matmul_sx(_p(probs), _p(vt), _p(out[i]), heads, n, hd, m, n, heads * (m // 8) * n * 16, (m // 8) * n * 16,
+                                        c, (m // 8) * c * 16, hd * 16, hd, c, 1.0, s_), 'ia_matmul_sx')
+    return out
 
 
 def pack_patch_weight_split(w):

@@ -116,3 +116,39 @@ def test_overlap_patch_embed_routes():
             mt.HIP_PATCH_EMBED = saved
     assert (H, W) == (H2, W2) == (24, 24) and got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize('b,n,m,c,heads', [(1, 1024, 1024, 1024, 4), (2, 100, 48, 64, 2), (1, 77, 4096, 512, 2), (1, 300, 160, 256, 1)])
+def test_attention_on_the_fp16_pair_gemm(b, n, m, c, heads):
+    """hipops.attention_sx (ia_tokens_split / _t, ia_matmul_sx, ia_softmax_split) against Attention.forward's arithmetic in fp64
+    (mix_transformer.py:83-116: q @ k^T * scale, softmax over the keys, @ v, heads back into the token layout)."""
+    from conftest import rnd
+    from invertavatar_amd import hipops
+    q, kv = rnd(90, b, n, c).cuda(), rnd(91, b, m, 2 * c).cuda()
+    hd = c // heads
+    scale = hd ** -0.5
+    got = hipops.attention_sx(q, kv, heads, scale)
+    qd = q.double().reshape(b, n, heads, hd).permute(0, 2, 1, 3)
+    k, v = kv.double().reshape(b, m, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = (((qd @ k.transpose(-2, -1)) * scale).softmax(dim=-1) @ v).transpose(1, 2).reshape(b, n, c)
+    assert got.shape == ref.shape and (got.double() - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_attention_module_routes_large_grids_through_the_gemm():
+    from invertavatar_amd.encoder_inversion.models.mmseg import mix_transformer as mt
+    from conftest import rnd
+    torch.manual_seed(2)
+    att = mt.Attention(1024, num_heads=4, sr_ratio=1).cuda().eval()
+    for p in att.parameters():
+        if p.dim() == 2:
+            p.data.normal_(0, 0.03)
+    x = rnd(92, 1, 1024, 1024).cuda()
+    with torch.no_grad():
+        got = att(x, 32, 32)
+        saved = mt.HIP_LINEAR, mt.HIP_ATTENTION
+        try:
+            mt.HIP_LINEAR = mt.HIP_ATTENTION = False
+            ref = att.double()(x.double(), 32, 32)
+        finally:
+            mt.HIP_LINEAR, mt.HIP_ATTENTION = saved
+    assert (got.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
