@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split / _t, ia_im2col_split, ia_linear_sx, ia_matmul_sx, ia_softmax_split; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split / _t, ia_im2col_split, ia_linear_sx / _splitk / _splitk_plan, ia_matmul_sx, ia_softmax_split; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -657,6 +657,14 @@ int ia_tokens_split(const float* x, int64_t ld, void* xs, int M, int K, void* st
  *   xs: fp16 [2][Kp/8][M][8];  ksize 7 or 3, zero padding;  OH = (H + 2 pad - ksize) / stride + 1.
  */
 int ia_im2col_split(const float* x, void* xs, int B, int C, int H, int W, int ksize, int stride, int pad, void* stream);
+/*
+ * The same product with K cut into `ksplit` slices over the launch (few rows, very long K: the deepest patch embedding is 64 tokens x
+ * 50 176 x 1 024): slice products into scratch [ksplit][M][N], then one pass sums them in slice order and adds the bias.
+ * ia_linear_splitk_plan gives the split the library would choose (1 = none) and the scratch it needs; K % (16 * ksplit) == 0.
+ */
+int ia_linear_splitk_plan(int M, int K, int N, int* ksplit, size_t* scratch_bytes);
+int ia_linear_sx_splitk(const void* xs, const void* w_split, int wk_exp, const float* bias, float* y, int M, int K, int N, int ksplit,
+                        float* scratch, size_t scratch_bytes, void* stream);
 int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, const float* bias, const float* residual, float* y, int M, int K, int N,
                  int act, void* stream);
 

@@ -83,6 +83,8 @@ _SIGNATURES = {
     'ia_softmax_split': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'ia_matmul_sx': [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_int64, c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p],
     'ia_im2col_split': [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+    'ia_linear_splitk_plan': [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_size_t)],
+    'ia_linear_sx_splitk': [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, ctypes.c_size_t, c_void_p],
     'ia_linear_sx': [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'ia_uv_rasterize': [c_void_p] * 5 + [c_int] * 8 + [c_float, c_int, c_void_p],
     'ia_layout_grid_u8': [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],

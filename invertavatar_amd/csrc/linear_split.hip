@@ -437,6 +437,50 @@ extern "C" int ia_matmul_sx(const void* a_split, const void* b_split, float* y, 
     return ia::check_launch("ia_matmul_sx");
 }
 
+namespace {
+// partial products of a K-split linear layer [S][M * N] -> y = sum over s (in order) + bias
+__global__ __launch_bounds__(256) void linear_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
+                                                            int S, int64_t MN, int N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float v = part[i];
+    for (int s = 1; s < S; ++s) v += part[(int64_t)s * MN + i];
+    y[i] = v + (bias ? bias[i % N] : 0.f);
+}
+}  // namespace
+
+extern "C" int ia_linear_splitk_plan(int M, int K, int N, int* ksplit, size_t* scratch_bytes) {
+    IA_REQUIRE(ksplit && scratch_bytes, "ksplit and scratch_bytes must be host pointers");
+    IA_REQUIRE(M > 0 && K > 0 && N > 0, "empty matrix");
+    // few output tiles and a long K (the deepest patch embedding: 64 tokens x 50 176 x 1 024): cut K until the launch has ~2 workgroups per CU,
+    // every slice a whole number of k-steps and at least 64 of them
+    const int64_t tiles = ia::ceil_div(M, 32) * ia::ceil_div(N, 64);
+    int s = 1;
+    if (K % 16 == 0 && tiles < ia::kNumCU)
+        while (s < 64 && tiles * s < 2 * ia::kNumCU && (K / 16) % (2 * s) == 0 && K / 16 / (2 * s) >= 64) s *= 2;
+    *ksplit = s;
+    *scratch_bytes = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    return IA_OK;
+}
+
+extern "C" int ia_linear_sx_splitk(const void* xs, const void* w_split, int wk_exp, const float* bias, float* y, int M, int K, int N, int ksplit,
+                                   float* scratch, size_t scratch_bytes, void* stream) {
+    IA_REQUIRE(xs && w_split && y, "xs, w_split and y must be device pointers");
+    IA_REQUIRE(M > 0 && K > 0 && N > 0 && ksplit >= 1 && ksplit <= 65535, "empty matrix or split count");
+    if (K % (16 * ksplit) != 0) return ia::fail(IA_ERR_UNSUPPORTED, "ia_linear_sx_splitk needs K %% (16 * ksplit) == 0 (got %d, %d)", K, ksplit);
+    IA_REQUIRE((int64_t)M * K <= (int64_t)1 << 30 && (int64_t)N * K <= (int64_t)1 << 30, "matrix too large for 32-bit plane offsets");
+    if (ksplit == 1) return ia_linear_sx(xs, w_split, wk_exp, bias, nullptr, y, M, K, N, 0, stream);
+    IA_REQUIRE(scratch && scratch_bytes >= (size_t)ksplit * M * N * sizeof(float), "scratch of ksplit * M * N floats (ia_linear_splitk_plan)");
+    const int k8s = K / 8 / ksplit;
+    LinParams p{static_cast<const h16x8*>(xs), static_cast<const h16x8*>(w_split), nullptr, nullptr, scratch, M, N, k8s, ldexpf(1.f, -wk_exp), 0,
+                M, N, (int64_t)(K / 8) * M * 16, (int64_t)(K / 8) * N * 16, (int64_t)k8s * M * 16, (int64_t)k8s * N * 16, (int64_t)M * N, N, 0};
+    const hipStream_t s = (hipStream_t)stream;
+    lin_launch(p, ksplit, s);
+    const int64_t mn = (int64_t)M * N;
+    hipLaunchKernelGGL(linear_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, scratch, bias, y, ksplit, mn, N);
+    return ia::check_launch("ia_linear_sx_splitk");
+}
+
 extern "C" int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, const float* bias, const float* residual, float* y, int M, int K, int N,
                             int act, void* stream) {
     IA_REQUIRE(xs && w_split && y, "xs, w_split and y must be device pointers");

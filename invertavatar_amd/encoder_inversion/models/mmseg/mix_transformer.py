@@ -19,7 +19,7 @@ HIP_ATTENTION = True      # device inference: softmax(QK^T)V of the 1024-dim / 4
 
 
 HIP_PATCH_EMBED = True      # device inference: OverlapPatchEmbed's strided convolution as ia_im2col_split + ia_linear_sx (tokens directly)
-HIP_PATCH_EMBED_MIN_TOKENS = 256
+HIP_PATCH_EMBED_MIN_TOKENS = 1
 
 
 HIP_LINEAR = True      # device inference: the blocks' nn.Linear layers (q / kv / proj, fc1 / fc2) as fp16-pair GEMMs through ia_linear_sx
@@ -221,13 +221,13 @@ class OverlapPatchEmbed(nn.Module):
                 and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros' and isinstance(conv.padding, tuple)):
             from .... import _runtime, hipops
             xs = hipops.im2col_split(x.contiguous(), conv.kernel_size[0], conv.stride[0], conv.padding[0])
-            if xs.rows >= HIP_PATCH_EMBED_MIN_TOKENS:          # (fewer rows leave the GEMM a handful of workgroups for a very long K)
+            if xs.rows >= HIP_PATCH_EMBED_MIN_TOKENS:          # (few rows and a very long K: linear_sx_splitk cuts K over the launch)
                 st = _runtime.state(conv)
                 key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.device)
                 if getattr(st, 'patch_w_key', None) != key:
                     st.patch_w, st.patch_w_key = hipops.pack_patch_weight_split(conv.weight), key
                 H, W = xs.grid
-                tokens = hipops.linear_sx(xs, st.patch_w, None if conv.bias is None else conv.bias.detach())      # [B, H * W, C]: tokens directly
+                tokens = hipops.linear_sx_splitk(xs, st.patch_w, None if conv.bias is None else conv.bias.detach())      # [B, H * W, C]: tokens directly
                 return self.norm(tokens), H, W
         x = self.proj(x)
         H, W = x.shape[-2:]

@@ -1173,6 +1173,25 @@ def im2col_split(x, ksize, stride, pad):
     return t
 
 
+def linear_sx_splitk(xs, w_split, bias=None):
+    """linear_sx with K cut over the launch when the library's plan says so (few rows, very long K; see ia_linear_sx_splitk)."""
+    k8, n = w_split.shape[2], w_split.shape[3]
+    ks, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)
+    _lib.check(_lib.load().ia_linear_splitk_plan(xs.rows, xs.cols, n, ctypes.byref(ks), ctypes.byref(nbytes)), 'ia_linear_splitk_plan')
+    if ks.value <= 1:
+        return linear_sx(xs, w_split, bias)
+    if k8 * 8 != xs.cols:
+        raise RuntimeError(f'linear_sx_splitk: {xs.cols} input features against a weight of {k8 * 8}')
+    y = torch.empty(*xs.lead_shape, n, device=xs.data.device, dtype=torch.float32)
+    scratch = torch.empty(nbytes.value // 4, device=y.device, dtype=torch.float32)
+    with torch.cuda.device(y.device), _Timed('linear_sx', 2.0 * xs.rows * xs.cols * n, 4.0 * (xs.rows * xs.cols + xs.cols * n + y.numel()),
+                                             f'M{xs.rows} K{xs.cols} N{n} splitk{ks.value}'):
+        st = _lib.load().ia_linear_sx_splitk(_p(xs.data), _p(w_split), int(w_split.wk_exp), _p(None if bias is None else _f32c(bias, 'bias')), _p(y),
+                                             xs.rows, xs.cols, n, ks.value, _p(scratch), nbytes.value, _lib.stream_ptr(y.device))
+    _lib.check(st, 'ia_linear_sx_splitk')
+    return y
+
+
 def linear_sx(xs, w_split, bias=None, residual=None, gelu=False):
     """act(x @ w^T + bias) + residual on the fp16-pair GEMM (see ia_linear_sx).  xs: SplitTokens; w_split: pack_linear_weight_split(w);
     residual: fp32 [..., N] like the output.  Returns fp32 [*lead, N]."""

@@ -152,3 +152,23 @@ def test_attention_module_routes_large_grids_through_the_gemm():
         finally:
             mt.HIP_LINEAR, mt.HIP_ATTENTION = saved
     assert (got.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_linear_with_k_cut_over_the_launch():
+    """Few rows x a very long K (the deepest patch embedding): ia_linear_splitk_plan cuts K, slice products are summed in slice order."""
+    import ctypes
+    from conftest import rnd
+    from invertavatar_amd import _lib, hipops
+    m, k, n = 64, 50176, 256
+    x, w, bias = rnd(95, 1, m, k).cuda(), (rnd(96, n, k) * 0.01).cuda(), rnd(97, n).cuda()
+    ks, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)
+    _lib.check(_lib.load().ia_linear_splitk_plan(m, k, n, ctypes.byref(ks), ctypes.byref(nbytes)), 'plan')
+    assert ks.value > 1 and nbytes.value == ks.value * m * n * 4 and k % (16 * ks.value) == 0
+    xs, ws = hipops.tokens_split(x), hipops.pack_linear_weight_split(w)
+    got = hipops.linear_sx_splitk(xs, ws, bias)
+    ref = x.double() @ w.double().t() + bias.double()
+    bound = x.double().abs() @ w.double().abs().t()
+    assert got.shape == ref.shape and ((got.double() - ref).abs() <= 5e-7 * bound + 1e-6).all()
+    assert torch.equal(got, hipops.linear_sx_splitk(xs, ws, bias))
+    _lib.check(_lib.load().ia_linear_splitk_plan(4096, 1024, 1024, ctypes.byref(ks), ctypes.byref(nbytes)), 'plan')
+    assert ks.value == 1 and nbytes.value == 0
