@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split / _t, ia_im2col_split, ia_linear_sx / _splitk / _splitk_plan, ia_matmul_sx, ia_softmax_split; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split / _t, ia_layernorm_split, ia_im2col_split, ia_linear_sx / _splitk / _splitk_plan, ia_matmul_sx, ia_softmax_split; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -648,6 +648,12 @@ int ia_attention(const float* q, const float* k, const float* v, float* out, int
  *       deterministic (fixed summation order for a given shape); no workspace.
  */
 int ia_tokens_split(const float* x, int64_t ld, void* xs, int M, int K, void* stream);
+/*
+ * nn.LayerNorm over the last dimension + ia_tokens_split of its result in one launch (Block.forward, mix_transformer.py:140-142: norm1
+ * feeds only q / kv, norm2 only fc1): xs = split((x - mean) * rsqrt(var + eps) * gamma + beta), biased variance, two passes in fp32.
+ * x [M][K] float32 dense; K 512, 1024 or 2048; gamma, beta [K].
+ */
+int ia_layernorm_split(const float* x, const float* gamma, const float* beta, float eps, void* xs, int M, int K, void* stream);
 /*
  * The overlapping patch embeddings of the same encoders (mix_transformer.py:155-190 OverlapPatchEmbed: a 7x7 stride-2 / stride-4
  * convolution whose output is flattened to tokens) as im2col-free GEMMs: ia_im2col_split writes the patches of an NCHW float32 image

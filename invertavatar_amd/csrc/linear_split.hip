@@ -102,6 +102,80 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restri
     xs[((int64_t)K8 + oct) * M + m] = lo;
 }
 
+// ---- LayerNorm over the features of a token + the split of its result (Block.forward: norm1 -> q / kv, norm2 -> fc1: the normalised
+// tokens have no other reader).  One wave per token, OPL = K / 512 octets per lane (octets l, 64 + l, ...: 2 KB runs of the row), mean and
+// variance in two passes over the registers (wave reductions), then (x - mean) * rstd * gamma + beta as fp16 pairs.  A workgroup takes
+// 16 consecutive tokens, four per wave, and hands them over through LDS so that the stores are 256-byte runs of an octet plane.
+template <int OPL>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              h16x8* __restrict__ xs, int M, float eps) {
+    constexpr int K8 = OPL * 64, K = K8 * 8;
+    extern __shared__ __attribute__((aligned(16))) h16x8 s_ln[];        // [2 planes][K8][16 tokens]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 16;
+    float g[OPL][8], bt[OPL][8];
+#pragma unroll
+    for (int i = 0; i < OPL; ++i) {
+        const float4* gp = reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 8);
+        const float4* bp = reinterpret_cast<const float4*>(beta + (i * 64 + lane) * 8);
+        const float4 a = gp[0], b = gp[1], c = bp[0], d = bp[1];
+        g[i][0] = a.x; g[i][1] = a.y; g[i][2] = a.z; g[i][3] = a.w; g[i][4] = b.x; g[i][5] = b.y; g[i][6] = b.z; g[i][7] = b.w;
+        bt[i][0] = c.x; bt[i][1] = c.y; bt[i][2] = c.z; bt[i][3] = c.w; bt[i][4] = d.x; bt[i][5] = d.y; bt[i][6] = d.z; bt[i][7] = d.w;
+    }
+    ia::SatWatch watch;
+    for (int t = 0; t < 4; ++t) {
+        const int ml = wave * 4 + t, m = m0 + ml;
+        if (m >= M) break;
+        float v[OPL][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < OPL; ++i) {
+            const float4* p = reinterpret_cast<const float4*>(x + (int64_t)m * K + (i * 64 + lane) * 8);
+            const float4 a = p[0], b = p[1];
+            v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w; v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[i][j];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        const float mean = sum * (1.f / K);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < OPL; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] -= mean;
+                sq = fmaf(v[i][j], v[i][j], sq);
+            }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sq += __shfl_xor(sq, d);
+        const float rstd = rsqrtf(sq * (1.f / K) + eps);
+#pragma unroll
+        for (int i = 0; i < OPL; ++i) {
+            h16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 h, l;
+                ia::split_f16(v[i][j] * rstd * g[i][j] + bt[i][j], h, l, watch);
+                hi[j] = h;
+                lo[j] = l;
+            }
+            s_ln[(i * 64 + lane) * 16 + ml] = hi;
+            s_ln[(K8 + i * 64 + lane) * 16 + ml] = lo;
+        }
+    }
+    watch.report();
+    __syncthreads();
+    // 256 threads = 16 octets x 16 tokens per pass
+    const int ml = threadIdx.x & 15, m = m0 + ml;
+    if (m < M) {
+        for (int o = threadIdx.x >> 4; o < K8; o += 16) {
+            xs[(int64_t)o * M + m] = s_ln[o * 16 + ml];
+            xs[((int64_t)K8 + o) * M + m] = s_ln[(K8 + o) * 16 + ml];
+        }
+    }
+}
+
 struct NoWatch { __device__ __forceinline__ void see(float) const {} };
 
 // ---- V of an attention layer, split ALONG THE KEYS: v [M keys][ld] (C columns) -> [2][M/8][C][8]: the B operand of P . V, whose k index is
@@ -379,6 +453,24 @@ extern "C" int ia_im2col_split(const float* x, void* xs, int B, int C, int H, in
     if (ksize == 7) hipLaunchKernelGGL(im2col_split_kernel<7>, grid, dim3(256), 0, s, x, static_cast<h16x8*>(xs), B, C, H, W, OH, OW, stride, pad, (int)(Kp / 8));
     else hipLaunchKernelGGL(im2col_split_kernel<3>, grid, dim3(256), 0, s, x, static_cast<h16x8*>(xs), B, C, H, W, OH, OW, stride, pad, (int)(Kp / 8));
     return ia::check_launch("ia_im2col_split");
+}
+
+extern "C" int ia_layernorm_split(const float* x, const float* gamma, const float* beta, float eps, void* xs, int M, int K, void* stream) {
+    IA_REQUIRE(x && gamma && beta && xs, "x, gamma, beta and xs must be device pointers");
+    IA_REQUIRE(M > 0 && K > 0, "empty matrix");
+    if (!(K == 512 || K == 1024 || K == 2048) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) != 0)
+        return ia::fail(IA_ERR_UNSUPPORTED, "ia_layernorm_split covers 512, 1024 and 2048 features on 16-byte aligned arrays (got K = %d)", K);
+    IA_REQUIRE((int64_t)M * K <= (int64_t)1 << 30, "matrix too large for 32-bit plane offsets");
+    const size_t lds = (size_t)2 * (K / 8) * 16 * 16;
+    const dim3 grid((unsigned)((M + 15) / 16));
+    const hipStream_t s = (hipStream_t)stream;
+    h16x8* out = static_cast<h16x8*>(xs);
+    auto go = [&](auto kern) -> int {
+        if (const int st = ia::reserve_lds((const void*)kern, lds, "ia_layernorm_split")) return st;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, gamma, beta, out, M, eps);
+        return ia::check_launch("ia_layernorm_split");
+    };
+    return K == 512 ? go(layernorm_split_kernel<1>) : K == 1024 ? go(layernorm_split_kernel<2>) : go(layernorm_split_kernel<4>);
 }
 
 extern "C" int ia_tokens_split_t(const float* v, int64_t ld, void* vt, int M, int C, void* stream) {

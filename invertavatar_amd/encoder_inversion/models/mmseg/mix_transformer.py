@@ -22,12 +22,26 @@ HIP_PATCH_EMBED = True      # device inference: OverlapPatchEmbed's strided conv
 HIP_PATCH_EMBED_MIN_TOKENS = 1
 
 
+HIP_LAYERNORM_SPLIT = True      # device inference: a block's LayerNorm inside the token split of the linear layers that read it
+
+
 HIP_LINEAR = True      # device inference: the blocks' nn.Linear layers (q / kv / proj, fc1 / fc2) as fp16-pair GEMMs through ia_linear_sx
 
 
 def _hip_linear_ok(x, *linears):
     return (HIP_LINEAR and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
             and all(m.in_features % 16 == 0 and m.weight.dtype == torch.float32 for m in linears))
+
+
+def _split_normed(x, norm):
+    """tokens_split(norm(x)): one launch when `norm` is a plain LayerNorm over a width ia_layernorm_split covers."""
+    from .... import hipops
+    if norm is None:
+        return hipops.tokens_split(x.contiguous())
+    if (HIP_LAYERNORM_SPLIT and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None and len(norm.normalized_shape) == 1
+            and hipops.layernorm_split_supported(x.shape[-1])):
+        return hipops.layernorm_split(x.contiguous(), norm)
+    return hipops.tokens_split(norm(x).contiguous())
 
 
 def _hip_linear(lin, xs, gelu=False, residual=None):
@@ -112,13 +126,16 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
         self.apply(_init_weights)
 
-    def forward(self, x, H, W, residual=None):
-        """`residual`: added to the result (Block.forward's x + mlp(norm2(x)); in fc2's epilogue on the device path)."""
+    def forward(self, x, H, W, residual=None, norm=None):
+        """`residual`: added to the result (Block.forward's x + mlp(norm2(x)); in fc2's epilogue on the device path).  `norm`: a LayerNorm to
+        apply to x first (Block.forward's norm2; on the device path inside the token split of fc1's input)."""
         exact_gelu = isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none'
         if exact_gelu and _hip_linear_ok(x, self.fc1, self.fc2) and not (self.training and self.drop.p > 0):
             from .... import hipops
-            h = self.dwconv(_hip_linear(self.fc1, hipops.tokens_split(x.contiguous())), H, W, gelu=True)
+            h = self.dwconv(_hip_linear(self.fc1, _split_normed(x, norm)), H, W, gelu=True)
             return _hip_linear(self.fc2, hipops.tokens_split(h.contiguous()), residual=None if residual is None else residual.contiguous())
+        if norm is not None:
+            x = norm(x)
         if exact_gelu:
             y = self.drop(self.fc2(self.drop(self.dwconv(self.fc1(x), H, W, gelu=True))))
         else:
@@ -145,14 +162,22 @@ class Attention(nn.Module):
             self.norm = nn.LayerNorm(dim)
         self.apply(_init_weights)
 
-    def forward(self, x, H, W, residual=None):
-        """`residual`: added to the result (Block.forward's x + attn(norm1(x)); in proj's epilogue on the device path)."""
+    def forward(self, x, H, W, residual=None, norm=None):
+        """`residual`: added to the result (Block.forward's x + attn(norm1(x)); in proj's epilogue on the device path).  `norm`: a LayerNorm
+        to apply to x first (Block.forward's norm1; with sr_ratio 1 on the device path inside the one token split that feeds q and kv)."""
         B, N, C = x.shape
         heads, hd = self.num_heads, C // self.num_heads
         lin = _hip_linear_ok(x, self.q, self.kv, self.proj) and not (self.training and self.proj_drop.p > 0)
+        if lin and self.sr_ratio == 1:
+            xs = _split_normed(x, norm)                        # one split for q and kv
+        else:
+            if norm is not None:
+                x = norm(x)
+            if lin:
+                from .... import hipops
+                xs = hipops.tokens_split(x.contiguous())
         if lin:
             from .... import hipops
-            xs = hipops.tokens_split(x.contiguous())          # one split for q and (sr_ratio 1) kv
             qp = _hip_linear(self.q, xs)
         else:
             qp = self.q(x)
@@ -195,8 +220,8 @@ class Block(nn.Module):
 
     def forward(self, x, H, W):
         if isinstance(self.drop_path, nn.Identity) or not self.training:      # (stochastic depth is the identity: the sums go into the projections)
-            x = self.attn(self.norm1(x), H, W, residual=x)
-            return self.mlp(self.norm2(x), H, W, residual=x)
+            x = self.attn(x, H, W, residual=x, norm=self.norm1)
+            return self.mlp(x, H, W, residual=x, norm=self.norm2)
         x = x + self.drop_path(self.attn(self.norm1(x), H, W))
         return x + self.drop_path(self.mlp(self.norm2(x), H, W))
 

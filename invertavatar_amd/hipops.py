@@ -1113,6 +1113,23 @@ def tokens_split(x):
     return SplitTokens(out, m, k, x.shape[:-1])
 
 
+def layernorm_split_supported(k):
+    return k in (512, 1024, 2048)
+
+
+def layernorm_split(x, norm):
+    """nn.LayerNorm `norm` over the last dimension of x [..., K] + tokens_split of the result, one launch (see ia_layernorm_split)."""
+    _f32c(x, 'x')
+    k = x.shape[-1]
+    m = x.numel() // k
+    out = torch.empty(2, k // 8, m, 8, device=x.device, dtype=torch.float16)
+    with torch.cuda.device(x.device), _Timed('layernorm_split', 8.0 * x.numel(), 8.0 * x.numel(), f'M{m} K{k}'):
+        st = _lib.load().ia_layernorm_split(_p(x), _p(_f32c(norm.weight.detach(), 'weight')), _p(_f32c(norm.bias.detach(), 'bias')), float(norm.eps),
+                                            _p(out), m, k, _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_layernorm_split')
+    return SplitTokens(out, m, k, x.shape[:-1])
+
+
 def attention_sx_supported(head_dim, n, m):
     return head_dim % 16 == 0 and m % 16 == 0 and m <= 4096
 

@@ -172,3 +172,22 @@ def test_linear_with_k_cut_over_the_launch():
     assert torch.equal(got, hipops.linear_sx_splitk(xs, ws, bias))
     _lib.check(_lib.load().ia_linear_splitk_plan(4096, 1024, 1024, ctypes.byref(ks), ctypes.byref(nbytes)), 'plan')
     assert ks.value == 1 and nbytes.value == 0
+
+
+@pytest.mark.parametrize('m_shape,k', [((1, 4096), 1024), ((2, 37), 512), ((1, 5), 2048)])
+def test_layernorm_inside_the_token_split(m_shape, k):
+    """ia_layernorm_split = ia_tokens_split(nn.LayerNorm(x)) in one launch: the reconstructed values against LayerNorm in fp64."""
+    from conftest import rnd
+    from invertavatar_amd import hipops
+    x = (rnd(100, *m_shape, k) * 3 + 0.7).cuda()
+    norm = torch.nn.LayerNorm(k).cuda()
+    norm.weight.data = (rnd(101, k) * 0.2 + 1).cuda()
+    norm.bias.data = (rnd(102, k) * 0.1).cuda()
+    xs = hipops.layernorm_split(x, norm)
+    m = x.numel() // k
+    assert xs.data.shape == (2, k // 8, m, 8) and xs.lead_shape == tuple(m_shape)
+    back = (xs.data[0].float() + xs.data[1].float() / 2048.0).permute(1, 0, 2).reshape(m, k)
+    ref = torch.nn.functional.layer_norm(x.double(), (k,), norm.weight.double(), norm.bias.double(), norm.eps).reshape(m, k)
+    assert (back.double() - ref).abs().max().item() <= 3e-6
+    with pytest.raises(RuntimeError, match='ia_layernorm_split covers'):
+        hipops.layernorm_split(torch.zeros(4, 768, device='cuda'), torch.nn.LayerNorm(768).cuda())
