@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split / _t, ia_layernorm_split, ia_im2col_split, ia_linear_sx / _splitk / _splitk_plan, ia_matmul_sx, ia_softmax_split; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split / _t, ia_layernorm_split, ia_dwconv3x3_tokens_split, ia_im2col_split, ia_linear_sx / _splitk / _splitk_plan, ia_matmul_sx, ia_softmax_split; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -422,6 +422,9 @@ int ia_upsample_bilinear_add(const float* x, const float* addend, float* y, int 
  *   x, y [B, H*W, C] float32; w9c [9][C]: the module's weight [C, 1, 3, 3] transposed; bias [C] or NULL; act 0 = none, 1 = GELU.  C % 4 == 0.
  */
 int ia_dwconv3x3_tokens(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, int act, void* stream);
+/* The same convolution (+ GELU) with its result written as the operand of the linear layer behind it (Mix-FFN: dwconv -> GELU -> fc2):
+ * xs fp16 [2][C/8][B*H*W][8], ia_tokens_split's format (one launch for both).  C % 16 == 0. */
+int ia_dwconv3x3_tokens_split(const float* x, const float* w9c, const float* bias, void* xs, int B, int H, int W, int C, int act, void* stream);
 
 /*
  * 3x3 convolution with stride 2 and padding 1 on an image of 2^2, 4^2 or 8^2 pixels (outputs 1^2, 2^2, 4^2): the last layers of a

@@ -59,6 +59,7 @@ _SIGNATURES = {
     'ia_bn_train_split': [c_void_p] * 7 + [c_int, c_void_p] + [c_int] * 5 + [c_float, c_float, c_void_p],
     'ia_upsample_bilinear_add': [c_void_p] * 3 + [c_int] * 5 + [c_void_p],
     'ia_dwconv3x3_tokens': [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
+    'ia_dwconv3x3_tokens_split': [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
     'ia_conv3x3_s2_tiny_supported': [c_int] * 4,
     'ia_conv3x3_s2_tiny': [c_void_p] * 4 + [c_int] * 6 + [c_float, c_void_p],
     'ia_conv2d_down_plan': [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_size_t)],

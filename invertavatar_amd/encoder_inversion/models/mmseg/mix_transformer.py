@@ -96,8 +96,9 @@ class DWConv(nn.Module):
         super().__init__()
         self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
 
-    def forward(self, x, H, W, gelu=False):
-        """`gelu`: also apply the GELU (erf form) that follows in Mix-FFN -- one launch on the device path (ia_dwconv3x3_tokens)."""
+    def forward(self, x, H, W, gelu=False, split=False):
+        """`gelu`: also apply the GELU (erf form) that follows in Mix-FFN -- one launch on the device path (ia_dwconv3x3_tokens).
+        `split`: return the result as hipops.SplitTokens, the operand of the linear layer behind it (device path only; None if not covered)."""
         B, N, C = x.shape
         conv = self.dwconv
         if (HIP_DWCONV and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and C % 4 == 0 and conv.kernel_size == (3, 3)
@@ -107,7 +108,12 @@ class DWConv(nn.Module):
             key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.device)
             if getattr(st, 'w9c_key', None) != key:
                 st.w9c, st.w9c_key = conv.weight.detach().float().reshape(C, 9).t().contiguous(), key
-            return hipops.dwconv3x3_tokens(x.contiguous(), st.w9c, None if conv.bias is None else conv.bias.detach().float(), H, W, gelu=gelu)
+            bias = None if conv.bias is None else conv.bias.detach().float()
+            if split:
+                return hipops.dwconv3x3_tokens_split(x.contiguous(), st.w9c, bias, H, W, gelu=gelu) if C % 16 == 0 else None
+            return hipops.dwconv3x3_tokens(x.contiguous(), st.w9c, bias, H, W, gelu=gelu)
+        if split:
+            return None
         y = conv(x.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)
         return torch.nn.functional.gelu(y) if gelu else y
 
@@ -132,8 +138,11 @@ class Mlp(nn.Module):
         exact_gelu = isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none'
         if exact_gelu and _hip_linear_ok(x, self.fc1, self.fc2) and not (self.training and self.drop.p > 0):
             from .... import hipops
-            h = self.dwconv(_hip_linear(self.fc1, _split_normed(x, norm)), H, W, gelu=True)
-            return _hip_linear(self.fc2, hipops.tokens_split(h.contiguous()), residual=None if residual is None else residual.contiguous())
+            h1 = _hip_linear(self.fc1, _split_normed(x, norm))
+            hs = self.dwconv(h1, H, W, gelu=True, split=True)          # convolution + GELU + the split of fc2's input in one launch
+            if hs is None:
+                hs = hipops.tokens_split(self.dwconv(h1, H, W, gelu=True).contiguous())
+            return _hip_linear(self.fc2, hs, residual=None if residual is None else residual.contiguous())
         if norm is not None:
             x = norm(x)
         if exact_gelu:

@@ -427,6 +427,21 @@ def dwconv3x3_tokens(x, w9c, bias, h, w, gelu=False):
     return y
 
 
+def dwconv3x3_tokens_split(x, w9c, bias, h, w, gelu=False):
+    """dwconv3x3_tokens with the result written as SplitTokens (the operand of the linear layer behind it; see ia_dwconv3x3_tokens_split)."""
+    _f32c(x, 'x')
+    _f32c(w9c, 'w9c')
+    b, n, c = x.shape
+    if n != h * w or tuple(w9c.shape) != (9, c) or c % 16:
+        raise RuntimeError(f'dwconv3x3_tokens_split: tokens {tuple(x.shape)} on a {h} x {w} grid with weights {tuple(w9c.shape)} (C % 16 == 0)')
+    out = torch.empty(2, c // 8, b * n, 8, device=x.device, dtype=torch.float16)
+    with torch.cuda.device(x.device):
+        st = _lib.load().ia_dwconv3x3_tokens_split(_p(x), _p(w9c), _p(None if bias is None else _f32c(bias, 'bias')), _p(out), b, h, w, c,
+                                                   1 if gelu else 0, _lib.stream_ptr(x.device))
+    _lib.check(st, 'ia_dwconv3x3_tokens_split')
+    return SplitTokens(out, b * n, c, (b, n))
+
+
 def conv_tiny_supported(i, o, h, w):
     """Shapes ia_conv3x3_s2_tiny covers (3x3, stride 2, padding 1 on 2^2 / 4^2 / 8^2 images)."""
     return bool(_lib.load().ia_conv3x3_s2_tiny_supported(int(i), int(o), int(h), int(w)))

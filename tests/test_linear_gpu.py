@@ -191,3 +191,14 @@ def test_layernorm_inside_the_token_split(m_shape, k):
     assert (back.double() - ref).abs().max().item() <= 3e-6
     with pytest.raises(RuntimeError, match='ia_layernorm_split covers'):
         hipops.layernorm_split(torch.zeros(4, 768, device='cuda'), torch.nn.LayerNorm(768).cuda())
+
+
+def test_dwconv_writes_the_split_of_its_result():
+    from conftest import rnd
+    from invertavatar_amd import hipops
+    b, h, w, c = 2, 9, 12, 48
+    x, w9c, bias = rnd(110, b, h * w, c).cuda(), (rnd(111, 9, c) * 0.3).cuda(), rnd(112, c).cuda()
+    for gelu in (False, True):
+        want = hipops.tokens_split(hipops.dwconv3x3_tokens(x, w9c, bias, h, w, gelu=gelu))
+        got = hipops.dwconv3x3_tokens_split(x, w9c, bias, h, w, gelu=gelu)
+        assert got.rows == want.rows and got.cols == want.cols and torch.equal(got.data, want.data)
