@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split / _t, ia_layernorm_split, ia_dwconv3x3_tokens_split, ia_im2col_split, ia_linear_sx / _splitk / _splitk_plan, ia_matmul_sx, ia_softmax_split; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
+#define IA_HIP_ABI_VERSION 7      /* 7 (r06, additive): ia_tokens_split / _t, ia_layernorm_split, ia_dwconv3x3_tokens_split, ia_im2col_split, ia_linear_sx / _splitk / _splitk_plan, ia_matmul_sx, ia_softmax_split, ia_attention_sx / _supported; 6 (r06): ia_render_rays (+ rgb_split, rgb_split_styles, rgb_split_planes), + ia_render_rays_box, ia_ray_limits_box / _parts; 5 (r05; ia_conv2d_mfma_sx_rgb narrowed to n <= 3 fused ToRGB channels, otherwise additive): ia_conv2d_down_sx / _plan, ia_conv3x3_s2_tiny, ia_bn_train_split, ia_convgru_gates_split / _update_split, ia_dwconv3x3_tokens, ia_se_gate_split, ia_upsample_bilinear_add; 4 (r04): + ia_upconv2d_rows_sx / _plan, ia_mouth_edge_blur, ia_split_saturation_poll, ia_conv2d_sx_supported; - ia_conv2d_small; 3 (r03, additive): ia_torgb, ia_upconv2d_fir_sx; 2 (r03): ia_render_rays (+ u_importance), ia_act_split (+ shift), ia_conv2d_mfma_sx (+ prelu_alpha), ia_uv_rasterize (+ binarize_mask) */
 
 typedef enum ia_status {
     IA_OK = 0,
@@ -684,7 +684,8 @@ int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, const float* b
  *   S[z] = scale * Q[z] K[z]^T   (ia_matmul_sx on ia_tokens_split(q), ia_tokens_split(k): head z = columns [z * hd, (z + 1) * hd))
  *   P = softmax(S) written as the next product's operand  (ia_softmax_split)
  *   O[:, z * hd : (z + 1) * hd] = P[z] V[z]   (ia_matmul_sx on P and ia_tokens_split_t(v)), straight into the [N, C] token layout.
- * ia_tokens_split_t: v [M keys][ld] float32, C columns -> vt fp16 [2][M/8][C][8], octets ALONG THE KEYS (M % 16 == 0).
+ * ia_tokens_split_t: v [M keys][ld] float32, C columns -> vt fp16 [2][M/8][C][8], octets ALONG THE KEYS (M % 16 == 0); perm = 1: the keys of
+ *   a 16-key step in the row order of the 32 x 32 MFMA accumulator (octet 2t + h = keys 16t + {0..3, 8..11} + 4h), the order ia_attention_sx reads.
  * ia_softmax_split: s [Z][N][M] float32 -> ps fp16 [2][Z][M/8][N][8]; M % 16 == 0, M <= 4096.
  * ia_matmul_sx: y[z][m][n] = scale * sum_k a[z][m][k] b[z][n][k] for z < batch, both operands token-side splits (low parts at 2^11):
  *   a_rows / b_rows      : rows of the split tensors the operands live in (their octet stride is rows * 16 bytes)
@@ -692,8 +693,18 @@ int ia_linear_sx(const void* xs, const void* w_split, int wk_exp, const float* b
  *                          (head z of [2][C/8][rows][8]: z * (hd / 8) * rows * 16;  P: (M / 8) * N * 16;  vt: z * hd * 16)
  *   y_batch_stride / y_row_stride in floats.  K % 16 == 0.  Deterministic; no workspace.
  */
-int ia_tokens_split_t(const float* v, int64_t ld, void* vt, int M, int C, void* stream);
+int ia_tokens_split_t(const float* v, int64_t ld, void* vt, int M, int C, int perm, void* stream);
 int ia_softmax_split(const float* s, void* ps, int Z, int N, int M, void* stream);
+/*
+ * The same attention in ONE launch, the score matrix never in memory (head_dim 256): a first pass over the keys finds every query's maximum,
+ * a second one forms exp(s - max), its sum and the output over 32-key blocks; both products on fp16 pairs.  A wave computes S^T = K Q^T so that a query's keys sit in the registers of two lanes (row maximum / sum are register
+ * reductions + one exchange) and its probabilities are, as they stand, a B fragment of O^T = V^T P^T -- no transposition anywhere.
+ *   q_split = ia_tokens_split(q [N][C]), k_split = ia_tokens_split(k [M][C]), v_split_t = ia_tokens_split_t(v [M][C], perm = 1);
+ *   out [N][C] float32 = (attn @ v).transpose(1, 2).reshape(N, C) of the reference; M % 16 == 0; deterministic.
+ */
+int ia_attention_sx_supported(int head_dim, int N, int M);
+int ia_attention_sx(const void* q_split, const void* k_split, const void* v_split_t, float* out, int heads, int N, int M, int head_dim,
+                    float scale, void* stream);
 int ia_matmul_sx(const void* a_split, const void* b_split, float* y, int batch, int M, int N, int K, int a_rows, int64_t a_plane_bytes,
                  int64_t a_batch_bytes, int b_rows, int64_t b_plane_bytes, int64_t b_batch_bytes, int64_t y_batch_stride, int64_t y_row_stride,
                  float scale, void* stream);

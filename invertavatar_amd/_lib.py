@@ -81,7 +81,9 @@ _SIGNATURES = {
     'ia_attention': [c_void_p] * 4 + [c_int] * 5 + [c_int64] * 8 + [c_float, c_void_p],
     'ia_tokens_split': [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p],
     'ia_layernorm_split': [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p],
-    'ia_tokens_split_t': [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p],
+    'ia_tokens_split_t': [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p],
+    'ia_attention_sx_supported': [c_int] * 3,
+    'ia_attention_sx': [c_void_p] * 4 + [c_int] * 4 + [c_float, c_void_p],
     'ia_softmax_split': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'ia_matmul_sx': [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_int64, c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p],
     'ia_im2col_split': [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],

@@ -180,7 +180,7 @@ struct NoWatch { __device__ __forceinline__ void see(float) const {} };
 
 // ---- V of an attention layer, split ALONG THE KEYS: v [M keys][ld] (C columns) -> [2][M/8][C][8]: the B operand of P . V, whose k index is
 // the key.  One thread = (key octet, column): eight reads that are contiguous over the columns of a wave, one 16-byte store per plane.
-__global__ __launch_bounds__(256) void tokens_split_t_kernel(const float* __restrict__ v, int64_t ld, h16x8* __restrict__ vt, int M8, int C) {
+__global__ __launch_bounds__(256) void tokens_split_t_kernel(const float* __restrict__ v, int64_t ld, h16x8* __restrict__ vt, int M8, int C, int perm) {
     const int c = blockIdx.x * 256 + threadIdx.x, mo = blockIdx.y;
     if (c >= C) return;
     ia::SatWatch watch;
@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256) void tokens_split_t_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         _Float16 h, l;
-        ia::split_f16(v[(int64_t)(mo * 8 + j) * ld + c], h, l, watch);
+        // perm: the keys of a 16-key step in the row order of the 32 x 32 MFMA accumulator (octet 2 t + hh = keys 16 t + {0..3, 8..11} + 4 hh):
+        // the probabilities a lane of ia_attention_sx holds are then a B fragment as they stand
+        const int key = perm ? 16 * (mo >> 1) + (j < 4 ? j : j + 4) + 4 * (mo & 1) : mo * 8 + j;
+        ia::split_f16(v[(int64_t)key * ld + c], h, l, watch);
         hi[j] = h;
         lo[j] = l;
     }
@@ -473,13 +476,13 @@ extern "C" int ia_layernorm_split(const float* x, const float* gamma, const floa
     return K == 512 ? go(layernorm_split_kernel<1>) : K == 1024 ? go(layernorm_split_kernel<2>) : go(layernorm_split_kernel<4>);
 }
 
-extern "C" int ia_tokens_split_t(const float* v, int64_t ld, void* vt, int M, int C, void* stream) {
+extern "C" int ia_tokens_split_t(const float* v, int64_t ld, void* vt, int M, int C, int perm, void* stream) {
     IA_REQUIRE(v && vt, "v and vt must be device pointers");
     IA_REQUIRE(M > 0 && C > 0 && ld >= C, "empty matrix, or a row stride shorter than a row");
     if (M % 16 != 0) return ia::fail(IA_ERR_UNSUPPORTED, "ia_tokens_split_t needs M %% 16 == 0 (got %d)", M);
     IA_REQUIRE((int64_t)M * C <= (int64_t)1 << 30 && M / 8 <= 65535, "matrix too large for 32-bit plane offsets");
     hipLaunchKernelGGL(tokens_split_t_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)(M / 8)), dim3(256), 0, (hipStream_t)stream, v, ld,
-                       static_cast<h16x8*>(vt), M / 8, C);
+                       static_cast<h16x8*>(vt), M / 8, C, perm);
     return ia::check_launch("ia_tokens_split_t");
 }
 

@@ -1145,6 +1145,9 @@ def layernorm_split(x, norm):
     return SplitTokens(out, m, k, x.shape[:-1])
 
 
+ATTENTION_SX_ONE_LAUNCH = True      # head_dim 256: ia_attention_sx (online softmax) instead of matmul / softmax / matmul
+
+
 def attention_sx_supported(head_dim, n, m):
     return head_dim % 16 == 0 and m % 16 == 0 and m <= 4096
 
@@ -1169,7 +1172,11 @@ def attention_sx(q, kv, heads, scale):
         vt = torch.empty(2, m // 8, c, 8, device=dev, dtype=torch.float16)
         for i in range(b):
             qs, ks = tokens_split(q[i]), tokens_split(kv[i, :, :c])
-            _lib.check(lib.ia_tokens_split_t(kv[i, :, c:].data_ptr(), kv.stride(1), _p(vt), m, c, s_), 'ia_tokens_split_t')
+            flash = ATTENTION_SX_ONE_LAUNCH and bool(lib.ia_attention_sx_supported(hd, n, m))
+            _lib.check(lib.ia_tokens_split_t(kv[i, :, c:].data_ptr(), kv.stride(1), _p(vt), m, c, int(flash), s_), 'ia_tokens_split_t')
+            if flash:        # one launch, no score matrix (head_dim 256)
+                _lib.check(lib.ia_attention_sx(_p(qs.data), _p(ks.data), _p(vt), _p(out[i]), heads, n, m, hd, float(scale), s_), 'ia_attention_sx')
+                continue
             _lib.check(lib.ia_matmul_sx(_p(qs.data), _p(ks.data), _p(scores), heads, n, m, hd, n, (c // 8) * n * 16, (hd // 8) * n * 16,
                                         m, (c // 8) * m * 16, (hd // 8) * m * 16, n * m, m, float(scale), s_), 'ia_matmul_sx')
             _lib.check(lib.ia_softmax_split(_p(scores), _p(probs), heads, n, m, s_), 'ia_softmax_split')

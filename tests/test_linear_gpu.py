@@ -118,12 +118,15 @@ def test_overlap_patch_embed_routes():
     assert (got - ref).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize('b,n,m,c,heads', [(1, 1024, 1024, 1024, 4), (2, 100, 48, 64, 2), (1, 77, 4096, 512, 2), (1, 300, 160, 256, 1)])
-def test_attention_on_the_fp16_pair_gemm(b, n, m, c, heads):
+@pytest.mark.parametrize('one_launch', [True, False])
+@pytest.mark.parametrize('b,n,m,c,heads', [(1, 1024, 1024, 1024, 4), (2, 100, 48, 64, 2), (1, 77, 4096, 512, 2), (1, 300, 160, 256, 1), (2, 130, 48, 512, 2)])
+def test_attention_on_the_fp16_pair_gemm(b, n, m, c, heads, one_launch, monkeypatch):
     """hipops.attention_sx (ia_tokens_split / _t, ia_matmul_sx, ia_softmax_split) against Attention.forward's arithmetic in fp64
-    (mix_transformer.py:83-116: q @ k^T * scale, softmax over the keys, @ v, heads back into the token layout)."""
+    (mix_transformer.py:83-116: q @ k^T * scale, softmax over the keys, @ v, heads back into the token layout); head_dim 256 in one launch
+    (ia_attention_sx: no score matrix) or, with the switch off and for other head sizes, as matmul / softmax / matmul."""
     from conftest import rnd
     from invertavatar_amd import hipops
+    monkeypatch.setattr(hipops, 'ATTENTION_SX_ONE_LAUNCH', one_launch)
     q, kv = rnd(90, b, n, c).cuda(), rnd(91, b, m, 2 * c).cuda()
     hd = c // heads
     scale = hd ** -0.5
