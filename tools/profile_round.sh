@@ -48,10 +48,16 @@ for s in ('fetch', 'write', 'sq'):
         e.update({c: v for c, v in d.items()})
 # durations of the SAME dispatches (kernel trace of the sq pass): matrix-pipe utilisation = busy cycles / (SIMDs x kernel cycles)
 import glob
-dur = collections.defaultdict(float)
+durs = collections.defaultdict(list)
 for kt in glob.glob('/tmp/pmc_sq/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(kt)):
-        dur[fam(r['Kernel_Name'])] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+        durs[fam(r['Kernel_Name'])].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+# a dispatch whose timestamps span a stall of the profiled process (r06: one family read 137 us per dispatch where GRBM_GUI_ACTIVE of the same
+# dispatches and every other measurement say 74) counts at most three times its family's median
+dur = {}
+for k, v in durs.items():
+    med = sorted(v)[len(v) // 2]
+    dur[k] = sum(min(d, 3.0 * med) for d in v)
 for k, e in summary.items():
     if dur.get(k) and e.get('SQ_INSTS_MFMA'):
         e['kernel_ns_in_sq_pass'] = dur[k]
