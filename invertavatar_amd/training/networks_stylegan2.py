@@ -38,10 +38,10 @@ FP16_BLOCKS_COMPUTE_FP32 = True
 # (tests/test_conv_gpu.py) and twice as fast.  False keeps every layer on v_mfma_f32_32x32x2_f32.
 FUSED_TORGB = True               # a block whose x nobody reads (last SR block): ToRGB evaluated in conv1's epilogue (ia_conv2d_mfma_sx_rgb)
 STREAMING_TORGB = True           # ToRGB layers through ia_conv1x1 (one streaming launch) instead of the tiled ia_conv2d_mfma form
-# ia_torgb re-reads the activations once per block of 32 output channels with 8-wave workgroups: past this many pixels x channel blocks
-# (the 96-channel ToRGB of the static backbone at 256^2) the 64-thread workgroups of ia_conv1x1 (+ ia_upfirdn2d) share the machine better
-# with the convolutions of the other streams.  Same-box frame A/B, final r03 tree: 16384 / 49152 / 65536 = 345.7 / 344.2 / 346.7 frames/s.
-TORGB_MAX_WORK = 65536
+# r03 - r05: ia_torgb re-read the activations once per block of 32 output channels, and past 65 536 pixels x channel blocks (the 96-channel
+# ToRGB of the static backbone at 256^2) ia_conv1x1 + ia_upfirdn2d shared the machine better (346.7 vs 344.2 frames/s).  Since r06 the large
+# images read their activations once (torgb_wide_kernel) and the limit costs 0.6 % (same-box 413.8 -> 416.3 without it): no limit.
+TORGB_MAX_WORK = 1 << 30
 # Up-sampling layers with at most this many input channels run as one stride-1 launch on the weight composed with the resample filter
 # (ia_upconv2d_fir_sx: 4x the products, no (2H+1)^2 fp32 image, no FIR launch): the 32 -> 256 @128^2 layer of the SR head
 COMPOSED_UPFIR = True
