@@ -61,7 +61,7 @@ class ConvGRU(torch.nn.Module):
         conv_ih, conv_hh, act = self.ih[0], self.hh[0], self.hh[1]
         packed = self._hip_convs(x)
         prelu_w = act.weight.detach().float().contiguous() if isinstance(act, nn.PReLU) else None
-        if packed is not None and self.channels % 8 == 0:
+        if packed is not None and self.channels % 8 == 0 and (x.shape[-2] * x.shape[-1]) % 4 == 0:      # (the split launches walk the pixels in fours)
             # the element-wise launches write the convolutions' operand format themselves (no fp32 cat, no ia_act_split: 4 launches per
             # step between the two convolutions and their fix-ups instead of 6)
             xs = xh if isinstance(xh, hipops.SplitAct) else hipops.act_split(xh)
