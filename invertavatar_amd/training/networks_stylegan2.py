@@ -37,6 +37,7 @@ FP16_BLOCKS_COMPUTE_FP32 = True
 # fp16 pairs on the fp16 MFMA (ia_conv2d_mfma_s): as accurate against an fp64 convolution as the fp32 MFMA form
 # (tests/test_conv_gpu.py) and twice as fast.  False keeps every layer on v_mfma_f32_32x32x2_f32.
 FUSED_TORGB = True               # a block whose x nobody reads (last SR block): ToRGB evaluated in conv1's epilogue (ia_conv2d_mfma_sx_rgb)
+HIP_FC_LINEAR = True             # FullyConnectedLayer (linear activation, with bias) on a device matrix through ia_tokens_split + ia_linear_sx
 STREAMING_TORGB = True           # ToRGB layers through ia_conv1x1 (one streaming launch) instead of the tiled ia_conv2d_mfma form
 # r03 - r05: ia_torgb re-read the activations once per block of 32 output channels, and past 65 536 pixels x channel blocks (the 96-channel
 # ToRGB of the static backbone at 256^2) ia_conv1x1 + ia_upfirdn2d shared the machine better (346.7 vs 344.2 frames/s).  Since r06 the large
@@ -212,6 +213,7 @@ class FullyConnectedLayer(torch.nn.Module):
         self.weight_gain = lr_multiplier / np.sqrt(in_features)
         self.bias_gain = lr_multiplier
         self._scaled = None   # (key, weight^T * gain, bias * gain): inference-time cache of the equalised-lr scaling
+        self._split = None    # (key, fp16-pair split of weight * gain, bias * gain): the operand of ia_linear_sx
 
     def _scaled_params(self, dtype):
         key = (self.weight.data_ptr(), self.weight._version, None if self.bias is None else self.bias._version, dtype, self.weight.device)
@@ -223,6 +225,14 @@ class FullyConnectedLayer(torch.nn.Module):
 
     def forward(self, x):
         if not _needs_autograd(x, self.weight, self.bias):
+            if (HIP_FC_LINEAR and self.activation == 'linear' and self.bias is not None and _on_device(x) and x.dtype == torch.float32 and x.dim() == 2
+                    and self.in_features % 16 == 0):
+                # the e4e heads' 512 x 512 layers on one row: the last library GEMM of the inversion flows goes through ia_linear_sx
+                key = (self.weight.data_ptr(), self.weight._version, self.bias._version, self.weight.device)
+                if getattr(self, '_split', None) is None or self._split[0] != key:
+                    self._split = (key, hipops.pack_linear_weight_split(self.weight.detach().float() * self.weight_gain),
+                                   (self.bias.detach().float() * self.bias_gain).contiguous())
+                return hipops.linear_sx(hipops.tokens_split(x.contiguous()), self._split[1], self._split[2])
             wt, b = self._scaled_params(x.dtype)
             if self.activation == 'linear' and b is not None:
                 return torch.addmm(b, x, wt)
