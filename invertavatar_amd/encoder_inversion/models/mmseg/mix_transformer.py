@@ -16,6 +16,8 @@ HIP_DWCONV = True      # Mix-FFN's depth-wise 3x3 (+ GELU) on the token grid thr
 
 
 HIP_ATTENTION = True      # device inference: softmax(QK^T)V of the 1024-dim / 4-head blocks through ia_attention
+HIP_ATTENTION_SX_MIN = 16384      # N * M from which ia_attention_sx (fp16 pairs) replaces ia_attention (fp32 MFMAs): graph replay 24.4 vs 24.0 us at
+                                  # 64 tokens, 32.3 vs 68.3 at 256
 
 
 HIP_PATCH_EMBED = True      # device inference: OverlapPatchEmbed's strided convolution as ia_im2col_split + ia_linear_sx (tokens directly)
@@ -205,9 +207,10 @@ class Attention(nn.Module):
             return y if residual is None else residual + y
         if (HIP_ATTENTION and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not (self.training and self.attn_drop.p > 0)):
             from .... import _lib, hipops
-            if _lib.load().ia_attention_supported(hd, N, kv.shape[1]):      # one launch: no [N, M] score matrix, no head permutes
-                return project(hipops.attention(qp.contiguous(), kv.contiguous(), heads, self.scale))
-            if HIP_LINEAR and hipops.attention_sx_supported(hd, N, kv.shape[1]):      # larger grids: the two products on the fp16-pair GEMM
+            sx = HIP_LINEAR and hipops.attention_sx_supported(hd, N, kv.shape[1])
+            if _lib.load().ia_attention_supported(hd, N, kv.shape[1]) and not (sx and hd == 256 and N * kv.shape[1] >= HIP_ATTENTION_SX_MIN):
+                return project(hipops.attention(qp.contiguous(), kv.contiguous(), heads, self.scale))      # one launch, fp32 MFMAs: the 8^2 grids
+            if sx:      # both products on fp16 pairs (head_dim 256: one launch, no score matrix): from 16^2 tokens up
                 return project(hipops.attention_sx(qp.contiguous(), kv.contiguous(), heads, self.scale))
         q = qp.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
         k, v = kv.reshape(B, -1, 2, heads, hd).permute(2, 0, 3, 1, 4)
